@@ -1,0 +1,88 @@
+/*
+ * oracle/oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C99) of the algorithm on oatk's syncasm hot path:
+ * homopolymer compression + closed-syncmer scan + k-mer hash, syncmer count /
+ * ID assignment, scan statistics, wavefront edit distance and per-read
+ * syncmer-chain error correction.  Every function cites the reference
+ * file:line it follows (paths relative to /root/reference).
+ *
+ * Parity status: PINNED.  oracle/_ref (the reference compiled from its own
+ * sources by oracle/Makefile) is run side by side with these functions in
+ * tests/test_oracle_vs_ref.py (this container), and the committed vectors in
+ * tests/golden/ were produced by that compiled reference with
+ * tools/make_golden.py.
+ *
+ * Nothing in the product path (oatk_amd/, include/, bench.py's timed region)
+ * may include, link or call anything in this directory.
+ */
+#ifndef OATK_ORACLE_H
+#define OATK_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_NO_HASH UINT64_MAX
+
+/* flat result of scanning a batch of reads; arrays are concatenated in read order */
+typedef struct {
+    uint64_t n_reads;
+    uint64_t tot_hoco, tot_bytes, tot_scm, tot_lrl, tot_nn;
+    uint32_t *hoco_l;   /* [n_reads]   sr_t.hoco_l                       */
+    uint32_t *n_scm;    /* [n_reads]   sr_t.n                            */
+    uint32_t *n_lrl;    /* [n_reads]   entries of ho_l_rl per read       */
+    uint32_t *n_nn;     /* [n_reads]   entries of n_nucl per read        */
+    uint8_t  *hoco_s;   /* [tot_bytes] ceil(hoco_l/4) bytes per read     */
+    uint8_t  *ho_rl;    /* [tot_hoco]                                    */
+    uint32_t *ho_l_rl;  /* [tot_lrl]                                     */
+    uint32_t *n_nucl;   /* [tot_nn]                                      */
+    uint32_t *m_pos;    /* [tot_scm]   pos << 1 | rev                    */
+    uint64_t *s_mer;    /* [tot_scm]   canonical s-mer << 1 | strand-ish */
+    uint64_t *k_mer;    /* [tot_scm]   MurmurHash64A of oriented k-mer   */
+} orc_scan_t;
+
+/* mode 0: streaming state machine (syncmer.c:243-421 restated step by step)
+ * mode 1: stateless window predicates (the formulation the HIP kernel uses) */
+orc_scan_t *orc_scan_batch(const uint8_t *seq, const uint64_t *off, uint64_t n_reads, int K, int S, int mode);
+void orc_scan_free(orc_scan_t *r);
+
+uint8_t  orc_nt4(uint8_t ch);
+uint64_t orc_hash64(uint64_t key, uint64_t mask);
+uint64_t orc_murmur64a(const void *key, uint32_t len, uint64_t seed);
+uint64_t orc_kmer_hash(const uint8_t *hoco_s, uint32_t pos, uint32_t rev, int K);
+/* MSB-first 2-bit packing of the oriented k-mer into out[(K-1)/4+1] */
+void orc_kmer_pack(const uint8_t *hoco_s, uint32_t pos, uint32_t rev, int K, uint8_t *out);
+
+/* syncmer database produced by the count step */
+typedef struct {
+    uint64_t n_scm, tot_occ;
+    uint64_t *h;       /* [n_scm] k-mer hash                                 */
+    uint64_t *s;       /* [n_scm] s-mer code                                 */
+    uint32_t *cov;     /* [n_scm]                                            */
+    uint64_t *occ_off; /* [n_scm+1] CSR offsets into occ                     */
+    uint64_t *occ;     /* [tot_occ] sid << 32 | idx << 1 | rev, (sid,idx) asc */
+    uint64_t *k_id;    /* [tot_occ of input order] rewritten sr->k_mer = id << 1 */
+    int      err;      /* 1 = identical k-mers with different s-mers (fatal in the reference) */
+} orc_count_t;
+
+orc_count_t *orc_count(const orc_scan_t *sc, int K);
+void orc_count_free(orc_count_t *c);
+
+/* edit distance (levdist.c); state is resumable across growing query prefixes */
+typedef struct orc_wf orc_wf_t;
+orc_wf_t *orc_wf_new(const char *ts, int32_t tl, int32_t bw);
+void orc_wf_step(orc_wf_t *w, const char *qs, int32_t ql, int32_t *out3);
+void orc_wf_free(orc_wf_t *w);
+orc_wf_t *orc_wf_clone(const orc_wf_t *w);
+void orc_wf_ed(int32_t tl, const char *ts, int32_t ql, const char *qs, int32_t bw, int32_t *out3);
+/* closed form by full DP: min over last row / last column, ties -> smallest diagonal */
+void orc_ed_bruteforce(int32_t tl, const char *ts, int32_t ql, const char *qs, int32_t *out3);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,228 @@
+/*
+ * oracle/ref_shim.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * A flat, ctypes-friendly window onto the *compiled reference* (c-zhou/oatk,
+ * sources read where they lie under /root/reference; nothing is copied into
+ * this repo).  oracle/Makefile compiles this file together with the
+ * reference's own .c files into oracle/_ref/liboatk_ref.so.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ *
+ * Every function here is a thin adaptor: it calls a public reference symbol
+ * (cited) and copies struct members into caller-provided flat arrays so that
+ * Python/numpy can compare them with the HIP path and with the oracle C files.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+
+#include "sstream.h"
+#include "syncmer.h"
+#include "syncasm.h"
+#include "graph.h"
+#include "levdist.h"
+#include "misc.h"
+
+/* each reference main() defines this global (run_syncasm.c:327); the library has none */
+int VERBOSE = 0;
+
+/* declared at run_syncasm.c:53, defined syncerr.c:819 */
+void read_error_correction(sr_db_t *sr_db, scg_t *g, double max_edist, uint32_t err_mer_c, uint32_t max_err_c,
+        uint32_t err_arc_c, double max_arc_f, int threads, FILE *fo, int verbose);
+/* defined syncerr.c:679 */
+int64_t find_error_syncmers(scg_t *g, uint32_t err_mer_c, uint32_t max_err_c, uint32_t err_arc_c, double max_arc_f, int del_err);
+/* defined run_syncasm.c:56 */
+int syncasm(char **file_in, int n_file, size_t m_data, int k, int s, int bubble_size, int tip_size, int min_k_cov,
+        double min_a_cov_f, double weak_cross, int do_ec, int do_unzip, int n_threads, char *out, scg_meta_t *meta, int VERBOSE);
+
+void refx_set_verbose(int v) { VERBOSE = v; }
+
+/* ---- scan: sstream_open (sstream.c:70) + sr_read (syncmer.c:487) ---- */
+sr_db_t *refx_scan(char **files, int n_files, int k, int s, int n_threads)
+{
+    sstream_t *rdr = sstream_open(files, n_files);
+    if (!rdr) return 0;
+    sr_db_t *db = (sr_db_t *) malloc(sizeof(sr_db_t));
+    sr_db_init(db, k, s);
+    sr_read(rdr, db, 0, n_threads);
+    sstream_close(rdr);
+    return db;
+}
+
+void refx_srdb_destroy(sr_db_t *db) { sr_db_destroy(db); }
+uint64_t refx_srdb_n(sr_db_t *db) { return db->n; }
+int refx_srdb_validate(sr_db_t *db) { return sr_db_validate(db); }
+
+/* per-read scalar members: hoco_l, n (sr_t, syncmer.h:48-70) */
+void refx_srdb_lengths(sr_db_t *db, uint32_t *hoco_l, uint32_t *n_scm, uint64_t *sid)
+{
+    size_t i;
+    for (i = 0; i < db->n; ++i) {
+        hoco_l[i] = db->a[i].hoco_l;
+        n_scm[i] = db->a[i].n;
+        sid[i] = db->a[i].sid;
+    }
+}
+
+/* concatenate per-read arrays in read order; any destination may be NULL */
+void refx_srdb_flatten(sr_db_t *db, uint8_t *hoco_s, uint8_t *ho_rl, uint32_t *ho_l_rl, uint64_t *n_l_rl,
+        uint32_t *m_pos, uint64_t *s_mer, uint64_t *k_mer)
+{
+    size_t i, j, ob = 0, orl = 0, ol = 0, os = 0;
+    for (i = 0; i < db->n; ++i) {
+        sr_t *r = &db->a[i];
+        size_t nb = ((size_t) r->hoco_l + 3) / 4, nl = 0;
+        if (hoco_s && nb) memcpy(hoco_s + ob, r->hoco_s, nb);
+        if (ho_rl && r->hoco_l) memcpy(ho_rl + orl, r->ho_rl, r->hoco_l);
+        for (j = 0; j < r->hoco_l; ++j)
+            if (r->ho_rl[j] == 255) {
+                if (ho_l_rl) ho_l_rl[ol + nl] = r->ho_l_rl[nl];
+                ++nl;
+            }
+        if (m_pos && r->n) memcpy(m_pos + os, r->m_pos, sizeof(uint32_t) * r->n);
+        if (s_mer && r->n) memcpy(s_mer + os, r->s_mer, sizeof(uint64_t) * r->n);
+        if (k_mer && r->n) memcpy(k_mer + os, r->k_mer, sizeof(uint64_t) * r->n);
+        ob += nb, orl += r->hoco_l, ol += nl, os += r->n;
+    }
+    if (n_l_rl) *n_l_rl = ol;
+}
+
+/* sr_t does not store how many entries n_nucl holds (syncmer.c:321); the caller knows */
+void refx_srdb_nnucl(sr_db_t *db, uint64_t i, uint32_t cnt, uint32_t *out)
+{
+    if (cnt) memcpy(out, db->a[i].n_nucl, sizeof(uint32_t) * cnt);
+}
+
+void refx_srdb_stat(sr_db_t *db, int32_t *out8, double *outd)
+{
+    FILE *fo = fopen("/dev/null", "w");
+    sr_db_stat(db, fo, 0); /* syncmer.c:867 */
+    fclose(fo);
+    sr_stat_t *st = db->stats;
+    if (!st) return;
+    out8[0] = st->smer_unique, out8[1] = st->smer_singleton, out8[2] = st->smer_peak_hom, out8[3] = st->smer_peak_het;
+    out8[4] = st->kmer_unique, out8[5] = st->kmer_singleton, out8[6] = st->kmer_peak_hom, out8[7] = st->kmer_peak_het;
+    outd[0] = (double) st->syncmer_n, outd[1] = st->syncmer_per_read, outd[2] = st->syncmer_avg_dist;
+    outd[3] = st->smer_avg_cnt, outd[4] = st->kmer_avg_cnt;
+}
+
+/* ---- count: collect_syncmer_from_reads (syncmer.c:1397) ---- */
+syncmer_db_t *refx_collect(sr_db_t *db) { return collect_syncmer_from_reads(db); }
+void refx_scmdb_destroy(syncmer_db_t *s) { syncmer_db_destroy(s); }
+uint64_t refx_scmdb_n(syncmer_db_t *s) { return s? s->n : 0; }
+uint64_t refx_scmdb_total_cov(syncmer_db_t *s)
+{
+    uint64_t t = 0; size_t i;
+    for (i = 0; i < s->n; ++i) t += s->a[i].cov;
+    return t;
+}
+void refx_scmdb_flatten(syncmer_db_t *s, uint64_t *h, uint64_t *smer, uint32_t *cov, uint8_t *del, uint64_t *m_pos)
+{
+    size_t i, o = 0;
+    for (i = 0; i < s->n; ++i) {
+        syncmer_t *a = &s->a[i];
+        if (h) h[i] = a->h;
+        if (smer) smer[i] = a->s;
+        if (cov) cov[i] = a->cov;
+        if (del) del[i] = a->del;
+        if (m_pos && a->cov) memcpy(m_pos + o, a->m_pos, sizeof(uint64_t) * a->cov);
+        o += a->cov;
+    }
+}
+
+/* ---- EC graph: make_syncmer_graph (syncasm.c:203), scg_consensus hoco (syncasm.c:716) ---- */
+scg_t *refx_make_graph(sr_db_t *db, syncmer_db_t *s, uint32_t min_k_cov, double min_a_cov_f)
+{
+    return make_syncmer_graph(db, s, min_k_cov, min_a_cov_f);
+}
+void refx_consensus(sr_db_t *db, scg_t *g, int hoco, int save) { scg_consensus(db, g, hoco, save, 0); }
+void refx_scg_destroy(scg_t *g) { scg_destroy(g); }
+int64_t refx_find_error_syncmers(scg_t *g, uint32_t err_mer_c, uint32_t max_err_c, uint32_t err_arc_c, double max_arc_f, int del_err)
+{
+    return find_error_syncmers(g, err_mer_c, max_err_c, err_arc_c, max_arc_f, del_err);
+}
+void refx_graph_dims(scg_t *g, uint64_t *n_vtx, uint64_t *n_arc, uint64_t *seq_bytes)
+{
+    asmg_t *a = g->utg_asmg;
+    uint64_t i, sb = 0;
+    *n_vtx = a->n_vtx, *n_arc = a->n_arc;
+    for (i = 0; i < a->n_vtx; ++i) if (a->vtx[i].seq) sb += a->vtx[i].len;
+    *seq_bytes = sb;
+}
+/* asmg_t (graph.h:39-63) flattened: vertices (len, del, seq offset), arcs in array order, CSR index */
+void refx_graph_flatten(scg_t *g, uint64_t *vtx_len, uint8_t *vtx_del, uint32_t *vtx_cov, uint64_t *vtx_seq_off, char *seq,
+        uint64_t *arc_v, uint64_t *arc_w, uint64_t *arc_ls, uint32_t *arc_cov, uint8_t *arc_del, uint8_t *arc_comp,
+        uint64_t *idx_p, uint64_t *idx_n)
+{
+    asmg_t *a = g->utg_asmg;
+    uint64_t i, so = 0;
+    for (i = 0; i < a->n_vtx; ++i) {
+        if (vtx_len) vtx_len[i] = a->vtx[i].len;
+        if (vtx_del) vtx_del[i] = a->vtx[i].del;
+        if (vtx_cov) vtx_cov[i] = a->vtx[i].cov;
+        if (vtx_seq_off) vtx_seq_off[i] = so;
+        if (a->vtx[i].seq) {
+            if (seq) memcpy(seq + so, a->vtx[i].seq, a->vtx[i].len);
+            so += a->vtx[i].len;
+        }
+    }
+    for (i = 0; i < a->n_arc; ++i) {
+        if (arc_v) arc_v[i] = a->arc[i].v;
+        if (arc_w) arc_w[i] = a->arc[i].w;
+        if (arc_ls) arc_ls[i] = a->arc[i].ls;
+        if (arc_cov) arc_cov[i] = a->arc[i].cov;
+        if (arc_del) arc_del[i] = a->arc[i].del;
+        if (arc_comp) arc_comp[i] = a->arc[i].comp;
+    }
+    if (idx_p) memcpy(idx_p, a->idx_p, sizeof(uint64_t) * a->n_vtx * 2);
+    if (idx_n) memcpy(idx_n, a->idx_n, sizeof(uint64_t) * a->n_vtx * 2);
+}
+
+/* ---- EC: read_error_correction (syncerr.c:819) ---- */
+void refx_ec(sr_db_t *db, scg_t *g, double max_edist, uint32_t err_mer_c, uint32_t max_err_c, uint32_t err_arc_c,
+        double max_arc_f, int n_threads)
+{
+    read_error_correction(db, g, max_edist, err_mer_c, max_err_c, err_arc_c, max_arc_f, n_threads, 0, 0);
+}
+
+/* ---- edit distance: wf_ed (levdist.c:312), resumable wf_ed_core (levdist.c:265) ---- */
+void refx_wf_ed(int32_t tl, const char *ts, int32_t ql, const char *qs, int32_t is_ext, int32_t bw, int32_t *out3)
+{
+    int32_t score = 0, t_end = 0, q_end = 0;
+    wf_ed(tl, ts, ql, qs, is_ext, bw, &score, &t_end, &q_end, 0);
+    out3[0] = score, out3[1] = t_end, out3[2] = q_end;
+}
+
+/* the state initialisation mirrors the caller at syncerr.c:465-482 */
+wf_config_t *refx_wf_new(int32_t tl, const char *ts, int32_t bw)
+{
+    wf_config_t *c = (wf_config_t *) calloc(1, sizeof(wf_config_t));
+    c->ts = (char *) malloc(tl + 8);
+    memcpy(c->ts, ts, tl);
+    c->tl = tl;
+    c->is_ext = 1;
+    c->bw = bw;
+    c->wf_diag = (wf_diag_t *) calloc(1, sizeof(wf_diag_t));
+    c->wf_diag->m = (size_t) tl * 4 + 16;
+    c->wf_diag->a = (wf_diag1_t *) malloc(sizeof(wf_diag1_t) * c->wf_diag->m);
+    c->wf_diag->n = 1;
+    c->wf_diag->a[0].d = 0;
+    c->wf_diag->a[0].k = -1;
+    return c;
+}
+/* advance the same state with a longer query (qs must extend the previous one) */
+void refx_wf_step(wf_config_t *c, int32_t ql, char *qs, int32_t *out3)
+{
+    c->qs = qs, c->ql = ql;
+    wf_ed_core(c);
+    out3[0] = c->score, out3[1] = c->t_end, out3[2] = c->q_end;
+}
+void refx_wf_free(wf_config_t *c) { c->qs = 0; wf_config_destroy(c, 1); }
+
+/* ---- whole program: syncasm() (run_syncasm.c:56) ---- */
+int refx_syncasm(char **files, int n_files, int k, int s, int min_k_cov, double min_a_cov_f, int do_ec, int do_unzip,
+        int n_threads, char *out)
+{
+    /* remaining defaults from run_syncasm.c:356-367 */
+    return syncasm(files, n_files, 0, k, s, 100000, 10000, min_k_cov, min_a_cov_f, 0.3, do_ec, do_unzip, n_threads, out, 0, 0);
+}

@@ -1,0 +1,110 @@
+"""Deterministic adversarial / edge-case reads for parity tests (never timed).
+
+Covers the cases SURVEY.md 8c lists: N next to syncmer boundaries, homopolymers > 256, di-/tri-nucleotide
+and longer tandem repeats (s-mer ties, first == last s-mer), reads shorter than K, lower case and U,
+empty reads, reverse-complement pairs, palindromes.
+"""
+import numpy as np
+
+_COMP = bytes.maketrans(b"ACGTacgtUuNn", b"TGCAtgcaAaNn")
+
+
+def revcomp(s: bytes) -> bytes:
+    return s.translate(_COMP)[::-1]
+
+
+def rand_dna(rng, n, alphabet=b"ACGT"):
+    a = np.frombuffer(alphabet, dtype=np.uint8)
+    return a[rng.integers(0, len(a), size=n)].tobytes()
+
+
+def rand_nohp(rng, n):
+    """random DNA with no two equal neighbours (HPC leaves it unchanged)"""
+    out = bytearray(n)
+    prev = 255
+    for i in range(n):
+        c = int(rng.integers(0, 4))
+        if c == prev:
+            c = (c + 1 + int(rng.integers(0, 3))) & 3
+        out[i] = b"ACGT"[c]
+        prev = c
+    return bytes(out)
+
+
+def reads(K, S, seed=7, scale=1.0):
+    rng = np.random.default_rng(seed)
+    L = int(max(4 * K, 600) * scale)
+    out = []
+    out.append(rand_dna(rng, L))
+    base = rand_dna(rng, 3 * L)
+    out.append(base)
+    out.append(revcomp(base))                                  # strand symmetry
+    out.append(base.lower())                                   # lower case
+    out.append(base.replace(b"T", b"U")[: 2 * L])              # U == T
+    # N placed around k-mer boundaries
+    for gap in (0, 1, S - 1, S, K - 1, K, K + 1, 2 * K):
+        r = bytearray(rand_dna(rng, 3 * K + 50))
+        p = K + (gap % (K + 7))
+        r[p] = ord("N")
+        if gap & 1:
+            r[min(len(r) - 1, p + K + 1)] = ord("n")
+        out.append(bytes(r))
+    r = bytearray(rand_nohp(rng, 3 * K + 10))                  # N exactly after a full k-mer, HPC-neutral
+    r[K] = ord("N")
+    out.append(bytes(r))
+    r = bytearray(rand_nohp(rng, 3 * K + 10))
+    r[2 * K + 3] = ord("R")
+    r[2 * K + 4] = ord("Y")
+    out.append(bytes(r))
+    out.append(b"N" * 17 + rand_dna(rng, 2 * K + 30) + b"NNN")  # N runs at both ends
+    out.append(b"N" * (K + 5))
+    # homopolymers
+    out.append(b"A" * 400 + rand_dna(rng, 2 * K) + b"C" * 256 + b"G" * 255 + b"T" * 257 + rand_dna(rng, K))
+    out.append(b"A" * (3 * K))
+    out.append(b"a" * 300 + b"A" * 300 + rand_nohp(rng, 2 * K + 5))
+    # tandem repeats (ties between s-mers; first == last s-mer)
+    for unit in (b"AC", b"ACG", b"ACGT", b"AACCGT", rand_nohp(rng, 8), rand_nohp(rng, 13), rand_nohp(rng, S),
+                 rand_nohp(rng, S + 1), rand_nohp(rng, max(2, K - S)), rand_nohp(rng, K - S + 1), rand_nohp(rng, K), rand_nohp(rng, 140)):
+        reps = (3 * K + 200) // len(unit) + 2
+        out.append((unit * reps)[: 3 * K + 200])
+        out.append(rand_nohp(rng, 57) + (unit * reps)[: 2 * K + 77] + rand_nohp(rng, K + 3))
+    # palindromic stretch (even S can make an s-mer its own reverse complement)
+    half = rand_nohp(rng, K)
+    out.append(half + revcomp(half))
+    out.append(b"ACGT" * 5 + rand_dna(rng, 10) + b"AATT" * (K // 2))
+    # lengths around the thresholds
+    for n in (0, 1, 3, 4, 5, S - 1, S, S + 1, K - 1, K, K + 1, K + 2, K + S):
+        out.append(rand_nohp(rng, n))
+    out.append(rand_dna(rng, K + 1))
+    # control bytes 1..3 are legal codes in the reference's table (syncmer.c:47-48)
+    out.append(rand_nohp(rng, K + 40) + bytes([1, 2, 3, 2, 1]) + rand_nohp(rng, K + 40))
+    # long mixed read
+    out.append(rand_dna(rng, 5 * L, b"ACGTACGTACGTN"))
+    out.append(rand_dna(rng, 6 * L))
+    return out
+
+
+def hifi_like(n_reads, genome_len, mean_len, seed=11, err=0.0005):
+    """small numpy model of HiFi sampling used by the CPU-side tests (the product generator is oatk_amd.synth)"""
+    rng = np.random.default_rng(seed)
+    genome = rand_dna(rng, genome_len)
+    gg = genome + genome
+    out = []
+    for _ in range(n_reads):
+        ln = int(np.clip(rng.normal(mean_len, 0.1 * mean_len), 200, min(genome_len, 2 * mean_len)))
+        st = int(rng.integers(0, genome_len))
+        r = bytearray(gg[st:st + ln])
+        ne = rng.binomial(ln, err)
+        for p in sorted(rng.integers(0, ln, size=ne).tolist(), reverse=True):
+            kind = int(rng.integers(0, 3))
+            if kind == 0:
+                r[p] = b"ACGT"[(b"ACGT".index(bytes([r[p]])) + 1 + int(rng.integers(0, 3))) & 3]
+            elif kind == 1:
+                r.insert(p, b"ACGT"[int(rng.integers(0, 4))])
+            else:
+                del r[p]
+        r = bytes(r)
+        if rng.integers(0, 2):
+            r = revcomp(r)
+        out.append(r)
+    return out
