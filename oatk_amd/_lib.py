@@ -1,0 +1,74 @@
+"""ctypes loader for the in-tree gfx950 library (oatk_amd/lib/liboatk_hip.so, C ABI in include/oatk_hip.h).
+
+The product path has no CPU fallback: if the library is missing or no MI355X is visible, callers get an
+exception, never a silently slower path.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "liboatk_hip.so")
+HOST_LIB_PATH = os.path.join(HERE, "lib", "liboatk_host.so")
+
+# names mirror include/oatk_hip.h
+OK, E_NODEV, E_ARG, E_STATE, E_SMER, E_SPLIT, E_NOMEM = range(7)
+READ_ALIGN = 64
+BUF = {name: i for i, name in enumerate([
+    "HOCO_L", "N_SCM", "N_NN", "N_LRL", "HO_RL", "HOCO_S", "NN_KEY", "LRL_KEY", "LRL_VAL",
+    "SCM_OFF", "POS_MPOS", "POS_SMER", "POS_HASH", "POS_KID",
+    "SCM_H", "SCM_S", "SCM_COV", "SCM_OCC_OFF", "SCM_OCC"])}
+TIMERS = ["hpc", "syncmer", "syncmer_n", "scan_post", "count_place", "count_sort", "count_group"]
+
+EXPORTS = [
+    "oatk_hip_abi_version", "oatk_hip_device_count", "oatk_hip_create", "oatk_hip_destroy", "oatk_hip_last_error",
+    "oatk_hip_stream", "oatk_hip_sync", "oatk_hip_max_k", "oatk_hip_scan", "oatk_hip_scan_host", "oatk_hip_count",
+    "oatk_hip_info", "oatk_hip_buffer", "oatk_hip_d2h", "oatk_hip_set_timing", "oatk_hip_get_timing",
+    "oatk_hip_debug_hash_mask",
+]
+
+
+class Info(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("seq_bytes", C.c_uint64), ("sid0", C.c_uint64),
+                ("k", C.c_int32), ("s", C.c_int32),
+                ("n_occ", C.c_uint64), ("n_nn", C.c_uint64), ("n_lrl", C.c_uint64), ("n_scm", C.c_uint64),
+                ("scan_retries", C.c_uint32), ("collisions", C.c_uint32)]
+
+
+class OatkHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load liboatk_hip.so; raises if it has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OatkHipError("%s is missing: build it with __graft_entry__.build()" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.oatk_hip_abi_version.restype = C.c_int
+    L.oatk_hip_device_count.restype = C.c_int
+    L.oatk_hip_create.restype = vp
+    L.oatk_hip_create.argtypes = [C.c_int]
+    L.oatk_hip_destroy.argtypes = [vp]
+    L.oatk_hip_last_error.restype = C.c_char_p
+    L.oatk_hip_last_error.argtypes = [vp]
+    L.oatk_hip_stream.restype = vp
+    L.oatk_hip_stream.argtypes = [vp]
+    L.oatk_hip_sync.argtypes = [vp]
+    L.oatk_hip_max_k.restype = C.c_int
+    L.oatk_hip_scan.argtypes = [vp, vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
+    L.oatk_hip_scan_host.argtypes = [vp, vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
+    L.oatk_hip_count.argtypes = [vp]
+    L.oatk_hip_info.argtypes = [vp, C.POINTER(Info)]
+    L.oatk_hip_buffer.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_uint64)]
+    L.oatk_hip_d2h.argtypes = [vp, vp, vp, C.c_uint64]
+    L.oatk_hip_set_timing.argtypes = [vp, C.c_int]
+    L.oatk_hip_get_timing.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
+    L.oatk_hip_debug_hash_mask.argtypes = [vp, C.c_uint64]
+    _lib = L
+    return L

@@ -1,0 +1,499 @@
+// oatk_amd/csrc/api.hip -- C ABI (include/oatk_hip.h) over the gfx950 kernels.
+//
+// Owns the device buffers of one resident batch of reads, launches the scan (kernel A + kernel B) and the
+// count pipeline on one HIP stream, and times phases with HIP events recorded on that stream.
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_transform.hpp>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+
+#include "../../include/oatk_hip.h"
+#include "common.hpp"
+#include "scan_hpc.hpp"
+#include "scan_syncmer.hpp"
+#include "count.hpp"
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    bool ensure(size_t bytes, hipStream_t st, bool zero_new = false)
+    {
+        if (bytes <= cap) return true;
+        if (p) { (void) hipStreamSynchronize(st); (void) hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return false; }
+        cap = want;
+        if (zero_new) (void) hipMemsetAsync(p, 0, want, st);
+        return true;
+    }
+    void release() { if (p) (void) hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return (T *) p; }
+};
+
+}  // namespace
+
+struct oatk_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool timing = false;
+    hipEvent_t ev[OATK_T_COUNT_ + 1][2];
+    bool ev_used[OATK_T_COUNT_ + 1];
+    float ms[OATK_T_COUNT_];
+    uint64_t hash_mask = ~0ULL;
+
+    // input (device view; owned only when uploaded through scan_host)
+    const uint8_t *d_seq = nullptr;
+    const uint64_t *d_off = nullptr;
+    const uint32_t *d_len = nullptr;
+    DevBuf in_seq, in_off, in_len;
+    uint64_t n_reads = 0, seq_bytes = 0, sid0 = 0;
+    int K = 0, S = 0;
+    bool scanned = false, counted = false;
+
+    // scan outputs
+    DevBuf hoco_l, n_scm, n_nn, n_lrl, ho_rl, hoco_s, nbits;
+    DevBuf nn_key, lrl_key, lrl_val, nn_key2, lrl_key2, lrl_val2;
+    DevBuf rec_hash, rec_lo, rec_smer, rec_mpos;
+    DevBuf counters;      // u32[4]
+    uint32_t rec_cap = 0, nn_cap = 0, lrl_cap = 0;
+    uint64_t n_occ = 0, tot_nn = 0, tot_lrl = 0, n_scm_total = 0;
+    uint32_t retries = 0, collisions = 0;
+    bool nn_sorted_in_2 = false, lrl_sorted_in_2 = false;
+
+    // count outputs / scratch
+    DevBuf n_scm64, scm_off, pos_hash, pos_lo, pos_smer, pos_mpos, pos_kid;
+    DevBuf key_hash, key_sorted, iota, perm, head, head_idx, newclus, clus_id, bad_head, tag, tmp_perm, flags;
+    DevBuf scm_h, scm_s, scm_cov, scm_occ_off, scm_occ;
+    DevBuf tmp;           // rocprim temporary storage
+};
+
+#define CK(call)                                                                                   \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                          \
+            return OATK_E_NODEV;                                                                   \
+        }                                                                                          \
+    } while (0)
+#define ENSURE(buf, bytes, ...)                                                                    \
+    do {                                                                                           \
+        if (!ctx->buf.ensure((bytes), ctx->stream, ##__VA_ARGS__)) {                               \
+            ctx->err = "hipMalloc failed for " #buf;                                               \
+            return OATK_E_NOMEM;                                                                   \
+        }                                                                                          \
+    } while (0)
+
+static void t_begin(oatk_hip_ctx *ctx, int which)
+{
+    if (!ctx->timing) return;
+    (void) hipEventRecord(ctx->ev[which][0], ctx->stream);
+}
+static void t_end(oatk_hip_ctx *ctx, int which)
+{
+    if (!ctx->timing) return;
+    (void) hipEventRecord(ctx->ev[which][1], ctx->stream);
+    ctx->ev_used[which] = true;
+}
+static void t_collect(oatk_hip_ctx *ctx, int first, int last)
+{
+    if (!ctx->timing) return;
+    (void) hipStreamSynchronize(ctx->stream);
+    for (int i = first; i <= last; ++i) {
+        ctx->ms[i] = 0.f;
+        if (ctx->ev_used[i]) (void) hipEventElapsedTime(&ctx->ms[i], ctx->ev[i][0], ctx->ev[i][1]);
+        ctx->ev_used[i] = false;
+    }
+}
+
+extern "C" {
+
+int oatk_hip_abi_version(void) { return OATK_HIP_ABI_VERSION; }
+
+int oatk_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int oatk_hip_max_k(void) { return 8192 - 16 * oatk::SYN_NT - 16 - 64; }
+
+oatk_hip_ctx *oatk_hip_create(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return nullptr;
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    oatk_hip_ctx *ctx = new oatk_hip_ctx();
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return nullptr; }
+    for (int i = 0; i <= OATK_T_COUNT_; ++i) {
+        (void) hipEventCreate(&ctx->ev[i][0]);
+        (void) hipEventCreate(&ctx->ev[i][1]);
+        ctx->ev_used[i] = false;
+    }
+    memset(ctx->ms, 0, sizeof(ctx->ms));
+    return ctx;
+}
+
+void oatk_hip_destroy(oatk_hip_ctx *ctx)
+{
+    if (!ctx) return;
+    (void) hipSetDevice(ctx->device);
+    (void) hipStreamSynchronize(ctx->stream);
+    DevBuf *all[] = {&ctx->in_seq, &ctx->in_off, &ctx->in_len, &ctx->hoco_l, &ctx->n_scm, &ctx->n_nn, &ctx->n_lrl, &ctx->ho_rl,
+                     &ctx->hoco_s, &ctx->nbits, &ctx->nn_key, &ctx->lrl_key, &ctx->lrl_val, &ctx->nn_key2, &ctx->lrl_key2,
+                     &ctx->lrl_val2, &ctx->rec_hash, &ctx->rec_lo, &ctx->rec_smer, &ctx->rec_mpos, &ctx->counters, &ctx->n_scm64,
+                     &ctx->scm_off, &ctx->pos_hash, &ctx->pos_lo, &ctx->pos_smer, &ctx->pos_mpos, &ctx->pos_kid, &ctx->key_hash,
+                     &ctx->key_sorted, &ctx->iota, &ctx->perm, &ctx->head, &ctx->head_idx, &ctx->newclus, &ctx->clus_id,
+                     &ctx->bad_head, &ctx->tag, &ctx->tmp_perm, &ctx->flags, &ctx->scm_h, &ctx->scm_s, &ctx->scm_cov,
+                     &ctx->scm_occ_off, &ctx->scm_occ, &ctx->tmp};
+    for (DevBuf *b : all) b->release();
+    for (int i = 0; i <= OATK_T_COUNT_; ++i) {
+        (void) hipEventDestroy(ctx->ev[i][0]);
+        (void) hipEventDestroy(ctx->ev[i][1]);
+    }
+    (void) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *oatk_hip_last_error(oatk_hip_ctx *ctx) { return ctx? ctx->err.c_str() : "no device context"; }
+void *oatk_hip_stream(oatk_hip_ctx *ctx) { return ctx? (void *) ctx->stream : nullptr; }
+int oatk_hip_sync(oatk_hip_ctx *ctx)
+{
+    if (!ctx) return OATK_E_NODEV;
+    CK(hipStreamSynchronize(ctx->stream));
+    return OATK_OK;
+}
+int oatk_hip_set_timing(oatk_hip_ctx *ctx, int enable)
+{
+    if (!ctx) return OATK_E_NODEV;
+    ctx->timing = enable != 0;
+    return OATK_OK;
+}
+int oatk_hip_get_timing(oatk_hip_ctx *ctx, float *ms, int n)
+{
+    if (!ctx) return OATK_E_NODEV;
+    for (int i = 0; i < n && i < OATK_T_COUNT_; ++i) ms[i] = ctx->ms[i];
+    return OATK_OK;
+}
+int oatk_hip_debug_hash_mask(oatk_hip_ctx *ctx, uint64_t mask)
+{
+    if (!ctx) return OATK_E_NODEV;
+    ctx->hash_mask = mask;
+    return OATK_OK;
+}
+
+__global__ void widen_kernel(const uint32_t *in, uint64_t *out, uint64_t n)
+{
+    uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i];
+    if (i == n) out[i] = 0;
+}
+
+static int launch_scan_kernels(oatk_hip_ctx *ctx)
+{
+    using namespace oatk;
+    const uint64_t n = ctx->n_reads;
+    CK(hipMemsetAsync(ctx->counters.p, 0, 4 * sizeof(uint32_t), ctx->stream));
+    HpcArgs h;
+    h.seq = ctx->d_seq, h.off = ctx->d_off, h.len = ctx->d_len, h.sid0 = ctx->sid0;
+    h.ho_rl = ctx->ho_rl.as<uint8_t>(), h.hoco_s = ctx->hoco_s.as<uint8_t>(), h.nbits = ctx->nbits.as<uint32_t>();
+    h.hoco_l = ctx->hoco_l.as<uint32_t>(), h.n_nn = ctx->n_nn.as<uint32_t>(), h.n_lrl = ctx->n_lrl.as<uint32_t>();
+    h.nn_key = ctx->nn_key.as<uint64_t>(), h.lrl_key = ctx->lrl_key.as<uint64_t>(), h.lrl_val = ctx->lrl_val.as<uint32_t>();
+    h.nn_cap = ctx->nn_cap, h.lrl_cap = ctx->lrl_cap, h.counters = ctx->counters.as<uint32_t>();
+    t_begin(ctx, OATK_T_HPC);
+    hipLaunchKernelGGL(hpc_pack_kernel, dim3((unsigned) n), dim3(HPC_NT), 0, ctx->stream, h);
+    t_end(ctx, OATK_T_HPC);
+
+    SynArgs s;
+    s.hoco_s = ctx->hoco_s.as<uint8_t>(), s.nbits = ctx->nbits.as<uint32_t>(), s.off = ctx->d_off;
+    s.hoco_l = ctx->hoco_l.as<uint32_t>(), s.n_nn = ctx->n_nn.as<uint32_t>(), s.sid0 = ctx->sid0;
+    s.K = ctx->K, s.S = ctx->S, s.want_n = 0, s.n_scm = ctx->n_scm.as<uint32_t>();
+    s.rec_hash = ctx->rec_hash.as<uint64_t>(), s.rec_lo = ctx->rec_lo.as<uint64_t>(), s.rec_smer = ctx->rec_smer.as<uint64_t>();
+    s.rec_mpos = ctx->rec_mpos.as<uint32_t>(), s.rec_cap = ctx->rec_cap, s.counters = ctx->counters.as<uint32_t>();
+    const bool small = ctx->K + 8 * SYN_NT + 8 + 64 <= 4096;
+    t_begin(ctx, OATK_T_SYNCMER);
+    if (small) hipLaunchKernelGGL((syncmer_kernel<8, 4096, false>), dim3((unsigned) n), dim3(SYN_NT), 0, ctx->stream, s);
+    else hipLaunchKernelGGL((syncmer_kernel<16, 8192, false>), dim3((unsigned) n), dim3(SYN_NT), 0, ctx->stream, s);
+    t_end(ctx, OATK_T_SYNCMER);
+    s.want_n = 1;
+    t_begin(ctx, OATK_T_SYNCMER_N);
+    if (small) hipLaunchKernelGGL((syncmer_kernel<8, 4096, true>), dim3((unsigned) n), dim3(SYN_NT), 0, ctx->stream, s);
+    else hipLaunchKernelGGL((syncmer_kernel<16, 8192, true>), dim3((unsigned) n), dim3(SYN_NT), 0, ctx->stream, s);
+    t_end(ctx, OATK_T_SYNCMER_N);
+    CK(hipGetLastError());
+    return OATK_OK;
+}
+
+int oatk_hip_scan(oatk_hip_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off, const uint32_t *d_len,
+                  uint64_t n_reads, uint64_t seq_bytes, uint64_t sid0, int k, int s)
+{
+    if (!ctx) return OATK_E_NODEV;
+    CK(hipSetDevice(ctx->device));
+    if (!(s > 0 && s < 32 && k > s) || k > oatk_hip_max_k()) { ctx->err = "k/s out of range for the device scan"; return OATK_E_ARG; }
+    if (seq_bytes % OATK_READ_ALIGN || n_reads >= 0xFFFFFFFFULL || sid0 + n_reads > 0xFFFFFFFFULL) { ctx->err = "bad batch geometry"; return OATK_E_ARG; }
+    ctx->d_seq = d_seq, ctx->d_off = d_off, ctx->d_len = d_len;
+    ctx->n_reads = n_reads, ctx->seq_bytes = seq_bytes, ctx->sid0 = sid0, ctx->K = k, ctx->S = s;
+    ctx->scanned = ctx->counted = false;
+    ctx->retries = 0, ctx->collisions = 0;
+    ctx->n_occ = ctx->tot_nn = ctx->tot_lrl = ctx->n_scm_total = 0;
+    if (n_reads == 0) { ctx->scanned = true; return OATK_OK; }
+
+    ENSURE(hoco_l, n_reads * 4); ENSURE(n_scm, n_reads * 4); ENSURE(n_nn, n_reads * 4); ENSURE(n_lrl, n_reads * 4);
+    ENSURE(ho_rl, seq_bytes + 64);
+    ENSURE(hoco_s, seq_bytes / 4 + 128);
+    ENSURE(nbits, seq_bytes / 8 + 128, true);          // all-zero invariant between scans; kernel B hands it back clean
+    ENSURE(counters, 64);
+    if (ctx->rec_cap == 0) ctx->rec_cap = 1u << 16;
+    if (ctx->nn_cap == 0) ctx->nn_cap = 1u << 14;
+    if (ctx->lrl_cap == 0) ctx->lrl_cap = 1u << 14;
+    uint64_t guess = seq_bytes / 256 + 1024;            // ~2.5x the expected density at k=1001
+    if (guess > 0xFFFFFFF0ULL) guess = 0xFFFFFFF0ULL;
+    if (ctx->rec_cap < guess) ctx->rec_cap = (uint32_t) guess;
+
+    for (;;) {
+        ENSURE(rec_hash, (size_t) ctx->rec_cap * 8); ENSURE(rec_lo, (size_t) ctx->rec_cap * 8);
+        ENSURE(rec_smer, (size_t) ctx->rec_cap * 8); ENSURE(rec_mpos, (size_t) ctx->rec_cap * 4);
+        ENSURE(nn_key, (size_t) ctx->nn_cap * 8); ENSURE(nn_key2, (size_t) ctx->nn_cap * 8);
+        ENSURE(lrl_key, (size_t) ctx->lrl_cap * 8); ENSURE(lrl_key2, (size_t) ctx->lrl_cap * 8);
+        ENSURE(lrl_val, (size_t) ctx->lrl_cap * 4); ENSURE(lrl_val2, (size_t) ctx->lrl_cap * 4);
+        int rc = launch_scan_kernels(ctx);
+        if (rc) return rc;
+        uint32_t c[4];
+        CK(hipMemcpyAsync(c, ctx->counters.p, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
+        bool again = false;
+        if (c[0] > ctx->nn_cap) ctx->nn_cap = c[0] + c[0] / 4, again = true;
+        if (c[1] > ctx->lrl_cap) ctx->lrl_cap = c[1] + c[1] / 4, again = true;
+        if (c[2] > ctx->rec_cap) ctx->rec_cap = c[2] + c[2] / 4, again = true;
+        ctx->tot_nn = c[0], ctx->tot_lrl = c[1], ctx->n_occ = c[2];
+        if (!again) break;
+        ++ctx->retries;
+        // a partial pass may have left ambiguity bits behind: restore the all-zero invariant
+        CK(hipMemsetAsync(ctx->nbits.p, 0, ctx->nbits.cap, ctx->stream));
+    }
+    if (ctx->timing) t_collect(ctx, OATK_T_HPC, OATK_T_SYNCMER_N);
+
+    // ---- post: order the rare-event lists, per-read slot offsets ----
+    t_begin(ctx, OATK_T_SCAN_POST);
+    ctx->nn_sorted_in_2 = ctx->lrl_sorted_in_2 = false;
+    if (ctx->tot_nn > 1) {
+        size_t tb = 0;
+        CK(rocprim::radix_sort_keys(nullptr, tb, ctx->nn_key.as<uint64_t>(), ctx->nn_key2.as<uint64_t>(), ctx->tot_nn, 0, 64, ctx->stream));
+        ENSURE(tmp, tb);
+        CK(rocprim::radix_sort_keys(ctx->tmp.p, tb, ctx->nn_key.as<uint64_t>(), ctx->nn_key2.as<uint64_t>(), ctx->tot_nn, 0, 64, ctx->stream));
+        ctx->nn_sorted_in_2 = true;
+    }
+    if (ctx->tot_lrl > 1) {
+        size_t tb = 0;
+        CK(rocprim::radix_sort_pairs(nullptr, tb, ctx->lrl_key.as<uint64_t>(), ctx->lrl_key2.as<uint64_t>(), ctx->lrl_val.as<uint32_t>(),
+                                     ctx->lrl_val2.as<uint32_t>(), ctx->tot_lrl, 0, 64, ctx->stream));
+        ENSURE(tmp, tb);
+        CK(rocprim::radix_sort_pairs(ctx->tmp.p, tb, ctx->lrl_key.as<uint64_t>(), ctx->lrl_key2.as<uint64_t>(), ctx->lrl_val.as<uint32_t>(),
+                                     ctx->lrl_val2.as<uint32_t>(), ctx->tot_lrl, 0, 64, ctx->stream));
+        ctx->lrl_sorted_in_2 = true;
+    }
+    {
+        ENSURE(n_scm64, (n_reads + 1) * 8); ENSURE(scm_off, (n_reads + 1) * 8);
+        unsigned nb = (unsigned) ((n_reads + 1 + 255) / 256);
+        hipLaunchKernelGGL(widen_kernel, dim3(nb), dim3(256), 0, ctx->stream, ctx->n_scm.as<uint32_t>(), ctx->n_scm64.as<uint64_t>(), n_reads);
+        size_t tb = 0;
+        CK(rocprim::exclusive_scan(nullptr, tb, ctx->n_scm64.as<uint64_t>(), ctx->scm_off.as<uint64_t>(), (uint64_t) 0, n_reads + 1,
+                                   rocprim::plus<uint64_t>(), ctx->stream));
+        ENSURE(tmp, tb);
+        CK(rocprim::exclusive_scan(ctx->tmp.p, tb, ctx->n_scm64.as<uint64_t>(), ctx->scm_off.as<uint64_t>(), (uint64_t) 0, n_reads + 1,
+                                   rocprim::plus<uint64_t>(), ctx->stream));
+    }
+    // records -> per-read slots (also the low-key order the count needs)
+    {
+        using namespace oatk;
+        size_t n = ctx->n_occ? ctx->n_occ : 1;
+        ENSURE(pos_hash, n * 8); ENSURE(pos_lo, n * 8); ENSURE(pos_smer, n * 8); ENSURE(pos_mpos, n * 4);
+        ENSURE(key_hash, n * 8); ENSURE(iota, n * 4);
+        if (ctx->n_occ) {
+            PlaceArgs p;
+            p.rec_hash = ctx->rec_hash.as<uint64_t>(), p.rec_lo = ctx->rec_lo.as<uint64_t>(), p.rec_smer = ctx->rec_smer.as<uint64_t>();
+            p.rec_mpos = ctx->rec_mpos.as<uint32_t>(), p.n_rec = (uint32_t) ctx->n_occ, p.sid0 = ctx->sid0;
+            p.scm_off = ctx->scm_off.as<uint64_t>(), p.hash_mask = ctx->hash_mask;
+            p.pos_hash = ctx->pos_hash.as<uint64_t>(), p.pos_lo = ctx->pos_lo.as<uint64_t>(), p.pos_smer = ctx->pos_smer.as<uint64_t>();
+            p.pos_mpos = ctx->pos_mpos.as<uint32_t>(), p.key_hash = ctx->key_hash.as<uint64_t>(), p.iota = ctx->iota.as<uint32_t>();
+            t_begin(ctx, OATK_T_COUNT_PLACE);
+            hipLaunchKernelGGL(place_records_kernel, dim3((unsigned) ((ctx->n_occ + 255) / 256)), dim3(256), 0, ctx->stream, p);
+            t_end(ctx, OATK_T_COUNT_PLACE);
+        }
+    }
+    t_end(ctx, OATK_T_SCAN_POST);
+    CK(hipGetLastError());
+    CK(hipStreamSynchronize(ctx->stream));
+    if (ctx->timing) t_collect(ctx, OATK_T_SCAN_POST, OATK_T_COUNT_PLACE);
+    ctx->scanned = true;
+    return OATK_OK;
+}
+
+int oatk_hip_scan_host(oatk_hip_ctx *ctx, const uint8_t *h_seq, const uint64_t *h_off, const uint32_t *h_len,
+                       uint64_t n_reads, uint64_t seq_bytes, uint64_t sid0, int k, int s)
+{
+    if (!ctx) return OATK_E_NODEV;
+    CK(hipSetDevice(ctx->device));
+    ENSURE(in_seq, seq_bytes + 64); ENSURE(in_off, (n_reads + 1) * 8); ENSURE(in_len, (n_reads + 1) * 4);
+    if (seq_bytes) CK(hipMemcpyAsync(ctx->in_seq.p, h_seq, seq_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (n_reads) {
+        CK(hipMemcpyAsync(ctx->in_off.p, h_off, n_reads * 8, hipMemcpyHostToDevice, ctx->stream));
+        CK(hipMemcpyAsync(ctx->in_len.p, h_len, n_reads * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    return oatk_hip_scan(ctx, ctx->in_seq.as<uint8_t>(), ctx->in_off.as<uint64_t>(), ctx->in_len.as<uint32_t>(), n_reads, seq_bytes, sid0, k, s);
+}
+
+int oatk_hip_count(oatk_hip_ctx *ctx)
+{
+    using namespace oatk;
+    if (!ctx) return OATK_E_NODEV;
+    if (!ctx->scanned) { ctx->err = "count before scan"; return OATK_E_STATE; }
+    CK(hipSetDevice(ctx->device));
+    ctx->counted = false;
+    ctx->n_scm_total = 0;
+    const uint64_t n = ctx->n_occ;
+    if (n == 0) { ctx->counted = true; return OATK_OK; }
+    const unsigned nb = (unsigned) ((n + 255) / 256);
+
+    ENSURE(key_sorted, n * 8); ENSURE(perm, n * 4); ENSURE(head, n * 4); ENSURE(head_idx, n * 4); ENSURE(newclus, n * 4);
+    ENSURE(clus_id, n * 4); ENSURE(bad_head, n * 4); ENSURE(tag, n * 4); ENSURE(tmp_perm, n * 4); ENSURE(flags, 64);
+    ENSURE(pos_kid, n * 8); ENSURE(scm_occ, n * 8);
+    CK(hipMemsetAsync(ctx->flags.p, 0, 64, ctx->stream));
+
+    // 2. stable sort by hash; the input is already in (sid, idx) order
+    t_begin(ctx, OATK_T_COUNT_SORT);
+    {
+        size_t tb = 0;
+        CK(rocprim::radix_sort_pairs(nullptr, tb, ctx->key_hash.as<uint64_t>(), ctx->key_sorted.as<uint64_t>(), ctx->iota.as<uint32_t>(),
+                                     ctx->perm.as<uint32_t>(), n, 0, 64, ctx->stream));
+        ENSURE(tmp, tb);
+        CK(rocprim::radix_sort_pairs(ctx->tmp.p, tb, ctx->key_hash.as<uint64_t>(), ctx->key_sorted.as<uint64_t>(), ctx->iota.as<uint32_t>(),
+                                     ctx->perm.as<uint32_t>(), n, 0, 64, ctx->stream));
+    }
+    t_end(ctx, OATK_T_COUNT_SORT);
+
+    t_begin(ctx, OATK_T_COUNT_GROUP);
+    GroupArgs g;
+    g.sorted_key = ctx->key_sorted.as<uint64_t>(), g.perm = ctx->perm.as<uint32_t>(), g.n_rec = (uint32_t) n;
+    g.pos_lo = ctx->pos_lo.as<uint64_t>(), g.pos_mpos = ctx->pos_mpos.as<uint32_t>(), g.hoco_s = ctx->hoco_s.as<uint8_t>();
+    g.off = ctx->d_off, g.sid0 = ctx->sid0, g.K = ctx->K;
+    g.head = ctx->head.as<uint32_t>(), g.head_idx = ctx->head_idx.as<uint32_t>(), g.newclus = ctx->newclus.as<uint32_t>();
+    g.flags = ctx->flags.as<uint32_t>();
+    hipLaunchKernelGGL(mark_heads_kernel, dim3(nb), dim3(256), 0, ctx->stream, g);
+    {   // head_idx := index of the latest head at or before i
+        size_t tb = 0;
+        CK(rocprim::inclusive_scan(nullptr, tb, ctx->head_idx.as<uint32_t>(), ctx->head_idx.as<uint32_t>(), n, rocprim::maximum<uint32_t>(), ctx->stream));
+        ENSURE(tmp, tb);
+        CK(rocprim::inclusive_scan(ctx->tmp.p, tb, ctx->head_idx.as<uint32_t>(), ctx->head_idx.as<uint32_t>(), n, rocprim::maximum<uint32_t>(), ctx->stream));
+    }
+    CK(hipMemsetAsync(ctx->bad_head.p, 0, n * 4, ctx->stream));
+    hipLaunchKernelGGL(verify_group_kernel, dim3((unsigned) ((n + 3) / 4)), dim3(256), 0, ctx->stream, g, ctx->bad_head.as<uint32_t>());
+    uint32_t fl[4];
+    CK(hipMemcpyAsync(fl, ctx->flags.p, sizeof(fl), hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    if (fl[0]) {
+        ctx->collisions = 1;
+        hipLaunchKernelGGL(split_collisions_kernel, dim3(nb), dim3(256), 0, ctx->stream, g, ctx->bad_head.as<uint32_t>(), ctx->perm.as<uint32_t>(),
+                           ctx->tag.as<uint32_t>(), ctx->tmp_perm.as<uint32_t>());
+    }
+    {   // ids
+        size_t tb = 0;
+        CK(rocprim::inclusive_scan(nullptr, tb, ctx->newclus.as<uint32_t>(), ctx->clus_id.as<uint32_t>(), n, rocprim::plus<uint32_t>(), ctx->stream));
+        ENSURE(tmp, tb);
+        CK(rocprim::inclusive_scan(ctx->tmp.p, tb, ctx->newclus.as<uint32_t>(), ctx->clus_id.as<uint32_t>(), n, rocprim::plus<uint32_t>(), ctx->stream));
+    }
+    uint32_t last_id = 0;
+    CK(hipMemcpyAsync(&last_id, ctx->clus_id.as<uint32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    const uint32_t n_scm = last_id;       // inclusive scan: last value = number of clusters
+    ENSURE(scm_h, (size_t) n_scm * 8); ENSURE(scm_s, (size_t) n_scm * 8); ENSURE(scm_cov, (size_t) n_scm * 4);
+    ENSURE(scm_occ_off, ((size_t) n_scm + 1) * 8);
+    // clus_id currently holds id+1; shift in place with a tiny transform
+    CK(rocprim::transform(ctx->clus_id.as<uint32_t>(), ctx->clus_id.as<uint32_t>(), n, [] __device__(uint32_t v) { return v - 1u; }, ctx->stream));
+    FinishArgs f;
+    f.perm = ctx->perm.as<uint32_t>(), f.newclus = ctx->newclus.as<uint32_t>(), f.clus_id = ctx->clus_id.as<uint32_t>(), f.n_rec = (uint32_t) n;
+    f.sorted_key = ctx->key_sorted.as<uint64_t>(), f.pos_lo = ctx->pos_lo.as<uint64_t>(), f.pos_smer = ctx->pos_smer.as<uint64_t>();
+    f.scm_h = ctx->scm_h.as<uint64_t>(), f.scm_s = ctx->scm_s.as<uint64_t>(), f.scm_occ_off = ctx->scm_occ_off.as<uint64_t>();
+    f.scm_occ = ctx->scm_occ.as<uint64_t>(), f.pos_kid = ctx->pos_kid.as<uint64_t>(), f.flags = ctx->flags.as<uint32_t>();
+    hipLaunchKernelGGL(finish_heads_kernel, dim3(nb), dim3(256), 0, ctx->stream, f, n_scm);
+    hipLaunchKernelGGL(check_smer_kernel, dim3(nb), dim3(256), 0, ctx->stream, f);
+    hipLaunchKernelGGL(cov_kernel, dim3((n_scm + 255) / 256), dim3(256), 0, ctx->stream, ctx->scm_occ_off.as<uint64_t>(), ctx->scm_cov.as<uint32_t>(), n_scm);
+    t_end(ctx, OATK_T_COUNT_GROUP);
+    CK(hipGetLastError());
+    CK(hipMemcpyAsync(fl, ctx->flags.p, sizeof(fl), hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    if (ctx->timing) t_collect(ctx, OATK_T_COUNT_SORT, OATK_T_COUNT_GROUP);
+    if (fl[2]) { ctx->err = "hash group with too many distinct k-mers"; return OATK_E_SPLIT; }
+    if (fl[1]) { ctx->err = "identical kmers have different smers"; return OATK_E_SMER; }
+    ctx->n_scm_total = n_scm;
+    ctx->counted = true;
+    return OATK_OK;
+}
+
+int oatk_hip_info(oatk_hip_ctx *ctx, oatk_hip_info_t *out)
+{
+    if (!ctx) return OATK_E_NODEV;
+    out->n_reads = ctx->n_reads, out->seq_bytes = ctx->seq_bytes, out->sid0 = ctx->sid0;
+    out->k = ctx->K, out->s = ctx->S;
+    out->n_occ = ctx->n_occ, out->n_nn = ctx->tot_nn, out->n_lrl = ctx->tot_lrl;
+    out->n_scm = ctx->n_scm_total;
+    out->scan_retries = ctx->retries, out->collisions = ctx->collisions;
+    return OATK_OK;
+}
+
+int oatk_hip_buffer(oatk_hip_ctx *ctx, int which, const void **d_ptr, uint64_t *bytes)
+{
+    if (!ctx) return OATK_E_NODEV;
+    if (!ctx->scanned) { ctx->err = "no resident scan"; return OATK_E_STATE; }
+    const uint64_t n = ctx->n_reads, occ = ctx->n_occ, ns = ctx->n_scm_total;
+    const void *p = nullptr;
+    uint64_t b = 0;
+    switch (which) {
+        case OATK_BUF_HOCO_L: p = ctx->hoco_l.p, b = n * 4; break;
+        case OATK_BUF_N_SCM: p = ctx->n_scm.p, b = n * 4; break;
+        case OATK_BUF_N_NN: p = ctx->n_nn.p, b = n * 4; break;
+        case OATK_BUF_N_LRL: p = ctx->n_lrl.p, b = n * 4; break;
+        case OATK_BUF_HO_RL: p = ctx->ho_rl.p, b = ctx->seq_bytes; break;
+        case OATK_BUF_HOCO_S: p = ctx->hoco_s.p, b = ctx->seq_bytes / 4 + 64; break;
+        case OATK_BUF_NN_KEY: p = ctx->nn_sorted_in_2? ctx->nn_key2.p : ctx->nn_key.p, b = ctx->tot_nn * 8; break;
+        case OATK_BUF_LRL_KEY: p = ctx->lrl_sorted_in_2? ctx->lrl_key2.p : ctx->lrl_key.p, b = ctx->tot_lrl * 8; break;
+        case OATK_BUF_LRL_VAL: p = ctx->lrl_sorted_in_2? ctx->lrl_val2.p : ctx->lrl_val.p, b = ctx->tot_lrl * 4; break;
+        case OATK_BUF_SCM_OFF: p = ctx->scm_off.p, b = (n + 1) * 8; break;
+        case OATK_BUF_POS_MPOS: p = ctx->pos_mpos.p, b = occ * 4; break;
+        case OATK_BUF_POS_SMER: p = ctx->pos_smer.p, b = occ * 8; break;
+        case OATK_BUF_POS_HASH: p = ctx->pos_hash.p, b = occ * 8; break;
+        default:
+            if (!ctx->counted) { ctx->err = "count results requested before oatk_hip_count"; return OATK_E_STATE; }
+            switch (which) {
+                case OATK_BUF_POS_KID: p = ctx->pos_kid.p, b = occ * 8; break;
+                case OATK_BUF_SCM_H: p = ctx->scm_h.p, b = ns * 8; break;
+                case OATK_BUF_SCM_S: p = ctx->scm_s.p, b = ns * 8; break;
+                case OATK_BUF_SCM_COV: p = ctx->scm_cov.p, b = ns * 4; break;
+                case OATK_BUF_SCM_OCC_OFF: p = ctx->scm_occ_off.p, b = (ns + 1) * 8; break;
+                case OATK_BUF_SCM_OCC: p = ctx->scm_occ.p, b = occ * 8; break;
+                default: ctx->err = "unknown buffer id"; return OATK_E_ARG;
+            }
+    }
+    *d_ptr = p, *bytes = b;
+    return OATK_OK;
+}
+
+int oatk_hip_d2h(oatk_hip_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes)
+{
+    if (!ctx) return OATK_E_NODEV;
+    if (bytes == 0) return OATK_OK;
+    CK(hipSetDevice(ctx->device));
+    CK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    return OATK_OK;
+}
+
+}  // extern "C"

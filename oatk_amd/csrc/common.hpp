@@ -1,0 +1,82 @@
+// oatk_amd/csrc/common.hpp -- device helpers shared by the gfx950 kernels.
+//
+// Written for MI355X (gfx950, wave64) only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define OATK_WAVE 64
+
+namespace oatk {
+
+// Exact restatement of the reference's 256-entry base table (syncmer.c:47-64) as arithmetic:
+// bytes 0..3 map to themselves, A/a C/c G/g T/t U/u -> 0 1 2 3 3, everything else -> 4.
+__device__ __forceinline__ uint32_t nt4_code(uint32_t ch)
+{
+    uint32_t up = ch & 0xDFu;                 // fold case
+    uint32_t t = up - 0x41u;                  // 'A' -> 0, 'C' -> 2, 'G' -> 6, 'T' -> 19, 'U' -> 20
+    bool letter = t < 32u && ((0x00180045u >> t) & 1u);
+    uint32_t code = (up >> 1) & 3u;           // A 0, C 1, G 3, T/U 2
+    code ^= code >> 1;                        // -> A 0, C 1, G 2, T/U 3
+    return ch < 4u ? ch : (letter ? code : 4u);
+}
+
+// Invertible 64-bit mix confined to 2S bits (syncmer.c:116-126).
+__device__ __forceinline__ uint64_t hash64(uint64_t x, uint64_t mask)
+{
+    x = (~x + (x << 21)) & mask;
+    x ^= x >> 24;
+    x = (x + (x << 3) + (x << 8)) & mask;
+    x ^= x >> 14;
+    x = (x + (x << 2) + (x << 4)) & mask;
+    x ^= x >> 28;
+    x = (x + (x << 31)) & mask;
+    return x;
+}
+
+// Reverse the order of the 32 two-bit groups of x and complement each (3 ^ c).
+__device__ __forceinline__ uint64_t revcomp32(uint64_t x)
+{
+    uint32_t lo = (uint32_t) x, hi = (uint32_t) (x >> 32);
+    uint32_t rlo = __builtin_bitreverse32(hi), rhi = __builtin_bitreverse32(lo);   // full 64-bit bit reversal
+    uint64_t r = (uint64_t) rhi << 32 | rlo;
+    r = ((r >> 1) & 0x5555555555555555ULL) | ((r & 0x5555555555555555ULL) << 1);  // restore bit order inside each pair
+    return ~r;
+}
+
+__device__ __forceinline__ uint64_t bswap64(uint64_t x) { return __builtin_bswap64(x); }
+
+// MurmurHash64A constants (syncmer.c:131-170), seed 1234 (syncmer.c:129)
+#define OATK_MURMUR_M 0xc6a4a7935bd1e995ULL
+#define OATK_MURMUR_SEED 1234ULL
+
+__device__ __forceinline__ uint64_t murmur_mix_word(uint64_t w)
+{
+    w *= OATK_MURMUR_M;
+    w ^= w >> 47;
+    w *= OATK_MURMUR_M;
+    return w;
+}
+
+// inclusive wave scan (sum) over 64 lanes
+__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < OATK_WAVE; d <<= 1) {
+        uint32_t o = __shfl_up(v, d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+__device__ __forceinline__ int32_t wave_incl_max(int32_t v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < OATK_WAVE; d <<= 1) {
+        int32_t o = __shfl_up(v, d);
+        if (lane >= d) v = v > o? v : o;
+    }
+    return v;
+}
+
+}  // namespace oatk

@@ -1,0 +1,204 @@
+// oatk_amd/csrc/count.hpp -- syncmer count / ID assignment on the device.
+//
+// Replaces `collect_syncmer_from_reads` + `process_kmer_cluster` (syncmer.c:1397-1451, :1270-1393).
+// The reference sorts 128-bit (hash, sid<<32|idx<<1|rev) records, walks equal-hash groups, splits true
+// 64-bit collisions by comparing the k-mer sequences, and hands out dense IDs in that order.  Here:
+//   1. place_records: scan records are unordered but carry (sid, ordinal), and the per-read counts are
+//      known, so each record has an exact slot scm_off[read] + ordinal.  Scattering them there yields the
+//      per-read arrays (m_pos, s_mer, hash) AND a sequence already ordered by the low 64 key bits.
+//   2. one stable 64-bit radix sort of (hash -> slot) finishes the 128-bit order.
+//   3. mark_heads / verify_group: equal-hash neighbours are compared base-for-base with their group head
+//      (one wave per record, one 32-base word per lane) -- the collision check the reference performs.
+//   4. split_collisions: groups that really hold different k-mers (never seen in practice; forced in tests
+//      by masking hash bits) are partitioned in first-seen order by one lane per group.
+//   5. IDs = prefix sum of new-cluster flags; coverage, CSR occurrence lists, s-mer consistency
+//      (syncmer.c:1365-1376) and the per-read k_mer = id << 1 rewrite (:1378) are one pass each.
+#pragma once
+#include "common.hpp"
+
+namespace oatk {
+
+struct PlaceArgs {
+    const uint64_t *rec_hash, *rec_lo, *rec_smer;
+    const uint32_t *rec_mpos;
+    uint32_t n_rec;
+    uint64_t sid0;
+    const uint64_t *scm_off;      // exclusive prefix of n_scm over reads
+    uint64_t hash_mask;           // debug knob (tests force collisions); ~0 in production
+    uint64_t *pos_hash, *pos_lo, *pos_smer;
+    uint32_t *pos_mpos;
+    uint64_t *key_hash;           // masked copy used as the sort key
+    uint32_t *iota;
+};
+
+__global__ void place_records_kernel(PlaceArgs a)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_rec) return;
+    uint64_t lo = a.rec_lo[i];
+    uint64_t rd = (lo >> 32) - a.sid0;
+    uint64_t p = a.scm_off[rd] + ((uint32_t) lo >> 1);
+    a.pos_hash[p] = a.rec_hash[i];
+    a.key_hash[p] = a.rec_hash[i] & a.hash_mask;
+    a.pos_lo[p] = lo;
+    a.pos_smer[p] = a.rec_smer[i];
+    a.pos_mpos[p] = a.rec_mpos[i];
+    a.iota[p] = (uint32_t) p;
+}
+
+// 32 oriented k-mer bases [32*wd, 32*wd+32) MSB-first, zero beyond K, straight from the hoco string in HBM
+__device__ __forceinline__ uint64_t kmer_word_global(const uint32_t *hs32, uint32_t pos, uint32_t rev, int K, int wd)
+{
+    int32_t t = rev? (int32_t) pos + K - 32 - 32 * wd : (int32_t) pos + 32 * wd;
+    int nb = K - 32 * wd;
+    nb = nb > 32? 32 : nb;
+    int32_t wi = t >> 4;
+    uint32_t sh = ((uint32_t) t & 15u) * 2u;
+    uint32_t w0 = wi >= 0? __builtin_bswap32(hs32[wi]) : 0u;
+    uint32_t w1 = wi + 1 >= 0? __builtin_bswap32(hs32[wi + 1]) : 0u;
+    uint32_t w2 = wi + 2 >= 0? __builtin_bswap32(hs32[wi + 2]) : 0u;
+    uint64_t hi = (uint64_t) w0 << 32 | w1;
+    uint64_t V = sh? (hi << sh) | ((uint64_t) w2 >> (32u - sh)) : hi;
+    if (rev) V = revcomp32(V);
+    if (nb < 32) V &= ~0ULL << (64 - 2 * nb);
+    return V;
+}
+
+struct GroupArgs {
+    const uint64_t *sorted_key;   // masked hash, ascending
+    const uint32_t *perm;         // sorted index -> slot
+    uint32_t n_rec;
+    const uint64_t *pos_lo;
+    const uint32_t *pos_mpos;
+    const uint8_t *hoco_s;
+    const uint64_t *off;
+    uint64_t sid0;
+    int K;
+    uint32_t *head;               // 1 where a new equal-hash group starts
+    uint32_t *head_idx;           // sorted index of the group head (filled by a max-scan)
+    uint32_t *newclus;            // 1 where a new syncmer (cluster) starts; starts as a copy of head
+    uint32_t *flags;              // [0] some group holds different k-mers, [1] s-mer mismatch, [2] too many clusters
+};
+
+__global__ void mark_heads_kernel(GroupArgs a)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_rec) return;
+    uint32_t h = i == 0 || a.sorted_key[i] != a.sorted_key[i - 1];
+    a.head[i] = h;
+    a.newclus[i] = h;
+    a.head_idx[i] = h? i : 0u;
+}
+
+// one wave per sorted record that is not a group head: is its k-mer identical to the head's?
+__global__ __launch_bounds__(256) void verify_group_kernel(GroupArgs a, uint32_t *bad_head)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= a.n_rec || a.head[i]) return;
+    const uint32_t hidx = a.head_idx[i];
+    const uint32_t p = a.perm[i], q = a.perm[hidx];
+    const uint64_t lo_p = a.pos_lo[p], lo_q = a.pos_lo[q];
+    const uint32_t *hs_p = (const uint32_t *) (a.hoco_s + (a.off[(lo_p >> 32) - a.sid0] >> 2));
+    const uint32_t *hs_q = (const uint32_t *) (a.hoco_s + (a.off[(lo_q >> 32) - a.sid0] >> 2));
+    const uint32_t mp = a.pos_mpos[p], mq = a.pos_mpos[q];
+    const int nw = (a.K + 31) / 32;
+    bool diff = false;
+    for (int wd = (int) lane; wd < nw; wd += 64)
+        diff |= kmer_word_global(hs_p, mp >> 1, mp & 1u, a.K, wd) != kmer_word_global(hs_q, mq >> 1, mq & 1u, a.K, wd);
+    if (__any(diff) && lane == 0) {
+        a.flags[0] = 1u;
+        bad_head[hidx] = 1u;
+    }
+}
+
+// one lane per colliding group: first-seen clustering, then a stable partition of the group's slice of perm
+#define OATK_MAX_SPLIT 16
+__global__ void split_collisions_kernel(GroupArgs a, const uint32_t *bad_head, uint32_t *perm_rw, uint32_t *tag, uint32_t *tmp_perm)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_rec || !a.head[i] || !bad_head[i]) return;
+    uint32_t e = i + 1;
+    while (e < a.n_rec && !a.head[e]) ++e;
+    const int nw = (a.K + 31) / 32;
+    uint32_t rep[OATK_MAX_SPLIT], nclus = 0;
+    for (uint32_t t = i; t < e; ++t) {
+        uint32_t p = perm_rw[t];
+        uint64_t lo_p = a.pos_lo[p];
+        const uint32_t *hs_p = (const uint32_t *) (a.hoco_s + (a.off[(lo_p >> 32) - a.sid0] >> 2));
+        uint32_t mp = a.pos_mpos[p], c;
+        for (c = 0; c < nclus; ++c) {
+            uint32_t q = perm_rw[rep[c]];
+            uint64_t lo_q = a.pos_lo[q];
+            const uint32_t *hs_q = (const uint32_t *) (a.hoco_s + (a.off[(lo_q >> 32) - a.sid0] >> 2));
+            uint32_t mq = a.pos_mpos[q];
+            bool same = true;
+            for (int wd = 0; wd < nw && same; ++wd)
+                same = kmer_word_global(hs_p, mp >> 1, mp & 1u, a.K, wd) == kmer_word_global(hs_q, mq >> 1, mq & 1u, a.K, wd);
+            if (same) break;
+        }
+        if (c == nclus) {
+            if (nclus == OATK_MAX_SPLIT) { a.flags[2] = 1u; return; }
+            rep[nclus++] = t;
+        }
+        tag[t] = c;
+    }
+    // stable partition by cluster; clusters keep first-seen order (syncmer.c:1324-1334, :1353-1360)
+    uint32_t w = i;
+    for (uint32_t c = 0; c < nclus; ++c) {
+        bool first = true;
+        for (uint32_t t = i; t < e; ++t)
+            if (tag[t] == c) {
+                tmp_perm[w] = perm_rw[t];
+                a.newclus[w] = first? 1u : 0u;
+                first = false;
+                ++w;
+            }
+    }
+    for (uint32_t t = i; t < e; ++t) perm_rw[t] = tmp_perm[t];
+}
+
+struct FinishArgs {
+    const uint32_t *perm;
+    const uint32_t *newclus;
+    const uint32_t *clus_id;      // inclusive scan of newclus, minus one
+    uint32_t n_rec;
+    const uint64_t *sorted_key, *pos_lo, *pos_smer;
+    uint64_t *scm_h, *scm_s;
+    uint64_t *scm_occ_off;        // [n_scm + 1]
+    uint64_t *scm_occ;            // [n_rec]
+    uint64_t *pos_kid;            // id << 1 per slot
+    uint32_t *flags;
+};
+
+__global__ void finish_heads_kernel(FinishArgs a, uint32_t n_scm)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_rec) return;
+    uint32_t p = a.perm[i], id = a.clus_id[i];
+    a.scm_occ[i] = a.pos_lo[p];
+    a.pos_kid[p] = (uint64_t) id << 1;
+    if (a.newclus[i]) {
+        a.scm_h[id] = a.sorted_key[i];
+        a.scm_s[id] = a.pos_smer[p];
+        a.scm_occ_off[id] = i;
+    }
+    if (i == a.n_rec - 1) a.scm_occ_off[n_scm] = a.n_rec;
+}
+
+// identical k-mers must carry the same s-mer (fatal in the reference, syncmer.c:1370-1376)
+__global__ void check_smer_kernel(FinishArgs a)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_rec) return;
+    uint32_t id = a.clus_id[i];
+    if (a.pos_smer[a.perm[i]] != a.scm_s[id]) a.flags[1] = 1u;
+}
+
+__global__ void cov_kernel(const uint64_t *occ_off, uint32_t *cov, uint32_t n_scm)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_scm) cov[i] = (uint32_t) (occ_off[i + 1] - occ_off[i]);
+}
+
+}  // namespace oatk

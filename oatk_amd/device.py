@@ -1,0 +1,153 @@
+"""Python host mirror over the C ABI (include/oatk_hip.h): one resident batch of reads on one MI355X.
+
+Vocabulary follows the reference: reads, hoco (homopolymer-compressed) strings, syncmers, occurrences.
+`scan` stands for sr_read's per-read analysis (syncmer.c:243-421), `count` for
+collect_syncmer_from_reads (syncmer.c:1397-1451).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+_DTYPES = {
+    "HOCO_L": np.uint32, "N_SCM": np.uint32, "N_NN": np.uint32, "N_LRL": np.uint32, "HO_RL": np.uint8, "HOCO_S": np.uint8,
+    "NN_KEY": np.uint64, "LRL_KEY": np.uint64, "LRL_VAL": np.uint32, "SCM_OFF": np.uint64, "POS_MPOS": np.uint32,
+    "POS_SMER": np.uint64, "POS_HASH": np.uint64, "POS_KID": np.uint64, "SCM_H": np.uint64, "SCM_S": np.uint64,
+    "SCM_COV": np.uint32, "SCM_OCC_OFF": np.uint64, "SCM_OCC": np.uint64,
+}
+
+
+def pack_reads(reads):
+    """list of bytes -> packed read stream (seq uint8, off uint64[n], len uint32[n]); reads start on 64-byte boundaries"""
+    n = len(reads)
+    lens = np.fromiter((len(r) for r in reads), dtype=np.uint32, count=n)
+    padded = (lens.astype(np.uint64) + (_lib.READ_ALIGN - 1)) // _lib.READ_ALIGN * _lib.READ_ALIGN
+    off = np.zeros(n, dtype=np.uint64)
+    if n > 1:
+        off[1:] = np.cumsum(padded[:-1], dtype=np.uint64)
+    total = int(padded.sum()) if n else 0
+    seq = np.zeros(max(total, _lib.READ_ALIGN), dtype=np.uint8)
+    for i, r in enumerate(reads):
+        if len(r):
+            seq[int(off[i]):int(off[i]) + len(r)] = np.frombuffer(r, dtype=np.uint8)
+    return seq, off, lens
+
+
+class HipSyncasm:
+    """Owns one oatk_hip_ctx.  Raises OatkHipError when the HIP library or the GPU is missing (no fallback)."""
+
+    def __init__(self, device=0):
+        self.L = _lib.load()
+        self.h = self.L.oatk_hip_create(device)
+        if not self.h:
+            raise _lib.OatkHipError("oatk_hip_create(%d) failed: no usable MI355X (gfx950) device" % device)
+        self.device = device
+
+    def close(self):
+        if self.h:
+            self.L.oatk_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != _lib.OK:
+            msg = self.L.oatk_hip_last_error(self.h)
+            raise _lib.OatkHipError("%s failed (code %d): %s" % (what, rc, msg.decode() if msg else ""))
+
+    # ---- scan ----
+    def scan_host(self, seq, off, lens, k, s, sid0=0):
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        n = len(off)
+        self._keep = (seq, off, lens)
+        rc = self.L.oatk_hip_scan_host(self.h, seq.ctypes.data, off.ctypes.data if n else None, lens.ctypes.data if n else None,
+                                       n, seq.size if n else 0, sid0, k, s)
+        self._check(rc, "oatk_hip_scan_host")
+
+    def scan_device(self, d_seq, d_off, d_len, n_reads, seq_bytes, k, s, sid0=0):
+        """device pointers (ints), e.g. torch tensors' data_ptr()"""
+        rc = self.L.oatk_hip_scan(self.h, d_seq, d_off, d_len, n_reads, seq_bytes, sid0, k, s)
+        self._check(rc, "oatk_hip_scan")
+
+    def count(self):
+        self._check(self.L.oatk_hip_count(self.h), "oatk_hip_count")
+
+    def info(self):
+        i = _lib.Info()
+        self._check(self.L.oatk_hip_info(self.h, C.byref(i)), "oatk_hip_info")
+        return {f[0]: getattr(i, f[0]) for f in _lib.Info._fields_}
+
+    def sync(self):
+        self._check(self.L.oatk_hip_sync(self.h), "oatk_hip_sync")
+
+    def stream(self):
+        return self.L.oatk_hip_stream(self.h)
+
+    def set_timing(self, on=True):
+        self.L.oatk_hip_set_timing(self.h, 1 if on else 0)
+
+    def timing(self):
+        ms = (C.c_float * len(_lib.TIMERS))()
+        self.L.oatk_hip_get_timing(self.h, ms, len(_lib.TIMERS))
+        return dict(zip(_lib.TIMERS, [float(x) for x in ms]))
+
+    def debug_hash_mask(self, mask):
+        self.L.oatk_hip_debug_hash_mask(self.h, C.c_uint64(mask & 0xFFFFFFFFFFFFFFFF))
+
+    # ---- results ----
+    def buffer(self, name):
+        p = C.c_void_p()
+        b = C.c_uint64()
+        self._check(self.L.oatk_hip_buffer(self.h, _lib.BUF[name], C.byref(p), C.byref(b)), "oatk_hip_buffer(%s)" % name)
+        return p.value, int(b.value)
+
+    def fetch(self, name):
+        p, b = self.buffer(name)
+        dt = np.dtype(_DTYPES[name])
+        out = np.zeros(b // dt.itemsize, dtype=dt)
+        if b:
+            self._check(self.L.oatk_hip_d2h(self.h, out.ctypes.data, p, b), "oatk_hip_d2h(%s)" % name)
+        return out
+
+    def fetch_scan(self, off, with_hash=True):
+        """Per-read arrays concatenated in read order -- the flat image of sr_t (syncmer.h:48-70)."""
+        off = np.asarray(off, dtype=np.uint64)
+        n = len(off)
+        hoco_l = self.fetch("HOCO_L")
+        n_scm = self.fetch("N_SCM")
+        n_nn = self.fetch("N_NN")
+        n_lrl = self.fetch("N_LRL")
+        ho_rl_slab = self.fetch("HO_RL")
+        hoco_s_slab = self.fetch("HOCO_S")
+        rl_parts, hs_parts = [], []
+        for r in range(n):
+            o = int(off[r])
+            rl_parts.append(ho_rl_slab[o:o + int(hoco_l[r])])
+            hs_parts.append(hoco_s_slab[o // 4:o // 4 + (int(hoco_l[r]) + 3) // 4])
+        cat = lambda parts, dt: np.concatenate(parts) if parts else np.zeros(0, dt)
+        out = {
+            "hoco_l": hoco_l, "n_scm": n_scm, "n_nn": n_nn, "n_lrl": n_lrl,
+            "ho_rl": cat(rl_parts, np.uint8), "hoco_s": cat(hs_parts, np.uint8),
+            "n_nucl": (self.fetch("NN_KEY") & np.uint64(0xFFFFFFFF)).astype(np.uint32),
+            "ho_l_rl": self.fetch("LRL_VAL"),
+            "nn_key": self.fetch("NN_KEY"), "lrl_key": self.fetch("LRL_KEY"),
+            "m_pos": self.fetch("POS_MPOS"), "s_mer": self.fetch("POS_SMER"),
+        }
+        if with_hash:
+            out["k_mer"] = self.fetch("POS_HASH")
+        return out
+
+    def fetch_count(self):
+        """Flat image of syncmer_db_t (syncmer.h:86-114) plus the rewritten per-read k_mer ids."""
+        return {
+            "n_scm": self.info()["n_scm"],
+            "h": self.fetch("SCM_H"), "s": self.fetch("SCM_S"), "cov": self.fetch("SCM_COV"),
+            "occ_off": self.fetch("SCM_OCC_OFF"), "occ": self.fetch("SCM_OCC"), "k_id": self.fetch("POS_KID"),
+        }

@@ -1,0 +1,94 @@
+"""GPU parity: HIP scan + count (through the C ABI) against the CPU oracle on the same inputs. Bit-exact."""
+import numpy as np
+import pytest
+
+import adversarial as A
+import oracle_lib as O
+from oatk_amd import pack_reads
+
+pytestmark = pytest.mark.gpu
+
+SCAN_FIELDS = ["hoco_l", "n_scm", "n_nn", "n_lrl", "hoco_s", "ho_rl", "ho_l_rl", "n_nucl", "m_pos", "s_mer", "k_mer"]
+KS = [(1001, 31), (101, 11), (61, 15), (33, 31), (25, 5), (64, 16), (40, 8), (2500, 31)]
+
+
+def run_hip(hip, reads, K, S):
+    seq, off, lens = pack_reads(reads)
+    hip.scan_host(seq, off, lens, K, S)
+    return hip.fetch_scan(off), off
+
+
+def compare_scan(got, want):
+    for f in SCAN_FIELDS:
+        g, w = got[f], want[f]
+        assert g.shape == w.shape, (f, g.shape, w.shape)
+        if not np.array_equal(g, w):
+            bad = np.nonzero(g != w)[0]
+            raise AssertionError("%s differs at %d positions, first %s: got %s want %s" % (f, len(bad), bad[:5], g[bad[:5]], w[bad[:5]]))
+
+
+@pytest.mark.parametrize("K,S", KS)
+def test_scan_adversarial(hip, K, S):
+    reads = A.reads(K, S)
+    got, _ = run_hip(hip, reads, K, S)
+    want = O.scan(reads, K, S, mode=0)
+    compare_scan(got, want)
+
+
+@pytest.mark.parametrize("K,S", [(1001, 31), (101, 11), (25, 5)])
+def test_count_adversarial(hip, K, S):
+    reads = A.reads(K, S) + A.hifi_like(60, 6000 if K < 1001 else 30000, 1500 if K < 1001 else 8000)
+    got, _ = run_hip(hip, reads, K, S)
+    hip.count()
+    c = hip.fetch_count()
+    want_scan, want = O.scan_and_count(reads, K, S, mode=0)
+    compare_scan(got, want_scan)
+    assert c["n_scm"] == want["n_scm"]
+    for f in ["h", "s", "cov", "occ_off", "occ", "k_id"]:
+        assert np.array_equal(c[f], want[f]), f
+
+
+def test_scan_hifi_like_k1001(hip):
+    reads = A.hifi_like(300, 200000, 15000, seed=3)
+    got, _ = run_hip(hip, reads, 1001, 31)
+    hip.count()
+    c = hip.fetch_count()
+    want_scan, want = O.scan_and_count(reads, 1001, 31, mode=0)
+    compare_scan(got, want_scan)
+    for f in ["h", "s", "cov", "occ_off", "occ", "k_id"]:
+        assert np.array_equal(c[f], want[f]), f
+    assert int(got["n_scm"].sum()) > 0
+
+
+def test_forced_hash_collisions(hip):
+    """AND the hashes down to a few bits so unrelated k-mers share a 'hash': exercises the sequence comparison
+    and first-seen split of process_kmer_cluster (syncmer.c:1293-1335)."""
+    K, S = 101, 11
+    reads = A.hifi_like(80, 5000, 1500, seed=5)
+    seq, off, lens = pack_reads(reads)
+    mask = 0xFF
+    hip.debug_hash_mask(mask)
+    try:
+        hip.scan_host(seq, off, lens, K, S)
+        hip.count()
+        c = hip.fetch_count()
+        assert hip.info()["collisions"] == 1
+    finally:
+        hip.debug_hash_mask(0xFFFFFFFFFFFFFFFF)
+    # oracle with the same masked hashes
+    oseq, ooff = O.pack_reads(reads)
+    L = O.lib()
+    out, p = O.scan_raw(oseq, ooff, K, S, 0)
+    n = int(p.contents.tot_scm)
+    for i in range(n):
+        p.contents.k_mer[i] &= mask
+    cp = L.orc_count(p, K)
+    cc = cp.contents
+    want = {"n_scm": int(cc.n_scm), "h": O._arr(cc.h, cc.n_scm, np.uint64), "s": O._arr(cc.s, cc.n_scm, np.uint64),
+            "cov": O._arr(cc.cov, cc.n_scm, np.uint32), "occ": O._arr(cc.occ, cc.tot_occ, np.uint64),
+            "k_id": O._arr(cc.k_id, cc.tot_occ, np.uint64), "err": int(cc.err)}
+    L.orc_count_free(cp)
+    L.orc_scan_free(p)
+    assert c["n_scm"] == want["n_scm"]
+    for f in ["h", "s", "cov", "occ", "k_id"]:
+        assert np.array_equal(c[f], want[f]), f
