@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- HiFi Gbases/s through the syncasm hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config2|config3] [--reads-per-gpu R]
+
+One "step" = one pass of the hot path (scan = homopolymer compression + closed-syncmer selection + k-mer
+hash; count = syncmer ID assignment) over one batch of synthetic HiFi reads that is already resident in
+HBM when the timed region starts.  At N = 1 the workload is BASELINE.json configs[1] (200 k reads x 15 kb,
+k = 1001, s = 31, scan + count).  For N > 1 (launched by torch.distributed.run, one rank per GPU) reads are
+sharded by record: rank r owns reads [r*R, (r+1)*R) of an N*R-read set ("weak" scaling) and the per-GPU
+syncmer tables are merged over RCCL (oatk_amd/multi.py).
+
+Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel against the HBM roofline with its
+duration measured live by HIP events on the stream the kernels run on; `cpu_baseline` is the compiled
+reference (oracle/_ref, built from the reference's own sources) timed on this box's host cores on a
+bounded sample of the same reads.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="config2")
+    ap.add_argument("--reads-per-gpu", type=int, default=0, help="override the number of reads each GPU owns")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-reads", type=int, default=80000)
+    ap.add_argument("--cpu-threads", type=int, default=8)
+    return ap.parse_args()
+
+
+def cpu_baseline(readset, first, n_sample, k, s, threads):
+    """Reference scan + count (sr_read + collect_syncmer_from_reads of the compiled reference) on host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ref_lib
+    if not ref_lib.available():
+        return None
+    seq, off, lens = readset.slice(first, n_sample)
+    bases = int(lens.sum())
+    fd, path = tempfile.mkstemp(suffix=".fa", dir=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        with os.fdopen(fd, "wb") as f:
+            for i in range(n_sample):
+                f.write(b">r%d\n" % i)
+                f.write(seq[int(off[i]):int(off[i]) + int(lens[i])].tobytes())
+                f.write(b"\n")
+        del seq
+        t0 = time.perf_counter()
+        db = ref_lib.SrDb([path], k, s, threads)
+        sc = ref_lib.ScmDb(db)
+        dt = time.perf_counter() - t0
+        n_scm = sc.n()
+        sc.close()
+        db.close()
+    finally:
+        os.unlink(path)
+    return {"value": bases / dt / 1e9, "unit": "Gbases/s", "cores": threads, "kind": "reference",
+            "sample": "first %d reads of the workload (%.2f Gbases) as FASTA through the compiled reference's sr_read + "
+                      "collect_syncmer_from_reads at -t %d, parse included; %.1f s wall, %d syncmers" % (n_sample, bases / 1e9, threads, dt, n_scm)}
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+    from oatk_amd import HipSyncasm
+    from oatk_amd.synth import CONFIGS, ReadSet
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    dev = torch.device("cuda", local_rank)
+
+    K, S = 1001, 31
+    cfg = dict(CONFIGS[args.workload])
+    per_gpu = args.reads_per_gpu or cfg["n_reads"]
+    cfg["n_reads"] = per_gpu * world
+    rs = ReadSet(**cfg)
+    first = rank * per_gpu
+
+    # ---- synthetic reads -> HBM (not timed) ----
+    seq, off, lens = rs.slice(first, per_gpu)
+    bases = int(lens.sum())
+    d_seq = torch.from_numpy(seq).to(dev)
+    d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+    d_len = torch.from_numpy(lens.view(np.int32)).to(dev)
+    seq_bytes = int(seq.size)
+    del seq
+    torch.cuda.synchronize()
+
+    hip = HipSyncasm(local_rank)
+    hip.set_timing(True)
+    merger = None
+    if world > 1:
+        from oatk_amd.multi import CountMerger
+        merger = CountMerger(hip, dist, dev)
+
+    def step():
+        hip.scan_device(d_seq.data_ptr(), d_off.data_ptr(), d_len.data_ptr(), per_gpu, seq_bytes, K, S, sid0=first)
+        hip.count()
+        if merger is not None:
+            merger.merge()
+
+    def fence():
+        hip.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    phase_ms = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        for name, v in hip.timing().items():
+            phase_ms[name] = phase_ms.get(name, 0.0) + v
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        tb = torch.tensor([bases], dtype=torch.int64, device=dev)
+        dist.all_reduce(tb)
+        total_bases = int(tb.item())
+    else:
+        total_bases = bases
+    info = hip.info()
+    for name in phase_ms:
+        phase_ms[name] /= max(args.steps, 1)
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel (by measured time) ----
+        hoco = int(hip.fetch("HOCO_L").astype(np.uint64).sum())
+        n_occ = info["n_occ"]
+        alg_bytes = {
+            # kernel A: ASCII in, 2-bit hoco_s + ho_rl out (1 + 0.25 rho + rho per raw base)
+            "hpc": bases + hoco // 4 + hoco,
+            # kernel B: 2-bit hoco_s in, one 28-byte record per syncmer occurrence out
+            "syncmer": hoco // 4 + 28 * n_occ,
+        }
+        dom = max(("hpc", "syncmer"), key=lambda k_: phase_ms.get(k_, 0.0))
+        dur_s = phase_ms[dom] / 1e3
+        achieved = alg_bytes[dom] / dur_s / 1e9 if dur_s > 0 else 0.0
+        roofline = {"bound": "hbm", "kernel": {"hpc": "hpc_pack_kernel", "syncmer": "syncmer_kernel<8,4096,false>"}[dom],
+                    "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "algorithmic_bytes_per_launch": alg_bytes[dom], "avg_launch_ms": round(phase_ms[dom], 4),
+                    "scan_bytes_per_base": round((alg_bytes["hpc"] + 28 * n_occ) / bases, 4),
+                    "scan_achieved_GBs": round((alg_bytes["hpc"] + 28 * n_occ) / ((phase_ms["hpc"] + phase_ms["syncmer"]) / 1e3) / 1e9, 2)}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(rs, first, min(args.cpu_sample_reads, per_gpu), K, S, args.cpu_threads)
+        out = {
+            "metric": "HiFi Gbases/s through syncasm scan+count (closed syncmers, k=1001 s=31)",
+            "value": round(total_bases * args.steps / dt / 1e9, 3), "unit": "Gbases/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "%s: %d reads x ~%d kb per GPU, k=1001 s=31, syncmer scan + count, reads resident in HBM"
+                                   % (args.workload, per_gpu, cfg["mean_len"] // 1000),
+                       "reads_per_gpu": per_gpu, "bases_per_gpu": bases, "genome_len": cfg["genome_len"],
+                       "parallelism": "reads sharded by record, %d rank(s)" % world},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "phases_ms": {k_: round(v, 4) for k_, v in phase_ms.items()},
+            "syncmers": {"occurrences": n_occ, "distinct": info["n_scm"], "hoco_ratio": round(hoco / bases, 4)},
+        }
+        print(json.dumps(out), flush=True)
+    hip.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
