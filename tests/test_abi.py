@@ -1,0 +1,57 @@
+"""CPU: the C-ABI libraries load and export every symbol their headers declare (no compute: there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from oatk_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared(header, prefix):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(%s\w+)\s*\(" % prefix, txt)))
+
+
+def test_hip_library_exports_every_declared_symbol():
+    assert os.path.exists(_lib.LIB_PATH), "build with __graft_entry__.build()"
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    names = declared("oatk_hip.h", "oatk_hip_")
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(L, n), n
+    assert set(_lib.EXPORTS) <= set(names)
+    assert L.oatk_hip_abi_version() == 1
+
+
+def test_host_library_exports_every_declared_symbol():
+    assert os.path.exists(_lib.HOST_LIB_PATH)
+    L = ctypes.CDLL(_lib.HOST_LIB_PATH)
+    for hdr in [h for h in os.listdir(os.path.join(ROOT, "include")) if h != "oatk_hip.h" and h.endswith(".h")]:
+        for n in declared(hdr, "oatk_"):
+            if n.startswith("oatk_hip_"):
+                continue
+            assert hasattr(L, n), (hdr, n)
+
+
+def test_no_silent_fallback_without_a_gpu():
+    """without a device the product path raises; it never computes on the CPU"""
+    L = _lib.load()
+    if L.oatk_hip_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    from oatk_amd import HipSyncasm, OatkHipError
+    with pytest.raises(OatkHipError):
+        HipSyncasm(0)
+
+
+def test_product_does_not_import_the_oracle():
+    """only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke may touch oracle/"""
+    pkg = os.path.join(ROOT, "oatk_amd")
+    for base, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".c", ".h", ".hip", ".hpp")):
+                txt = open(os.path.join(base, f), errors="ignore").read()
+                assert "oracle_lib" not in txt and "ref_lib" not in txt and "liboatk_oracle" not in txt and "oracle/" not in txt, f

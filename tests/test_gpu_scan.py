@@ -92,3 +92,24 @@ def test_forced_hash_collisions(hip):
     assert c["n_scm"] == want["n_scm"]
     for f in ["h", "s", "cov", "occ", "k_id"]:
         assert np.array_equal(c[f], want[f]), f
+
+
+import golden_util as G  # noqa: E402
+
+
+@pytest.mark.parametrize("case", G.SCAN_CASES)
+def test_against_reference_golden_vectors(hip, case):
+    """HIP path vs the outputs of the compiled reference committed under tests/golden (no oracle in between)."""
+    g = G.load(case)
+    K, S = int(g["K"]), int(g["S"])
+    reads = G.reads_of(g)
+    seq, off, lens = pack_reads(reads)
+    hip.scan_host(seq, off, lens, K, S)
+    got = hip.fetch_scan(off)
+    for f in G.SCAN_FIELDS:
+        assert got[f].shape == g[f].shape and np.array_equal(got[f], g[f]), (case, f)
+    hip.count()
+    c = hip.fetch_count()
+    assert np.array_equal(c["h"], g["scm_h"]) and np.array_equal(c["s"], g["scm_s"])
+    assert np.array_equal(c["cov"], g["scm_cov"]) and np.array_equal(c["occ"], g["scm_occ"])
+    assert np.array_equal(c["k_id"], g["k_id"])

@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz with the COMPILED REFERENCE (oracle/_ref/liboatk_ref.so, built from the
+reference's own sources by `make -C oracle ref`).  Runs only in the authoring container, where
+/root/reference exists; the fixtures are data (inputs + the reference's outputs), committed so that the
+CPU and GPU suites can check the oracle and the HIP path anywhere.
+
+    python tools/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+
+import adversarial as A  # noqa: E402
+import ref_lib as R  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def pack(reads):
+    off = np.zeros(len(reads) + 1, np.uint64)
+    off[1:] = np.cumsum([len(r) for r in reads], dtype=np.uint64)
+    seq = np.frombuffer(b"".join(reads), dtype=np.uint8)
+    return seq, off
+
+
+def scan_count_case(name, reads, K, S, threads=1):
+    n_nn = np.array([sum(1 for c in r if c not in b"ACGTacgtUu\x00\x01\x02\x03") for r in reads], np.uint32)
+    db = R.SrDb.from_reads(reads, K, S, threads)
+    sc = db.flatten(n_nn=n_nn)
+    st_i, st_d = db.stat()
+    cdb = R.ScmDb(db)
+    cnt = cdb.flatten()
+    after = db.flatten()
+    seq, off = pack(reads)
+    np.savez_compressed(
+        os.path.join(GOLD, name + ".npz"), K=K, S=S, seq=seq, off=off,
+        hoco_l=sc["hoco_l"], n_scm=sc["n_scm"], n_nn=n_nn, hoco_s=sc["hoco_s"], ho_rl=sc["ho_rl"], ho_l_rl=sc["ho_l_rl"],
+        n_nucl=sc["n_nucl"], m_pos=sc["m_pos"], s_mer=sc["s_mer"], k_mer=sc["k_mer"],
+        stat_i=st_i, stat_d=st_d,
+        scm_h=cnt["h"], scm_s=cnt["s"], scm_cov=cnt["cov"], scm_occ=cnt["occ"], k_id=after["k_mer"])
+    print("%-28s K=%-5d S=%-3d reads=%-4d syncmers=%-6d distinct=%d" % (name, K, S, len(reads), len(sc["m_pos"]), cnt["n_scm"]))
+    cdb.close()
+    db.close()
+
+
+def levdist_case():
+    rng = np.random.default_rng(2024)
+    # the reference's own built-in self-test pair (levdist.c:445-446, LEVDIST_TEST_NAIVE prints ED=8 tL=124 t_EN=59 qL=56 q_EN=56)
+    ts0 = b"AATGCTCTCATGACATATGAGATAGATACATAGAGACAGATATAGATACACACAGAGATATATGACGTCTGTATGCTCTCTCTCATAGATATACTCTGTAGACTGTCATATACATGCAGAAAAA"
+    qs0 = b"CGCTCTCATGACANATGAGATAGATACATAGAGNCAGATATAGATACACACAGTTT"
+    assert R.wf_ed(ts0, qs0, -1) == (8, 59, 56)
+    T, Q, BW, OUT = [ts0], [qs0], [-1], [R.wf_ed(ts0, qs0, -1)]
+    for it in range(600):
+        alpha = [b"ACGT", b"AC", b"A"][it % 3]
+        ts = A.rand_dna(rng, int(rng.integers(1, 160)), alpha)
+        q = bytearray(ts)
+        for _ in range(int(rng.integers(0, 7))):
+            if not q:
+                break
+            p, kind = int(rng.integers(0, len(q))), int(rng.integers(0, 3))
+            if kind == 0:
+                q[p] = alpha[int(rng.integers(0, len(alpha)))]
+            elif kind == 1:
+                q.insert(p, alpha[int(rng.integers(0, len(alpha)))])
+            else:
+                del q[p]
+        q = bytes(q)
+        if it % 4 == 0:
+            q = q[:max(1, len(q) // 2)]
+        if it % 4 == 1:
+            q = q + A.rand_dna(rng, int(rng.integers(1, 60)), alpha)
+        q = q or b"A"
+        bw = [-1, 2, 6, 12][it % 4]
+        w = R.Wavefront(ts, bw)          # wf_ed_core with the caller's initial state (syncerr.c:465-482)
+        r = w.step(q)
+        w.close()
+        T.append(ts), Q.append(q), BW.append(bw), OUT.append(r)
+    # resumable traces: one target, a growing query, result after every step (syncerr.c:165-195)
+    traces = []
+    for it in range(120):
+        ts = A.rand_dna(rng, int(rng.integers(10, 400)))
+        q = bytearray(ts)
+        for _ in range(int(rng.integers(0, 9))):
+            p, kind = int(rng.integers(0, len(q))), int(rng.integers(0, 3))
+            if kind == 0:
+                q[p] = b"ACGT"[int(rng.integers(0, 4))]
+            elif kind == 1:
+                q.insert(p, b"ACGT"[int(rng.integers(0, 4))])
+            else:
+                del q[p]
+        q = bytes(q) + A.rand_dna(rng, 60)
+        bw = int(rng.integers(2, 16))
+        w = R.Wavefront(ts, bw)
+        ql, steps = 0, []
+        while ql < len(q):
+            ql = min(len(q), ql + int(rng.integers(1, 140)))
+            r = w.step(q[:ql])
+            steps.append((ql,) + r)
+            if r[0] > bw:
+                break
+        w.close()
+        traces.append((ts, q, bw, steps))
+    np.savez_compressed(
+        os.path.join(GOLD, "levdist.npz"),
+        pairs_t=np.array(T, dtype=object), pairs_q=np.array(Q, dtype=object), pairs_bw=np.array(BW, np.int32),
+        pairs_out=np.array(OUT, np.int32),
+        tr_t=np.array([t[0] for t in traces], dtype=object), tr_q=np.array([t[1] for t in traces], dtype=object),
+        tr_bw=np.array([t[2] for t in traces], np.int32),
+        tr_steps=np.array([np.array(t[3], np.int32) for t in traces], dtype=object), allow_pickle=True)
+    print("levdist: %d pairs, %d resumable traces" % (len(T), len(traces)))
+
+
+def main():
+    if not R.available():
+        sys.exit("oracle/_ref/liboatk_ref.so missing: run `make -C oracle ref` (needs /root/reference)")
+    os.makedirs(GOLD, exist_ok=True)
+    for (K, S) in [(101, 11), (61, 15), (33, 31), (25, 5), (64, 16)]:
+        scan_count_case("adversarial_k%d_s%d" % (K, S), A.reads(K, S, scale=0.5), K, S)
+    scan_count_case("adversarial_k1001_s31", A.reads(1001, 31, scale=0.5), 1001, 31)
+    scan_count_case("hifi_k1001_s31", A.hifi_like(120, 60000, 9000, seed=21), 1001, 31, threads=3)
+    scan_count_case("hifi_k101_s11", A.hifi_like(200, 8000, 1500, seed=22) + A.reads(101, 11, seed=9, scale=0.3), 101, 11)
+    levdist_case()
+
+
+if __name__ == "__main__":
+    main()
