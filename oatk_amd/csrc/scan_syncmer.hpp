@@ -22,6 +22,8 @@
 #pragma once
 #include "common.hpp"
 
+#define OATK_MI(i) ((((uint32_t) (i)) & (R - 1)) + ((((uint32_t) (i)) & (R - 1)) >> 5))
+
 namespace oatk {
 
 constexpr int SYN_NT = 256;
@@ -52,7 +54,8 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_kernel(SynArgs a)
     constexpr int NWMAX = R / 32;          // Murmur blocks per k-mer, upper bound
     constexpr int NWAVE = SYN_NT / OATK_WAVE;
 
-    __shared__ uint64_t m_ring[R];
+    // one pad slot per 32: lanes walk this ring with a stride of C slots, which would otherwise land on 4 banks
+    __shared__ uint64_t m_ring[R + R / 32];
     __shared__ uint64_t cm_ring[NCH];
     __shared__ uint64_t st_a[NCH], st_b[NCH];
     __shared__ uint32_t pb[PBW];
@@ -60,7 +63,8 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_kernel(SynArgs a)
     __shared__ uint32_t nb_ring[HAS_N? R / 32 : 1];
     __shared__ uint64_t kmix[SYN_EM_CAP * NWMAX];
     __shared__ uint32_t em_e[SYN_EM_CAP];
-    __shared__ uint32_t em_kind[SYN_EM_CAP];
+    __shared__ uint32_t em_rev[SYN_EM_CAP];
+    __shared__ uint64_t em_code[SYN_EM_CAP];
     __shared__ uint32_t w_cnt[NWAVE];
     __shared__ int32_t w_max[NWAVE];
     __shared__ uint32_t s_gbase;
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_kernel(SynArgs a)
     int st_level = 0;                                   // sparse-table level for ranges of D-1 chunks
     while ((2 << st_level) <= D - 1) ++st_level;
 
-    for (uint32_t i = tid; i < R; i += SYN_NT) m_ring[i] = UINT64_MAX;
+    for (uint32_t i = tid; i < R + R / 32; i += SYN_NT) m_ring[i] = UINT64_MAX;
     for (uint32_t i = tid; i < NCH; i += SYN_NT) cm_ring[i] = UINT64_MAX;
     for (uint32_t i = tid; i < PBW; i += SYN_NT) pb[i] = 0;
     __syncthreads();
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_kernel(SynArgs a)
                 }
                 uint64_t mv = UINT64_MAX;
                 if (ok && fw != rv) mv = hash64(fw < rv? fw : rv, mask);
-                m_ring[i & (R - 1)] = mv;
+                m_ring[OATK_MI(i)] = mv;
                 cmin = mv < cmin? mv : cmin;
             }
             cm_ring[((uint32_t) i0 / C) & (NCH - 1)] = cmin;
@@ -211,10 +215,10 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_kernel(SynArgs a)
                 const int32_t a0 = ca * C;
                 uint64_t v[C], g[C + 1], sv[C];
 #pragma unroll
-                for (int o = 0; o < C; ++o) v[o] = m_ring[(a0 + o) & (R - 1)];
-                uint64_t x = a0 > 0? m_ring[(a0 - 1) & (R - 1)] : UINT64_MAX;
+                for (int o = 0; o < C; ++o) v[o] = m_ring[OATK_MI(a0 + o)];
+                uint64_t x = a0 > 0? m_ring[OATK_MI(a0 - 1)] : UINT64_MAX;
 #pragma unroll
-                for (int t = 0; t <= C; ++t) g[t] = m_ring[(a0 + w - 1 + t) & (R - 1)];
+                for (int t = 0; t <= C; ++t) g[t] = m_ring[OATK_MI(a0 + w - 1 + t)];
                 uint64_t bmin[C];
                 if (D >= 1) {
                     uint64_t run = UINT64_MAX;
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_kernel(SynArgs a)
                     for (int o = C - 1; o >= 0; --o) { run = v[o] < run? v[o] : run; sv[o] = run; }
                     uint64_t E0 = UINT64_MAX;                    // far chunk, part before the window end
                     for (int t = 0; t < rem; ++t) {
-                        uint64_t u = m_ring[(a0 + w - 1 - rem + t) & (R - 1)];
+                        uint64_t u = m_ring[OATK_MI(a0 + w - 1 - rem + t)];
                         E0 = u < E0? u : E0;
                     }
                     uint64_t rmq1 = UINT64_MAX;                  // chunks ca+1 .. ca+D-1
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_kernel(SynArgs a)
                     for (int o = 0; o < C; ++o) {
                         uint64_t bb = UINT64_MAX;
                         for (int t = 0; t < w; ++t) {
-                            uint64_t u = m_ring[(a0 + o + t) & (R - 1)];
+                            uint64_t u = m_ring[OATK_MI(a0 + o + t)];
                             bb = u < bb? u : bb;
                         }
                         bmin[o] = bb;
@@ -284,13 +288,23 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_kernel(SynArgs a)
             if (total) {
                 if (tid == 0) s_gbase = atomicAdd(&a.counters[2], total);
                 for (uint32_t rb = 0; rb < total; rb += SYN_EM_CAP) {
-                    // this lane's selections that fall in [rb, rb + EM_CAP)
+                    // this lane's selections that fall in [rb, rb + EM_CAP): note the k-mer end, the s-mer code and strand
                     if (cnt && ex < rb + SYN_EM_CAP && ex + cnt > rb) {
                         uint32_t q = ex;
 #pragma unroll
                         for (int o = 0; o < C; ++o) {
-                            if ((close_m >> o) & 1u) { if (q >= rb && q < rb + SYN_EM_CAP) em_e[q - rb] = (uint32_t) (ca * C + o + w), em_kind[q - rb] = 0u; ++q; }
-                            if ((open_m >> o) & 1u) { if (q >= rb && q < rb + SYN_EM_CAP) em_e[q - rb] = (uint32_t) (ca * C + o + w), em_kind[q - rb] = 1u; ++q; }
+                            const uint32_t sel = ((close_m >> o) & 1u) | (((open_m >> o) & 1u) << 1);
+                            if (sel) {
+                                if (q >= rb && q < rb + SYN_EM_CAP) {
+                                    const int32_t E = ca * C + o + w;
+                                    const bool is_open = sel == 2u;
+                                    uint64_t code = smer_code(is_open? E - w : E);     // first s-mer ends at E-w, last at E
+                                    em_e[q - rb] = (uint32_t) E;
+                                    em_rev[q - rb] = (uint32_t) (code & 1ULL);
+                                    em_code[q - rb] = is_open? code : code ^ 1ULL;      // Close stores S ^ 1 (syncmer.c:345)
+                                }
+                                ++q;
+                            }
                         }
                     }
                     __syncthreads();
@@ -299,32 +313,35 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_kernel(SynArgs a)
                     // the little-endian word the reference reads from its byte buffer (syncmer.c:139-151)
                     for (uint32_t it = tid; it < nround * (uint32_t) NW; it += SYN_NT) {
                         const uint32_t e = it / (uint32_t) NW, wd = it % (uint32_t) NW;
-                        const int32_t E = (int32_t) em_e[e], j = E - K + 1;
-                        const uint64_t code = smer_code(em_kind[e]? j + S - 1 : E);
-                        const uint32_t rev = (uint32_t) (code & 1ULL);
+                        const int32_t j = (int32_t) em_e[e] - K + 1;
                         int nb = K - 32 * (int) wd;
                         nb = nb > 32? 32 : nb;
-                        uint64_t V = rev? revcomp32(get64(j + K - 32 - 32 * (int32_t) wd)) : get64(j + 32 * (int32_t) wd);
+                        uint64_t V = em_rev[e]? revcomp32(get64(j + K - 32 - 32 * (int32_t) wd)) : get64(j + 32 * (int32_t) wd);
                         if (nb < 32) V &= ~0ULL << (64 - 2 * nb);
                         uint64_t word = bswap64(V);
                         kmix[e * NWMAX + wd] = (int) wd < nfull? murmur_mix_word(word) : word;
                     }
                     __syncthreads();
                     if (tid < nround) {
-                        const int32_t E = (int32_t) em_e[tid], j = E - K + 1;
-                        const uint32_t kind = em_kind[tid];
-                        uint64_t code = smer_code(kind? j + S - 1 : E);
-                        const uint32_t rev = (uint32_t) (code & 1ULL);
-                        if (!kind) code ^= 1ULL;                                  // Close stores S ^ 1 (syncmer.c:345)
+                        const int32_t j = (int32_t) em_e[tid] - K + 1;
+                        const uint32_t rev = em_rev[tid];
                         uint64_t h = OATK_MURMUR_SEED ^ ((uint64_t) (uint32_t) nbytes * OATK_MURMUR_M);
-                        for (int wd = 0; wd < nfull; ++wd) { h ^= kmix[tid * NWMAX + wd]; h *= OATK_MURMUR_M; }
-                        if (nrem) { h ^= kmix[tid * NWMAX + nfull]; h *= OATK_MURMUR_M; }
+                        const uint64_t *km = &kmix[tid * NWMAX];
+                        int wd = 0;
+                        for (; wd + 8 <= nfull; wd += 8) {                 // fetch eight blocks, then run the dependent chain on registers
+                            uint64_t k0 = km[wd], k1 = km[wd + 1], k2 = km[wd + 2], k3 = km[wd + 3];
+                            uint64_t k4 = km[wd + 4], k5 = km[wd + 5], k6 = km[wd + 6], k7 = km[wd + 7];
+                            h = (h ^ k0) * OATK_MURMUR_M; h = (h ^ k1) * OATK_MURMUR_M; h = (h ^ k2) * OATK_MURMUR_M; h = (h ^ k3) * OATK_MURMUR_M;
+                            h = (h ^ k4) * OATK_MURMUR_M; h = (h ^ k5) * OATK_MURMUR_M; h = (h ^ k6) * OATK_MURMUR_M; h = (h ^ k7) * OATK_MURMUR_M;
+                        }
+                        for (; wd < nfull; ++wd) h = (h ^ km[wd]) * OATK_MURMUR_M;
+                        if (nrem) h = (h ^ km[nfull]) * OATK_MURMUR_M;
                         h ^= h >> 47; h *= OATK_MURMUR_M; h ^= h >> 47;
                         const uint32_t slot = s_gbase + rb + tid, ordn = ord0 + rb + tid;
                         if (slot < a.rec_cap) {
                             a.rec_hash[slot] = h;
                             a.rec_lo[slot] = sid << 32 | (uint64_t) ordn << 1 | rev;
-                            a.rec_smer[slot] = code;
+                            a.rec_smer[slot] = em_code[tid];
                             a.rec_mpos[slot] = (uint32_t) j << 1 | rev;
                         }
                     }
