@@ -119,6 +119,7 @@ enum {
     OATK_T_COUNT_PLACE,    /* place_records                                                */
     OATK_T_COUNT_SORT,     /* radix sort by hash                                           */
     OATK_T_COUNT_GROUP,    /* heads + collision verification + ids + finish                */
+    OATK_T_KMER_HASH,      /* MurmurHash64A of every syncmer's k-mer (kmer_hash.hpp)       */
     OATK_T_COUNT_
 };
 int oatk_hip_set_timing(oatk_hip_ctx *ctx, int enable);
@@ -128,6 +129,8 @@ int oatk_hip_get_timing(oatk_hip_ctx *ctx, float *ms, int n);
 /* test hook: AND every k-mer hash with `mask` before grouping, to force "hash collisions" through the
  * sequence-comparison path.  ~0 (default) in production. */
 int oatk_hip_debug_hash_mask(oatk_hip_ctx *ctx, uint64_t mask);
+/* test hook: 1 = always use the general syncmer kernel (scan_syncmer.hpp), 0 = use the fast path where it applies */
+int oatk_hip_debug_force_general(oatk_hip_ctx *ctx, int on);
 
 #ifdef __cplusplus
 }

@@ -17,13 +17,13 @@ BUF = {name: i for i, name in enumerate([
     "HOCO_L", "N_SCM", "N_NN", "N_LRL", "HO_RL", "HOCO_S", "NN_KEY", "LRL_KEY", "LRL_VAL",
     "SCM_OFF", "POS_MPOS", "POS_SMER", "POS_HASH", "POS_KID",
     "SCM_H", "SCM_S", "SCM_COV", "SCM_OCC_OFF", "SCM_OCC"])}
-TIMERS = ["hpc", "syncmer", "syncmer_n", "scan_post", "count_place", "count_sort", "count_group"]
+TIMERS = ["hpc", "syncmer", "syncmer_n", "scan_post", "count_place", "count_sort", "count_group", "kmer_hash"]
 
 EXPORTS = [
     "oatk_hip_abi_version", "oatk_hip_device_count", "oatk_hip_create", "oatk_hip_destroy", "oatk_hip_last_error",
     "oatk_hip_stream", "oatk_hip_sync", "oatk_hip_max_k", "oatk_hip_scan", "oatk_hip_scan_host", "oatk_hip_count",
     "oatk_hip_info", "oatk_hip_buffer", "oatk_hip_d2h", "oatk_hip_set_timing", "oatk_hip_get_timing",
-    "oatk_hip_debug_hash_mask",
+    "oatk_hip_debug_hash_mask", "oatk_hip_debug_force_general",
 ]
 
 
@@ -70,5 +70,6 @@ def load():
     L.oatk_hip_set_timing.argtypes = [vp, C.c_int]
     L.oatk_hip_get_timing.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
     L.oatk_hip_debug_hash_mask.argtypes = [vp, C.c_uint64]
+    L.oatk_hip_debug_force_general.argtypes = [vp, C.c_int]
     _lib = L
     return L

@@ -15,6 +15,8 @@
 #include "common.hpp"
 #include "scan_hpc.hpp"
 #include "scan_syncmer.hpp"
+#include "scan_syncmer_fast.hpp"
+#include "kmer_hash.hpp"
 #include "count.hpp"
 
 namespace {
@@ -47,6 +49,7 @@ struct oatk_hip_ctx {
     bool ev_used[OATK_T_COUNT_ + 1];
     float ms[OATK_T_COUNT_];
     uint64_t hash_mask = ~0ULL;
+    bool force_general = false;   // test hook: run the general syncmer kernel even where the fast one applies
 
     // input (device view; owned only when uploaded through scan_host)
     const uint8_t *d_seq = nullptr;
@@ -61,8 +64,10 @@ struct oatk_hip_ctx {
     DevBuf hoco_l, n_scm, n_nn, n_lrl, ho_rl, hoco_s, nbits;
     DevBuf nn_key, lrl_key, lrl_val, nn_key2, lrl_key2, lrl_val2;
     DevBuf rec_hash, rec_lo, rec_smer, rec_mpos;
+    DevBuf raw_lo, raw_smer, raw_mpos, shard_cnt, shard_prefix;   // sharded append regions (scan_syncmer.hpp)
+    uint32_t region_cap = 0;
     DevBuf counters;      // u32[4]
-    uint32_t rec_cap = 0, nn_cap = 0, lrl_cap = 0;
+    uint32_t nn_cap = 0, lrl_cap = 0;
     uint64_t n_occ = 0, tot_nn = 0, tot_lrl = 0, n_scm_total = 0;
     uint32_t retries = 0, collisions = 0;
     bool nn_sorted_in_2 = false, lrl_sorted_in_2 = false;
@@ -149,7 +154,7 @@ void oatk_hip_destroy(oatk_hip_ctx *ctx)
     (void) hipStreamSynchronize(ctx->stream);
     DevBuf *all[] = {&ctx->in_seq, &ctx->in_off, &ctx->in_len, &ctx->hoco_l, &ctx->n_scm, &ctx->n_nn, &ctx->n_lrl, &ctx->ho_rl,
                      &ctx->hoco_s, &ctx->nbits, &ctx->nn_key, &ctx->lrl_key, &ctx->lrl_val, &ctx->nn_key2, &ctx->lrl_key2,
-                     &ctx->lrl_val2, &ctx->rec_hash, &ctx->rec_lo, &ctx->rec_smer, &ctx->rec_mpos, &ctx->counters, &ctx->n_scm64,
+                     &ctx->lrl_val2, &ctx->rec_hash, &ctx->rec_lo, &ctx->rec_smer, &ctx->rec_mpos, &ctx->raw_lo, &ctx->raw_smer, &ctx->raw_mpos, &ctx->shard_cnt, &ctx->shard_prefix, &ctx->counters, &ctx->n_scm64,
                      &ctx->scm_off, &ctx->pos_hash, &ctx->pos_lo, &ctx->pos_smer, &ctx->pos_mpos, &ctx->pos_kid, &ctx->key_hash,
                      &ctx->key_sorted, &ctx->iota, &ctx->perm, &ctx->head, &ctx->head_idx, &ctx->newclus, &ctx->clus_id,
                      &ctx->bad_head, &ctx->tag, &ctx->tmp_perm, &ctx->flags, &ctx->scm_h, &ctx->scm_s, &ctx->scm_cov,
@@ -183,6 +188,12 @@ int oatk_hip_get_timing(oatk_hip_ctx *ctx, float *ms, int n)
     for (int i = 0; i < n && i < OATK_T_COUNT_; ++i) ms[i] = ctx->ms[i];
     return OATK_OK;
 }
+int oatk_hip_debug_force_general(oatk_hip_ctx *ctx, int on)
+{
+    if (!ctx) return OATK_E_NODEV;
+    ctx->force_general = on != 0;
+    return OATK_OK;
+}
 int oatk_hip_debug_hash_mask(oatk_hip_ctx *ctx, uint64_t mask)
 {
     if (!ctx) return OATK_E_NODEV;
@@ -202,6 +213,7 @@ static int launch_scan_kernels(oatk_hip_ctx *ctx)
     using namespace oatk;
     const uint64_t n = ctx->n_reads;
     CK(hipMemsetAsync(ctx->counters.p, 0, 4 * sizeof(uint32_t), ctx->stream));
+    CK(hipMemsetAsync(ctx->shard_cnt.p, 0, oatk::OATK_REC_SHARDS * sizeof(uint32_t), ctx->stream));
     HpcArgs h;
     h.seq = ctx->d_seq, h.off = ctx->d_off, h.len = ctx->d_len, h.sid0 = ctx->sid0;
     h.ho_rl = ctx->ho_rl.as<uint8_t>(), h.hoco_s = ctx->hoco_s.as<uint8_t>(), h.nbits = ctx->nbits.as<uint32_t>();
@@ -216,11 +228,14 @@ static int launch_scan_kernels(oatk_hip_ctx *ctx)
     s.hoco_s = ctx->hoco_s.as<uint8_t>(), s.nbits = ctx->nbits.as<uint32_t>(), s.off = ctx->d_off;
     s.hoco_l = ctx->hoco_l.as<uint32_t>(), s.n_nn = ctx->n_nn.as<uint32_t>(), s.sid0 = ctx->sid0;
     s.K = ctx->K, s.S = ctx->S, s.want_n = 0, s.n_scm = ctx->n_scm.as<uint32_t>();
-    s.rec_hash = ctx->rec_hash.as<uint64_t>(), s.rec_lo = ctx->rec_lo.as<uint64_t>(), s.rec_smer = ctx->rec_smer.as<uint64_t>();
-    s.rec_mpos = ctx->rec_mpos.as<uint32_t>(), s.rec_cap = ctx->rec_cap, s.counters = ctx->counters.as<uint32_t>();
+    s.rec_hash = nullptr, s.rec_lo = ctx->raw_lo.as<uint64_t>(), s.rec_smer = ctx->raw_smer.as<uint64_t>();
+    s.rec_mpos = ctx->raw_mpos.as<uint32_t>(), s.region_cap = ctx->region_cap, s.shard_cnt = ctx->shard_cnt.as<uint32_t>();
     const bool small = ctx->K + 8 * SYN_NT + 8 + 64 <= 4096;
+    const int fast_ring = ctx->force_general? 0 : syncmer_fast_ring(ctx->K, ctx->S);
     t_begin(ctx, OATK_T_SYNCMER);
-    if (small) hipLaunchKernelGGL((syncmer_kernel<8, 4096, false>), dim3((unsigned) n), dim3(SYN_NT), 0, ctx->stream, s);
+    if (fast_ring == 4096 && ctx->S == 31) hipLaunchKernelGGL((syncmer_fast_kernel<4096, true>), dim3((unsigned) n), dim3(SYN_NT), 0, ctx->stream, s);
+    else if (fast_ring == 4096) hipLaunchKernelGGL((syncmer_fast_kernel<4096, false>), dim3((unsigned) n), dim3(SYN_NT), 0, ctx->stream, s);
+    else if (small) hipLaunchKernelGGL((syncmer_kernel<8, 4096, false>), dim3((unsigned) n), dim3(SYN_NT), 0, ctx->stream, s);
     else hipLaunchKernelGGL((syncmer_kernel<16, 8192, false>), dim3((unsigned) n), dim3(SYN_NT), 0, ctx->stream, s);
     t_end(ctx, OATK_T_SYNCMER);
     s.want_n = 1;
@@ -251,16 +266,20 @@ int oatk_hip_scan(oatk_hip_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off
     ENSURE(hoco_s, seq_bytes / 4 + 128);
     ENSURE(nbits, seq_bytes / 8 + 128, true);          // all-zero invariant between scans; kernel B hands it back clean
     ENSURE(counters, 64);
-    if (ctx->rec_cap == 0) ctx->rec_cap = 1u << 16;
     if (ctx->nn_cap == 0) ctx->nn_cap = 1u << 14;
     if (ctx->lrl_cap == 0) ctx->lrl_cap = 1u << 14;
-    uint64_t guess = seq_bytes / 256 + 1024;            // ~2.5x the expected density at k=1001
-    if (guess > 0xFFFFFFF0ULL) guess = 0xFFFFFFF0ULL;
-    if (ctx->rec_cap < guess) ctx->rec_cap = (uint32_t) guess;
+    const uint32_t NSH = oatk::OATK_REC_SHARDS;
+    {   // ~2.5x the expected density at k=1001, split over the shards (reads are dealt round-robin, so shards stay balanced)
+        uint64_t guess = (seq_bytes / 256 + 1024) / NSH + 256;
+        if (ctx->region_cap < guess) ctx->region_cap = (uint32_t) guess;
+    }
+    ENSURE(shard_cnt, NSH * 4); ENSURE(shard_prefix, NSH * 8);
+    uint32_t sc[oatk::OATK_REC_SHARDS];
+    uint64_t spfx[oatk::OATK_REC_SHARDS];
 
     for (;;) {
-        ENSURE(rec_hash, (size_t) ctx->rec_cap * 8); ENSURE(rec_lo, (size_t) ctx->rec_cap * 8);
-        ENSURE(rec_smer, (size_t) ctx->rec_cap * 8); ENSURE(rec_mpos, (size_t) ctx->rec_cap * 4);
+        const size_t raw_n = (size_t) ctx->region_cap * NSH;
+        ENSURE(raw_lo, raw_n * 8); ENSURE(raw_smer, raw_n * 8); ENSURE(raw_mpos, raw_n * 4);
         ENSURE(nn_key, (size_t) ctx->nn_cap * 8); ENSURE(nn_key2, (size_t) ctx->nn_cap * 8);
         ENSURE(lrl_key, (size_t) ctx->lrl_cap * 8); ENSURE(lrl_key2, (size_t) ctx->lrl_cap * 8);
         ENSURE(lrl_val, (size_t) ctx->lrl_cap * 4); ENSURE(lrl_val2, (size_t) ctx->lrl_cap * 4);
@@ -268,18 +287,47 @@ int oatk_hip_scan(oatk_hip_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off
         if (rc) return rc;
         uint32_t c[4];
         CK(hipMemcpyAsync(c, ctx->counters.p, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipMemcpyAsync(sc, ctx->shard_cnt.p, sizeof(sc), hipMemcpyDeviceToHost, ctx->stream));
         CK(hipStreamSynchronize(ctx->stream));
         bool again = false;
         if (c[0] > ctx->nn_cap) ctx->nn_cap = c[0] + c[0] / 4, again = true;
         if (c[1] > ctx->lrl_cap) ctx->lrl_cap = c[1] + c[1] / 4, again = true;
-        if (c[2] > ctx->rec_cap) ctx->rec_cap = c[2] + c[2] / 4, again = true;
-        ctx->tot_nn = c[0], ctx->tot_lrl = c[1], ctx->n_occ = c[2];
+        uint64_t tot = 0;
+        uint32_t mx = 0;
+        for (uint32_t i = 0; i < NSH; ++i) { spfx[i] = tot; tot += sc[i]; if (sc[i] > mx) mx = sc[i]; }
+        if (mx > ctx->region_cap) ctx->region_cap = mx + mx / 4 + 16, again = true;
+        if (tot > 0xFFFFFFF0ULL) { ctx->err = "more than 2^32 syncmer occurrences in one batch"; return OATK_E_ARG; }
+        ctx->tot_nn = c[0], ctx->tot_lrl = c[1], ctx->n_occ = tot;
         if (!again) break;
         ++ctx->retries;
         // a partial pass may have left ambiguity bits behind: restore the all-zero invariant
         CK(hipMemsetAsync(ctx->nbits.p, 0, ctx->nbits.cap, ctx->stream));
     }
+    // shard regions -> dense record arrays
+    if (ctx->n_occ) {
+        ENSURE(rec_hash, (size_t) ctx->n_occ * 8); ENSURE(rec_lo, (size_t) ctx->n_occ * 8);
+        ENSURE(rec_smer, (size_t) ctx->n_occ * 8); ENSURE(rec_mpos, (size_t) ctx->n_occ * 4);
+        CK(hipMemcpyAsync(ctx->shard_prefix.p, spfx, sizeof(spfx), hipMemcpyHostToDevice, ctx->stream));
+        oatk::CompactArgs ca;
+        ca.raw_lo = ctx->raw_lo.as<uint64_t>(), ca.raw_smer = ctx->raw_smer.as<uint64_t>(), ca.raw_mpos = ctx->raw_mpos.as<uint32_t>();
+        ca.shard_cnt = ctx->shard_cnt.as<uint32_t>(), ca.shard_prefix = ctx->shard_prefix.as<uint64_t>(), ca.region_cap = ctx->region_cap;
+        ca.rec_lo = ctx->rec_lo.as<uint64_t>(), ca.rec_smer = ctx->rec_smer.as<uint64_t>(), ca.rec_mpos = ctx->rec_mpos.as<uint32_t>();
+        hipLaunchKernelGGL(oatk::compact_records_kernel, dim3(NSH), dim3(256), 0, ctx->stream, ca);
+        CK(hipStreamSynchronize(ctx->stream));     // spfx lives on this stack frame
+    }
     if (ctx->timing) t_collect(ctx, OATK_T_HPC, OATK_T_SYNCMER_N);
+
+    // ---- k-mer hashes of all records, one lane per syncmer (kmer_hash.hpp) ----
+    if (ctx->n_occ) {
+        oatk::KmerHashArgs kh;
+        kh.hoco_s = ctx->hoco_s.as<uint8_t>(), kh.off = ctx->d_off, kh.sid0 = ctx->sid0;
+        kh.rec_lo = ctx->rec_lo.as<uint64_t>(), kh.rec_mpos = ctx->rec_mpos.as<uint32_t>(), kh.rec_hash = ctx->rec_hash.as<uint64_t>();
+        kh.n_rec = (uint32_t) ctx->n_occ, kh.K = ctx->K;
+        const int nw = ((ctx->K - 1) / 4 + 1 + 7) / 8;
+        t_begin(ctx, OATK_T_KMER_HASH);
+        hipLaunchKernelGGL(oatk::kmer_hash_kernel, dim3((unsigned) ((ctx->n_occ + 63) / 64)), dim3(64), (size_t) 64 * (nw + 1) * 8, ctx->stream, kh);
+        t_end(ctx, OATK_T_KMER_HASH);
+    }
 
     // ---- post: order the rare-event lists, per-read slot offsets ----
     t_begin(ctx, OATK_T_SCAN_POST);
@@ -332,7 +380,7 @@ int oatk_hip_scan(oatk_hip_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off
     t_end(ctx, OATK_T_SCAN_POST);
     CK(hipGetLastError());
     CK(hipStreamSynchronize(ctx->stream));
-    if (ctx->timing) t_collect(ctx, OATK_T_SCAN_POST, OATK_T_COUNT_PLACE);
+    if (ctx->timing) { t_collect(ctx, OATK_T_SCAN_POST, OATK_T_COUNT_PLACE); t_collect(ctx, OATK_T_KMER_HASH, OATK_T_KMER_HASH); }
     ctx->scanned = true;
     return OATK_OK;
 }

@@ -18,6 +18,29 @@
 
 namespace oatk {
 
+// shard regions -> dense record arrays (shard i's records land at prefix[i] ...)
+struct CompactArgs {
+    const uint64_t *raw_lo, *raw_smer;
+    const uint32_t *raw_mpos;
+    const uint32_t *shard_cnt;
+    const uint64_t *shard_prefix;
+    uint32_t region_cap;
+    uint64_t *rec_lo, *rec_smer;
+    uint32_t *rec_mpos;
+};
+
+__global__ __launch_bounds__(256) void compact_records_kernel(CompactArgs a)
+{
+    const uint32_t sh = blockIdx.x, n = a.shard_cnt[sh];
+    const size_t src = (size_t) sh * a.region_cap;
+    const uint64_t dst = a.shard_prefix[sh];
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        a.rec_lo[dst + i] = a.raw_lo[src + i];
+        a.rec_smer[dst + i] = a.raw_smer[src + i];
+        a.rec_mpos[dst + i] = a.raw_mpos[src + i];
+    }
+}
+
 struct PlaceArgs {
     const uint64_t *rec_hash, *rec_lo, *rec_smer;
     const uint32_t *rec_mpos;

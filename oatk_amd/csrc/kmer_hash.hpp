@@ -1,0 +1,54 @@
+// oatk_amd/csrc/kmer_hash.hpp -- MurmurHash64A of oriented k-mers, one LANE per syncmer.
+//
+// Replaces `kmer_hash64` (syncmer.c:175-226) for all syncmer records of a batch at once.  Inside the scan kernel the
+// hash is poison for a wave64 machine: a 251-byte k-mer is a 31-step dependent chain that keeps one lane busy while
+// 63 idle.  Here a wave owns 64 records: first all 64 lanes cooperatively fetch and pre-mix the 8-byte Murmur blocks
+// (coalesced reads of each record's contiguous hoco bytes, results parked in LDS), then every lane runs the dependent
+// chain of ITS record, so the chain phase issues with all 64 lanes active.
+#pragma once
+#include "common.hpp"
+#include "count.hpp"   // kmer_word_global
+
+namespace oatk {
+
+struct KmerHashArgs {
+    const uint8_t *hoco_s;        // read r at off[r] / 4
+    const uint64_t *off;
+    uint64_t sid0;
+    const uint64_t *rec_lo;       // sid << 32 | ordinal << 1 | rev
+    const uint32_t *rec_mpos;     // pos << 1 | rev
+    uint64_t *rec_hash;           // out
+    uint32_t n_rec;
+    int K;
+};
+
+__global__ __launch_bounds__(64) void kmer_hash_kernel(KmerHashArgs a)
+{
+    extern __shared__ uint64_t kmix[];          // 64 records x (NW + 1)
+    const uint32_t lane = threadIdx.x;
+    const uint32_t base = blockIdx.x * 64u;
+    const int K = a.K;
+    const int nbytes = (K - 1) / 4 + 1, nfull = nbytes >> 3, nrem = nbytes & 7, NW = nfull + (nrem? 1 : 0);
+    const int stride = NW + 1;
+    const uint32_t nrec = a.n_rec - base < 64u? a.n_rec - base : 64u;
+    const uint32_t items = nrec * (uint32_t) NW;
+    for (uint32_t it = lane; it < items; it += 64u) {
+        const uint32_t rr = it / (uint32_t) NW, wd = it - rr * (uint32_t) NW;
+        const uint32_t rec = base + rr;
+        const uint32_t mp = a.rec_mpos[rec];
+        const uint32_t *hs = (const uint32_t *) (a.hoco_s + (a.off[(a.rec_lo[rec] >> 32) - a.sid0] >> 2));
+        uint64_t word = bswap64(kmer_word_global(hs, mp >> 1, mp & 1u, K, (int) wd));
+        kmix[rr * (uint32_t) stride + wd] = (int) wd < nfull? murmur_mix_word(word) : word;
+    }
+    __syncthreads();
+    if (lane < nrec) {
+        const uint64_t *km = &kmix[lane * (uint32_t) stride];
+        uint64_t h = OATK_MURMUR_SEED ^ ((uint64_t) (uint32_t) nbytes * OATK_MURMUR_M);
+        for (int wd = 0; wd < nfull; ++wd) h = (h ^ km[wd]) * OATK_MURMUR_M;
+        if (nrem) h = (h ^ km[nfull]) * OATK_MURMUR_M;
+        h ^= h >> 47; h *= OATK_MURMUR_M; h ^= h >> 47;
+        a.rec_hash[base + lane] = h;
+    }
+}
+
+}  // namespace oatk

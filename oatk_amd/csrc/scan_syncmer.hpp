@@ -2,8 +2,8 @@
 //
 // Replaces the second half of the reference's per-read loop (syncmer.c:306-394) and `kmer_hash64`
 // (syncmer.c:175-226).  Input is the 2-bit hoco string written by kernel A (scan_hpc.hpp); output is
-// one record per closed syncmer: (MurmurHash64A of the oriented k-mer, sid<<32 | ordinal<<1 | rev,
-// s-mer code, pos<<1 | rev).  Records are appended unordered; (sid, ordinal) makes them self-describing.
+// one record per closed syncmer: (sid<<32 | ordinal<<1 | rev, s-mer code, pos<<1 | rev); the MurmurHash64A of
+// the oriented k-mer is added by kmer_hash_kernel.  Records are appended unordered; (sid, ordinal) makes them self-describing.
 //
 // The reference keeps a Q-slot ring with a tracked minimum and re-scans it when the minimum expires.
 // Here every k-mer is decided independently from the array M[] of s-mer hashes (indexed by the END
@@ -17,8 +17,8 @@
 // MI355X mapping: one 256-thread workgroup per read walks tiles of T = 256*C hoco positions.  M lives in
 // an LDS ring (no halo recompute across tiles); b is a van-Herk style window minimum assembled from a
 // lane's own chunk suffix, a sparse-table range minimum over chunk minima, and the far chunk's prefix.
-// Selected syncmers (about one per 486 positions at K=1001) are compacted with a workgroup scan and their
-// 251-byte k-mers are hashed cooperatively: one lane per 8-byte Murmur block, one lane per chain.
+// Selected syncmers (about one per 486 positions at K=1001) are compacted with a workgroup scan; their 251-byte
+// k-mers are hashed afterwards by kmer_hash_kernel (kmer_hash.hpp), one lane per syncmer.
 #pragma once
 #include "common.hpp"
 
@@ -27,6 +27,7 @@
 namespace oatk {
 
 constexpr int SYN_NT = 256;
+constexpr uint32_t OATK_REC_SHARDS = 1024;
 constexpr int SYN_EM_CAP = 8;     // syncmers hashed per cooperative round
 
 struct SynArgs {
@@ -41,8 +42,10 @@ struct SynArgs {
     uint32_t *n_scm;          // per read
     uint64_t *rec_hash, *rec_lo, *rec_smer;
     uint32_t *rec_mpos;
-    uint32_t rec_cap;
-    uint32_t *counters;       // [2] records appended (may exceed rec_cap)
+    // Records are appended to one of OATK_REC_SHARDS regions (shard = blockIdx & (SHARDS-1)), each with its own counter:
+    // a single global counter took ~260 k atomics per 50 k reads and, at ~88 atomics/us on one address, WAS the kernel time.
+    uint32_t region_cap;      // slots per shard region
+    uint32_t *shard_cnt;      // [OATK_REC_SHARDS] records appended per shard (may exceed region_cap)
 };
 
 template <int C, int R, bool HAS_N>
@@ -51,7 +54,6 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_kernel(SynArgs a)
     constexpr int T = SYN_NT * C;          // END positions per tile
     constexpr int NCH = R / C;             // chunk ring
     constexpr int PBW = R / 16;            // packed-base ring, 16 bases per word
-    constexpr int NWMAX = R / 32;          // Murmur blocks per k-mer, upper bound
     constexpr int NWAVE = SYN_NT / OATK_WAVE;
 
     // one pad slot per 32: lanes walk this ring with a stride of C slots, which would otherwise land on 4 banks
@@ -61,10 +63,6 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_kernel(SynArgs a)
     __shared__ uint32_t pb[PBW];
     __shared__ uint16_t lr_ring[HAS_N? R : 1];
     __shared__ uint32_t nb_ring[HAS_N? R / 32 : 1];
-    __shared__ uint64_t kmix[SYN_EM_CAP * NWMAX];
-    __shared__ uint32_t em_e[SYN_EM_CAP];
-    __shared__ uint32_t em_rev[SYN_EM_CAP];
-    __shared__ uint64_t em_code[SYN_EM_CAP];
     __shared__ uint32_t w_cnt[NWAVE];
     __shared__ int32_t w_max[NWAVE];
     __shared__ uint32_t s_gbase;
@@ -87,7 +85,6 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_kernel(SynArgs a)
     const uint64_t mask = (1ULL << (2 * S)) - 1;
     const uint32_t *ghs = (const uint32_t *) (a.hoco_s + (a.off[r] >> 2));
     uint32_t *gnb = a.nbits + (a.off[r] >> 5);
-    const int nbytes = (K - 1) / 4 + 1, nfull = nbytes >> 3, nrem = nbytes & 7, NW = nfull + (nrem? 1 : 0);
     const int D = (w - 1) / C, rem = (w - 1) % C;      // far-chunk geometry of the window [E-w, E-1]
     int st_level = 0;                                   // sparse-table level for ranges of D-1 chunks
     while ((2 << st_level) <= D - 1) ++st_level;
@@ -286,66 +283,29 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_kernel(SynArgs a)
                 total += w_cnt[ww];
             }
             if (total) {
-                if (tid == 0) s_gbase = atomicAdd(&a.counters[2], total);
-                for (uint32_t rb = 0; rb < total; rb += SYN_EM_CAP) {
-                    // this lane's selections that fall in [rb, rb + EM_CAP): note the k-mer end, the s-mer code and strand
-                    if (cnt && ex < rb + SYN_EM_CAP && ex + cnt > rb) {
-                        uint32_t q = ex;
-#pragma unroll
-                        for (int o = 0; o < C; ++o) {
-                            const uint32_t sel = ((close_m >> o) & 1u) | (((open_m >> o) & 1u) << 1);
-                            if (sel) {
-                                if (q >= rb && q < rb + SYN_EM_CAP) {
-                                    const int32_t E = ca * C + o + w;
-                                    const bool is_open = sel == 2u;
-                                    uint64_t code = smer_code(is_open? E - w : E);     // first s-mer ends at E-w, last at E
-                                    em_e[q - rb] = (uint32_t) E;
-                                    em_rev[q - rb] = (uint32_t) (code & 1ULL);
-                                    em_code[q - rb] = is_open? code : code ^ 1ULL;      // Close stores S ^ 1 (syncmer.c:345)
-                                }
-                                ++q;
-                            }
-                        }
-                    }
-                    __syncthreads();
-                    const uint32_t nround = total - rb < (uint32_t) SYN_EM_CAP? total - rb : (uint32_t) SYN_EM_CAP;
-                    // one Murmur block per lane: oriented k-mer bases [32*wd, 32*wd+32), MSB-first, then byte-swapped to
-                    // the little-endian word the reference reads from its byte buffer (syncmer.c:139-151)
-                    for (uint32_t it = tid; it < nround * (uint32_t) NW; it += SYN_NT) {
-                        const uint32_t e = it / (uint32_t) NW, wd = it % (uint32_t) NW;
-                        const int32_t j = (int32_t) em_e[e] - K + 1;
-                        int nb = K - 32 * (int) wd;
-                        nb = nb > 32? 32 : nb;
-                        uint64_t V = em_rev[e]? revcomp32(get64(j + K - 32 - 32 * (int32_t) wd)) : get64(j + 32 * (int32_t) wd);
-                        if (nb < 32) V &= ~0ULL << (64 - 2 * nb);
-                        uint64_t word = bswap64(V);
-                        kmix[e * NWMAX + wd] = (int) wd < nfull? murmur_mix_word(word) : word;
-                    }
-                    __syncthreads();
-                    if (tid < nround) {
-                        const int32_t j = (int32_t) em_e[tid] - K + 1;
-                        const uint32_t rev = em_rev[tid];
-                        uint64_t h = OATK_MURMUR_SEED ^ ((uint64_t) (uint32_t) nbytes * OATK_MURMUR_M);
-                        const uint64_t *km = &kmix[tid * NWMAX];
-                        int wd = 0;
-                        for (; wd + 8 <= nfull; wd += 8) {                 // fetch eight blocks, then run the dependent chain on registers
-                            uint64_t k0 = km[wd], k1 = km[wd + 1], k2 = km[wd + 2], k3 = km[wd + 3];
-                            uint64_t k4 = km[wd + 4], k5 = km[wd + 5], k6 = km[wd + 6], k7 = km[wd + 7];
-                            h = (h ^ k0) * OATK_MURMUR_M; h = (h ^ k1) * OATK_MURMUR_M; h = (h ^ k2) * OATK_MURMUR_M; h = (h ^ k3) * OATK_MURMUR_M;
-                            h = (h ^ k4) * OATK_MURMUR_M; h = (h ^ k5) * OATK_MURMUR_M; h = (h ^ k6) * OATK_MURMUR_M; h = (h ^ k7) * OATK_MURMUR_M;
-                        }
-                        for (; wd < nfull; ++wd) h = (h ^ km[wd]) * OATK_MURMUR_M;
-                        if (nrem) h = (h ^ km[nfull]) * OATK_MURMUR_M;
-                        h ^= h >> 47; h *= OATK_MURMUR_M; h ^= h >> 47;
-                        const uint32_t slot = s_gbase + rb + tid, ordn = ord0 + rb + tid;
-                        if (slot < a.rec_cap) {
-                            a.rec_hash[slot] = h;
+                if (tid == 0) s_gbase = atomicAdd(&a.shard_cnt[blockIdx.x & (OATK_REC_SHARDS - 1)], total);
+                __syncthreads();
+                // records carry (sid | ordinal | strand, s-mer code, position); the k-mer hash is filled in afterwards by
+                // kmer_hash_kernel, one lane per record
+                if (cnt) {
+                    uint32_t q = ex;
+                    for (int o = 0; o < C; ++o) {
+                        const uint32_t sel = ((close_m >> o) & 1u) | (((open_m >> o) & 1u) << 1);
+                        if (!sel) continue;
+                        const int32_t E = ca * C + o + w, j = E - K + 1;
+                        const bool is_open = sel == 2u;
+                        uint64_t code = smer_code(is_open? E - w : E);          // first s-mer ends at E-w, last at E
+                        const uint32_t rev = (uint32_t) (code & 1ULL);
+                        if (!is_open) code ^= 1ULL;                              // Close stores S ^ 1 (syncmer.c:345)
+                        const uint32_t loc = s_gbase + q, ordn = ord0 + q;
+                        if (loc < a.region_cap) {
+                            const size_t slot = (size_t) (blockIdx.x & (OATK_REC_SHARDS - 1)) * a.region_cap + loc;
                             a.rec_lo[slot] = sid << 32 | (uint64_t) ordn << 1 | rev;
-                            a.rec_smer[slot] = em_code[tid];
+                            a.rec_smer[slot] = code;
                             a.rec_mpos[slot] = (uint32_t) j << 1 | rev;
                         }
+                        ++q;
                     }
-                    __syncthreads();
                 }
                 ord0 += total;
             }

@@ -1,0 +1,348 @@
+// oatk_amd/csrc/scan_syncmer_fast.hpp -- kernel B, fast path (reads without ambiguous bases, 520 <= K-S <= 1031).
+//
+// Same contract and rule as scan_syncmer.hpp (the general kernel, kept for reads with N and unusual K/S); the
+// difference is HOW MUCH work and HOW MANY stalls are spent per position.  PMC on MI355X showed the general kernel
+// issuing ~1500 VALU wave-instructions per 2048-position tile per wave (486 of them in the unavoidable s-mer
+// hashing) and, once that was trimmed, waves sitting 72 % of their life in s_waitcnt / s_barrier.  Here:
+//
+//  * the window decision sits behind a NECESSARY condition that costs two 32-bit compares per position:
+//      Close at k-mer end E needs  M[E]   <= every hash in [E-w, E-1]  -> in particular <= the D chunk minima before E's chunk
+//      Open  at k-mer end E needs  M[E-w] <= every hash in (E-w, E-1]  -> in particular <= the D chunk minima after (E-w)'s chunk
+//    (D = w/8 - 1 = 120 chunks of 8 at K=1001).  Only the top 32 bits of the hashes take part; the bounds come from
+//    one wave-level prefix-min and suffix-min over 32-bit keys done with DPP row shifts + v_readlane (VALU only, no
+//    LDS round trips).  About one position in 480 survives; only those get the exact 64-bit window minimum, computed
+//    cooperatively by a wave from chunk minima + ragged ends, and the full Close/Open rule.
+//  * candidates are found with wave ballots (a scalar loop over the few set lanes), kept in per-wave, double-buffered
+//    LDS lists, so a tile needs three workgroup barriers instead of ten.
+//  * selected syncmers leave as (sid|ordinal|rev, s-mer code, pos) records; their 251-byte k-mers are hashed
+//    afterwards by kmer_hash_kernel (one lane per syncmer) instead of by a lone lane inside this kernel.
+#pragma once
+#include "common.hpp"
+#include "scan_syncmer.hpp"
+
+namespace oatk {
+
+constexpr int SYF_C = 8;                 // positions per lane per tile (one chunk)
+constexpr int SYF_T = SYN_NT * SYF_C;    // 2048 positions per tile
+constexpr int SYF_BLK = 64;              // chunks per wave = block of the prefix/suffix minima
+constexpr int SYF_SEG = 64;              // candidate slots per wave per round
+
+// ring size (positions) the fast kernel needs for this K, or 0 if it does not apply
+static inline int syncmer_fast_ring(int K, int S)
+{
+    const int w = K - S;
+    if (w / SYF_C - 1 < SYF_BLK || w / SYF_C - 1 >= 2 * SYF_BLK) return 0;     // 64 <= D <= 127: at most one whole block in a filter range
+    if (K + SYF_T + SYF_C + 64 <= 4096) return 4096;
+    return 0;
+}
+
+// ---- DPP helpers (gfx9 DPP: row = 16 lanes) ----
+#define OATK_DPP_ROW_SHL(n) (0x100 + (n))
+#define OATK_DPP_ROW_SHR(n) (0x110 + (n))
+#define OATK_DPP_ROW_BCAST15 0x142
+#define OATK_DPP_ROW_BCAST31 0x143
+
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t src)
+{
+    return (uint32_t) __builtin_amdgcn_update_dpp((int) old, (int) src, CTRL, ROW_MASK, 0xf, false);
+}
+
+// inclusive prefix-min and suffix-min over the 64 lanes of a wave (lanes without a source keep their value)
+__device__ __forceinline__ void wave_prefix_suffix_min_u32(uint32_t v, uint32_t lane, uint32_t &pre, uint32_t &suf)
+{
+    uint32_t p = v, s = v, t;
+    t = dpp_u32<OATK_DPP_ROW_SHR(1)>(p, p); p = t < p? t : p;
+    t = dpp_u32<OATK_DPP_ROW_SHR(2)>(p, p); p = t < p? t : p;
+    t = dpp_u32<OATK_DPP_ROW_SHR(4)>(p, p); p = t < p? t : p;
+    t = dpp_u32<OATK_DPP_ROW_SHR(8)>(p, p); p = t < p? t : p;
+    t = dpp_u32<OATK_DPP_ROW_SHL(1)>(s, s); s = t < s? t : s;
+    t = dpp_u32<OATK_DPP_ROW_SHL(2)>(s, s); s = t < s? t : s;
+    t = dpp_u32<OATK_DPP_ROW_SHL(4)>(s, s); s = t < s? t : s;
+    t = dpp_u32<OATK_DPP_ROW_SHL(8)>(s, s); s = t < s? t : s;
+    // row totals: prefix totals sit in lanes 15/31/47, suffix totals in lanes 16/32/48
+    const uint32_t r15 = __builtin_amdgcn_readlane(p, 15), r31 = __builtin_amdgcn_readlane(p, 31), r47 = __builtin_amdgcn_readlane(p, 47);
+    const uint32_t p2 = r31 < r15? r31 : r15, p3 = r47 < p2? r47 : p2;
+    const uint32_t s48 = __builtin_amdgcn_readlane(s, 48), s32 = __builtin_amdgcn_readlane(s, 32), s16 = __builtin_amdgcn_readlane(s, 16);
+    const uint32_t q2 = s32 < s48? s32 : s48, q1 = s16 < q2? s16 : q2;
+    const uint32_t row = lane >> 4;
+    const uint32_t padd = row == 1? r15 : (row == 2? p2 : (row == 3? p3 : 0xFFFFFFFFu));
+    const uint32_t sadd = row == 0? q1 : (row == 1? q2 : (row == 2? s48 : 0xFFFFFFFFu));
+    pre = padd < p? padd : p;
+    suf = sadd < s? sadd : s;
+}
+
+template <int R, bool S31>
+__global__ __launch_bounds__(SYN_NT) void syncmer_fast_kernel(SynArgs a)
+{
+    constexpr int C = SYF_C, T = SYF_T, NCH = R / C, NWAVE = SYN_NT / OATK_WAVE;
+    constexpr int PBW = 512;                    // packed-base ring: 8192 positions, so the next tile's bases can be fetched early
+    static_assert((R & (R - 1)) == 0, "power-of-two ring: index arithmetic is one AND (a 3200-slot ring raised occupancy from 3 to 4\n"
+                  "workgroups per CU but its modulo arithmetic cost more issue slots than the occupancy returned)");
+
+    __shared__ uint64_t m_ring[R + R / 32];     // s-mer hashes by END position; one pad slot per 32 against bank conflicts
+    __shared__ uint64_t cm_ring[NCH];           // chunk minima (64-bit, for the exact window minimum)
+    __shared__ uint32_t pre32[NCH], suf32[NCH]; // per-wave-block inclusive prefix / suffix minima of the chunk minima's top 32 bits
+    __shared__ uint32_t pb[PBW];                // packed bases, 16 per word, MSB-first
+    __shared__ uint32_t cand[2][NWAVE][SYF_SEG]; // k-mer ends of candidates: per wave, position order, double-buffered
+    __shared__ uint8_t surv[2][NWAVE][SYF_SEG];  // 0 none, 1 Close, 2 Open
+    __shared__ uint32_t w_cnt[2][NWAVE];
+
+    const uint32_t r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (a.n_nn[r] != 0) return;                 // reads with ambiguous bases take the general kernel
+
+    const int K = a.K, S = S31? 31 : a.S, w = K - S;
+    const uint32_t hl = a.hoco_l[r];
+    if (hl < (uint32_t) K) { if (tid == 0) a.n_scm[r] = 0; return; }
+    const uint64_t sid = a.sid0 + r;
+    const uint64_t mask = (1ULL << (2 * S)) - 1;
+    const uint32_t *ghs = (const uint32_t *) (a.hoco_s + (a.off[r] >> 2));
+    const int D = w / C - 1;                    // chunks that lie inside the window of EVERY position of a chunk
+
+    auto rpos = [](int32_t i) -> uint32_t { return (uint32_t) i & (uint32_t) (R - 1); };
+    auto mi = [&](int32_t i) -> uint32_t { uint32_t p = rpos(i); return p + (p >> 5); };
+    auto rch = [](int32_t c) -> uint32_t { return (uint32_t) c & (uint32_t) (NCH - 1); };
+    auto load_bases = [&](uint32_t I0) {
+        if (tid < T / 16) {
+            uint32_t wi = I0 / 16 + tid;
+            uint32_t v = wi * 16 < hl? ghs[wi] : 0u;
+            pb[wi % (uint32_t) PBW] = __builtin_bswap32(v);     // hoco_s bytes are MSB-first; make the word MSB-first too
+        }
+    };
+
+    for (uint32_t i = tid; i < R + R / 32; i += SYN_NT) m_ring[i] = UINT64_MAX;
+    for (uint32_t i = tid; i < NCH; i += SYN_NT) cm_ring[i] = UINT64_MAX, pre32[i] = suf32[i] = 0xFFFFFFFFu;
+    for (uint32_t i = tid; i < PBW; i += SYN_NT) pb[i] = 0;
+    __syncthreads();
+    load_bases(0);
+    __syncthreads();
+
+    auto get64 = [&](int32_t t) -> uint64_t {
+        int32_t wi = t >> 4;
+        uint32_t sh = ((uint32_t) t & 15u) * 2u;
+        uint32_t p0 = (uint32_t) (wi + PBW) % (uint32_t) PBW, p1 = p0 + 1 == PBW? 0 : p0 + 1, p2 = p1 + 1 == PBW? 0 : p1 + 1;
+        uint64_t hi = (uint64_t) pb[p0] << 32 | pb[p1];
+        uint32_t w2 = pb[p2];
+        return sh? (hi << sh) | ((uint64_t) w2 >> (32u - sh)) : hi;
+    };
+    auto smer_code = [&](int32_t e) -> uint64_t {
+        uint64_t X = get64(e - S + 1) & (~0ULL << (64 - 2 * S));
+        uint64_t fw = X >> (64 - 2 * S), rv = revcomp32(X) & mask;
+        return fw < rv? fw << 1 : rv << 1 | 1ULL;
+    };
+    const uint32_t *m_hi = (const uint32_t *) m_ring;    // top word of entry e is m_hi[2e + 1]
+
+    uint32_t ord0 = 0, par = 0;                 // syncmers so far; parity of the candidate buffers
+
+    // One round: the selected waves list candidates from the selected lanes (sel_wave/sel_lo < 0 = all), every wave helps
+    // with the exact decisions, wave 0 writes the records.  Rounds consume buffers `par`, `par^1`, ... alternately; a buffer
+    // is rewritten two barriers after its last reader.
+    auto round = [&](uint32_t cmask, int32_t i0, int sel_wave, int sel_lo) {
+        uint32_t (*cd)[SYF_SEG] = cand[par];
+        uint8_t (*sv)[SYF_SEG] = surv[par];
+        uint32_t *wc = w_cnt[par];
+        // ---- list: a scalar walk over the lanes that have candidates ----
+        {
+            uint32_t mine = cmask;
+            if (sel_wave >= 0 && (int) wid != sel_wave) mine = 0;
+            if (sel_lo >= 0 && ((int) lane < sel_lo || (int) lane >= sel_lo + 8)) mine = 0;
+            uint64_t bal = __ballot(mine != 0);
+            uint32_t n = 0;
+            while (bal) {
+                const int l = __builtin_ctzll(bal);
+                bal &= bal - 1;
+                uint32_t mm = __builtin_amdgcn_readlane(mine, l);
+                const int32_t base = __builtin_amdgcn_readlane(i0, l);
+                while (mm) {
+                    const int o = __builtin_ctz(mm);
+                    mm &= mm - 1;
+                    if (n < (uint32_t) SYF_SEG && lane == 0) cd[wid][n] = (uint32_t) (base + o);
+                    ++n;
+                }
+            }
+            if (lane == 0) wc[wid] = n;         // may exceed SYF_SEG: the caller then falls back to lane-group rounds
+        }
+        __syncthreads();
+        uint32_t cw[NWAVE], nc = 0, over = 0;
+#pragma unroll
+        for (int ww = 0; ww < NWAVE; ++ww) { cw[ww] = wc[ww]; over |= cw[ww] > (uint32_t) SYF_SEG; nc += cw[ww]; }
+        if (over) return true;                  // nothing consumed yet; uniform across the workgroup
+        // ---- exact decision, one wave per candidate ----
+        for (uint32_t ci = wid; ci < nc; ci += NWAVE) {
+            uint32_t seg = 0, idx = ci;
+#pragma unroll
+            for (int ww = 0; ww < NWAVE - 1; ++ww) if (seg == (uint32_t) ww && idx >= cw[ww]) { idx -= cw[ww]; seg = ww + 1; }
+            const int32_t E = (int32_t) cd[seg][idx], lo = E - w, hi = E - 1;
+            const int32_t c_first = (lo + C - 1) / C, c_last = (hi + 1) / C - 1;
+            uint64_t v = UINT64_MAX;
+            for (int32_t cc = c_first + (int32_t) lane; cc <= c_last; cc += OATK_WAVE) {
+                uint64_t u = cm_ring[rch(cc)];
+                v = u < v? u : v;
+            }
+            const int32_t hd = c_first * C - lo, tl0 = (c_last + 1) * C, tl = hi - tl0 + 1;
+            if ((int32_t) lane < hd) { uint64_t u = m_ring[mi(lo + (int32_t) lane)]; v = u < v? u : v; }
+            if ((int32_t) lane >= 8 && (int32_t) lane - 8 < tl) { uint64_t u = m_ring[mi(tl0 + (int32_t) lane - 8)]; v = u < v? u : v; }
+            // (rare path: ~1 candidate per wave per tile.  A DPP reduction was tried here and mis-compiled in this
+            // context -- divergent producers of v -- so the reduction stays on ds_bpermute shuffles.)
+            uint64_t b = v;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { uint64_t o2 = __shfl_xor(b, d); b = o2 < b? o2 : b; }
+            if (lane == 0) {
+                const uint64_t yy = m_ring[mi(E)], f = m_ring[mi(lo)], x = m_ring[mi(lo - 1)];
+                bool cl = yy != UINT64_MAX && (yy < b || (yy == b && (x >= b || f == b)));
+                bool op = f != UINT64_MAX && f <= b && f <= yy;
+                sv[seg][idx] = (uint8_t) (cl && op? 0 : (cl? 1 : (op? 2 : 0)));
+            }
+        }
+        __syncthreads();
+        // ---- survivors -> records: wave 0 only (nobody else needs the running ordinal) ----
+        if (wid == 0) {
+            uint32_t nsurv = 0, my_rank[NWAVE], my_kind[NWAVE];
+#pragma unroll
+            for (int ww = 0; ww < NWAVE; ++ww) {
+                const uint32_t k = lane < cw[ww]? (uint32_t) sv[ww][lane] : 0u;
+                const uint64_t bl = __ballot(k != 0);
+                my_kind[ww] = k;
+                my_rank[ww] = nsurv + __builtin_popcountll(bl & ((1ULL << lane) - 1ULL));
+                nsurv += (uint32_t) __builtin_popcountll(bl);
+            }
+            if (nsurv) {
+                uint32_t gb = 0;
+                if (lane == 0) gb = atomicAdd(&a.shard_cnt[blockIdx.x & (OATK_REC_SHARDS - 1)], nsurv);
+                gb = __builtin_amdgcn_readfirstlane(gb);
+#pragma unroll
+                for (int ww = 0; ww < NWAVE; ++ww) {
+                    if (my_kind[ww]) {
+                        const int32_t E = (int32_t) cd[ww][lane], j = E - K + 1;
+                        uint64_t code = smer_code(my_kind[ww] == 2u? E - w : E);     // Open: first s-mer; Close: last s-mer
+                        const uint32_t rev = (uint32_t) (code & 1ULL);
+                        if (my_kind[ww] == 1u) code ^= 1ULL;                          // Close stores S ^ 1 (syncmer.c:345)
+                        const uint32_t loc = gb + my_rank[ww], ordn = ord0 + my_rank[ww];
+                        if (loc < a.region_cap) {
+                            const size_t slot = (size_t) (blockIdx.x & (OATK_REC_SHARDS - 1)) * a.region_cap + loc;
+                            a.rec_lo[slot] = sid << 32 | (uint64_t) ordn << 1 | rev;
+                            a.rec_smer[slot] = code;
+                            a.rec_mpos[slot] = (uint32_t) j << 1 | rev;
+                        }
+                    }
+                }
+            }
+            ord0 += nsurv;                      // meaningful in wave 0 only
+        }
+        par ^= 1u;
+        return false;
+    };
+
+    for (uint32_t I0 = 0; I0 < hl; I0 += T) {
+        // ---- P1: s-mer hashes of this lane's chunk, chunk minimum, wave prefix/suffix minima ----
+        const int32_t i0 = (int32_t) (I0 + tid * C);
+        const int32_t ch = i0 / C;                      // chunk index; ch % 64 == lane
+        uint64_t y[C];
+        {
+            const uint32_t vbh = (uint32_t) (get64(i0) >> 32);      // the chunk's 8 bases sit in the top word
+            const uint64_t vb = (uint64_t) vbh << 32;
+            uint64_t X = get64(i0 - S) & (~0ULL << (64 - 2 * S));
+            uint64_t fw = X >> (64 - 2 * S), rv = revcomp32(X) & mask;
+            uint64_t cmin = UINT64_MAX;
+            const uint32_t mbase = mi(i0);              // 8 consecutive positions never straddle a pad slot
+            if (i0 + 1 >= S && (uint32_t) (i0 + C) <= hl) {
+#pragma unroll
+                for (int b = 0; b < C; ++b) {
+                    const uint64_t c = (vbh >> (30 - 2 * b)) & 3u;
+                    fw = (fw << 2 | c) & mask;
+                    rv = rv >> 2 | (3ULL ^ c) << (2 * S - 2);
+                    // (S31: an odd-length s-mer is never its own reverse complement, so no fw != rv test)
+                    uint64_t mv = (S31 || fw != rv)? hash64(fw < rv? fw : rv, mask) : UINT64_MAX;
+                    y[b] = mv;
+                    m_ring[mbase + b] = mv;
+                    cmin = mv < cmin? mv : cmin;
+                }
+            } else {                                    // first / last chunk of the read
+#pragma unroll
+                for (int b = 0; b < C; ++b) {
+                    const int32_t i = i0 + b;
+                    const uint64_t c = (vb >> (62 - 2 * b)) & 3ULL;
+                    fw = (fw << 2 | c) & mask;
+                    rv = rv >> 2 | (3ULL ^ c) << (2 * S - 2);
+                    uint64_t mv = UINT64_MAX;
+                    if (i + 1 >= S && (uint32_t) i < hl && fw != rv) mv = hash64(fw < rv? fw : rv, mask);
+                    y[b] = mv;
+                    m_ring[mbase + b] = mv;
+                    cmin = mv < cmin? mv : cmin;
+                }
+            }
+            uint32_t pre, suf;
+#ifdef OATK_SCAN_SHFL
+            pre = suf = (uint32_t) (cmin >> 32);
+            for (int d = 1; d < OATK_WAVE; d <<= 1) {
+                uint32_t up = __shfl_up(pre, d), dn = __shfl_down(suf, d);
+                if ((int) lane >= d) pre = up < pre? up : pre;
+                if ((int) lane + d < OATK_WAVE) suf = dn < suf? dn : suf;
+            }
+#else
+            wave_prefix_suffix_min_u32((uint32_t) (cmin >> 32), lane, pre, suf);
+#endif
+            const uint32_t cs = rch(ch);
+            cm_ring[cs] = cmin;
+            pre32[cs] = pre;
+            suf32[cs] = suf;
+        }
+        if (I0 + T < hl) load_bases(I0 + T);            // next tile's bases ride on this barrier
+        __syncthreads();
+
+        // ---- P3: filter on 32-bit keys (straight-line code: 64 <= D <= 127 means at most ONE whole block inside a range) ----
+        uint32_t cmask = 0;
+        {
+            // minimum of the chunk minima over chunks [lo, hi], hi - lo = D - 1: suffix of lo's block, prefix of hi's block and,
+            // when the two are not adjacent, the one whole block between them.  Chunks before the read map to ring slots that
+            // still hold the initial MAX, which is exactly "no constraint".
+            auto range_min = [&](int32_t lo, int32_t hi) -> uint32_t {
+                const uint32_t a0 = suf32[rch(lo)], a1 = pre32[rch(hi)];
+                const uint32_t mid = pre32[rch(((lo >> 6) + 1) * 64 + 63)];
+                const uint32_t a2 = (hi >> 6) - (lo >> 6) == 2? mid : 0xFFFFFFFFu;
+                const uint32_t v = a0 < a1? a0 : a1;
+                return a2 < v? a2 : v;
+            };
+            const int32_t a_first = i0 - w;             // first s-mer of the k-mer that ends at i0
+            const int32_t ca0 = a_first >> 3;
+            const int sh = (-w) & (C - 1);              // = a_first & 7, the same for every lane
+            const uint32_t backF = range_min(ch - D, ch - 1);            // Close bound
+            const uint32_t fwd0 = range_min(ca0 + 1, ca0 + D);           // Open bound, first s-mers ending in chunk ca0
+            const uint32_t fwd1 = range_min(ca0 + 2, ca0 + 1 + D);       // ... and in chunk ca0 + 1
+            const uint32_t fbase = rpos(a_first);
+            uint32_t hit = 0;
+#pragma unroll
+            for (int o = 0; o < C; ++o) {
+                const uint32_t fp = (fbase + (uint32_t) o) & (uint32_t) (R - 1);
+                const uint32_t fhi = m_hi[2u * (fp + (fp >> 5)) + 1u];
+                const uint32_t yhi = (uint32_t) (y[o] >> 32);
+                const uint32_t fb = o + sh < C? fwd0 : fwd1;
+                // (a MAX sentinel passes only when its whole window is MAX; the exact rule rejects it)
+                hit |= (uint32_t) ((yhi <= backF) | ((fhi <= fb) & (fhi <= yhi))) << o;
+            }
+            // k-mers that do not fit the read: E + 1 < K at the start, E >= hoco_l at the end
+            if (hit) {
+                if (i0 + 1 >= K && (uint32_t) (i0 + C) <= hl) cmask = hit;
+                else {
+#pragma unroll
+                    for (int o = 0; o < C; ++o)
+                        if ((uint32_t) (i0 + o) < hl && i0 + o + 1 >= K) cmask |= hit & (1u << o);
+                }
+            }
+        }
+        // ---- candidates -> exact decisions -> records ----
+        if (round(cmask, i0, -1, -1)) {
+            // a wave found more than SYF_SEG candidates (low-complexity sequence): redo wave by wave, eight lanes at a time,
+            // which keeps every list <= 64 entries and the ordinals in position order
+            for (int ww = 0; ww < NWAVE; ++ww)
+                for (int g = 0; g < OATK_WAVE; g += 8) {
+                    __syncthreads();
+                    round(cmask, i0, ww, g);
+                }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) a.n_scm[r] = ord0;            // tid 0 is in wave 0
+}
+
+}  // namespace oatk

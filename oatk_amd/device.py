@@ -98,6 +98,9 @@ class HipSyncasm:
         self.L.oatk_hip_get_timing(self.h, ms, len(_lib.TIMERS))
         return dict(zip(_lib.TIMERS, [float(x) for x in ms]))
 
+    def debug_force_general(self, on=True):
+        self.L.oatk_hip_debug_force_general(self.h, 1 if on else 0)
+
     def debug_hash_mask(self, mask):
         self.L.oatk_hip_debug_hash_mask(self.h, C.c_uint64(mask & 0xFFFFFFFFFFFFFFFF))
 

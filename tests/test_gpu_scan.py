@@ -113,3 +113,24 @@ def test_against_reference_golden_vectors(hip, case):
     assert np.array_equal(c["h"], g["scm_h"]) and np.array_equal(c["s"], g["scm_s"])
     assert np.array_equal(c["cov"], g["scm_cov"]) and np.array_equal(c["occ"], g["scm_occ"])
     assert np.array_equal(c["k_id"], g["k_id"])
+
+
+def test_general_kernel_still_matches_at_k1001(hip):
+    """K=1001 normally takes the fast syncmer kernel; force the general one and check it agrees with the oracle too."""
+    reads = A.reads(1001, 31, seed=31, scale=0.6) + A.hifi_like(40, 40000, 9000, seed=8)
+    want = O.scan(reads, 1001, 31, mode=0)
+    hip.debug_force_general(True)
+    try:
+        got, _ = run_hip(hip, reads, 1001, 31)
+    finally:
+        hip.debug_force_general(False)
+    compare_scan(got, want)
+    got2, _ = run_hip(hip, reads, 1001, 31)
+    compare_scan(got2, want)
+
+
+@pytest.mark.parametrize("K,S", [(550, 31), (1500, 21), (1976, 31), (1977, 31)])
+def test_fast_kernel_k_range(hip, K, S):
+    reads = A.hifi_like(30, 30000, 9000, seed=K) + A.reads(K, S, seed=3, scale=0.3)[:30]
+    got, _ = run_hip(hip, reads, K, S)
+    compare_scan(got, O.scan(reads, K, S, mode=1))
