@@ -6,10 +6,15 @@
 // list (:301-302); every non-ACGT byte is its own position stored as base A with run 1, and its raw
 // coordinate goes to n_nucl (:316-321).
 //
-// MI355X mapping: HBM-bound streaming kernel.  One 256-thread workgroup per read walks 4 KiB tiles;
-// each lane loads one aligned 16-byte vector (reads start on 64-byte boundaries of the packed stream),
-// a workgroup scan of (run-start count, last run-start position) turns raw coordinates into hoco
-// coordinates, finished runs are staged in an LDS ring and leave as full 16-byte stores.
+// MI355X mapping: the HBM-streaming kernel of the scan (1 B read + 1.25*rho B written per raw base).
+// One 256-thread workgroup per read walks 4 KiB tiles; each lane owns one aligned 16-byte vector (reads
+// start on 64-byte boundaries of the packed stream) and the next tile's vector is requested before the
+// current one is processed.  Bytes are classified through a 256-entry LDS table (the reference's own
+// table semantics, syncmer.c:47-64); a workgroup scan of (run-start count, last run-start position) --
+// DPP row shifts inside a wave, one LDS exchange across waves -- turns raw coordinates into hoco
+// coordinates; finished runs are staged in an LDS ring (one byte store per run, the 2-bit codes of a lane
+// OR-ed in as at most two words) and leave as full 16-byte stores.  Ambiguous bases and runs > 255 are
+// rare and handled off the fast path.
 #pragma once
 #include "common.hpp"
 
@@ -36,10 +41,42 @@ struct HpcArgs {
     uint32_t *counters;       // [0] appended to nn, [1] appended to lrl (may exceed the capacities)
 };
 
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ uint32_t hpc_dpp(uint32_t old, uint32_t src)
+{
+    return (uint32_t) __builtin_amdgcn_update_dpp((int) old, (int) src, CTRL, ROW_MASK, 0xf, false);
+}
+
+// inclusive wave scans with DPP row shifts (row = 16 lanes) + v_readlane across rows: VALU only
+__device__ __forceinline__ uint32_t wave_incl_sum_dpp(uint32_t v, uint32_t lane)
+{
+    v += hpc_dpp<0x111>(0u, v);
+    v += hpc_dpp<0x112>(0u, v);
+    v += hpc_dpp<0x114>(0u, v);
+    v += hpc_dpp<0x118>(0u, v);
+    const uint32_t r15 = __builtin_amdgcn_readlane(v, 15), r31 = __builtin_amdgcn_readlane(v, 31), r47 = __builtin_amdgcn_readlane(v, 47);
+    const uint32_t row = lane >> 4;
+    return v + (row == 0? 0u : (row == 1? r15 : (row == 2? r15 + r31 : r15 + r31 + r47)));
+}
+__device__ __forceinline__ int32_t wave_incl_max_dpp(int32_t v, uint32_t lane)
+{
+    int32_t t;
+    t = (int32_t) hpc_dpp<0x111>((uint32_t) v, (uint32_t) v); v = t > v? t : v;
+    t = (int32_t) hpc_dpp<0x112>((uint32_t) v, (uint32_t) v); v = t > v? t : v;
+    t = (int32_t) hpc_dpp<0x114>((uint32_t) v, (uint32_t) v); v = t > v? t : v;
+    t = (int32_t) hpc_dpp<0x118>((uint32_t) v, (uint32_t) v); v = t > v? t : v;
+    const int32_t r15 = __builtin_amdgcn_readlane(v, 15), r31 = __builtin_amdgcn_readlane(v, 31), r47 = __builtin_amdgcn_readlane(v, 47);
+    const int32_t p2 = r31 > r15? r31 : r15, p3 = r47 > p2? r47 : p2;
+    const uint32_t row = lane >> 4;
+    const int32_t add = row == 1? r15 : (row == 2? p2 : (row == 3? p3 : -1));
+    return add > v? add : v;
+}
+
 __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
 {
-    __shared__ uint4 ring_rl4[HPC_RING / 16];
-    __shared__ uint4 ring_hs4[HPC_RING / 64];
+    __shared__ uint4 ring_rl4[HPC_RING / 16];      // run lengths, one byte per staged hoco position
+    __shared__ uint4 ring_hs4[HPC_RING / 64];      // 2-bit codes, 16 per word, MSB-first words (byte-swapped on the way out)
+    __shared__ uint8_t lut[256];
     __shared__ uint32_t w_cnt[HPC_NT / OATK_WAVE];
     __shared__ int32_t w_max[HPC_NT / OATK_WAVE];
     __shared__ uint32_t s_nn, s_lrl;
@@ -56,16 +93,28 @@ __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
     uint8_t *out_hs = a.hoco_s + (o >> 2);
     uint32_t *out_nb = a.nbits + (o >> 5);
 
+    lut[tid] = (uint8_t) nt4_code(tid);
     for (uint32_t i = tid; i < HPC_RING / 16; i += HPC_NT) ring_hs[i] = 0;
     if (tid == 0) s_nn = 0, s_lrl = 0;
-    __syncthreads();
 
-    // a finished run: hoco index h, raw start position p0, length rl, class c of its bases
-    auto finish_run = [&](uint32_t h, uint32_t p0, uint32_t rl, uint32_t c) {
-        uint32_t code = c < 4u? c : 0u;
-        uint32_t hr = h & (HPC_RING - 1);
-        ring_rl[hr] = (uint8_t) ((rl > 256u? 256u : rl) - 1u);
-        if (code) atomicOr(&ring_hs[hr >> 4], code << (8u * ((h >> 2) & 3u) + (((h & 3u) ^ 3u) << 1)));
+    // move finished 64-position groups [g0, g1) from the LDS ring to HBM as 16-byte stores
+    auto flush = [&](uint32_t g0, uint32_t g1) {
+        uint32_t n_item = (g1 - g0) * 5u;
+        for (uint32_t it = tid; it < n_item; it += HPC_NT) {
+            uint32_t g = g0 + it / 5u, q = it % 5u;
+            uint32_t hr = (g * 64u) & (HPC_RING - 1);
+            if (q < 4u) {
+                ((uint4 *) out_rl)[g * 4u + q] = ring_rl4[hr / 16u + q];
+            } else {
+                uint4 v = ring_hs4[hr / 64u];
+                ring_hs4[hr / 64u] = make_uint4(0, 0, 0, 0);
+                v.x = __builtin_bswap32(v.x), v.y = __builtin_bswap32(v.y), v.z = __builtin_bswap32(v.z), v.w = __builtin_bswap32(v.w);
+                ((uint4 *) out_hs)[g] = v;
+            }
+        }
+    };
+    // rare events of one finished run: hoco index h, raw start p0, length rl, class c
+    auto rare = [&](uint32_t h, uint32_t p0, uint32_t rl, uint32_t c) {
         if (rl > 255u) {
             uint32_t idx = atomicAdd(&a.counters[1], 1u);
             if (idx < a.lrl_cap) a.lrl_key[idx] = sid << 32 | h, a.lrl_val[idx] = rl - 1u;
@@ -78,90 +127,149 @@ __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
             atomicAdd(&s_nn, 1u);
         }
     };
-    // move finished 64-position groups [g0, g1) from the LDS ring to HBM as 16-byte stores
-    auto flush = [&](uint32_t g0, uint32_t g1) {
-        uint32_t n_item = (g1 - g0) * 5u;
-        for (uint32_t it = tid; it < n_item; it += HPC_NT) {
-            uint32_t g = g0 + it / 5u, q = it % 5u;
-            uint32_t hr = (g * 64u) & (HPC_RING - 1);
-            if (q < 4u) {
-                ((uint4 *) out_rl)[g * 4u + q] = ring_rl4[hr / 16u + q];
-            } else {
-                ((uint4 *) out_hs)[g] = ring_hs4[hr / 64u];
-                ring_hs4[hr / 64u] = make_uint4(0, 0, 0, 0);
-            }
-        }
-    };
 
     uint32_t nstart = 0;      // run starts seen in earlier tiles
     int32_t last_start = -1;  // raw position of the most recent one
     uint32_t flushed = 0;     // 64-groups already in HBM
 
+    uint4 vnext = make_uint4(0, 0, 0, 0);
+    if (tid * HPC_BPT < L) vnext = *(const uint4 *) (in + tid * HPC_BPT);
+    __syncthreads();
+
     for (uint32_t t0 = 0; t0 < L; t0 += HPC_TILE) {
         const uint32_t b0 = t0 + tid * HPC_BPT;
-        uint32_t cls[HPC_BPT];
-        int nvalid = 0;
-        uint32_t up = 5u;   // class of the byte before this lane's first byte (5 = none)
-        if (b0 < L) {
-            uint4 v = *(const uint4 *) (in + b0);
-            nvalid = (int) (L - b0 < (uint32_t) HPC_BPT? L - b0 : (uint32_t) HPC_BPT);
-            uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        const uint4 v = vnext;
+        if (b0 + HPC_TILE < L) vnext = *(const uint4 *) (in + b0 + HPC_TILE);      // next tile's bytes, in flight while this one is processed
+        const int nvalid = b0 < L? (int) (L - b0 < (uint32_t) HPC_BPT? L - b0 : (uint32_t) HPC_BPT) : 0;
+
+        // ---- classes as 16 nibbles (cx: bytes 0-7, cy: bytes 8-15); bytes past the read end get class 7 ----
+        uint32_t cx = 0x77777777u, cy = 0x77777777u, up = 7u;
+        if (nvalid) {
+            cx = cy = 0;
+            const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int b = 0; b < HPC_BPT; ++b) cls[b] = nt4_code((w[b >> 2] >> (8 * (b & 3))) & 0xffu);
-            if (b0 > 0) up = nt4_code(in[b0 - 1]);
-        } else {
-#pragma unroll
-            for (int b = 0; b < HPC_BPT; ++b) cls[b] = 5u;
-        }
-        // pass 1: run starts in this lane's bytes
-        uint32_t smask = 0, cnt = 0, pc = up;
-        int32_t lpos = -1;
-#pragma unroll
-        for (int b = 0; b < HPC_BPT; ++b) {
-            if (b < nvalid) {
-                uint32_t c = cls[b];
-                bool st = (c == 4u) | (c != pc);   // position 0 has pc == 5, so it always starts a run
-                if (st) smask |= 1u << b, ++cnt, lpos = (int32_t) (b0 + b);
-                pc = c;
+            for (int b = 0; b < 8; ++b) {
+                cx |= (uint32_t) lut[(wds[b >> 2] >> (8 * (b & 3))) & 0xffu] << (4 * b);
+                cy |= (uint32_t) lut[(wds[2 + (b >> 2)] >> (8 * (b & 3))) & 0xffu] << (4 * b);
             }
+            if (nvalid < HPC_BPT) {     // tail lane: blank the nibbles beyond the read
+                const uint64_t keep = nvalid >= 16? ~0ULL : ((1ULL << (4 * nvalid)) - 1ULL);
+                uint64_t cc = ((uint64_t) cy << 32 | cx);
+                cc = (cc & keep) | (0x7777777777777777ULL & ~keep);
+                cx = (uint32_t) cc, cy = (uint32_t) (cc >> 32);
+            }
+            if (b0 > 0) up = lut[in[b0 - 1]];
         }
-        uint32_t icnt = wave_incl_sum(cnt, lane);
-        int32_t imax = wave_incl_max(lpos, lane);
+        // ---- run starts: class differs from the previous byte's, or the byte is ambiguous (class 4) ----
+        // nibble-parallel: d = c ^ prev; start <=> d != 0 or c == 4; positions past the end (class 7) never start
+        uint32_t smask;
+        {
+            const uint32_t px = cx << 4 | up, py = cy << 4 | cx >> 28;
+            const uint32_t dx = cx ^ px, dy = cy ^ py;
+            const uint32_t LOW = 0x11111111u;
+            uint32_t sx = (dx | dx >> 1 | dx >> 2) & LOW, sy = (dy | dy >> 1 | dy >> 2) & LOW;
+            sx |= (cx >> 2) & ~(cx >> 1) & ~cx & LOW;           // class 4 = 0b100
+            sy |= (cy >> 2) & ~(cy >> 1) & ~cy & LOW;
+            sx &= ~((cx >> 2) & (cx >> 1) & cx) & LOW;          // class 7 = padding
+            sy &= ~((cy >> 2) & (cy >> 1) & cy) & LOW;
+            // gather bits 0,4,...,28 into bits 0..7: multiply so that bit 4k lands on bit 28+k... use the classic 3-step fold
+            auto squeeze = [](uint32_t s) -> uint32_t {
+                s = (s | s >> 3) & 0x03030303u;     // pairs
+                s = (s | s >> 6) & 0x000f000fu;     // nibbles
+                s = (s | s >> 12) & 0x000000ffu;    // byte
+                return s;
+            };
+            smask = squeeze(sx) | squeeze(sy) << 8;
+        }
+        const uint32_t cnt = __builtin_popcount(smask);
+        const int32_t lpos = smask? (int32_t) (b0 + 31 - __builtin_clz(smask)) : -1;
+        // ---- workgroup scan: run starts before this lane, and the position of the latest one ----
+        const uint32_t icnt = wave_incl_sum_dpp(cnt, lane);
+        const int32_t imax = wave_incl_max_dpp(lpos, lane);
         if (lane == 63) w_cnt[wid] = icnt, w_max[wid] = imax;
         __syncthreads();
         uint32_t n = nstart + icnt - cnt;
-        int32_t ls = __shfl_up(imax, 1);
+        int32_t ls = (int32_t) hpc_dpp<0x138>((uint32_t) -1, (uint32_t) imax);   // wave_shr:1 -> the previous lane's inclusive max
         if (lane == 0) ls = -1;
         if (last_start > ls) ls = last_start;
-        for (uint32_t w = 0; w < wid; ++w) {
-            n += w_cnt[w];
-            if (w_max[w] > ls) ls = w_max[w];
-        }
-        // pass 2: a run is finished when the next one starts
-        pc = up;
+        uint32_t tot = 0;
+        int32_t tmax = last_start;
 #pragma unroll
-        for (int b = 0; b < HPC_BPT; ++b) {
-            if (b < nvalid) {
+        for (uint32_t ww = 0; ww < HPC_NT / OATK_WAVE; ++ww) {
+            const uint32_t c = w_cnt[ww];
+            const int32_t m = w_max[ww];
+            if (ww < wid) { n += c; ls = m > ls? m : ls; }
+            tot += c;
+            tmax = m > tmax? m : tmax;
+        }
+        // ---- a run is finished when the next one starts: this lane finishes one run per start it holds ----
+        if (smask) {
+            // hoco index of the run finished by the k-th start of this lane: (n + k) - 1; the very first start of a
+            // read (position 0) finishes nothing
+            uint64_t codes = 0;
+            uint32_t k = 0, special = 0;
+            int32_t prev = ls;
+            const uint64_t cls64 = (uint64_t) cy << 32 | cx;
+#pragma unroll
+            for (int b = 0; b < HPC_BPT; ++b) {
                 if ((smask >> b) & 1u) {
-                    uint32_t i = b0 + b;
-                    if (i > 0) finish_run(n - 1u, (uint32_t) ls, i - (uint32_t) ls, pc);
-                    ++n, ls = (int32_t) i;
+                    const int32_t i = (int32_t) (b0 + b);
+                    if (i > 0) {
+                        const uint32_t rl = (uint32_t) (i - prev);
+                        const uint32_t pc = b? (uint32_t) (cls64 >> (4 * (b - 1))) & 7u : up;
+                        const uint32_t h = n + k - 1u;
+                        ring_rl[h & (HPC_RING - 1)] = (uint8_t) ((rl > 256u? 256u : rl) - 1u);
+                        codes = codes << 2 | (pc & 3u);
+                        special |= (rl > 255u) | (pc == 4u);
+                    }
+                    prev = i;
+                    ++k;
                 }
-                pc = cls[b];
+            }
+            const uint32_t kfin = k - (b0 == 0? 1u : 0u);            // runs this lane finished
+            if (kfin) {
+                const uint32_t hfirst = n - 1u + (b0 == 0? 1u : 0u);
+                // left-align the kfin codes, then drop them at bit offset 2*(hfirst % 16) of the MSB-first word stream
+                const uint64_t al = codes << (64u - 2u * kfin);
+                const uint32_t off = (hfirst & 15u) * 2u;
+                const uint64_t sh = al >> off;
+                const uint32_t w0 = (hfirst & (HPC_RING - 1)) >> 4;
+                const uint32_t hiw = (uint32_t) (sh >> 32), low = (uint32_t) sh;
+                if (hiw) atomicOr(&ring_hs[w0], hiw);
+                if (low) atomicOr(&ring_hs[(w0 + 1) & (HPC_RING / 16 - 1)], low);
+                // codes beyond 64 - off bits cannot exist: kfin <= 16 -> 32 bits, off <= 30
+            }
+            if (special) {                                             // ambiguous bases / very long runs: walk again, slowly
+                uint32_t k2 = 0;
+                int32_t p2 = ls;
+                for (int b = 0; b < HPC_BPT; ++b) {
+                    if ((smask >> b) & 1u) {
+                        const int32_t i = (int32_t) (b0 + b);
+                        if (i > 0) {
+                            const uint32_t pc = b? (uint32_t) (cls64 >> (4 * (b - 1))) & 7u : up;
+                            rare(n + k2 - 1u, (uint32_t) p2, (uint32_t) (i - p2), pc);
+                        }
+                        p2 = i;
+                        ++k2;
+                    }
+                }
             }
         }
         __syncthreads();
-        for (uint32_t w = 0; w < HPC_NT / OATK_WAVE; ++w) {
-            nstart += w_cnt[w];
-            if (w_max[w] > last_start) last_start = w_max[w];
-        }
-        uint32_t done = nstart? (nstart - 1u) >> 6 : 0u;   // complete 64-groups among finished runs
+        nstart += tot;
+        last_start = tmax;
+        const uint32_t done = nstart? (nstart - 1u) >> 6 : 0u;   // complete 64-groups among finished runs
         flush(flushed, done);
         flushed = done;
         __syncthreads();
     }
     // the last run ends with the read
-    if (tid == 0 && nstart) finish_run(nstart - 1u, (uint32_t) last_start, L - (uint32_t) last_start, nt4_code(in[L - 1]));
+    if (tid == 0 && nstart) {
+        const uint32_t h = nstart - 1u, rl = L - (uint32_t) last_start, c = lut[in[L - 1]];
+        ring_rl[h & (HPC_RING - 1)] = (uint8_t) ((rl > 256u? 256u : rl) - 1u);
+        if (c & 3u & (c < 4u? 3u : 0u)) atomicOr(&ring_hs[(h & (HPC_RING - 1)) >> 4], (c & 3u) << (30u - 2u * (h & 15u)));
+        rare(h, (uint32_t) last_start, rl, c);
+    }
     __syncthreads();
     flush(flushed, (nstart + 63u) >> 6);
     if (tid == 0) {
