@@ -157,16 +157,17 @@ def main():
         alg_bytes = {
             # kernel A: ASCII in, 2-bit hoco_s + ho_rl out (1 + 0.25 rho + rho per raw base)
             "hpc": bases + hoco // 4 + hoco,
-            # kernel B: 2-bit hoco_s in, one 28-byte record per syncmer occurrence out
-            "syncmer": hoco // 4 + 28 * n_occ,
+            # kernel B: 2-bit hoco_s in, one 20-byte record per syncmer occurrence out (the 8-byte hash comes from kmer_hash_kernel)
+            "syncmer": hoco // 4 + 20 * n_occ,
         }
         dom = max(("hpc", "syncmer"), key=lambda k_: phase_ms.get(k_, 0.0))
         dur_s = phase_ms[dom] / 1e3
         achieved = alg_bytes[dom] / dur_s / 1e9 if dur_s > 0 else 0.0
-        roofline = {"bound": "hbm", "kernel": {"hpc": "hpc_pack_kernel", "syncmer": "syncmer_kernel<8,4096,false>"}[dom],
+        roofline = {"bound": "hbm", "kernel": {"hpc": "oatk::hpc_pack_kernel", "syncmer": "oatk::syncmer_fast_kernel<4096, true>"}[dom],
                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                     "algorithmic_bytes_per_launch": alg_bytes[dom], "avg_launch_ms": round(phase_ms[dom], 4),
+                    "note": "kernel B is integer-VALU bound (hash64 of every s-mer: ~50 VALU instructions per hoco base), see DESIGN.md 5",
                     "scan_bytes_per_base": round((alg_bytes["hpc"] + 28 * n_occ) / bases, 4),
                     "scan_achieved_GBs": round((alg_bytes["hpc"] + 28 * n_occ) / ((phase_ms["hpc"] + phase_ms["syncmer"]) / 1e3) / 1e9, 2)}
         cpu = None
