@@ -1,0 +1,90 @@
+/*
+ * include/oatk_syncasm.h -- host mirror of the reference's hot-path data structures and entry points.
+ *
+ * The structs below are LAYOUT-COMPATIBLE with the reference's (same member order, types and widths), because
+ * the rest of oatk -- make_syncmer_graph, scg_consensus, read_error_correction's caller, pathfinder_minicircle --
+ * keeps consuming them unchanged.  They are declared under oatk_-prefixed names so this header can be
+ * included next to the reference's own syncmer.h in one translation unit (tests do exactly that through the shim and
+ * hand these objects to the reference's functions).
+ *
+ *   oatk_sr_t          <->  sr_t          syncmer.h:48-70
+ *   oatk_sr_db_t       <->  sr_db_t       syncmer.h:79-84   (kvec: n, m, a; then k, s, stats)
+ *   oatk_syncmer_t     <->  syncmer_t     syncmer.h:86-96
+ *   oatk_syncmer_db_t  <->  syncmer_db_t  syncmer.h:99-114
+ *
+ * Every array handed out is malloc-family memory: the reference frees members with free() (syncmer.c:1047-1110).
+ */
+#ifndef OATK_SYNCASM_H
+#define OATK_SYNCASM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "oatk_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    uint64_t sid;          /* read id = index in input order */
+    char *sname;
+    uint32_t hoco_l;       /* homopolymer-compressed length */
+    uint8_t *hoco_s;       /* 2-bit bases, 4 per byte, MSB first; ambiguous bases stored as A */
+    uint8_t *ho_rl;        /* min(run, 256) - 1 per hoco position */
+    uint32_t *ho_l_rl;     /* run - 1 for runs > 255, in position order (NULL if none) */
+    uint32_t *n_nucl;      /* raw coordinates of ambiguous bases (NULL if none) */
+    uint32_t n;            /* syncmers on the read */
+    uint32_t *m_pos;       /* hoco position << 1 | strand */
+    uint64_t *s_mer;       /* canonical s-mer << 1 | open/close-strand bit */
+    uint64_t *k_mer;       /* k-mer hash after the scan; syncmer id << 1 | corrected after the count */
+} oatk_sr_t;
+
+typedef struct {
+    uint64_t syncmer_n;
+    double syncmer_per_read, syncmer_avg_dist, smer_avg_cnt, kmer_avg_cnt;
+    int smer_unique, smer_singleton, smer_peak_hom, smer_peak_het;
+    int kmer_unique, kmer_singleton, kmer_peak_hom, kmer_peak_het;
+} oatk_sr_stat_t;
+
+typedef struct {
+    size_t n, m;
+    oatk_sr_t *a;
+    int k, s;
+    oatk_sr_stat_t *stats;
+} oatk_sr_db_t;
+
+typedef struct {
+    uint64_t h, s;         /* k-mer hash, s-mer code */
+    uint32_t cov:31, del:1;
+    uint64_t *m_pos;       /* occurrences: sid << 32 | index on read << 1 | strand */
+} oatk_syncmer_t;
+
+typedef struct {
+    size_t n, m;
+    oatk_syncmer_t *a;
+    uint16_t *c;
+    uint64_t *h;
+} oatk_syncmer_db_t;
+
+/* malloc'ed and initialised like sr_db_init (syncmer.c:1060-1067) */
+oatk_sr_db_t *oatk_sr_db_new(int k, int s);
+
+/* Scan a packed read stream on the device (oatk_hip_scan_host) and fill sr_db->a[0..n_reads) from the resident
+ * results -- the body of sr_read (syncmer.c:487) after the reader loop.  sr_db must be initialised (k, s set, n = 0).
+ * names[i] (may be NULL) is adopted as sname.  Returns an OATK_* code; the resident batch stays in ctx for the count. */
+int oatk_sr_read_packed(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, const uint8_t *seq, const uint64_t *off, const uint32_t *len,
+                        uint64_t n_reads, uint64_t seq_bytes, char **names);
+
+/* collect_syncmer_from_reads (syncmer.c:1397): count on the device, build syncmer_db_t, rewrite sr->k_mer to id << 1.
+ * Returns NULL when there are no syncmers (syncmer.c:1414-1417) or on error (*rc set). */
+oatk_syncmer_db_t *oatk_collect_syncmer_from_reads(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, int *rc);
+
+/* same destructors as the reference (syncmer.c:1047-1110) for objects that are not handed to it */
+void oatk_sr_db_clean(oatk_sr_db_t *sr_db);
+void oatk_syncmer_db_destroy(oatk_syncmer_db_t *scm_db);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -14,6 +14,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <math.h>
 #include <stdint.h>
 
 #include "sstream.h"
@@ -225,4 +226,81 @@ int refx_syncasm(char **files, int n_files, int k, int s, int min_k_cov, double 
 {
     /* remaining defaults from run_syncasm.c:356-367 */
     return syncasm(files, n_files, 0, k, s, 100000, 10000, min_k_cov, min_a_cov_f, 0.3, do_ec, do_unzip, n_threads, out, 0, 0);
+}
+
+/* ---- the rest of syncasm() after the scan and the count (run_syncasm.c:107-319), on caller-provided databases ----
+ * Lets a test feed sr_db / scm_db built by ANOTHER implementation (this repo's device path) into the reference's own
+ * graph construction, error correction, cleaning, unzipping and GFA output, and compare the GFA bytes.  Only calls
+ * public reference functions, in the order run_syncasm.c does. */
+int refx_syncasm_tail(sr_db_t *sr_db, syncmer_db_t *scm_db, int k, int bubble_size, int tip_size, int min_k_cov,
+        double min_a_cov_f, double weak_cross, int do_ec, int do_unzip, int n_threads, const char *out)
+{
+    scg_t *scg = 0;
+    scg_ra_v *ra_db = 0;
+    FILE *fo, *nul = fopen("/dev/null", "w");
+    char path[4096];
+    int ret = 0;
+    if (do_ec) {                                                   /* run_syncasm.c:107-133 */
+        scg = make_syncmer_graph(sr_db, scm_db, 0, 0.);
+        scg_consensus(sr_db, scg, 1, 1, 0);
+        read_error_correction(sr_db, scg, 0.02, min_k_cov, min_k_cov * 10, min_k_cov, min_a_cov_f, n_threads, 0, 0);
+        sr_db_stat(sr_db, nul, 0);
+        scg_destroy(scg); scg = 0;
+    }
+    scg = make_syncmer_graph(sr_db, scm_db, min_k_cov, min_a_cov_f);  /* :138 */
+    if (!scg || scg_is_empty(scg)) { ret = 1; goto done; }
+    process_mergeable_unitigs(scg);                                /* :161 */
+    snprintf(path, sizeof(path), "%s.utg.gfa", out);
+    fo = fopen(path, "w"); scg_consensus(sr_db, scg, 0, 0, fo); fclose(fo);
+    {
+        uint64_t cleaned = 1;                                      /* :183-193 */
+        while (cleaned) {
+            cleaned = 0;
+            if (do_unzip <= 0) {
+                cleaned += asmg_pop_bubble(scg->utg_asmg, bubble_size, 0, 0, 1, 0, 0);
+                cleaned += asmg_remove_weak_crosslink(scg->utg_asmg, weak_cross, 10, 0, 0);
+            }
+            cleaned += asmg_drop_tip(scg->utg_asmg, INT32_MAX, tip_size, 1, 0, 0);
+        }
+        process_mergeable_unitigs(scg);
+    }
+    ra_db = (scg_ra_v *) calloc(1, sizeof(scg_ra_v));
+    if (do_unzip > 0) {                                            /* :209-292 */
+        int round = 0, updated = 1;
+        uint32_t max_n_scm = (uint32_t) ceil(30000.0 / k);
+        while (updated != 0 && round < do_unzip) {
+            ++round;
+            scg_read_alignment(sr_db, ra_db, scg, n_threads, 1);
+            scg_update_utg_cov(scg);
+            updated = scg_multiplex(scg, ra_db, max_n_scm, 10, .3);
+        }
+        scg_read_alignment(sr_db, ra_db, scg, n_threads, 1);
+        scg_ra_arc_coverage(scg, sr_db, ra_db, 0, 0);
+        asmg_remove_weak_crosslink(scg->utg_asmg, weak_cross, 10, 0, 0);
+        scg_demultiplex(scg);
+        scg_read_alignment(sr_db, ra_db, scg, n_threads, 0);
+        scg_ra_utg_coverage(scg, sr_db, ra_db, 0);
+        scg_ra_arc_coverage(scg, sr_db, ra_db, 1, 0);
+        scg_consensus(sr_db, scg, 0, 0, 0);
+        {
+            uint64_t cleaned = 1;
+            while (cleaned) {
+                cleaned = 0;
+                cleaned += asmg_pop_bubble(scg->utg_asmg, bubble_size, 0, 0, 1, 0, 0);
+                cleaned += asmg_remove_weak_crosslink(scg->utg_asmg, weak_cross, 10, 0, 0);
+                cleaned += asmg_drop_tip(scg->utg_asmg, INT32_MAX, tip_size, 1, 0, 0);
+            }
+        }
+        process_mergeable_unitigs(scg);
+    }
+    scg_read_alignment(sr_db, ra_db, scg, n_threads, 0);           /* :295-303 */
+    scg_ra_utg_coverage(scg, sr_db, ra_db, 0);
+    scg_ra_arc_coverage(scg, sr_db, ra_db, 1, 0);
+    snprintf(path, sizeof(path), "%s.utg.final.gfa", out);
+    fo = fopen(path, "w"); scg_consensus(sr_db, scg, 0, 0, fo); fclose(fo);
+done:
+    fclose(nul);
+    scg_destroy(scg);
+    scg_ra_v_destroy(ra_db);
+    return ret;
 }

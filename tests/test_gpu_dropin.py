@@ -1,0 +1,84 @@
+"""GPU drop-in test: the device path fills the reference's own structs (sr_db_t / syncmer_db_t, through
+liboatk_host.so), the COMPILED REFERENCE runs the rest of syncasm() on them (graph, error correction, cleaning,
+unzipping, GFA output -- oracle/ref_shim.c::refx_syncasm_tail), and the GFA bytes must equal a pure reference run.
+Needs the GPU and oracle/_ref (built in the authoring container; travels to the GPU box)."""
+import ctypes as C
+import filecmp
+import os
+
+import numpy as np
+import pytest
+
+import adversarial as A
+import ref_lib as R
+from oatk_amd import _lib, pack_reads
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not R.available(), reason="oracle/_ref not built")]
+
+
+def host_lib():
+    H = C.CDLL(_lib.HOST_LIB_PATH)
+    vp = C.c_void_p
+    H.oatk_sr_db_new.restype = vp
+    H.oatk_sr_db_new.argtypes = [C.c_int, C.c_int]
+    H.oatk_sr_read_packed.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, C.c_uint64, vp]
+    H.oatk_collect_syncmer_from_reads.restype = vp
+    H.oatk_collect_syncmer_from_reads.argtypes = [vp, vp, C.POINTER(C.c_int)]
+    return H
+
+
+def device_dbs(hip, reads, K, S):
+    H = host_lib()
+    seq, off, lens = pack_reads(reads)
+    db = H.oatk_sr_db_new(K, S)
+    rc = H.oatk_sr_read_packed(hip.h, db, seq.ctypes.data, off.ctypes.data, lens.ctypes.data, len(reads), seq.size, None)
+    assert rc == 0, hip.L.oatk_hip_last_error(hip.h)
+    rcc = C.c_int(0)
+    scm = H.oatk_collect_syncmer_from_reads(hip.h, db, C.byref(rcc))
+    assert rcc.value == 0 and scm
+    return db, scm
+
+
+@pytest.mark.parametrize("K,S,cov,do_ec,do_unzip", [(1001, 31, 8, 1, 3), (1001, 31, 8, 0, 0), (301, 21, 6, 1, 3)])
+def test_gfa_identical_to_reference(hip, tmp_path, K, S, cov, do_ec, do_unzip):
+    L = R.lib()
+    L.refx_syncasm_tail.restype = C.c_int
+    L.refx_syncasm_tail.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,
+                                    C.c_int, C.c_char_p]
+    reads = A.hifi_like(260, 50000, 9000 if K > 500 else 5000, seed=K)
+    fa = str(tmp_path / "reads.fa")
+    R.write_fasta(reads, fa)
+    out_ref, out_dev = str(tmp_path / "ref"), str(tmp_path / "dev")
+    # pure reference
+    rc = L.refx_syncasm(R._files_arg([fa]), 1, K, S, cov, 0.35, do_ec, do_unzip, 4, out_ref.encode())
+    assert rc == 0
+    # device scan + count, reference tail
+    db, scm = device_dbs(hip, reads, K, S)
+    rc = L.refx_syncasm_tail(db, scm, K, 100000, 10000, cov, 0.35, 0.3, do_ec, do_unzip, 4, out_dev.encode())
+    assert rc == 0
+    for suffix in (".utg.gfa", ".utg.final.gfa"):
+        assert os.path.getsize(out_ref + suffix) > 100
+        assert filecmp.cmp(out_ref + suffix, out_dev + suffix, shallow=False), suffix
+    # the reference's own destructors free what liboatk_host malloc'ed
+    L.refx_scmdb_destroy(scm)
+    L.refx_srdb_destroy(db)
+
+
+def test_structs_equal_reference_structs(hip):
+    """member-by-member: reference flatteners applied to OUR sr_db / scm_db vs the reference's own"""
+    K, S = 1001, 31
+    reads = A.reads(K, S, seed=77, scale=0.5) + A.hifi_like(50, 40000, 9000, seed=12)
+    n_nn = np.array([sum(1 for c in r if c not in b"ACGTacgtUu\x00\x01\x02\x03") for r in reads], np.uint32)
+    db, scm = device_dbs(hip, reads, K, S)
+    mine_db, mine_scm = object.__new__(R.SrDb), object.__new__(R.ScmDb)
+    mine_db._h, mine_db.K, mine_db.S = db, K, S
+    mine_scm._h = scm
+    got, got_c = mine_db.flatten(n_nn=n_nn), mine_scm.flatten()
+    ref_db = R.SrDb.from_reads(reads, K, S, threads=2)
+    ref_scm = R.ScmDb(ref_db)
+    want, want_c = ref_db.flatten(n_nn=n_nn), ref_scm.flatten()
+    for f in want:
+        assert np.array_equal(got[f], want[f]), f
+    for f in want_c:
+        assert np.array_equal(np.asarray(got_c[f]), np.asarray(want_c[f])), f
+    mine_scm.close(), mine_db.close(), ref_scm.close(), ref_db.close()
