@@ -1,0 +1,56 @@
+/*
+ * include/oatk_hip_ec.h -- C ABI of the device error correction (replaces read_error_correction, syncerr.c:819).
+ *
+ * Call order: oatk_hip_scan[_host] -> oatk_hip_count -> oatk_hip_ec.  The per-read syncmer chains, the hoco strings and
+ * the syncmer table of the batch are already resident in the handle; the caller supplies the EC graph that the
+ * reference builds on the host (make_syncmer_graph(sr_db, scm_db, 0, 0.) + scg_consensus(hoco), run_syncasm.c:109-117),
+ * flattened in arc-array order.  Vertex sequences are NOT needed: in this graph vertex i is syncmer i and its hoco
+ * consensus is the oriented k-mer of the syncmer's first occurrence (syncasm.c:910-940), which the device reads in place.
+ */
+#ifndef OATK_HIP_EC_H
+#define OATK_HIP_EC_H
+
+#include "oatk_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* asmg_t (graph.h:39-63) flattened; HOST pointers.  n_vtx must equal the number of syncmers of the resident count. */
+typedef struct {
+    uint64_t n_vtx, n_arc;
+    const uint64_t *idx_p;     /* [2 n_vtx] asmg_t.idx_p: first arc of oriented vertex v            */
+    const uint64_t *idx_n;     /* [2 n_vtx] asmg_t.idx_n: number of arcs                             */
+    const uint64_t *arc_v;     /* [n_arc]   asmg_arc_t.v                                             */
+    const uint64_t *arc_w;     /* [n_arc]   asmg_arc_t.w                                             */
+    const uint64_t *arc_ls;    /* [n_arc]   asmg_arc_t.ls (overlap in hoco bases)                    */
+    const uint32_t *arc_cov;   /* [n_arc]   asmg_arc_t.cov                                           */
+    const uint8_t *arc_del;    /* [n_arc]   asmg_arc_t.del                                           */
+} oatk_ec_graph_t;
+
+/* read_error_correction(sr_db, g, max_edist, err_mer_c, max_err_c, err_arc_c, max_arc_f, ...) (syncerr.c:819):
+ * marks error syncmers (find_error_syncmers :679), corrects every read's chain (:339-612), refreshes the syncmer table
+ * (update_syncmer_db :769).  Results stay resident; see OATK_BUF_EC_*. */
+int oatk_hip_ec(oatk_hip_ctx *ctx, const oatk_ec_graph_t *g, double max_edist, uint32_t err_mer_c, uint32_t max_err_c,
+                uint32_t err_arc_c, double max_arc_f);
+
+/* the reference's stats[11] (syncerr.c:76): [0] tail blocks, [1..4] by status FAILURE/SUCCESS/AMBISNQ/AMBISEQ,
+ * [5] middle blocks, [6..9] by status, [10] blocks shorter than 10 bases; plus [11] blocks re-run with large slabs */
+int oatk_hip_ec_stats(oatk_hip_ctx *ctx, uint64_t *stats12);
+
+/* Resident results of oatk_hip_ec (ids for oatk_hip_buffer):
+ *   EC_N_SCM   u32[n_reads]      sr_t.n after correction
+ *   EC_SCM_OFF u64[n_reads+1]    slots of the corrected chains
+ *   EC_KMER    u64[n_occ']       sr_t.k_mer: id << 1 | corrected        EC_MPOS u32  sr_t.m_pos   EC_SMER u64  sr_t.s_mer
+ *   EC_SCM_COV u32[n_scm], EC_SCM_DEL u8[n_scm], EC_SCM_OCC_OFF u64[n_scm+1], EC_SCM_OCC u64[n_occ']   (update_syncmer_db)
+ *   EC_ERR_DEL u8[n_scm]         syncmer_t.del right after find_error_syncmers (before the refresh)
+ */
+enum {
+    OATK_BUF_EC_N_SCM = 100, OATK_BUF_EC_SCM_OFF, OATK_BUF_EC_KMER, OATK_BUF_EC_MPOS, OATK_BUF_EC_SMER,
+    OATK_BUF_EC_SCM_COV, OATK_BUF_EC_SCM_DEL, OATK_BUF_EC_SCM_OCC_OFF, OATK_BUF_EC_SCM_OCC, OATK_BUF_EC_ERR_DEL
+};
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <vector>
 
 #include "../../include/oatk_hip.h"
 #include "common.hpp"
@@ -77,6 +78,7 @@ struct oatk_hip_ctx {
     DevBuf key_hash, key_sorted, iota, perm, head, head_idx, newclus, clus_id, bad_head, tag, tmp_perm, flags;
     DevBuf scm_h, scm_s, scm_cov, scm_occ_off, scm_occ;
     DevBuf tmp;           // rocprim temporary storage
+    struct EcState *ec = nullptr;   // error-correction buffers (api_ec.inc)
 };
 
 #define CK(call)                                                                                   \
@@ -116,6 +118,8 @@ static void t_collect(oatk_hip_ctx *ctx, int first, int last)
         ctx->ev_used[i] = false;
     }
 }
+
+#include "api_ec.inc"
 
 extern "C" {
 
@@ -160,6 +164,7 @@ void oatk_hip_destroy(oatk_hip_ctx *ctx)
                      &ctx->bad_head, &ctx->tag, &ctx->tmp_perm, &ctx->flags, &ctx->scm_h, &ctx->scm_s, &ctx->scm_cov,
                      &ctx->scm_occ_off, &ctx->scm_occ, &ctx->tmp};
     for (DevBuf *b : all) b->release();
+    ec_state_free(ctx);
     for (int i = 0; i <= OATK_T_COUNT_; ++i) {
         (void) hipEventDestroy(ctx->ev[i][0]);
         (void) hipEventDestroy(ctx->ev[i][1]);
@@ -527,7 +532,7 @@ int oatk_hip_buffer(oatk_hip_ctx *ctx, int which, const void **d_ptr, uint64_t *
                 case OATK_BUF_SCM_COV: p = ctx->scm_cov.p, b = ns * 4; break;
                 case OATK_BUF_SCM_OCC_OFF: p = ctx->scm_occ_off.p, b = (ns + 1) * 8; break;
                 case OATK_BUF_SCM_OCC: p = ctx->scm_occ.p, b = occ * 8; break;
-                default: ctx->err = "unknown buffer id"; return OATK_E_ARG;
+                default: return ec_buffer(ctx, which, d_ptr, bytes);     // error-correction results (api_ec.inc)
             }
     }
     *d_ptr = p, *bytes = b;

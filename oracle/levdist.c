@@ -138,6 +138,11 @@ orc_wf_t *orc_wf_clone(const orc_wf_t *w)
     return c;
 }
 
+void orc_wf_state(const orc_wf_t *w, int32_t *out3)
+{
+    out3[0] = w->score, out3[1] = w->t_end, out3[2] = w->q_end;
+}
+
 void orc_ed_bruteforce(int32_t tl, const char *ts, int32_t ql, const char *qs, int32_t *out3)
 {
     int32_t i, j, W = ql + 1;

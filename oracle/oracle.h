@@ -81,6 +81,41 @@ orc_wf_t *orc_wf_clone(const orc_wf_t *w);
 void orc_wf_ed(int32_t tl, const char *ts, int32_t ql, const char *qs, int32_t bw, int32_t *out3);
 /* closed form by full DP: min over last row / last column, ties -> smallest diagonal */
 void orc_ed_bruteforce(int32_t tl, const char *ts, int32_t ql, const char *qs, int32_t *out3);
+/* (score, t_end, q_end) currently held by the state */
+void orc_wf_state(const orc_wf_t *w, int32_t *out3);
+
+/* error correction (oracle/ec.c).  The reference's asmg_t flattened in arc-array order. */
+typedef struct {
+    uint64_t n_vtx, n_arc;
+    const uint64_t *vtx_len;      /* [n_vtx] consensus length                       */
+    uint8_t *vtx_del;             /* [n_vtx] updated by orc_find_error_syncmers      */
+    const uint64_t *vtx_seq_off;  /* [n_vtx] offset of the hoco consensus in seq     */
+    const char *seq;
+    const uint64_t *arc_w;        /* [n_arc] target oriented vertex                  */
+    const uint64_t *arc_ls;       /* [n_arc] overlap length                          */
+    const uint32_t *arc_cov;      /* [n_arc]                                         */
+    uint8_t *arc_del;             /* [n_arc] updated by orc_find_error_syncmers      */
+    const uint64_t *idx_p, *idx_n; /* [2 n_vtx] first arc / arc count per oriented vertex */
+} orc_graph_t;
+
+int64_t orc_find_error_syncmers(const orc_graph_t *g, const uint32_t *scm_cov, uint8_t *scm_del, uint32_t err_mer_c,
+                                uint32_t max_err_c, uint32_t err_arc_c, double max_arc_f);
+
+typedef struct {
+    uint64_t tot, updated_reads;
+    uint32_t *n_scm;              /* [n_reads] syncmers per read after correction    */
+    uint64_t *k_mer;              /* [tot] id << 1 | corrected                       */
+    uint32_t *m_pos;              /* [tot]                                           */
+    uint64_t *s_mer;              /* [tot]                                           */
+    long stats[11];               /* syncerr.c:76: tail {n, fail, ok, ambiseq?...}, middle {...}, overlapped */
+} orc_ec_out_t;
+
+void orc_ec_reads(const orc_graph_t *g, const uint8_t *scm_del, const uint64_t *scm_s, int K, double max_edist, uint64_t n_reads,
+                  const uint32_t *hoco_l, const uint8_t *hoco_s, const uint64_t *hoco_byte_off, const uint32_t *n_scm,
+                  const uint64_t *k_mer, const uint32_t *m_pos, const uint64_t *s_mer, orc_ec_out_t *out);
+void orc_ec_out_free(orc_ec_out_t *o);
+void orc_update_db(uint64_t n_reads, const uint32_t *n_scm, const uint64_t *k_mer, const uint32_t *m_pos, uint64_t n_syncmers,
+                   uint32_t *cov, uint8_t *del, uint64_t *occ_off, uint64_t *occ);
 
 #ifdef __cplusplus
 }
