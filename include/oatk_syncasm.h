@@ -80,6 +80,38 @@ int oatk_sr_read_packed(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, const uint8_t *s
  * Returns NULL when there are no syncmers (syncmer.c:1414-1417) or on error (*rc set). */
 oatk_syncmer_db_t *oatk_collect_syncmer_from_reads(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, int *rc);
 
+/* ---- assembly graph as the reference builds it (graph.h:39-63), layout-compatible; only read here ---- */
+typedef struct {
+    uint64_t v, w;         /* oriented vertices: id << 1 | rev */
+    uint64_t ln, ls;       /* overlap in syncmers / in consensus bases */
+    uint32_t cov:30, del:1, comp:1;
+    uint64_t link_id;
+} oatk_asmg_arc_t;
+
+typedef struct {
+    uint64_t n;
+    uint64_t *a;
+    char *seq;
+    uint64_t len;
+    uint32_t cov:30, del:1, circ:1;
+} oatk_asmg_vtx_t;
+
+typedef struct {
+    uint64_t n_vtx, m_vtx;
+    oatk_asmg_vtx_t *vtx;
+    uint64_t n_arc, m_arc;
+    oatk_asmg_arc_t *arc;
+    uint64_t *idx_p, *idx_n;
+} oatk_asmg_t;
+
+/* read_error_correction (syncerr.c:819) on the device: `asmg` is scg->utg_asmg of the EC graph the reference built with
+ * make_syncmer_graph(sr_db, scm_db, 0, 0.) + scg_consensus(hoco) (run_syncasm.c:109-117).  Rewrites every read's
+ * k_mer / m_pos / s_mer / n and the syncmer table's cov / del / m_pos exactly like the reference, marks the graph's
+ * deleted vertices and arcs like find_error_syncmers(..., del_err = 1), and returns the block statistics in stats12
+ * (layout of include/oatk_hip_ec.h).  The batch must still be resident in ctx (scan + count done on it). */
+int oatk_read_error_correction(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, oatk_syncmer_db_t *scm_db, oatk_asmg_t *asmg, double max_edist,
+                               uint32_t err_mer_c, uint32_t max_err_c, uint32_t err_arc_c, double max_arc_f, uint64_t *stats12);
+
 /* same destructors as the reference (syncmer.c:1047-1110) for objects that are not handed to it */
 void oatk_sr_db_clean(oatk_sr_db_t *sr_db);
 void oatk_syncmer_db_destroy(oatk_syncmer_db_t *scm_db);

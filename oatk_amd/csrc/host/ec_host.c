@@ -1,0 +1,100 @@
+/*
+ * oatk_amd/csrc/host/ec_host.c -- host side of the drop-in boundary for read_error_correction (syncerr.c:819).
+ *
+ * Flattens the reference's asmg_t (array of arc structs + CSR index, graph.h:39-63) into the plain arrays
+ * oatk_hip_ec takes, runs the correction on the MI355X on the batch that is still resident from scan + count, and
+ * writes the results back into the reference's structs the way the reference itself would:
+ *   - every read: k_mer / m_pos / s_mer / n                      (syncerr.c:600-612)
+ *   - syncmer table: cov, del, m_pos; c and h released           (update_syncmer_db, syncerr.c:769-814)
+ *   - graph: deleted error syncmers and their arcs              (find_error_syncmers with del_err = 1, syncerr.c:748-752)
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "oatk_hip_ec.h"
+#include "oatk_syncasm.h"
+
+static void *xmalloc(size_t n)
+{
+    void *p = malloc(n? n : 1);
+    if (!p) { fprintf(stderr, "[E::%s] out of memory\n", __func__); exit(EXIT_FAILURE); }
+    return p;
+}
+
+static void *fetch(oatk_hip_ctx *ctx, int which, uint64_t *bytes, int *rc)
+{
+    const void *d = 0;
+    *bytes = 0;
+    *rc = oatk_hip_buffer(ctx, which, &d, bytes);
+    if (*rc) return 0;
+    void *h = xmalloc(*bytes);
+    *rc = oatk_hip_d2h(ctx, h, d, *bytes);
+    if (*rc) { free(h); return 0; }
+    return h;
+}
+
+int oatk_read_error_correction(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, oatk_syncmer_db_t *scm_db, oatk_asmg_t *asmg, double max_edist,
+                               uint32_t err_mer_c, uint32_t max_err_c, uint32_t err_arc_c, double max_arc_f, uint64_t *stats12)
+{
+    const uint64_t nv = asmg->n_vtx, na = asmg->n_arc;
+    uint64_t i, j;
+    /* asmg_t -> flat arrays */
+    uint64_t *idx_n = (uint64_t *) xmalloc(8 * 2 * nv), *arc_v = (uint64_t *) xmalloc(8 * na), *arc_w = (uint64_t *) xmalloc(8 * na);
+    uint64_t *arc_ls = (uint64_t *) xmalloc(8 * na);
+    uint32_t *arc_cov = (uint32_t *) xmalloc(4 * na);
+    uint8_t *arc_del = (uint8_t *) xmalloc(na);
+    memcpy(idx_n, asmg->idx_n, 8 * 2 * nv);
+    for (i = 0; i < na; ++i) {
+        const oatk_asmg_arc_t *a = &asmg->arc[i];
+        arc_v[i] = a->v, arc_w[i] = a->w, arc_ls[i] = a->ls, arc_cov[i] = a->cov, arc_del[i] = (uint8_t) a->del;
+    }
+    oatk_ec_graph_t g;
+    g.n_vtx = nv, g.n_arc = na, g.idx_p = asmg->idx_p, g.idx_n = idx_n, g.arc_v = arc_v, g.arc_w = arc_w, g.arc_ls = arc_ls;
+    g.arc_cov = arc_cov, g.arc_del = arc_del;
+    int rc = oatk_hip_ec(ctx, &g, max_edist, err_mer_c, max_err_c, err_arc_c, max_arc_f);
+    free(idx_n); free(arc_ls); free(arc_cov); free(arc_del);
+    if (rc) { free(arc_v); free(arc_w); return rc; }
+    if (stats12) oatk_hip_ec_stats(ctx, stats12);
+
+    uint64_t b;
+    uint32_t *new_n = (uint32_t *) fetch(ctx, OATK_BUF_EC_N_SCM, &b, &rc); if (rc) return rc;
+    uint64_t *new_k = (uint64_t *) fetch(ctx, OATK_BUF_EC_KMER, &b, &rc); if (rc) return rc;
+    uint32_t *new_m = (uint32_t *) fetch(ctx, OATK_BUF_EC_MPOS, &b, &rc); if (rc) return rc;
+    uint64_t *new_s = (uint64_t *) fetch(ctx, OATK_BUF_EC_SMER, &b, &rc); if (rc) return rc;
+    uint32_t *cov = (uint32_t *) fetch(ctx, OATK_BUF_EC_SCM_COV, &b, &rc); if (rc) return rc;
+    uint8_t *del = (uint8_t *) fetch(ctx, OATK_BUF_EC_SCM_DEL, &b, &rc); if (rc) return rc;
+    uint8_t *err_del = (uint8_t *) fetch(ctx, OATK_BUF_EC_ERR_DEL, &b, &rc); if (rc) return rc;
+    uint64_t *occ_off = (uint64_t *) fetch(ctx, OATK_BUF_EC_SCM_OCC_OFF, &b, &rc); if (rc) return rc;
+    uint64_t *occ = (uint64_t *) fetch(ctx, OATK_BUF_EC_SCM_OCC, &b, &rc); if (rc) return rc;
+
+    /* graph: what find_error_syncmers(..., del_err = 1) leaves behind -- every arc touching a marked syncmer */
+    for (i = 0; i < nv; ++i) if (err_del[i]) asmg->vtx[i].del = 1;
+    for (i = 0; i < na; ++i) if (err_del[arc_v[i] >> 1] || err_del[arc_w[i] >> 1]) asmg->arc[i].del = 1;
+    free(arc_v); free(arc_w);
+
+    /* reads */
+    uint64_t o = 0;
+    for (i = 0; i < sr_db->n; ++i) {
+        oatk_sr_t *r = &sr_db->a[i];
+        const uint32_t n = new_n[i];
+        free(r->k_mer); free(r->m_pos); free(r->s_mer);
+        r->k_mer = (uint64_t *) memcpy(xmalloc(8 * (size_t) n), new_k + o, 8 * (size_t) n);
+        r->m_pos = (uint32_t *) memcpy(xmalloc(4 * (size_t) n), new_m + o, 4 * (size_t) n);
+        r->s_mer = (uint64_t *) memcpy(xmalloc(8 * (size_t) n), new_s + o, 8 * (size_t) n);
+        r->n = n;
+        o += n;
+    }
+    /* syncmer table */
+    free(scm_db->c); scm_db->c = 0;
+    free(scm_db->h); scm_db->h = 0;
+    for (i = 0; i < scm_db->n; ++i) {
+        oatk_syncmer_t *m = &scm_db->a[i];
+        free(m->m_pos);
+        m->cov = cov[i], m->del = del[i];
+        m->m_pos = (uint64_t *) xmalloc(8 * (size_t) cov[i]);
+        for (j = 0; j < cov[i]; ++j) m->m_pos[j] = occ[occ_off[i] + j];
+    }
+    free(new_n); free(new_k); free(new_m); free(new_s); free(cov); free(del); free(err_del); free(occ_off); free(occ);
+    return OATK_OK;
+}

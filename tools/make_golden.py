@@ -115,6 +115,32 @@ def levdist_case():
     print("levdist: %d pairs, %d resumable traces" % (len(T), len(traces)))
 
 
+def ec_case(name, reads, K, S, c, a=0.35, max_edist=0.02):
+    """error correction: inputs = the reference's scan/count databases + its EC graph (make_syncmer_graph(…, 0, 0.) and the
+    hoco consensus, run_syncasm.c:109-117) flattened; outputs = what read_error_correction (syncerr.c:819) leaves behind."""
+    import ec_util as E
+    db = R.SrDb.from_reads(reads, K, S, threads=2)
+    scm = R.ScmDb(db)
+    sr0, sc0 = db.flatten(), scm.flatten()
+    g, G = E.ref_graph(db, scm)
+    summary = E.reference_ec(db, scm, g, max_edist, c, a)
+    sr1, sc1 = db.flatten(), scm.flatten()
+    np.savez_compressed(
+        os.path.join(GOLD, name + ".npz"), K=K, S=S, c=c, a=a, max_edist=max_edist,
+        in_hoco_l=sr0["hoco_l"], in_hoco_s=sr0["hoco_s"], in_n_scm=sr0["n_scm"], in_k_mer=sr0["k_mer"], in_m_pos=sr0["m_pos"], in_s_mer=sr0["s_mer"],
+        in_scm_s=sc0["s"], in_scm_cov=sc0["cov"], in_scm_del=sc0["del"],
+        g_vtx_len=G["vtx_len"], g_vtx_seq_off=G["vtx_seq_off"], g_seq=G["seq"], g_arc_v=G["arc_v"], g_arc_w=G["arc_w"], g_arc_ls=G["arc_ls"],
+        g_arc_cov=G["arc_cov"], g_arc_del=G["arc_del"], g_vtx_del=G["vtx_del"], g_idx_p=G["idx_p"], g_idx_n=G["idx_n"],
+        out_n_scm=sr1["n_scm"], out_k_mer=sr1["k_mer"], out_m_pos=sr1["m_pos"], out_s_mer=sr1["s_mer"],
+        out_scm_cov=sc1["cov"], out_scm_del=sc1["del"], out_scm_occ=sc1["occ"],
+        out_summary=np.array([summary["total"], summary["uncorrected"], summary["corrected"], summary["ambiseq"], summary["ambipath"]], np.int64))
+    print("%-28s K=%-5d blocks=%d corrected=%d uncorrected=%d ambiguous=%d/%d" % (
+        name, K, summary["total"], summary["corrected"], summary["uncorrected"], summary["ambiseq"], summary["ambipath"]))
+    R.lib().refx_scg_destroy(g)
+    scm.close()
+    db.close()
+
+
 def main():
     if not R.available():
         sys.exit("oracle/_ref/liboatk_ref.so missing: run `make -C oracle ref` (needs /root/reference)")
@@ -125,6 +151,10 @@ def main():
     scan_count_case("hifi_k1001_s31", A.hifi_like(120, 60000, 9000, seed=21), 1001, 31, threads=3)
     scan_count_case("hifi_k101_s11", A.hifi_like(200, 8000, 1500, seed=22) + A.reads(101, 11, seed=9, scale=0.3), 101, 11)
     levdist_case()
+    import test_gpu_ec as T     # read generators shared with the GPU suite
+    ec_case("ec_diploid_k101", T.diploid_reads(101, 6000, 150, 500, 1200, 0.006), 101, 11, 4)
+    ec_case("ec_repeats_k301", T.sample_reads(T.genome_with_repeats(7, 25000, unit=1500, copies=4), 320, 4000, 0.003, 8), 301, 21, 5)
+    ec_case("ec_hifi_k1001", A.hifi_like(120, 30000, 9000, seed=1009, err=0.0008), 1001, 31, 6)
 
 
 if __name__ == "__main__":
