@@ -50,6 +50,23 @@ enum {
     OATK_BUF_EC_SCM_COV, OATK_BUF_EC_SCM_DEL, OATK_BUF_EC_SCM_OCC_OFF, OATK_BUF_EC_SCM_OCC, OATK_BUF_EC_ERR_DEL
 };
 
+/* Builds the EC graph on the device from the resident scan + count instead of taking it from the host:
+ * make_syncmer_graph(sr_db, scm_db, 0, 0.) (syncasm.c:203-299: one vertex per syncmer, one arc + its complement per pair of
+ * syncmers adjacent on a read, arc.cov = number of such adjacencies, arcs in (v, w) order, graph.c:70-113) and the arc
+ * overlaps scg_consensus(hoco) assigns (syncasm.c:793-812 with calc_syncmer_overlap :477-582, khashl tie order included).
+ * After it, oatk_hip_ec(ctx, NULL, ...) corrects against the resident graph and nothing of the EC round touches the host.
+ * Returns OATK_E_SPLIT for the corner the reference leaves unspecified (duplicate (v, w) arcs, graph.c:252).
+ *
+ * Resident graph (ids for oatk_hip_buffer), oriented vertex = syncmer id << 1 | strand:
+ *   EG_IDX_P u64[2 n_scm] (valid where EG_IDX_N > 0)   EG_IDX_N u32[2 n_scm]
+ *   EG_ARC_V u64[n_arc]  EG_ARC_W u64[n_arc]  EG_ARC_LS u32[n_arc]  EG_ARC_COV u32[n_arc]  EG_ARC_COMP u8[n_arc] */
+int oatk_hip_ec_graph(oatk_hip_ctx *ctx);
+
+enum {
+    OATK_BUF_EG_IDX_P = 120, OATK_BUF_EG_IDX_N, OATK_BUF_EG_ARC_V, OATK_BUF_EG_ARC_W, OATK_BUF_EG_ARC_LS, OATK_BUF_EG_ARC_COV,
+    OATK_BUF_EG_ARC_COMP
+};
+
 #ifdef __cplusplus
 }
 #endif

@@ -98,6 +98,26 @@ typedef struct {
     const uint64_t *idx_p, *idx_n; /* [2 n_vtx] first arc / arc count per oriented vertex */
 } orc_graph_t;
 
+/* the graph reads are corrected against (oracle/ecgraph.c): make_syncmer_graph(…, 0, 0.) + arc overlaps */
+typedef struct {
+    uint64_t n_scm;
+    const uint64_t *occ_off;      /* [n_scm + 1] */
+    const uint64_t *occ;          /* sid << 32 | idx << 1 | rev, (sid, idx) ascending per syncmer */
+} orc_count_view_t;
+
+typedef struct {
+    uint64_t n_vtx, n_arc;
+    uint64_t *arc_v, *arc_w, *arc_ls;
+    uint32_t *arc_cov;
+    uint8_t *arc_comp;
+    uint64_t *idx_p, *idx_n;
+    int multi_arc;                /* duplicate (v, w): the reference's order is then unspecified (graph.c:252 "TODO fix multi-arc") */
+} orc_ecgraph_t;
+
+orc_ecgraph_t *orc_ecgraph_build(uint64_t n_reads, const uint32_t *n_scm, const uint64_t *k_mer, const uint32_t *m_pos,
+                                 const orc_count_view_t *c, int K);
+void orc_ecgraph_free(orc_ecgraph_t *g);
+
 int64_t orc_find_error_syncmers(const orc_graph_t *g, const uint32_t *scm_cov, uint8_t *scm_del, uint32_t err_mer_c,
                                 uint32_t max_err_c, uint32_t err_arc_c, double max_arc_f);
 

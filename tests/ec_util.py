@@ -117,3 +117,45 @@ def reference_ec(db, scm, g, max_edist, c, a, threads=2):
         return int(m.group(1)) if m else None
     return {"total": grab("total number of error blocks"), "uncorrected": grab("- uncorrected"), "corrected": grab("- corrected"),
             "ambiseq": grab("- ambiguous seqs"), "ambipath": grab("- ambiguous path"), "text": txt}
+
+
+class CountViewT(C.Structure):
+    _fields_ = [("n_scm", C.c_uint64), ("occ_off", C.c_void_p), ("occ", C.c_void_p)]
+
+
+class EcGraphOutT(C.Structure):
+    _fields_ = [("n_vtx", C.c_uint64), ("n_arc", C.c_uint64), ("arc_v", C.POINTER(C.c_uint64)), ("arc_w", C.POINTER(C.c_uint64)),
+                ("arc_ls", C.POINTER(C.c_uint64)), ("arc_cov", C.POINTER(C.c_uint32)), ("arc_comp", C.POINTER(C.c_uint8)),
+                ("idx_p", C.POINTER(C.c_uint64)), ("idx_n", C.POINTER(C.c_uint64)), ("multi_arc", C.c_int)]
+
+
+def occ_lists(n_scm, k_mer, m_pos, n_syncmers):
+    """syncmer occurrence lists of a fresh count: sid << 32 | idx << 1 | rev in (sid, idx) order (syncmer.c:560-575)"""
+    sid = np.repeat(np.arange(len(n_scm), dtype=np.uint64), n_scm)
+    start = np.repeat(np.cumsum(n_scm, dtype=np.uint64) - n_scm, n_scm)
+    idx = np.arange(len(k_mer), dtype=np.uint64) - start
+    ids = k_mer >> np.uint64(1)
+    occ = sid << np.uint64(32) | idx << np.uint64(1) | (m_pos.astype(np.uint64) & np.uint64(1))
+    order = np.argsort(ids, kind="stable")
+    off = np.zeros(n_syncmers + 1, np.uint64)
+    off[1:] = np.cumsum(np.bincount(ids.astype(np.int64), minlength=n_syncmers))
+    return off, np.ascontiguousarray(occ[order])
+
+
+def oracle_ecgraph(n_scm, k_mer, m_pos, occ_off, occ, K):
+    """oracle/ecgraph.c: make_syncmer_graph(sr_db, scm_db, 0, 0.) + arc overlaps, as a dict shaped like flatten_graph's"""
+    L = O.lib()
+    L.orc_ecgraph_build.restype = C.POINTER(EcGraphOutT)
+    L.orc_ecgraph_build.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(CountViewT), C.c_int]
+    L.orc_ecgraph_free.argtypes = [C.POINTER(EcGraphOutT)]
+    arrs = [np.ascontiguousarray(a) for a in (n_scm, k_mer, m_pos, occ_off, occ)]
+    cv = CountViewT(len(occ_off) - 1, arrs[3].ctypes.data, arrs[4].ctypes.data)
+    gp = L.orc_ecgraph_build(len(n_scm), arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data, C.byref(cv), K)
+    g = gp.contents
+    nv, na = g.n_vtx, g.n_arc
+    out = {"n_vtx": nv, "n_arc": na, "multi_arc": g.multi_arc,
+           "arc_v": O._arr(g.arc_v, na, np.uint64), "arc_w": O._arr(g.arc_w, na, np.uint64), "arc_ls": O._arr(g.arc_ls, na, np.uint64),
+           "arc_cov": O._arr(g.arc_cov, na, np.uint32), "arc_comp": O._arr(g.arc_comp, na, np.uint8),
+           "idx_p": O._arr(g.idx_p, 2 * nv, np.uint64), "idx_n": O._arr(g.idx_n, 2 * nv, np.uint64)}
+    L.orc_ecgraph_free(gp)
+    return out

@@ -34,13 +34,46 @@ def fetch_ec(hip, name):
     return out
 
 
+EG_BUF = {"idx_p": (120, np.uint64), "idx_n": (121, np.uint32), "arc_v": (122, np.uint64), "arc_w": (123, np.uint64),
+          "arc_ls": (124, np.uint32), "arc_cov": (125, np.uint32), "arc_comp": (126, np.uint8)}
+
+
+def device_graph(hip):
+    """oatk_hip_ec_graph on the resident scan + count; returns the resident graph as numpy arrays"""
+    L = hip.L
+    L.oatk_hip_ec_graph.argtypes = [C.c_void_p]
+    hip._check(L.oatk_hip_ec_graph(hip.h), "oatk_hip_ec_graph")
+    out = {}
+    for k, (which, dt) in EG_BUF.items():
+        p, b = C.c_void_p(), C.c_uint64()
+        hip._check(L.oatk_hip_buffer(hip.h, which, C.byref(p), C.byref(b)), "oatk_hip_buffer(EG %s)" % k)
+        out[k] = np.zeros(b.value // np.dtype(dt).itemsize, dtype=dt)
+        if b.value:
+            hip._check(L.oatk_hip_d2h(hip.h, out[k].ctypes.data, p, b.value), "d2h")
+    return out
+
+
+def assert_graph_equal(D, G):
+    na = G["n_arc"]
+    assert len(D["arc_v"]) == na and len(D["idx_n"]) == 2 * G["n_vtx"]
+    for k in ("arc_v", "arc_w", "arc_cov", "arc_comp", "arc_ls"):
+        assert np.array_equal(D[k].astype(np.uint64), G[k][:na].astype(np.uint64)), k
+    assert np.array_equal(D["idx_n"].astype(np.uint64), G["idx_n"])
+    has = G["idx_n"] > 0
+    assert np.array_equal(D["idx_p"][has], G["idx_p"][has])
+
+
 def device_ec(hip, G, max_edist, c, a):
+    """G = flattened host graph, or None to correct against the graph oatk_hip_ec_graph left resident"""
     L = hip.L
     L.oatk_hip_ec.argtypes = [C.c_void_p, C.POINTER(EcGraphT), C.c_double, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double]
     L.oatk_hip_ec_stats.argtypes = [C.c_void_p, C.c_void_p]
-    g = EcGraphT(G["n_vtx"], G["n_arc"], G["idx_p"].ctypes.data, G["idx_n"].ctypes.data, G["arc_v"].ctypes.data, G["arc_w"].ctypes.data,
-                 G["arc_ls"].ctypes.data, G["arc_cov"].ctypes.data, G["arc_del"].ctypes.data)
-    hip._check(L.oatk_hip_ec(hip.h, C.byref(g), max_edist, c, 10 * c, c, a), "oatk_hip_ec")
+    if G is None:
+        hip._check(L.oatk_hip_ec(hip.h, None, max_edist, c, 10 * c, c, a), "oatk_hip_ec")
+    else:
+        g = EcGraphT(G["n_vtx"], G["n_arc"], G["idx_p"].ctypes.data, G["idx_n"].ctypes.data, G["arc_v"].ctypes.data, G["arc_w"].ctypes.data,
+                     G["arc_ls"].ctypes.data, G["arc_cov"].ctypes.data, G["arc_del"].ctypes.data)
+        hip._check(L.oatk_hip_ec(hip.h, C.byref(g), max_edist, c, 10 * c, c, a), "oatk_hip_ec")
     st = np.zeros(12, np.uint64)
     hip._check(L.oatk_hip_ec_stats(hip.h, st.ctypes.data), "oatk_hip_ec_stats")
     return st
@@ -109,8 +142,9 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("graph", ["host", "device"])
 @pytest.mark.parametrize("case", range(len(CASES)))
-def test_device_ec_matches_reference(hip, case):
+def test_device_ec_matches_reference(hip, case, graph):
     K, S, c, mk = CASES[case]
     reads = mk()
     db, scm = device_dbs(hip, reads, K, S)                  # reference-layout structs built from the device scan + count
@@ -118,7 +152,13 @@ def test_device_ec_matches_reference(hip, case):
     g = L.refx_make_graph(db, scm, 0, 0.0)                  # run_syncasm.c:109
     L.refx_consensus(db, g, 1, 1)                           # run_syncasm.c:117
     G = E.flatten_graph(g)
-    st = device_ec(hip, G, 0.02, c, 0.35)
+    if graph == "device":                                   # graph built on the device too: nothing of the EC round on the host
+        assert_graph_equal(device_graph(hip), G)
+        st = device_ec(hip, None, 0.02, c, 0.35)
+        st2 = device_ec(hip, None, 0.02, c, 0.35)           # the resident graph survives a correction
+        assert np.array_equal(st, st2)
+    else:
+        st = device_ec(hip, G, 0.02, c, 0.35)
     got = {k: fetch_ec(hip, k) for k in EC_BUF}
     # reference on the very same structs
     summary = E.reference_ec(_H(db), _H(scm), g, 0.02, c, 0.35, threads=3)

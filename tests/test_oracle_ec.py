@@ -59,3 +59,45 @@ def test_oracle_ec_side_by_side():
     R.lib().refx_scg_destroy(g)
     scm.close()
     db.close()
+
+
+def assert_ecgraph(og, want_v, want_w, want_ls, want_cov, want_idx_p, want_idx_n):
+    na = og["n_arc"]
+    assert not og["multi_arc"] and na == int(want_idx_n.sum()) and na > 0
+    assert np.array_equal(og["arc_v"], want_v[:na]) and np.array_equal(og["arc_w"], want_w[:na])
+    assert np.array_equal(og["arc_cov"], want_cov[:na])
+    assert np.array_equal(og["arc_ls"], want_ls[:na])
+    assert np.array_equal(og["idx_n"], want_idx_n)
+    has = want_idx_n > 0
+    assert np.array_equal(og["idx_p"][has], want_idx_p[has])
+
+
+@pytest.mark.parametrize("case", EC_CASES)
+def test_oracle_ecgraph_matches_reference_golden(case):
+    """oracle/ecgraph.c against the graph the compiled reference built for the golden EC cases (make_syncmer_graph +
+    scg_consensus), including the khashl-order tie rule of the arc overlaps"""
+    g = G.load(case)
+    off, occ = E.occ_lists(g["in_n_scm"], g["in_k_mer"], g["in_m_pos"], len(g["in_scm_s"]))
+    og = E.oracle_ecgraph(g["in_n_scm"], g["in_k_mer"], g["in_m_pos"], off, occ, int(g["K"]))
+    assert_ecgraph(og, g["g_arc_v"], g["g_arc_w"], g["g_arc_ls"], g["g_arc_cov"], g["g_idx_p"], g["g_idx_n"])
+
+
+@pytest.mark.skipif(not R.available(), reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("K,S,err,seed", [(101, 11, 0.01, 5), (301, 21, 0.002, 6), (1001, 31, 0.0008, 7)])
+def test_oracle_ecgraph_side_by_side(K, S, err, seed):
+    import adversarial as A
+    reads = A.hifi_like(220, 12 * K, 5 * K, seed=seed, err=err)
+    db = R.SrDb.from_reads(reads, K, S, threads=2)
+    scm = R.ScmDb(db)
+    sr0, sc0 = db.flatten(), scm.flatten()
+    g, Gd = E.ref_graph(db, scm)
+    occ_off = np.zeros(sc0["n_scm"] + 1, np.uint64)
+    occ_off[1:] = np.cumsum(sc0["cov"], dtype=np.uint64)
+    og = E.oracle_ecgraph(sr0["n_scm"], sr0["k_mer"], sr0["m_pos"], occ_off, sc0["occ"], K)
+    off2, occ2 = E.occ_lists(sr0["n_scm"], sr0["k_mer"], sr0["m_pos"], sc0["n_scm"])       # the golden test rebuilds the lists this way
+    assert np.array_equal(off2, occ_off) and np.array_equal(occ2, sc0["occ"])
+    assert_ecgraph(og, Gd["arc_v"], Gd["arc_w"], Gd["arc_ls"], Gd["arc_cov"], Gd["idx_p"], Gd["idx_n"])
+    assert np.array_equal(og["arc_comp"], Gd["arc_comp"][:og["n_arc"]])
+    R.lib().refx_scg_destroy(g)
+    scm.close()
+    db.close()
