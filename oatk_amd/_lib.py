@@ -17,6 +17,11 @@ BUF = {name: i for i, name in enumerate([
     "HOCO_L", "N_SCM", "N_NN", "N_LRL", "HO_RL", "HOCO_S", "NN_KEY", "LRL_KEY", "LRL_VAL",
     "SCM_OFF", "POS_MPOS", "POS_SMER", "POS_HASH", "POS_KID",
     "SCM_H", "SCM_S", "SCM_COV", "SCM_OCC_OFF", "SCM_OCC"])}
+# include/oatk_hip_ec.h
+BUF.update({name: 100 + i for i, name in enumerate([
+    "EC_N_SCM", "EC_SCM_OFF", "EC_KMER", "EC_MPOS", "EC_SMER", "EC_SCM_COV", "EC_SCM_DEL", "EC_SCM_OCC_OFF", "EC_SCM_OCC", "EC_ERR_DEL"])})
+BUF.update({name: 120 + i for i, name in enumerate([
+    "EG_IDX_P", "EG_IDX_N", "EG_ARC_V", "EG_ARC_W", "EG_ARC_LS", "EG_ARC_COV", "EG_ARC_COMP"])})
 TIMERS = ["hpc", "syncmer", "syncmer_n", "scan_post", "count_place", "count_sort", "count_group", "kmer_hash"]
 
 EXPORTS = [
@@ -24,7 +29,14 @@ EXPORTS = [
     "oatk_hip_stream", "oatk_hip_sync", "oatk_hip_max_k", "oatk_hip_scan", "oatk_hip_scan_host", "oatk_hip_count",
     "oatk_hip_info", "oatk_hip_buffer", "oatk_hip_d2h", "oatk_hip_set_timing", "oatk_hip_get_timing",
     "oatk_hip_debug_hash_mask", "oatk_hip_debug_force_general",
+    "oatk_hip_ec_graph", "oatk_hip_ec", "oatk_hip_ec_stats",
 ]
+
+
+class EcGraph(C.Structure):
+    """oatk_ec_graph_t (include/oatk_hip_ec.h): the reference's asmg_t flattened, host pointers"""
+    _fields_ = [("n_vtx", C.c_uint64), ("n_arc", C.c_uint64), ("idx_p", C.c_void_p), ("idx_n", C.c_void_p), ("arc_v", C.c_void_p),
+                ("arc_w", C.c_void_p), ("arc_ls", C.c_void_p), ("arc_cov", C.c_void_p), ("arc_del", C.c_void_p)]
 
 
 class Info(C.Structure):
@@ -71,5 +83,8 @@ def load():
     L.oatk_hip_get_timing.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
     L.oatk_hip_debug_hash_mask.argtypes = [vp, C.c_uint64]
     L.oatk_hip_debug_force_general.argtypes = [vp, C.c_int]
+    L.oatk_hip_ec_graph.argtypes = [vp]
+    L.oatk_hip_ec.argtypes = [vp, C.POINTER(EcGraph), C.c_double, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double]
+    L.oatk_hip_ec_stats.argtypes = [vp, vp]
     _lib = L
     return L

@@ -43,6 +43,7 @@ struct DevBuf {
 
 struct oatk_hip_ctx {
     int device = 0;
+    int n_cu = 256;
     hipStream_t stream = nullptr;
     std::string err;
     bool timing = false;
@@ -141,6 +142,7 @@ oatk_hip_ctx *oatk_hip_create(int device)
     if (hipSetDevice(device) != hipSuccess) return nullptr;
     oatk_hip_ctx *ctx = new oatk_hip_ctx();
     ctx->device = device;
+    { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) ctx->n_cu = cu; }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return nullptr; }
     for (int i = 0; i <= OATK_T_COUNT_; ++i) {
         (void) hipEventCreate(&ctx->ev[i][0]);

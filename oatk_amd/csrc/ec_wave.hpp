@@ -1,0 +1,382 @@
+// oatk_amd/csrc/ec_wave.hpp -- the error-block solver, one WAVEFRONT per block.
+//
+// Same search as dfs_search + wf_ed_core (syncerr.c:144-286, levdist.c:75-310), organised for a 64-wide wave:
+//   * strings are 2-bit packed, sixteen bases per 32-bit word, field s of word i = base 16 i + s; the read segment (ts)
+//     and the growing consensus (cs) live in LDS, gathered sixteen bases at a time from the resident hoco strings;
+//   * a Landau-Vishkin step runs with one lane GROUP per diagonal: the 64 lanes are split evenly over the (power-of-two
+//     rounded) diagonals, every lane XORs one 16-base window of its diagonal, a ballot finds the first mismatch of each
+//     group -- the common case (a correct path, 1-7 diagonals, hundreds of matching bases) takes one or two rounds;
+//   * the diagonals of a wavefront are consecutive, so a wavefront is (d0, n, k[n]); DFS frames keep it in a per-wave
+//     arena in HBM written and read with coalesced lanes;
+//   * waves pull blocks from a shared counter (block costs vary by orders of magnitude).
+// Blocks that outgrow the LDS carve-up are flagged and re-run by the BIG instantiation with every array in an HBM slab.
+//
+// The order of evaluation that the results depend on is kept exactly: a step ends at the LOWEST diagonal that reaches an
+// end, with only the diagonals below it extended (levdist.c:166-180); ties between optimum paths compare the consensus
+// and then the path (syncerr.c:216-243).
+#pragma once
+#include "ec.hpp"
+
+namespace oatk {
+
+__device__ __forceinline__ uint32_t ecw_rev_in_bytes(uint32_t x)      // reverse the four 2-bit fields of every byte
+{
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    return ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+}
+__device__ __forceinline__ uint32_t ecw_rev16(uint32_t x)             // reverse the order of the sixteen 2-bit fields
+{
+    x = __builtin_bitreverse32(x);
+    return ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+}
+// field s = base p + s of a hoco string (MSB-first bytes, syncmer.c:268-283); hs is 4-byte aligned, 8 bytes of slack behind
+__device__ __forceinline__ uint32_t ecw_src16(const uint8_t *hs, uint32_t p)
+{
+    const uint32_t *w = (const uint32_t *) hs + (p >> 4);
+    const uint64_t v = (uint64_t) ecw_rev_in_bytes(w[1]) << 32 | ecw_rev_in_bytes(w[0]);
+    return (uint32_t) (v >> ((p & 15u) << 1));
+}
+// ascending: field s = base(start + s); descending: field s = 3 ^ base(start - s).  Fields that fall before base 0 are garbage.
+__device__ __forceinline__ uint32_t ecw_gather16(const uint8_t *hs, int64_t start, bool desc)
+{
+    if (!desc) return start >= 0? ecw_src16(hs, (uint32_t) start) : ecw_src16(hs, 0) << ((uint32_t) (-start) << 1);
+    const int64_t lo = start - 15;
+    return ~(lo >= 0? ecw_rev16(ecw_src16(hs, (uint32_t) lo)) : ecw_rev16(ecw_src16(hs, 0)) >> ((uint32_t) (-lo) << 1));
+}
+// sixteen fields starting at base p of a packed array (one pad word behind the data)
+__device__ __forceinline__ uint32_t ecw_win16(const uint32_t *W, int32_t p)
+{
+    const int32_t i = p >> 4;
+    return (uint32_t) (((uint64_t) W[i + 1] << 32 | W[i]) >> ((p & 15) << 1));
+}
+__device__ __forceinline__ int32_t ecw_uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t ecw_uni64(uint64_t v)
+{
+    return (uint64_t) (uint32_t) __builtin_amdgcn_readfirstlane((int32_t) (v >> 32)) << 32 | (uint32_t) __builtin_amdgcn_readfirstlane((int32_t) v);
+}
+
+struct EcwScratch {
+    uint32_t *ts, *cs, *os;       // target, consensus, optimum consensus (packed)
+    int32_t *ka, *kb;             // two wavefront buffers, cap_w + 2 entries each
+    uint64_t *c_path, *o_path;    // current and optimum path
+    uint8_t *frames;              // DFS frame arena
+    int32_t cap_t, cap_c, cap_w, cap_path, cap_f;
+};
+
+struct EcwFrame {                 // state at the entry of one DFS level (syncerr.c:158-171), followed by k[n]
+    uint64_t arc_i, arc_end;
+    int32_t l0, score, t_end, q_end, n, d0, prev_off, koff;
+};
+
+struct EcwWave {                  // the working wavefront: diagonals d0 .. d0 + n - 1, furthest target index per diagonal in k[]
+    int32_t *k, *spare;
+    int32_t n, d0;
+};
+
+// one wavefront step (levdist.c:156-224, extension mode, no traceback); returns 1 when an end was reached
+__device__ int ecw_step(const uint32_t *ts, int32_t tl, const uint32_t *qs, int32_t ql, int32_t bw, EcwWave &wv, int32_t *buf_a, int32_t *buf_b,
+                        int32_t &t_end, int32_t &q_end)
+{
+    const int lane = threadIdx.x;
+    const int32_t n = wv.n, d0 = wv.d0;
+    int32_t *k = wv.k;
+    t_end = q_end = -1;
+    int lg = 0;                                        // lanes per diagonal = 1 << lg
+    if (n <= 32) lg = n <= 1? 6 : __builtin_clz((uint32_t) (n - 1)) - 26;      // 64 / next_pow2(n)
+    const int G = 1 << lg, c = lane & (G - 1), gbase = lane & ~(G - 1);
+    const uint64_t gmask = G == 64? ~0ULL : (1ULL << G) - 1ULL;
+    for (int32_t base = 0; base < n; base += 64) {
+        const int32_t j = base + (lane >> lg);
+        const bool valid = j < n;
+        int32_t kk = valid? k[j] : 0;
+        const int32_t dd = d0 + j;
+        const bool act0 = valid && !(kk >= tl || kk + dd >= ql);
+        bool act = act0;
+        const int32_t lim = (ql - dd < tl? ql - dd : tl) - 1;
+        while (__ballot(act)) {
+            const int32_t rem = lim - kk, o = c << 4;
+            int32_t m = 0;
+            if (act && o < rem) {
+                const uint32_t x = ecw_win16(ts, kk + 1 + o) ^ ecw_win16(qs, kk + dd + 1 + o);
+                m = x? __builtin_ctz(x) >> 1 : 16;
+                if (m > rem - o) m = rem - o;
+            }
+            const bool full = act && m == 16;
+            const uint64_t gb = (__ballot(!full) >> gbase) & gmask;
+            const int first = gb? __builtin_ctzll(gb) : 0;
+            const int32_t mm = __shfl(m, gbase + first);
+            if (act) {
+                if (gb == 0) kk += G << 4;
+                else kk += (first << 4) + mm, act = false;
+            }
+        }
+        const bool reached = act0 && (kk + dd == ql - 1 || kk == tl - 1);
+        const uint64_t rmask = __ballot(reached && c == 0);
+        if (rmask) {
+            const int fl = __builtin_ctzll(rmask);
+            const int32_t jf = base + (fl >> lg);
+            if (act0 && c == 0 && j < jf) k[j] = kk;
+            t_end = ecw_uni(__shfl(kk, fl));
+            q_end = t_end + d0 + jf;
+            __syncthreads();
+            return 1;
+        }
+        if (act0 && c == 0) k[j] = kk;
+    }
+    __syncthreads();
+    // next wavefront: diagonals d0 - 1 .. d0 + n (levdist.c:183-205)
+    int32_t *nk = wv.spare;
+    for (int32_t i = lane; i < n + 2; i += 64) {
+        const int32_t jj = i - 1;
+        int32_t v = INT32_MIN;
+        if (jj - 1 >= 0) v = k[jj - 1];
+        if (jj >= 0 && jj < n) { const int32_t u = k[jj] + 1; v = u > v? u : v; }
+        if (jj + 1 < n) { const int32_t u = k[jj + 1] + 1; v = u > v? u : v; }
+        nk[i] = v;
+    }
+    int32_t st = 0, en = n + 2;
+    const int32_t nd0 = d0 - 1;
+    if (bw < 0 || n < 2 * bw + 1) {
+        if (nd0 < -tl) ++st;
+        if (nd0 + n + 1 > ql) --en;
+    } else {
+        const int32_t lo = -bw > -tl? -bw : -tl, hi = bw > ql? bw : ql;     // the LARGER of bw and ql, as in levdist.c:108
+        while (nd0 + st < lo) ++st;
+        while (nd0 + en - 1 > hi) --en;
+    }
+    wv.n = en - st, wv.d0 = nd0 + st;
+    wv.k = nk + st;
+    wv.spare = nk == buf_a? buf_b : buf_a;
+    __syncthreads();
+    return 0;
+}
+
+// Solve one block with the whole wave.  Returns false when the scratch is too small (the block is then re-run BIG).
+__device__ bool ecw_solve_block(const EcGraph &g, const EcReads &rd, const EcWork &wk, const EcwScratch &s, double max_edist,
+                                uint32_t &status_out, uint32_t &np_out)
+{
+    const int lane = threadIdx.x;
+    const EcBlock &b = wk.b;
+    const int K = rd.K;
+    const int32_t tl = b.l;
+    int32_t bw = (int32_t) ceil((double) tl * max_edist);
+    if (bw < EC_MIN_ERR_BASE) bw = EC_MIN_ERR_BASE;
+    if (tl > s.cap_t || 2 * bw + 8 > s.cap_w) return false;
+    // target: the read segment, reverse-complemented for a leading block (get_kmer_dna_seq, syncmer.c:1237)
+    const uint8_t *hs = rd.hoco_s + (rd.off[wk.read] >> 2);
+    for (int32_t wi = lane; (wi << 4) < tl; wi += 64)
+        s.ts[wi] = b.r? ecw_gather16(hs, (int64_t) b.beg_pos + tl - 1 - (wi << 4), true) : ecw_gather16(hs, (int64_t) b.beg_pos + (wi << 4), false);
+
+    int32_t status = EC_FAILURE, n_path = 0, edist = INT32_MAX, s_edist = INT32_MAX;
+    int32_t c_len = 0, o_len = 0, np = 0;
+    int32_t score = 0, t_end = 0, q_end = 0;
+    EcwWave wv;
+    wv.k = s.ka, wv.spare = s.kb, wv.n = 1, wv.d0 = 0;
+    if (lane == 0) s.ka[0] = -1, s.c_path[0] = b.beg_utg;
+    int32_t fsz = 0, top = -1, nfr = 0;
+    __syncthreads();
+
+    auto push_frame = [&](uint64_t src) -> bool {
+        const int32_t need = ((int32_t) sizeof(EcwFrame) + 4 * wv.n + 7) & ~7;
+        if (fsz + need > s.cap_f) return false;
+        EcwFrame *f = (EcwFrame *) (s.frames + fsz);
+        if (lane == 0) {
+            f->arc_i = g.idx_p[src], f->arc_end = f->arc_i + g.idx_n[src];
+            f->l0 = c_len, f->score = score, f->t_end = t_end, f->q_end = q_end, f->n = wv.n, f->d0 = wv.d0, f->prev_off = top, f->koff = 0;
+        }
+        int32_t *sv = (int32_t *) (f + 1);
+        for (int32_t j = lane; j < wv.n; j += 64) sv[j] = wv.k[j];
+        top = fsz;
+        fsz += need;
+        ++nfr;
+        return true;
+    };
+    if (!push_frame(b.beg_utg)) return false;
+
+    while (nfr > 0) {
+        __syncthreads();
+        EcwFrame *f = (EcwFrame *) (s.frames + top);
+        const int32_t depth = nfr - 1;
+        const uint64_t a = ecw_uni64(f->arc_i), a_end = ecw_uni64(f->arc_end);
+        if (a == a_end) {                             // level exhausted: return to the parent
+            fsz = top;
+            top = ecw_uni(f->prev_off);
+            --nfr;
+            continue;
+        }
+        if (lane == 0) f->arc_i = a + 1;
+        if (g.arc_del[a]) continue;
+        // restore the state this level was entered with (syncerr.c:277-284)
+        c_len = ecw_uni(f->l0), score = ecw_uni(f->score), t_end = ecw_uni(f->t_end), q_end = ecw_uni(f->q_end);
+        wv.n = ecw_uni(f->n), wv.d0 = ecw_uni(f->d0), wv.k = s.ka, wv.spare = s.kb;
+        {
+            const int32_t *sv = (const int32_t *) (f + 1);
+            for (int32_t j = lane; j < wv.n; j += 64) s.ka[j] = sv[j];
+        }
+        const int32_t t_end0 = t_end;
+        const uint64_t w = ecw_uni64(g.arc_w[a]);
+        const int32_t ls = ecw_uni((int32_t) g.arc_ls[a]), ext = K - ls;
+        if (depth + 2 > s.cap_path || c_len + ext > s.cap_c) return false;
+        if (lane == 0) s.c_path[depth + 1] = w;
+        int32_t cn = depth + 2;                       // entries in c_path
+        {   // append the part of w's k-mer that lies beyond the overlap (syncerr.c:186-190).  With F the vertex's forward
+            // string, base t of the extension is F[ls + t] for a forward w and comp(F[K - ls - 1 - t]) for a reverse one; F itself is
+            // the first occurrence's k-mer, reverse-complemented when that occurrence is reverse: two cases remain.
+            const uint8_t *vs = rd.hoco_s + ecw_uni64(g.vtx_hs_off[w >> 1]);
+            const uint32_t mp = (uint32_t) ecw_uni((int32_t) g.vtx_mpos[w >> 1]), pos = mp >> 1;
+            const bool asc = (uint32_t) (w & 1ULL) == (mp & 1u);
+            const int32_t w0 = c_len >> 4, w1 = (c_len + ext - 1) >> 4;
+            for (int32_t wi = w0 + lane; wi <= w1; wi += 64) {
+                const int32_t t0 = (wi << 4) - c_len;
+                uint32_t x = asc? ecw_gather16(vs, (int64_t) pos + ls + t0, false) : ecw_gather16(vs, (int64_t) pos + K - 1 - ls - t0, true);
+                if (t0 < 0) {
+                    const uint32_t keep = (1u << ((uint32_t) (-t0) << 1)) - 1u;
+                    x = (s.cs[wi] & keep) | (x & ~keep);
+                }
+                s.cs[wi] = x;
+            }
+            c_len += ext;
+        }
+        __syncthreads();
+        // wf_ed_core (levdist.c:265-310)
+        for (;;) {
+            if (ecw_step(s.ts, tl, s.cs, c_len, bw, wv, s.ka, s.kb, t_end, q_end)) break;
+            ++score;
+            if (score > bw) break;
+        }
+        t_end += 1, q_end += 1;
+        const int32_t ql = c_len;
+        const int32_t sc = score + tl - t_end;        // syncerr.c:209
+        if (sc <= bw && (b.end_utg == EC_NONE || b.end_utg == w)) {
+            status = EC_SUCCESS;
+            if (sc <= edist) {
+                if (t_end > t_end0) s_edist = edist;
+                edist = sc;
+                if (b.end_utg == EC_NONE && q_end < ql) --cn;
+                if (edist == s_edist) {
+                    bool diff = q_end != o_len;
+                    if (!diff) {
+                        bool d = false;
+                        const int32_t nw = (q_end + 15) >> 4;
+                        for (int32_t wi = lane; wi < nw; wi += 64) {
+                            uint32_t x = s.cs[wi] ^ s.os[wi];
+                            if (wi == nw - 1 && (q_end & 15)) x &= (1u << ((q_end & 15) << 1)) - 1u;
+                            d |= x != 0;
+                        }
+                        diff = __ballot(d) != 0;
+                    }
+                    if (diff) status = EC_AMBISEQ;
+                    if (status == EC_SUCCESS) {
+                        bool pd = cn != np;
+                        if (!pd) {
+                            bool d = false;
+                            for (int32_t i = lane; i < cn; i += 64) d |= s.c_path[i] != s.o_path[i];
+                            pd = __ballot(d) != 0;
+                        }
+                        if (pd) status = EC_AMBISNQ;
+                    }
+                }
+                __syncthreads();
+                for (int32_t wi = lane; wi < ((q_end + 15) >> 4); wi += 64) s.os[wi] = s.cs[wi];
+                o_len = q_end;
+                for (int32_t i = lane; i < cn; i += 64) s.o_path[i] = s.c_path[i];
+                np = cn;
+            } else if (sc < s_edist) {
+                s_edist = sc;
+            }
+        }
+        if (score <= bw && ql - K <= tl + bw && ((b.end_utg != EC_NONE && b.end_utg != w) || t_end < tl)) {
+            if (n_path < EC_MAX_DFS_PATH) {           // the callee would return at once otherwise (syncerr.c:146-148)
+                if (!push_frame(w)) return false;
+            }
+        } else {
+            ++n_path;
+        }
+    }
+    __syncthreads();
+    status_out = (uint32_t) status, np_out = (uint32_t) np;
+    return true;
+}
+
+struct EcwArgs {
+    EcGraph g;
+    EcReads rd;
+    const EcWork *work;
+    uint64_t n_work;
+    const uint32_t *todo;         // optional list of work indices (BIG pass); NULL = all
+    uint64_t n_todo;
+    double max_edist;
+    uint8_t *slabs;               // per-wave HBM slab: (os, frames) or, BIG, everything
+    uint64_t slab_bytes;
+    int32_t cap_t, cap_c, cap_w, cap_path, cap_f;
+    EcBlockOut *out;              // [n_work]
+    uint64_t *path_pool;          // optimum paths; bump-allocated
+    uint64_t pool_cap;
+    unsigned long long *pool_cursor;
+    unsigned long long *next;     // work counter
+};
+
+__host__ __device__ inline uint32_t ecw_words(int32_t bases) { return (uint32_t) ((bases + 15) / 16 + 2); }
+// 32-bit words of the LDS carve-up (ts, cs, two wavefronts, two paths)
+__host__ __device__ inline uint32_t ecw_lds_words(int32_t cap_t, int32_t cap_c, int32_t cap_w, int32_t cap_path)
+{
+    return ((ecw_words(cap_t) + ecw_words(cap_c) + 2u * (uint32_t) (cap_w + 2) + 1u) & ~1u) + 4u * (uint32_t) cap_path;
+}
+__host__ __device__ inline uint64_t ecw_slab_bytes(bool big, int32_t cap_t, int32_t cap_c, int32_t cap_w, int32_t cap_path, int32_t cap_f)
+{
+    uint64_t b = ((uint64_t) ecw_words(cap_c) * 4 + 7) / 8 * 8 + (uint64_t) cap_f;
+    if (big) b += (uint64_t) ecw_lds_words(cap_t, cap_c, cap_w, cap_path) * 4;
+    return (b + 63) & ~63ULL;
+}
+
+template <bool BIG>
+__global__ __launch_bounds__(64) void ec_wave_kernel(EcwArgs a)
+{
+    extern __shared__ uint32_t ecw_lds[];
+    const int lane = threadIdx.x;
+    uint8_t *slab = a.slabs + (uint64_t) blockIdx.x * a.slab_bytes;
+    EcwScratch s;
+    s.cap_t = a.cap_t, s.cap_c = a.cap_c, s.cap_w = a.cap_w, s.cap_path = a.cap_path, s.cap_f = a.cap_f;
+    s.os = (uint32_t *) slab;
+    s.frames = slab + ((uint64_t) ecw_words(a.cap_c) * 4 + 7) / 8 * 8;
+    uint32_t *p = BIG? (uint32_t *) (s.frames + a.cap_f) : ecw_lds;
+    s.ts = p, p += ecw_words(a.cap_t);
+    s.cs = p, p += ecw_words(a.cap_c);
+    s.ka = (int32_t *) p, p += a.cap_w + 2;
+    s.kb = (int32_t *) p, p += a.cap_w + 2;
+    p = (uint32_t *) (((uintptr_t) p + 7) & ~(uintptr_t) 7);
+    s.c_path = (uint64_t *) p, p += 2 * a.cap_path;
+    s.o_path = (uint64_t *) p;
+    const uint64_t total = a.todo? a.n_todo : a.n_work;
+    for (;;) {
+        unsigned long long t = 0;
+        if (lane == 0) t = atomicAdd(a.next, 1ULL);
+        t = ecw_uni64(t);
+        if (t >= total) break;
+        const uint64_t wi = a.todo? a.todo[t] : t;
+        const EcWork &wk = a.work[wi];
+        EcBlockOut o;
+        o.status = EC_FAILURE, o.np = 0, o.path_off = 0, o.flags = 0, o.short_block = 0;
+        if (wk.b.l < EC_MIN_ERR_SEQ_LEN) {
+            o.short_block = 1;                         // syncerr.c:502-504
+        } else {
+            uint32_t st = 0, np = 0;
+            if (!ecw_solve_block(a.g, a.rd, wk, s, a.max_edist, st, np)) {
+                o.flags = 1;
+            } else {
+                o.status = st, o.np = np;
+                if (st == EC_SUCCESS && np) {
+                    unsigned long long off = 0;
+                    if (lane == 0) off = atomicAdd(a.pool_cursor, (unsigned long long) np);
+                    off = ecw_uni64(off);
+                    o.path_off = off;
+                    if (off + np <= a.pool_cap) for (uint32_t i = lane; i < np; i += 64) a.path_pool[off + i] = s.o_path[i];
+                }
+            }
+        }
+        if (lane == 0) a.out[wi] = o;
+        __syncthreads();
+    }
+}
+
+}  // namespace oatk

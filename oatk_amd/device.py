@@ -15,6 +15,10 @@ _DTYPES = {
     "NN_KEY": np.uint64, "LRL_KEY": np.uint64, "LRL_VAL": np.uint32, "SCM_OFF": np.uint64, "POS_MPOS": np.uint32,
     "POS_SMER": np.uint64, "POS_HASH": np.uint64, "POS_KID": np.uint64, "SCM_H": np.uint64, "SCM_S": np.uint64,
     "SCM_COV": np.uint32, "SCM_OCC_OFF": np.uint64, "SCM_OCC": np.uint64,
+    "EC_N_SCM": np.uint32, "EC_SCM_OFF": np.uint64, "EC_KMER": np.uint64, "EC_MPOS": np.uint32, "EC_SMER": np.uint64,
+    "EC_SCM_COV": np.uint32, "EC_SCM_DEL": np.uint8, "EC_SCM_OCC_OFF": np.uint64, "EC_SCM_OCC": np.uint64, "EC_ERR_DEL": np.uint8,
+    "EG_IDX_P": np.uint64, "EG_IDX_N": np.uint32, "EG_ARC_V": np.uint64, "EG_ARC_W": np.uint64, "EG_ARC_LS": np.uint32,
+    "EG_ARC_COV": np.uint32, "EG_ARC_COMP": np.uint8,
 }
 
 
@@ -78,6 +82,28 @@ class HipSyncasm:
 
     def count(self):
         self._check(self.L.oatk_hip_count(self.h), "oatk_hip_count")
+
+    # ---- error correction (include/oatk_hip_ec.h) ----
+    def ec_graph(self):
+        """make_syncmer_graph(sr_db, scm_db, 0, 0.) + hoco arc overlaps on the device (run_syncasm.c:109-117)"""
+        self._check(self.L.oatk_hip_ec_graph(self.h), "oatk_hip_ec_graph")
+
+    def ec(self, max_edist, c, a, graph=None):
+        """read_error_correction(sr_db, g, max_edist, c, 10 c, c, a) (run_syncasm.c:124, syncerr.c:819); `graph` = dict of
+        host arrays shaped like oatk_ec_graph_t, or None for the graph ec_graph() left resident.  Returns stats[12]."""
+        if graph is None:
+            rc = self.L.oatk_hip_ec(self.h, None, max_edist, c, 10 * c, c, a)
+        else:
+            keep = {k: np.ascontiguousarray(graph[k], dtype=dt) for k, dt in
+                    (("idx_p", np.uint64), ("idx_n", np.uint64), ("arc_v", np.uint64), ("arc_w", np.uint64), ("arc_ls", np.uint64),
+                     ("arc_cov", np.uint32), ("arc_del", np.uint8))}
+            g = _lib.EcGraph(int(graph["n_vtx"]), int(graph["n_arc"]), *[keep[k].ctypes.data for k in
+                             ("idx_p", "idx_n", "arc_v", "arc_w", "arc_ls", "arc_cov", "arc_del")])
+            rc = self.L.oatk_hip_ec(self.h, C.byref(g), max_edist, c, 10 * c, c, a)
+        self._check(rc, "oatk_hip_ec")
+        st = np.zeros(12, np.uint64)
+        self._check(self.L.oatk_hip_ec_stats(self.h, st.ctypes.data), "oatk_hip_ec_stats")
+        return st
 
     def info(self):
         i = _lib.Info()
