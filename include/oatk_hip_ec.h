@@ -38,6 +38,10 @@ int oatk_hip_ec(oatk_hip_ctx *ctx, const oatk_ec_graph_t *g, double max_edist, u
  * [5] middle blocks, [6..9] by status, [10] blocks shorter than 10 bases; plus [11] blocks re-run with large slabs */
 int oatk_hip_ec_stats(oatk_hip_ctx *ctx, uint64_t *stats12);
 
+/* Test hook: the longest block (hoco bases) the first and the second solver tier accept; longer blocks fall through to the
+ * next tier (the last one keeps its scratch in HBM and takes anything).  0 = defaults (2048, 16384).  Results never depend on it. */
+int oatk_hip_debug_ec_tiers(oatk_hip_ctx *ctx, int cap_t0, int cap_t1);
+
 /* Resident results of oatk_hip_ec (ids for oatk_hip_buffer):
  *   EC_N_SCM   u32[n_reads]      sr_t.n after correction
  *   EC_SCM_OFF u64[n_reads+1]    slots of the corrected chains

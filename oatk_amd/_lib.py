@@ -29,7 +29,7 @@ EXPORTS = [
     "oatk_hip_stream", "oatk_hip_sync", "oatk_hip_max_k", "oatk_hip_scan", "oatk_hip_scan_host", "oatk_hip_count",
     "oatk_hip_info", "oatk_hip_buffer", "oatk_hip_d2h", "oatk_hip_set_timing", "oatk_hip_get_timing",
     "oatk_hip_debug_hash_mask", "oatk_hip_debug_force_general",
-    "oatk_hip_ec_graph", "oatk_hip_ec", "oatk_hip_ec_stats",
+    "oatk_hip_ec_graph", "oatk_hip_ec", "oatk_hip_ec_stats", "oatk_hip_debug_ec_tiers",
 ]
 
 
@@ -86,5 +86,6 @@ def load():
     L.oatk_hip_ec_graph.argtypes = [vp]
     L.oatk_hip_ec.argtypes = [vp, C.POINTER(EcGraph), C.c_double, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double]
     L.oatk_hip_ec_stats.argtypes = [vp, vp]
+    L.oatk_hip_debug_ec_tiers.argtypes = [vp, C.c_int, C.c_int]
     _lib = L
     return L

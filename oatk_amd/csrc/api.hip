@@ -52,6 +52,7 @@ struct oatk_hip_ctx {
     float ms[OATK_T_COUNT_];
     uint64_t hash_mask = ~0ULL;
     bool force_general = false;   // test hook: run the general syncmer kernel even where the fast one applies
+    int ec_cap_t0 = 0, ec_cap_t1 = 0;   // test hook: block-length limits of the first two EC solver tiers (0 = default)
 
     // input (device view; owned only when uploaded through scan_host)
     const uint8_t *d_seq = nullptr;

@@ -3,7 +3,7 @@
 // Replaces, on flat arrays that stay resident in HBM:
 //   find_error_syncmers            syncerr.c:679-757   -> ec_mark_kernel, ec_arc_del_kernel
 //   error blocks of a read         syncerr.c:339-612   -> ec_blocks (device function, shared by three kernels)
-//   dfs_search + wf_ed_core        syncerr.c:144-286, levdist.c:75-310 -> ec_solve_kernel
+//   dfs_search + wf_ed_core        syncerr.c:144-286, levdist.c:75-310 -> ec_wave_kernel (ec_wave.hpp)
 //   update_syncmer_db              syncerr.c:769-814   -> ec_cov_kernel (+ a stable radix sort in api.hip)
 //
 // The graph is the reference's asmg_t in arc-array order (sorted (v,w), graph.c:70-83) as CSR over oriented vertices.
@@ -12,11 +12,8 @@
 // vertex is materialised: bases are read in place from the resident hoco strings of the reads.
 //
 // Mapping: error blocks of one read are independent (they are delimited on the ORIGINAL chain), so the unit of work is
-// one block = one lane: a depth-first search over the good-syncmer graph that extends a consensus string arc by arc
-// and re-aligns it to the read segment with a resumable Landau-Vishkin wavefront.  Per-lane state (strings, DFS frames
-// with the saved wavefront, paths) lives in a private scratch slab in HBM.  Blocks that outgrow the slab are flagged
-// and re-run with large slabs.  This is irregular, latency-bound work (~4 % of the reference's CPU time); correctness
-// (bit-identical chains) is the bar here, not a roofline.
+// one block: a depth-first search over the good-syncmer graph that extends a consensus string arc by arc and re-aligns
+// it to the read segment with a resumable Landau-Vishkin wavefront.  One WAVE solves one block (ec_wave.hpp).
 #pragma once
 #include "common.hpp"
 
@@ -178,257 +175,69 @@ __global__ void ec_count_blocks_kernel(EcReads rd, const uint8_t *scm_del, uint3
     n_blocks[r] = (uint32_t) nb;
 }
 
-struct EcWork {
-    uint32_t read;
-    EcBlock b;
+// The arcs the search may follow: the graph's arc array with the deleted arcs squeezed out (same order), each carrying
+// what the search needs to know about its target, so that one 32-byte load per arc is the only graph access.  At high
+// coverage a good syncmer has thousands of deleted arcs to one-off error syncmers; the search never sees them.
+struct __attribute__((aligned(32))) EcLiveArc {
+    uint32_t w, ls;               // target oriented vertex, overlap
+    uint32_t hs16, mpos;          // the target's k-mer: hoco byte offset / 16 of its read, pos << 1 | rev on it
+    uint32_t lp, ln;              // the target's own live arcs
+    uint32_t pad[2];
+};
+struct EcLive {
+    const uint32_t *idx_p, *idx_n;  // [2 n_vtx] first live arc / live arc count of an oriented vertex
+    const EcLiveArc *arc;
 };
 
-__global__ void ec_list_blocks_kernel(EcReads rd, const uint8_t *scm_del, const uint64_t *blk_off, EcWork *work)
+struct __attribute__((aligned(16))) EcWork {   // one block, self-contained for the solver
+    uint64_t beg_utg, end_utg;
+    uint32_t read, beg_pos;
+    int32_t l, r;
+    uint32_t hs16;                // hoco byte offset / 16 of the read
+    uint32_t lp, ln;              // live arcs of beg_utg
+    uint32_t pad;
+};
+
+__global__ void ec_list_blocks_kernel(EcReads rd, EcLive lv, const uint8_t *scm_del, const uint64_t *blk_off, EcWork *work)
 {
     uint64_t r = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rd.n_reads) return;
     const uint64_t o = rd.scm_off[r];
     const int32_t n = (int32_t) (rd.scm_off[r + 1] - o);
     EcWork *w = work + blk_off[r];
+    const uint32_t hs16 = (uint32_t) (rd.off[r] >> 6);
     ec_blocks(scm_del, rd.k_mer + o, rd.m_pos + o, n, rd.hoco_l[r], rd.K,
-              [&](int k, const EcBlock &b) { w[k].read = (uint32_t) r; w[k].b = b; }, [](int32_t, int32_t) {});
+              [&](int k, const EcBlock &b) {
+                  EcWork x;
+                  x.beg_utg = b.beg_utg, x.end_utg = b.end_utg, x.read = (uint32_t) r, x.beg_pos = b.beg_pos, x.l = b.l, x.r = b.r;
+                  x.hs16 = hs16, x.lp = lv.idx_p[b.beg_utg], x.ln = lv.idx_n[b.beg_utg], x.pad = 0;
+                  w[k] = x;
+              }, [](int32_t, int32_t) {});
 }
 
-// ---- the solver ----
-struct EcScratch {                // carved out of one lane's slab
-    uint8_t *ts, *cs, *os;        // target, current consensus, optimum consensus (one base code per byte)
-    int32_t cap_t, cap_c;
-    uint64_t *c_path;
-    int32_t cap_path;
-    int32_t *wd, *wk, *nd, *nk;   // working wavefront + next
-    int32_t cap_w;
-    uint8_t *frames;              // LIFO arena of DFS frames
-    int32_t cap_f;
-};
-
-struct EcFrame {                  // state at the entry of one DFS level (syncerr.c:158-171)
-    uint64_t arc_i, arc_end;
-    int32_t l0, score, t_end, q_end, n, prev_off;      // prev_off: arena offset of the parent's frame (-1 for the root)
-};
-
-// one wavefront step (levdist.c:156-224, extension mode, no traceback); returns 1 when an end was reached
-__device__ int ec_wf_step(const uint8_t *ts, int32_t tl, const uint8_t *qs, int32_t ql, int32_t bw, int32_t *d, int32_t *k, int32_t *nd, int32_t *nk,
-                          int32_t &n, int32_t &t_end, int32_t &q_end)
+__global__ void ec_live_flag_kernel(uint64_t n_arc, const uint8_t *arc_del, uint32_t *live)
 {
-    t_end = q_end = -1;
-    for (int32_t j = 0; j < n; ++j) {
-        int32_t kk = k[j];
-        const int32_t dd = d[j];
-        if (kk >= tl || kk + dd >= ql) continue;
-        const int32_t lim = (ql - dd < tl? ql - dd : tl) - 1;
-        while (kk < lim && ts[kk + 1] == qs[kk + dd + 1]) ++kk;
-        if (kk + dd == ql - 1 || kk == tl - 1) { t_end = kk, q_end = kk + dd; return 1; }
-        k[j] = kk;
-    }
-    nd[0] = d[0] - 1, nk[0] = k[0] + 1;
-    nd[1] = d[0], nk[1] = ((n == 1 || k[0] > k[1])? k[0] : k[1]) + 1;
-    for (int32_t j = 1; j < n - 1; ++j) {
-        int32_t kk = k[j - 1];
-        if (k[j] + 1 > kk) kk = k[j] + 1;
-        if (k[j + 1] + 1 > kk) kk = k[j + 1] + 1;
-        nd[j + 1] = d[j], nk[j + 1] = kk;
-    }
-    if (n >= 2) nd[n] = d[n - 1], nk[n] = k[n - 2] > k[n - 1] + 1? k[n - 2] : k[n - 1] + 1;
-    nd[n + 1] = d[n - 1] + 1, nk[n + 1] = k[n - 1];
-    int32_t st = 0, en = n + 2;
-    if (bw < 0 || n < 2 * bw + 1) {
-        if (nd[0] < -tl) ++st;
-        if (nd[n + 1] > ql) --en;
-    } else {
-        const int32_t lo = -bw > -tl? -bw : -tl, hi = bw > ql? bw : ql;     // the LARGER of bw and ql, as in levdist.c:108
-        while (nd[st] < lo) ++st;
-        while (nd[en - 1] > hi) --en;
-    }
-    n = en - st;
-    for (int32_t j = 0; j < n; ++j) d[j] = nd[st + j], k[j] = nk[st + j];
-    return 0;
+    uint64_t a = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (a < n_arc) live[a] = !arc_del[a];
 }
-
-// Solve one block.  Returns false when the scratch slab is too small (nothing is written then).
-__device__ bool ec_solve_block(const EcGraph &g, const EcReads &rd, const EcWork &wk, const EcScratch &s, double max_edist,
-                               uint32_t &status_out, uint32_t &np_out, uint64_t *path_out, int32_t path_cap)
+__global__ void ec_live_idx_kernel(uint64_t n_ovtx, const uint64_t *idx_p, const uint32_t *idx_n, const uint64_t *live_off, uint32_t *lidx_p, uint32_t *lidx_n)
 {
-    const EcBlock &b = wk.b;
-    const int K = rd.K;
-    const int32_t tl = b.l;
-    int32_t bw = (int32_t) ceil((double) tl * max_edist);
-    if (bw < EC_MIN_ERR_BASE) bw = EC_MIN_ERR_BASE;
-    if (tl > s.cap_t || 2 * bw + 8 > s.cap_w) return false;
-    // target: the read segment, reverse-complemented for a leading block (get_kmer_dna_seq, syncmer.c:1237)
-    const uint8_t *hs = rd.hoco_s + (rd.off[wk.read] >> 2);
-    for (int32_t i = 0; i < tl; ++i)
-        s.ts[i] = b.r? (uint8_t) (3u ^ hoco_base(hs, b.beg_pos + (uint32_t) (tl - 1 - i))) : (uint8_t) hoco_base(hs, b.beg_pos + (uint32_t) i);
-
-    int32_t status = EC_FAILURE, n_path = 0, edist = INT32_MAX, s_edist = INT32_MAX;
-    int32_t c_len = 0, o_len = 0, np = 0;            // consensus length, optimum consensus length, optimum path entries
-    int32_t depth = 0;                               // c_path holds depth + 1 entries while iterating a level
-    int32_t fsz = 0;                                 // bytes used in the frame arena
-    // working alignment state
-    int32_t score = 0, t_end = 0, q_end = 0, n = 1;
-    s.wd[0] = 0, s.wk[0] = -1;
-    s.c_path[0] = b.beg_utg;
-
-    int32_t top = -1, nfr = 0;                       // arena offset of the innermost frame, number of frames
-    auto push_frame = [&](uint64_t src) -> bool {
-        const int32_t need = ((int32_t) sizeof(EcFrame) + 8 * n + 7) & ~7;
-        if (fsz + need > s.cap_f) return false;
-        EcFrame *f = (EcFrame *) (s.frames + fsz);
-        f->arc_i = g.idx_p[src], f->arc_end = f->arc_i + g.idx_n[src];
-        f->l0 = c_len, f->score = score, f->t_end = t_end, f->q_end = q_end, f->n = n, f->prev_off = top;
-        int32_t *sv = (int32_t *) (f + 1);
-        for (int32_t j = 0; j < n; ++j) sv[2 * j] = s.wd[j], sv[2 * j + 1] = s.wk[j];
-        top = fsz;
-        fsz += need;
-        ++nfr;
-        return true;
-    };
-    if (!push_frame(b.beg_utg)) return false;
-
-    while (nfr > 0) {
-        EcFrame *f = (EcFrame *) (s.frames + top);
-        depth = nfr - 1;
-        if (f->arc_i == f->arc_end) {                 // level exhausted: return to the parent
-            fsz = top;
-            top = f->prev_off;
-            --nfr;
-            continue;
-        }
-        const uint64_t a = f->arc_i++;
-        if (g.arc_del[a]) continue;
-        // restore the state this level was entered with (syncerr.c:277-284)
-        c_len = f->l0, score = f->score, t_end = f->t_end, q_end = f->q_end, n = f->n;
-        {
-            const int32_t *sv = (const int32_t *) (f + 1);
-            for (int32_t j = 0; j < n; ++j) s.wd[j] = sv[2 * j], s.wk[j] = sv[2 * j + 1];
-        }
-        const int32_t t_end0 = f->t_end;
-        const uint64_t w = g.arc_w[a];
-        const int32_t ls = (int32_t) g.arc_ls[a], ext = K - ls;
-        if (depth + 2 > s.cap_path || c_len + ext > s.cap_c) return false;
-        s.c_path[depth + 1] = w;
-        int32_t cn = depth + 2;                       // entries in c_path
-        {   // append the part of w's k-mer that lies beyond the overlap (syncerr.c:186-190)
-            const uint8_t *vs = rd.hoco_s + g.vtx_hs_off[w >> 1];
-            const uint32_t mp = g.vtx_mpos[w >> 1], pos = mp >> 1, vrev = mp & 1u;
-            // forward string of the vertex: F[j] = vrev ? comp(base[pos + K-1-j]) : base[pos + j]
-            for (int32_t t = 0; t < ext; ++t) {
-                // w forward: F[ls + t];  w reverse: comp(F[K - ls - 1 - t])
-                const int32_t j = (w & 1ULL)? K - ls - 1 - t : ls + t;
-                uint32_t c = vrev? 3u ^ hoco_base(vs, pos + (uint32_t) (K - 1 - j)) : hoco_base(vs, pos + (uint32_t) j);
-                if (w & 1ULL) c ^= 3u;
-                s.cs[c_len + t] = (uint8_t) c;
-            }
-            c_len += ext;
-        }
-        // wf_ed_core (levdist.c:265-310)
-        for (;;) {
-            if (ec_wf_step(s.ts, tl, s.cs, c_len, bw, s.wd, s.wk, s.nd, s.nk, n, t_end, q_end)) break;
-            ++score;
-            if (score > bw) break;
-        }
-        t_end += 1, q_end += 1;
-        const int32_t ql = c_len;
-        const int32_t sc = score + tl - t_end;        // syncerr.c:209
-        if (sc <= bw && (b.end_utg == EC_NONE || b.end_utg == w)) {
-            status = EC_SUCCESS;
-            if (sc <= edist) {
-                if (t_end > t_end0) s_edist = edist;
-                edist = sc;
-                if (b.end_utg == EC_NONE && q_end < ql) --cn;
-                if (edist == s_edist) {
-                    bool diff = q_end != o_len;
-                    for (int32_t i = 0; !diff && i < q_end; ++i) diff = s.cs[i] != s.os[i];
-                    if (diff) status = EC_AMBISEQ;
-                    if (status == EC_SUCCESS) {
-                        bool pd = cn != np;
-                        for (int32_t i = 0; !pd && i < cn; ++i) pd = s.c_path[i] != path_out[i];
-                        if (pd) status = EC_AMBISNQ;
-                    }
-                }
-                if (cn > path_cap) return false;
-                for (int32_t i = 0; i < q_end; ++i) s.os[i] = s.cs[i];
-                o_len = q_end;
-                for (int32_t i = 0; i < cn; ++i) path_out[i] = s.c_path[i];
-                np = cn;
-            } else if (sc < s_edist) {
-                s_edist = sc;
-            }
-        }
-        if (score <= bw && ql - K <= tl + bw && ((b.end_utg != EC_NONE && b.end_utg != w) || t_end < tl)) {
-            if (n_path < EC_MAX_DFS_PATH) {           // the callee would return at once otherwise (syncerr.c:146-148)
-                if (!push_frame(w)) return false;
-            }
-        } else {
-            ++n_path;
-        }
-    }
-    status_out = (uint32_t) status, np_out = (uint32_t) np;
-    return true;
+    uint64_t v = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_ovtx) return;
+    const uint32_t n = idx_n[v];
+    const uint64_t p = n? live_off[idx_p[v]] : 0;
+    lidx_p[v] = (uint32_t) p, lidx_n[v] = n? (uint32_t) (live_off[idx_p[v] + n] - p) : 0u;
 }
-
-struct EcSolveArgs {
-    EcGraph g;
-    EcReads rd;
-    const EcWork *work;
-    uint64_t n_work;
-    const uint32_t *todo;         // optional list of work indices (second, large-slab pass); NULL = all
-    uint64_t n_todo;
-    double max_edist;
-    uint8_t *slabs;               // one slab per launched lane
-    uint64_t slab_bytes;
-    int32_t cap_t, cap_path, cap_w, cap_f;
-    EcBlockOut *out;              // [n_work]
-    uint64_t *path_pool;          // optimum paths; bump-allocated
-    uint64_t pool_cap;
-    unsigned long long *pool_cursor;
-};
-
-__global__ __launch_bounds__(64) void ec_solve_kernel(EcSolveArgs a)
+__global__ void ec_live_arc_kernel(uint64_t n_arc, const uint8_t *arc_del, const uint64_t *live_off, const uint64_t *arc_w, const uint32_t *arc_ls,
+                                   const uint64_t *vtx_hs_off, const uint32_t *vtx_mpos, const uint32_t *lidx_p, const uint32_t *lidx_n, EcLiveArc *larc)
 {
-    const uint64_t lane_id = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x, n_lanes = (uint64_t) gridDim.x * blockDim.x;
-    uint8_t *slab = a.slabs + lane_id * a.slab_bytes;
-    EcScratch s;
-    const int32_t cap_c = a.cap_t + a.cap_t / 8 + 2 * a.rd.K + 64;
-    uint8_t *p = slab;
-    s.cap_t = a.cap_t, s.cap_c = cap_c, s.cap_path = a.cap_path, s.cap_w = a.cap_w, s.cap_f = a.cap_f;
-    s.ts = p, p += (a.cap_t + 7) & ~7;
-    s.cs = p, p += (cap_c + 7) & ~7;
-    s.os = p, p += (cap_c + 7) & ~7;
-    s.c_path = (uint64_t *) p, p += 8 * (size_t) a.cap_path;
-    uint64_t *path_tmp = (uint64_t *) p; p += 8 * (size_t) a.cap_path;
-    s.wd = (int32_t *) p, p += 4 * (size_t) a.cap_w;
-    s.wk = (int32_t *) p, p += 4 * (size_t) a.cap_w;
-    s.nd = (int32_t *) p, p += 4 * (size_t) a.cap_w;
-    s.nk = (int32_t *) p, p += 4 * (size_t) a.cap_w;
-    s.frames = p;
-    const uint64_t total = a.todo? a.n_todo : a.n_work;
-    for (uint64_t t = lane_id; t < total; t += n_lanes) {
-        const uint64_t wi = a.todo? a.todo[t] : t;
-        const EcWork &wk = a.work[wi];
-        EcBlockOut o;
-        o.status = EC_FAILURE, o.np = 0, o.path_off = 0, o.flags = 0, o.short_block = 0;
-        if (wk.b.l < EC_MIN_ERR_SEQ_LEN) {
-            o.short_block = 1;                         // syncerr.c:502-504
-        } else {
-            uint32_t st = 0, np = 0;
-            if (!ec_solve_block(a.g, a.rd, wk, s, a.max_edist, st, np, path_tmp, a.cap_path)) {
-                o.flags = 1;
-            } else {
-                o.status = st, o.np = np;
-                if (st == EC_SUCCESS && np) {
-                    const unsigned long long off = atomicAdd(a.pool_cursor, (unsigned long long) np);
-                    o.path_off = off;
-                    if (off + np <= a.pool_cap) for (uint32_t i = 0; i < np; ++i) a.path_pool[off + i] = path_tmp[i];
-                }
-            }
-        }
-        a.out[wi] = o;
-    }
+    uint64_t a = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n_arc || arc_del[a]) return;
+    const uint64_t w = arc_w[a];
+    EcLiveArc x;
+    x.w = (uint32_t) w, x.ls = arc_ls[a], x.hs16 = (uint32_t) (vtx_hs_off[w >> 1] >> 4), x.mpos = vtx_mpos[w >> 1];
+    x.lp = lidx_p[w], x.ln = lidx_n[w], x.pad[0] = x.pad[1] = 0;
+    larc[live_off[a]] = x;
 }
 
 // ---- assemble the corrected chains (syncerr.c:513-542, :585-612): pass 0 counts, pass 1 writes ----

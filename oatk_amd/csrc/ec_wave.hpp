@@ -1,15 +1,20 @@
 // oatk_amd/csrc/ec_wave.hpp -- the error-block solver, one WAVEFRONT per block.
 //
 // Same search as dfs_search + wf_ed_core (syncerr.c:144-286, levdist.c:75-310), organised for a 64-wide wave:
-//   * strings are 2-bit packed, sixteen bases per 32-bit word, field s of word i = base 16 i + s; the read segment (ts)
-//     and the growing consensus (cs) live in LDS, gathered sixteen bases at a time from the resident hoco strings;
+//   * strings are 2-bit packed, sixteen bases per 32-bit word, field s of word i = base 16 i + s; the read segment (ts),
+//     the growing consensus (cs) and the optimum consensus (os) live in LDS, gathered sixteen bases at a time from the
+//     resident hoco strings;
 //   * a Landau-Vishkin step runs with one lane GROUP per diagonal: the 64 lanes are split evenly over the (power-of-two
 //     rounded) diagonals, every lane XORs one 16-base window of its diagonal, a ballot finds the first mismatch of each
 //     group -- the common case (a correct path, 1-7 diagonals, hundreds of matching bases) takes one or two rounds;
-//   * the diagonals of a wavefront are consecutive, so a wavefront is (d0, n, k[n]); DFS frames keep it in a per-wave
-//     arena in HBM written and read with coalesced lanes;
-//   * waves pull blocks from a shared counter (block costs vary by orders of magnitude).
-// Blocks that outgrow the LDS carve-up are flagged and re-run by the BIG instantiation with every array in an HBM slab.
+//   * the diagonals of a wavefront are consecutive, so a wavefront is (d0, n, k[n]); DFS frames keep it in an LDS arena;
+//   * the work is latency-bound (a block is a chain of dependent random HBM reads), so the chain is kept short: a block
+//     descriptor and a live-arc record carry everything the search needs next (ec.hpp: EcWork, EcLiveArc), and the first
+//     arc of the vertex being entered is fetched while its k-mer is gathered and aligned;
+//   * waves pull blocks eight at a time from a shared counter (block costs vary by orders of magnitude) and take space
+//     for optimum paths from the pool in chunks -- one contended atomic per many blocks.
+// Blocks that outgrow a tier's LDS carve-up are flagged and re-run by a larger tier; the last tier (BIG) keeps every
+// array in an HBM slab and has no limit but the slab.
 //
 // The order of evaluation that the results depend on is kept exactly: a step ends at the LOWEST diagonal that reaches an
 // end, with only the diagonals below it extended (levdist.c:166-180); ties between optimum paths compare the consensus
@@ -50,10 +55,16 @@ __device__ __forceinline__ uint32_t ecw_win16(const uint32_t *W, int32_t p)
     return (uint32_t) (((uint64_t) W[i + 1] << 32 | W[i]) >> ((p & 15) << 1));
 }
 __device__ __forceinline__ int32_t ecw_uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ uint64_t ecw_uni64(uint64_t v)
-{
-    return (uint64_t) (uint32_t) __builtin_amdgcn_readfirstlane((int32_t) (v >> 32)) << 32 | (uint32_t) __builtin_amdgcn_readfirstlane((int32_t) v);
-}
+__device__ __forceinline__ uint32_t ecw_uniu(uint32_t v) { return (uint32_t) __builtin_amdgcn_readfirstlane((int32_t) v); }
+__device__ __forceinline__ uint64_t ecw_uni64(uint64_t v) { return (uint64_t) ecw_uniu((uint32_t) (v >> 32)) << 32 | ecw_uniu((uint32_t) v); }
+
+#ifdef ECW_PROF
+#define ECW_T(i) do { const unsigned long long _t = __builtin_readcyclecounter(); s.prof[i] += _t - s.t_last; s.t_last = _t; } while (0)
+#define ECW_C(i, v) do { s.prof[i] += (v); } while (0)
+#else
+#define ECW_T(i) do {} while (0)
+#define ECW_C(i, v) do {} while (0)
+#endif
 
 struct EcwScratch {
     uint32_t *ts, *cs, *os;       // target, consensus, optimum consensus (packed)
@@ -61,11 +72,14 @@ struct EcwScratch {
     uint64_t *c_path, *o_path;    // current and optimum path
     uint8_t *frames;              // DFS frame arena
     int32_t cap_t, cap_c, cap_w, cap_path, cap_f;
+#ifdef ECW_PROF
+    mutable unsigned long long prof[32], t_last;
+#endif
 };
 
 struct EcwFrame {                 // state at the entry of one DFS level (syncerr.c:158-171), followed by k[n]
-    uint64_t arc_i, arc_end;
-    int32_t l0, score, t_end, q_end, n, d0, prev_off, koff;
+    uint32_t arc_i, arc_end;
+    int32_t l0, score, t_end, q_end, n, d0, prev_off, pad;
 };
 
 struct EcwWave {                  // the working wavefront: diagonals d0 .. d0 + n - 1, furthest target index per diagonal in k[]
@@ -151,38 +165,57 @@ __device__ int ecw_step(const uint32_t *ts, int32_t tl, const uint32_t *qs, int3
     return 0;
 }
 
-// Solve one block with the whole wave.  Returns false when the scratch is too small (the block is then re-run BIG).
-__device__ bool ecw_solve_block(const EcGraph &g, const EcReads &rd, const EcWork &wk, const EcwScratch &s, double max_edist,
+// a live-arc record in flight: issued as two loads, made uniform only where it is used
+struct EcwArcRegs {
+    uint4 a;                      // w, ls, hs16, mpos
+    uint2 b;                      // lp, ln
+};
+__device__ __forceinline__ EcwArcRegs ecw_arc_load(const EcLiveArc *arc, uint32_t i)
+{
+    EcwArcRegs r;
+    const uint4 *q = (const uint4 *) (arc + i);
+    r.a = q[0];
+    r.b = *(const uint2 *) (q + 1);
+    return r;
+}
+
+// Solve one block with the whole wave.  Returns false when the scratch is too small (the block is then re-run by a larger tier).
+__device__ bool ecw_solve_block(const EcLive &lv, const EcReads &rd, const EcWork &wk, const EcwScratch &s, double max_edist,
                                 uint32_t &status_out, uint32_t &np_out)
 {
     const int lane = threadIdx.x;
-    const EcBlock &b = wk.b;
     const int K = rd.K;
-    const int32_t tl = b.l;
+    const int32_t tl = wk.l;
     int32_t bw = (int32_t) ceil((double) tl * max_edist);
     if (bw < EC_MIN_ERR_BASE) bw = EC_MIN_ERR_BASE;
-    if (tl > s.cap_t || 2 * bw + 8 > s.cap_w) return false;
+    ECW_C(16 + (31 - __builtin_clz((uint32_t) tl | 1u)), 1);                  // 16..: histogram of log2(tl)
+    if (tl > s.cap_t || 2 * bw + 8 > s.cap_w) { ECW_C(11, 1); return false; }
+    // the first arc out of the source is fetched while the target is gathered
+    EcwArcRegs pre;
+    pre.a = make_uint4(0, 0, 0, 0), pre.b = make_uint2(0, 0);
+    uint32_t pre_idx = 0xFFFFFFFFu;
+    if (wk.ln) pre = ecw_arc_load(lv.arc, wk.lp), pre_idx = wk.lp;
     // target: the read segment, reverse-complemented for a leading block (get_kmer_dna_seq, syncmer.c:1237)
-    const uint8_t *hs = rd.hoco_s + (rd.off[wk.read] >> 2);
+    const uint8_t *hs = rd.hoco_s + ((uint64_t) wk.hs16 << 4);
     for (int32_t wi = lane; (wi << 4) < tl; wi += 64)
-        s.ts[wi] = b.r? ecw_gather16(hs, (int64_t) b.beg_pos + tl - 1 - (wi << 4), true) : ecw_gather16(hs, (int64_t) b.beg_pos + (wi << 4), false);
-
+        s.ts[wi] = wk.r? ecw_gather16(hs, (int64_t) wk.beg_pos + tl - 1 - (wi << 4), true) : ecw_gather16(hs, (int64_t) wk.beg_pos + (wi << 4), false);
+    ECW_T(0);                                          // 0: target gather
     int32_t status = EC_FAILURE, n_path = 0, edist = INT32_MAX, s_edist = INT32_MAX;
     int32_t c_len = 0, o_len = 0, np = 0;
     int32_t score = 0, t_end = 0, q_end = 0;
     EcwWave wv;
     wv.k = s.ka, wv.spare = s.kb, wv.n = 1, wv.d0 = 0;
-    if (lane == 0) s.ka[0] = -1, s.c_path[0] = b.beg_utg;
+    if (lane == 0) s.ka[0] = -1, s.c_path[0] = wk.beg_utg;
     int32_t fsz = 0, top = -1, nfr = 0;
     __syncthreads();
 
-    auto push_frame = [&](uint64_t src) -> bool {
+    auto push_frame = [&](uint32_t lp, uint32_t ln) -> bool {
         const int32_t need = ((int32_t) sizeof(EcwFrame) + 4 * wv.n + 7) & ~7;
         if (fsz + need > s.cap_f) return false;
         EcwFrame *f = (EcwFrame *) (s.frames + fsz);
         if (lane == 0) {
-            f->arc_i = g.idx_p[src], f->arc_end = f->arc_i + g.idx_n[src];
-            f->l0 = c_len, f->score = score, f->t_end = t_end, f->q_end = q_end, f->n = wv.n, f->d0 = wv.d0, f->prev_off = top, f->koff = 0;
+            f->arc_i = lp, f->arc_end = lp + ln;
+            f->l0 = c_len, f->score = score, f->t_end = t_end, f->q_end = q_end, f->n = wv.n, f->d0 = wv.d0, f->prev_off = top;
         }
         int32_t *sv = (int32_t *) (f + 1);
         for (int32_t j = lane; j < wv.n; j += 64) sv[j] = wv.k[j];
@@ -191,21 +224,26 @@ __device__ bool ecw_solve_block(const EcGraph &g, const EcReads &rd, const EcWor
         ++nfr;
         return true;
     };
-    if (!push_frame(b.beg_utg)) return false;
+    if (!push_frame(wk.lp, wk.ln)) { ECW_C(12, 1); return false; }
 
     while (nfr > 0) {
         __syncthreads();
         EcwFrame *f = (EcwFrame *) (s.frames + top);
         const int32_t depth = nfr - 1;
-        const uint64_t a = ecw_uni64(f->arc_i), a_end = ecw_uni64(f->arc_end);
+        const uint32_t a = ecw_uniu(f->arc_i), a_end = ecw_uniu(f->arc_end);
         if (a == a_end) {                             // level exhausted: return to the parent
             fsz = top;
             top = ecw_uni(f->prev_off);
             --nfr;
+            ECW_T(1);                                  // 1: pops
             continue;
         }
         if (lane == 0) f->arc_i = a + 1;
-        if (g.arc_del[a]) continue;
+        ECW_C(8, 1);                                   // 8: arcs tried
+        if (pre_idx != a) pre = ecw_arc_load(lv.arc, a);
+        const uint64_t w = ecw_uniu(pre.a.x);
+        const int32_t ls = (int32_t) ecw_uniu(pre.a.y), ext = K - ls;
+        const uint32_t w_hs16 = ecw_uniu(pre.a.z), w_mpos = ecw_uniu(pre.a.w), w_lp = ecw_uniu(pre.b.x), w_ln = ecw_uniu(pre.b.y);
         // restore the state this level was entered with (syncerr.c:277-284)
         c_len = ecw_uni(f->l0), score = ecw_uni(f->score), t_end = ecw_uni(f->t_end), q_end = ecw_uni(f->q_end);
         wv.n = ecw_uni(f->n), wv.d0 = ecw_uni(f->d0), wv.k = s.ka, wv.spare = s.kb;
@@ -214,17 +252,19 @@ __device__ bool ecw_solve_block(const EcGraph &g, const EcReads &rd, const EcWor
             for (int32_t j = lane; j < wv.n; j += 64) s.ka[j] = sv[j];
         }
         const int32_t t_end0 = t_end;
-        const uint64_t w = ecw_uni64(g.arc_w[a]);
-        const int32_t ls = ecw_uni((int32_t) g.arc_ls[a]), ext = K - ls;
-        if (depth + 2 > s.cap_path || c_len + ext > s.cap_c) return false;
+        if (depth + 2 > s.cap_path || c_len + ext > s.cap_c) { ECW_C(depth + 2 > s.cap_path? 13 : 14, 1); return false; }
         if (lane == 0) s.c_path[depth + 1] = w;
         int32_t cn = depth + 2;                       // entries in c_path
+        // the arc most likely to be tried next: the first one out of w (in flight during the gather and the alignment)
+        pre_idx = 0xFFFFFFFFu;
+        if (w_ln) pre = ecw_arc_load(lv.arc, w_lp), pre_idx = w_lp;
+        ECW_T(3);                                      // 3: restore + arc fetch
         {   // append the part of w's k-mer that lies beyond the overlap (syncerr.c:186-190).  With F the vertex's forward
             // string, base t of the extension is F[ls + t] for a forward w and comp(F[K - ls - 1 - t]) for a reverse one; F itself is
             // the first occurrence's k-mer, reverse-complemented when that occurrence is reverse: two cases remain.
-            const uint8_t *vs = rd.hoco_s + ecw_uni64(g.vtx_hs_off[w >> 1]);
-            const uint32_t mp = (uint32_t) ecw_uni((int32_t) g.vtx_mpos[w >> 1]), pos = mp >> 1;
-            const bool asc = (uint32_t) (w & 1ULL) == (mp & 1u);
+            const uint8_t *vs = rd.hoco_s + ((uint64_t) w_hs16 << 4);
+            const uint32_t pos = w_mpos >> 1;
+            const bool asc = (uint32_t) (w & 1ULL) == (w_mpos & 1u);
             const int32_t w0 = c_len >> 4, w1 = (c_len + ext - 1) >> 4;
             for (int32_t wi = w0 + lane; wi <= w1; wi += 64) {
                 const int32_t t0 = (wi << 4) - c_len;
@@ -238,21 +278,24 @@ __device__ bool ecw_solve_block(const EcGraph &g, const EcReads &rd, const EcWor
             c_len += ext;
         }
         __syncthreads();
+        ECW_T(4);                                      // 4: consensus append
         // wf_ed_core (levdist.c:265-310)
         for (;;) {
             if (ecw_step(s.ts, tl, s.cs, c_len, bw, wv, s.ka, s.kb, t_end, q_end)) break;
             ++score;
+            ECW_C(9, 1);                               // 9: wavefront steps beyond the first
             if (score > bw) break;
         }
+        ECW_T(5);                                      // 5: wavefront steps
         t_end += 1, q_end += 1;
         const int32_t ql = c_len;
         const int32_t sc = score + tl - t_end;        // syncerr.c:209
-        if (sc <= bw && (b.end_utg == EC_NONE || b.end_utg == w)) {
+        if (sc <= bw && (wk.end_utg == EC_NONE || wk.end_utg == w)) {
             status = EC_SUCCESS;
             if (sc <= edist) {
                 if (t_end > t_end0) s_edist = edist;
                 edist = sc;
-                if (b.end_utg == EC_NONE && q_end < ql) --cn;
+                if (wk.end_utg == EC_NONE && q_end < ql) --cn;
                 if (edist == s_edist) {
                     bool diff = q_end != o_len;
                     if (!diff) {
@@ -285,48 +328,49 @@ __device__ bool ecw_solve_block(const EcGraph &g, const EcReads &rd, const EcWor
                 s_edist = sc;
             }
         }
-        if (score <= bw && ql - K <= tl + bw && ((b.end_utg != EC_NONE && b.end_utg != w) || t_end < tl)) {
+        if (score <= bw && ql - K <= tl + bw && ((wk.end_utg != EC_NONE && wk.end_utg != w) || t_end < tl)) {
             if (n_path < EC_MAX_DFS_PATH) {           // the callee would return at once otherwise (syncerr.c:146-148)
-                if (!push_frame(w)) return false;
+                if (!push_frame(w_lp, w_ln)) { ECW_C(12, 1); return false; }
             }
         } else {
             ++n_path;
         }
+        ECW_T(6);                                      // 6: result handling + push
     }
     __syncthreads();
     status_out = (uint32_t) status, np_out = (uint32_t) np;
     return true;
 }
 
+#define ECW_BATCH 8               // blocks taken from the queue per atomic
+#define ECW_POOL_CHUNK 512        // path-pool entries taken per atomic
+
 struct EcwArgs {
-    EcGraph g;
+    EcLive lv;
     EcReads rd;
     const EcWork *work;
     uint64_t n_work;
-    const uint32_t *todo;         // optional list of work indices (BIG pass); NULL = all
+    const uint32_t *todo;         // optional list of work indices (larger tiers); NULL = all
     uint64_t n_todo;
     double max_edist;
-    uint8_t *slabs;               // per-wave HBM slab: (os, frames) or, BIG, everything
+    uint8_t *slabs;               // BIG: one HBM slab per wave with every array
     uint64_t slab_bytes;
     int32_t cap_t, cap_c, cap_w, cap_path, cap_f;
     EcBlockOut *out;              // [n_work]
-    uint64_t *path_pool;          // optimum paths; bump-allocated
+    uint64_t *path_pool;          // optimum paths; bump-allocated in chunks
     uint64_t pool_cap;
     unsigned long long *pool_cursor;
     unsigned long long *next;     // work counter
+#ifdef ECW_PROF
+    unsigned long long *prof;
+#endif
 };
 
 __host__ __device__ inline uint32_t ecw_words(int32_t bases) { return (uint32_t) ((bases + 15) / 16 + 2); }
-// 32-bit words of the LDS carve-up (ts, cs, two wavefronts, two paths)
-__host__ __device__ inline uint32_t ecw_lds_words(int32_t cap_t, int32_t cap_c, int32_t cap_w, int32_t cap_path)
+// 32-bit words of one wave's carve-up: ts, cs, os, two wavefronts, two paths, frames
+__host__ __device__ inline uint32_t ecw_scratch_words(int32_t cap_t, int32_t cap_c, int32_t cap_w, int32_t cap_path, int32_t cap_f)
 {
-    return ((ecw_words(cap_t) + ecw_words(cap_c) + 2u * (uint32_t) (cap_w + 2) + 1u) & ~1u) + 4u * (uint32_t) cap_path;
-}
-__host__ __device__ inline uint64_t ecw_slab_bytes(bool big, int32_t cap_t, int32_t cap_c, int32_t cap_w, int32_t cap_path, int32_t cap_f)
-{
-    uint64_t b = ((uint64_t) ecw_words(cap_c) * 4 + 7) / 8 * 8 + (uint64_t) cap_f;
-    if (big) b += (uint64_t) ecw_lds_words(cap_t, cap_c, cap_w, cap_path) * 4;
-    return (b + 63) & ~63ULL;
+    return ((ecw_words(cap_t) + 2u * ecw_words(cap_c) + 2u * (uint32_t) (cap_w + 2) + 1u) & ~1u) + 4u * (uint32_t) cap_path + (uint32_t) cap_f / 4u;
 }
 
 template <bool BIG>
@@ -334,49 +378,78 @@ __global__ __launch_bounds__(64) void ec_wave_kernel(EcwArgs a)
 {
     extern __shared__ uint32_t ecw_lds[];
     const int lane = threadIdx.x;
-    uint8_t *slab = a.slabs + (uint64_t) blockIdx.x * a.slab_bytes;
     EcwScratch s;
     s.cap_t = a.cap_t, s.cap_c = a.cap_c, s.cap_w = a.cap_w, s.cap_path = a.cap_path, s.cap_f = a.cap_f;
-    s.os = (uint32_t *) slab;
-    s.frames = slab + ((uint64_t) ecw_words(a.cap_c) * 4 + 7) / 8 * 8;
-    uint32_t *p = BIG? (uint32_t *) (s.frames + a.cap_f) : ecw_lds;
+    uint32_t *p = BIG? (uint32_t *) (a.slabs + (uint64_t) blockIdx.x * a.slab_bytes) : ecw_lds;
     s.ts = p, p += ecw_words(a.cap_t);
     s.cs = p, p += ecw_words(a.cap_c);
+    s.os = p, p += ecw_words(a.cap_c);
     s.ka = (int32_t *) p, p += a.cap_w + 2;
     s.kb = (int32_t *) p, p += a.cap_w + 2;
     p = (uint32_t *) (((uintptr_t) p + 7) & ~(uintptr_t) 7);
     s.c_path = (uint64_t *) p, p += 2 * a.cap_path;
-    s.o_path = (uint64_t *) p;
+    s.o_path = (uint64_t *) p, p += 2 * a.cap_path;
+    s.frames = (uint8_t *) p;
+#ifdef ECW_PROF
+    for (int i = 0; i < 32; ++i) s.prof[i] = 0;
+    s.t_last = __builtin_readcyclecounter();
+#endif
     const uint64_t total = a.todo? a.n_todo : a.n_work;
+    uint64_t pool_at = 0, pool_end = 0;                // this wave's chunk of the path pool
     for (;;) {
-        unsigned long long t = 0;
-        if (lane == 0) t = atomicAdd(a.next, 1ULL);
-        t = ecw_uni64(t);
-        if (t >= total) break;
-        const uint64_t wi = a.todo? a.todo[t] : t;
-        const EcWork &wk = a.work[wi];
-        EcBlockOut o;
-        o.status = EC_FAILURE, o.np = 0, o.path_off = 0, o.flags = 0, o.short_block = 0;
-        if (wk.b.l < EC_MIN_ERR_SEQ_LEN) {
-            o.short_block = 1;                         // syncerr.c:502-504
-        } else {
-            uint32_t st = 0, np = 0;
-            if (!ecw_solve_block(a.g, a.rd, wk, s, a.max_edist, st, np)) {
-                o.flags = 1;
+        ECW_T(7);                                      // 7: queue + output
+        unsigned long long t0 = 0;
+        if (lane == 0) t0 = atomicAdd(a.next, (unsigned long long) ECW_BATCH);
+        t0 = ecw_uni64(t0);
+        if (t0 >= total) break;
+        const int cnt = total - t0 < ECW_BATCH? (int) (total - t0) : ECW_BATCH;
+        // lane i holds block i of the batch
+        uint64_t my_wi = 0;
+        uint4 m0 = make_uint4(0, 0, 0, 0), m1 = m0, m2 = m0;
+        if (lane < cnt) {
+            my_wi = a.todo? a.todo[t0 + lane] : t0 + lane;
+            const uint4 *q = (const uint4 *) (a.work + my_wi);
+            m0 = q[0], m1 = q[1], m2 = q[2];
+        }
+        for (int i = 0; i < cnt; ++i) {
+            EcWork wk;
+            const uint64_t wi = ecw_uni64(__shfl(my_wi, i));
+            wk.beg_utg = (uint64_t) ecw_uniu(__shfl(m0.y, i)) << 32 | ecw_uniu(__shfl(m0.x, i));
+            wk.end_utg = (uint64_t) ecw_uniu(__shfl(m0.w, i)) << 32 | ecw_uniu(__shfl(m0.z, i));
+            wk.read = ecw_uniu(__shfl(m1.x, i)), wk.beg_pos = ecw_uniu(__shfl(m1.y, i));
+            wk.l = (int32_t) ecw_uniu(__shfl(m1.z, i)), wk.r = (int32_t) ecw_uniu(__shfl(m1.w, i));
+            wk.hs16 = ecw_uniu(__shfl(m2.x, i)), wk.lp = ecw_uniu(__shfl(m2.y, i)), wk.ln = ecw_uniu(__shfl(m2.z, i)), wk.pad = 0;
+            EcBlockOut o;
+            o.status = EC_FAILURE, o.np = 0, o.path_off = 0, o.flags = 0, o.short_block = 0;
+            if (wk.l < EC_MIN_ERR_SEQ_LEN) {
+                o.short_block = 1;                     // syncerr.c:502-504
             } else {
-                o.status = st, o.np = np;
-                if (st == EC_SUCCESS && np) {
-                    unsigned long long off = 0;
-                    if (lane == 0) off = atomicAdd(a.pool_cursor, (unsigned long long) np);
-                    off = ecw_uni64(off);
-                    o.path_off = off;
-                    if (off + np <= a.pool_cap) for (uint32_t i = lane; i < np; i += 64) a.path_pool[off + i] = s.o_path[i];
+                uint32_t st = 0, np = 0;
+                if (!ecw_solve_block(a.lv, a.rd, wk, s, a.max_edist, st, np)) {
+                    o.flags = 1;
+                } else {
+                    o.status = st, o.np = np;
+                    if (st == EC_SUCCESS && np) {
+                        if (pool_at + np > pool_end) {
+                            const unsigned long long want = np > ECW_POOL_CHUNK? np : ECW_POOL_CHUNK;
+                            unsigned long long off = 0;
+                            if (lane == 0) off = atomicAdd(a.pool_cursor, want);
+                            pool_at = ecw_uni64(off), pool_end = pool_at + want;
+                        }
+                        o.path_off = pool_at;
+                        if (pool_at + np <= a.pool_cap) for (uint32_t j = lane; j < np; j += 64) a.path_pool[pool_at + j] = s.o_path[j];
+                        pool_at += np;
+                    }
                 }
             }
+            if (lane == 0) a.out[wi] = o;
+            __syncthreads();
+            ECW_C(10, 1);                              // 10: blocks
         }
-        if (lane == 0) a.out[wi] = o;
-        __syncthreads();
     }
+#ifdef ECW_PROF
+    if (lane == 0) for (int i = 0; i < 32; ++i) atomicAdd(a.prof + i, s.prof[i]);
+#endif
 }
 
 }  // namespace oatk

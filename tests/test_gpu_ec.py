@@ -142,17 +142,20 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("graph", ["host", "device"])
+@pytest.mark.parametrize("graph", ["host", "device", "device-tiers"])
 @pytest.mark.parametrize("case", range(len(CASES)))
 def test_device_ec_matches_reference(hip, case, graph):
     K, S, c, mk = CASES[case]
     reads = mk()
+    # tiny first tiers: most blocks run in the large-LDS tier and in the HBM-slab tier
+    t0, t1 = (48, 160) if graph == "device-tiers" else (0, 0)
+    hip._check(hip.L.oatk_hip_debug_ec_tiers(hip.h, t0, t1), "oatk_hip_debug_ec_tiers")
     db, scm = device_dbs(hip, reads, K, S)                  # reference-layout structs built from the device scan + count
     L = R.lib()
     g = L.refx_make_graph(db, scm, 0, 0.0)                  # run_syncasm.c:109
     L.refx_consensus(db, g, 1, 1)                           # run_syncasm.c:117
     G = E.flatten_graph(g)
-    if graph == "device":                                   # graph built on the device too: nothing of the EC round on the host
+    if graph != "host":                                     # graph built on the device too: nothing of the EC round on the host
         assert_graph_equal(device_graph(hip), G)
         st = device_ec(hip, None, 0.02, c, 0.35)
         st2 = device_ec(hip, None, 0.02, c, 0.35)           # the resident graph survives a correction
@@ -176,5 +179,8 @@ def test_device_ec_matches_reference(hip, case, graph):
     assert total == summary["total"] and total > 0
     assert int(st[2] + st[7]) == summary["corrected"] and int(st[1] + st[6]) == summary["uncorrected"]
     assert int(st[3] + st[8]) == summary["ambiseq"] and int(st[4] + st[9]) == summary["ambipath"]   # the reference prints stats[3]+[8] under "ambiguous seqs"
+    if graph == "device-tiers":
+        assert int(st[11]) > 0                               # blocks did fall through
+        hip._check(hip.L.oatk_hip_debug_ec_tiers(hip.h, 0, 0), "oatk_hip_debug_ec_tiers")
     L.refx_scg_destroy(g)
     rscm.close(), rdb.close()
