@@ -260,7 +260,9 @@ struct EcAssembleArgs {
 __global__ void ec_assemble_kernel(EcAssembleArgs a)
 {
     uint64_t r = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= a.rd.n_reads) return;
+    uint32_t loc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // this lane's share of stats[11]; one atomic per wave and counter
+    const bool live = r < a.rd.n_reads;
+    if (live) {
     const uint64_t o = a.rd.scm_off[r];
     const int32_t n = (int32_t) (a.rd.scm_off[r + 1] - o);
     const uint64_t *km = a.rd.k_mer + o;
@@ -276,9 +278,9 @@ __global__ void ec_assemble_kernel(EcAssembleArgs a)
         [&](int k, const EcBlock &b) {
             const EcBlockOut &x = bo[k];
             if (a.pass == 0) {
-                if (x.short_block) atomicAdd(&a.stats[10], 1ULL);
-                else if (b.end_utg == EC_NONE) { atomicAdd(&a.stats[0], 1ULL); atomicAdd(&a.stats[1 + x.status], 1ULL); }
-                else { atomicAdd(&a.stats[5], 1ULL); atomicAdd(&a.stats[6 + x.status], 1ULL); }
+                if (x.short_block) ++loc[10];
+                else if (b.end_utg == EC_NONE) ++loc[0], ++loc[1 + x.status];
+                else ++loc[5], ++loc[6 + x.status];
             }
             if (x.status == EC_SUCCESS) {
                 const uint64_t *path = a.path_pool + x.path_off;
@@ -305,6 +307,14 @@ __global__ void ec_assemble_kernel(EcAssembleArgs a)
         cnt = (uint32_t) n;
     }
     if (!a.pass) a.new_n[r] = cnt;
+    }
+    if (!a.pass) {
+        for (int i = 0; i < 11; ++i) {
+            uint32_t v = loc[i];
+            for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d);
+            if ((threadIdx.x & 63) == 0 && v) atomicAdd(&a.stats[i], (unsigned long long) v);
+        }
+    }
 }
 
 // ---- update_syncmer_db (syncerr.c:769-814): coverage, forward-strand presence; occurrence lists come from a stable sort ----

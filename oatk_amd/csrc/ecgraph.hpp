@@ -5,8 +5,10 @@
 //   make_syncmer_graph(sr_db, scm_db, 0, 0.)   syncasm.c:203-299  -> egr_pair_keys_kernel, one 64-bit radix sort, a run-length
 //                                                                    encode (= the khashl arc counter :242-261), egr_expand /
 //                                                                    egr_unpack kernels, a second sort into (v, w) order
-//   asmg_arc_index / asmg_arc_fix_symm          graph.c:85-113, :205-233 -> egr_index_kernel (+ the self-complement flag flip)
-//   arc overlaps of scg_consensus(hoco)         syncasm.c:793-812, calc_syncmer_overlap :477-582 -> egr_overlap_kernel
+//   asmg_arc_index / asmg_arc_fix_symm          graph.c:85-113, :205-233 -> egr_unpack_kernel (+ the self-complement flag flip)
+//   arc overlaps of scg_consensus(hoco)         syncasm.c:793-812, calc_syncmer_overlap :477-582 -> egr_mode_kernel: the distance
+//                                                                    of every adjacent pair rides through the key sort, so a run
+//                                                                    of equal keys IS the multiset the reference tabulates
 //
 // The overlap of an arc is K minus the MOST FREQUENT distance between its two syncmers on the reads; ties go to the first
 // key in khashl bucket order (syncasm.c:558-571).  Low-coverage arcs tie all the time (two reads, two distances), so the
@@ -19,19 +21,25 @@ namespace oatk {
 
 #define EGR_INVALID 0xFFFFFFFFFFFFFFFFULL
 
-// canonical key of every pair of syncmers adjacent on a read (syncasm.c:242-261); slot 0 of a read carries no pair
-__global__ void egr_pair_keys_kernel(uint64_t n_reads, const uint64_t *scm_off, const uint64_t *k_mer, const uint32_t *m_pos, uint64_t *keys)
+// canonical key of every pair of syncmers adjacent on a read (syncasm.c:242-261) and the distance between the two; slot 0
+// of a read carries no pair.  Entries are produced in (read, slot) order, which is the order calc_syncmer_overlap meets
+// the pairs of one arc in (it walks the occurrences of the arc's first syncmer, syncasm.c:497-556; the slot of that
+// syncmer is the pair's first or second slot, and two pairs of one arc never share it).
+__global__ void egr_pair_keys_kernel(uint64_t n_reads, const uint64_t *scm_off, const uint64_t *k_mer, const uint32_t *m_pos, uint64_t *keys, uint32_t *dist)
 {
     uint64_t r = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
     const uint64_t o = scm_off[r], n = scm_off[r + 1] - o;
     if (n == 0) return;
-    keys[o] = EGR_INVALID;
+    keys[o] = EGR_INVALID, dist[o] = 0;
     uint64_t v0 = (k_mer[o] >> 1) << 1 | (m_pos[o] & 1u);
+    uint32_t p0 = m_pos[o] >> 1;
     for (uint64_t j = 1; j < n; ++j) {
         const uint64_t v1 = (k_mer[o + j] >> 1) << 1 | (m_pos[o + j] & 1u);
+        const uint32_t p1 = m_pos[o + j] >> 1;
         keys[o + j] = v0 <= v1? v0 << 32 | v1 : (v1 ^ 1ULL) << 32 | (v0 ^ 1ULL);
-        v0 = v1;
+        dist[o + j] = p1 - p0;
+        v0 = v1, p0 = p1;
     }
 }
 
@@ -46,15 +54,17 @@ __global__ void egr_expand_count_kernel(uint64_t n_keys, const uint64_t *ukeys, 
     n_out[i] = (v1 ^ 1ULL) != v0? 2u : 1u;
 }
 
-__global__ void egr_expand_kernel(uint64_t n_keys, const uint64_t *ukeys, const uint32_t *counts, const uint64_t *out_off, uint64_t *akey, uint64_t *aval)
+// payload of an arc through the (v, w) sort: overlap << 44 | coverage << 1 | complement flag
+__global__ void egr_expand_kernel(uint64_t n_keys, const uint64_t *ukeys, const uint32_t *counts, const uint32_t *run_ls, const uint64_t *out_off,
+                                  uint64_t *akey, uint64_t *aval)
 {
     uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_keys) return;
     const uint64_t k = ukeys[i];
     if (k == EGR_INVALID) return;
-    const uint64_t v0 = k >> 32, v1 = k & 0xFFFFFFFFULL, o = out_off[i], c = counts[i];
-    akey[o] = k, aval[o] = c << 1;                                        // comp = 0
-    if ((v1 ^ 1ULL) != v0) akey[o + 1] = (v1 ^ 1ULL) << 32 | (v0 ^ 1ULL), aval[o + 1] = c << 1 | 1ULL;
+    const uint64_t v0 = k >> 32, v1 = k & 0xFFFFFFFFULL, o = out_off[i], c = (uint64_t) run_ls[i] << 44 | (uint64_t) counts[i] << 1;
+    akey[o] = k, aval[o] = c;                                             // comp = 0
+    if ((v1 ^ 1ULL) != v0) akey[o + 1] = (v1 ^ 1ULL) << 32 | (v0 ^ 1ULL), aval[o + 1] = c | 1ULL;
 }
 
 struct EgrArcs {
@@ -77,7 +87,7 @@ __global__ void egr_unpack_kernel(EgrArcs a, const uint64_t *skey, const uint64_
     a.arc_cov[i] = (uint32_t) (sval[i] >> 1);
     uint8_t comp = (uint8_t) (sval[i] & 1ULL);
     if ((w ^ 1ULL) == v) comp ^= 1;
-    a.arc_comp[i] = comp, a.arc_del[i] = 0, a.arc_ls[i] = 0;
+    a.arc_comp[i] = comp, a.arc_del[i] = 0, a.arc_ls[i] = (uint32_t) (sval[i] >> 44);
     if (i && skey[i - 1] == k) a.flags[0] = 1u;
     if (i == 0 || (skey[i - 1] >> 32) != v) a.idx_p[v] = i;               // asmg_arc_index, graph.c:85-113
     atomicAdd(&a.idx_n[v], 1u);
@@ -140,47 +150,131 @@ struct MiniKh {
     }
 };
 
-struct EgrOverlapArgs {
-    EgrArcs a;
-    int K;
-    uint64_t sid0;
-    const uint64_t *occ_off, *occ;    // syncmer occurrence lists (resident count)
-    const uint64_t *scm_off;          // slots of the per-read chains
-    const uint32_t *m_pos;
+// the same table for a whole wave: arrays in LDS, scalars uniform; every lane runs the same code on the same values
+struct WaveKh {
+    int32_t *keys, *vals;         // [64] in LDS
+    uint64_t used;
+    uint32_t bits, count;
+    bool overflow;
+
+    __device__ void init(int32_t *k, int32_t *v) { keys = k, vals = v, used = 0, bits = 0, count = 0, overflow = false; }
+    __device__ uint32_t nb() const { return bits? 1U << bits : 0U; }
+    __device__ bool due() const { const uint32_t n = nb(); return count >= (n >> 1) + (n >> 2); }
+    __device__ void resize(uint32_t want)
+    {
+        uint32_t j = 0, x = want;
+        while ((x >>= 1) != 0) ++j;
+        if (want & (want - 1)) ++j;
+        const uint32_t nbits = j > 2? j : 2;
+        if (nbits > 6) { overflow = true; return; }
+        const uint32_t n_old = nb(), n_new = 1U << nbits;
+        uint64_t nused = 0;
+        for (j = 0; j != n_old; ++j) {
+            if (!((used >> j) & 1ULL)) continue;
+            int32_t key = keys[j], val = vals[j];
+            used &= ~(1ULL << j);
+            for (;;) {
+                uint32_t i = MiniKh::h2b((uint32_t) key, nbits);
+                while ((nused >> i) & 1ULL) i = (i + 1) & (n_new - 1);
+                nused |= 1ULL << i;
+                if (i < n_old && ((used >> i) & 1ULL)) {
+                    const int32_t tk = keys[i], tv = vals[i];
+                    keys[i] = key, vals[i] = val, key = tk, val = tv;
+                    used &= ~(1ULL << i);
+                } else {
+                    keys[i] = key, vals[i] = val;
+                    break;
+                }
+            }
+        }
+        used = nused, bits = nbits;
+    }
+    // `cnt` add_ovl_count calls for one distance, the first of them at run position `first`; returns true for a new key
+    __device__ bool add(int32_t key, int32_t cnt)
+    {
+        for (int pass = 0; pass < 2; ++pass) {
+            uint32_t n = nb(), i = 0;
+            bool found = false;
+            if (n) {
+                i = MiniKh::h2b((uint32_t) key, bits);
+                const uint32_t last = i;
+                while (((used >> i) & 1ULL) && keys[i] != key) { i = (i + 1U) & (n - 1); if (i == last) break; }
+                found = (used >> i) & 1ULL;
+            }
+            if (due()) {                               // every call checks first (khashl.h:199): the one after a threshold insert grows the table
+                resize(n + 1U);
+                if (overflow) return false;
+                continue;
+            }
+            if (found) { vals[i] += cnt; return false; }
+            keys[i] = key, vals[i] = cnt, used |= 1ULL << i, ++count;
+            return true;
+        }
+        return false;
+    }
+    __device__ int32_t mode() const
+    {
+        int32_t movl = 0, mcnt = 0;
+        for (uint32_t k = 0; k < nb(); ++k) if (((used >> k) & 1ULL) && vals[k] > mcnt) mcnt = vals[k], movl = keys[k];
+        return movl;
+    }
 };
 
-// one lane per non-complement arc: calc_syncmer_overlap (syncasm.c:477-582) and the arc.ls assignment (:793-812)
-__global__ void egr_overlap_kernel(EgrOverlapArgs g)
+#define EGR_SMALL_RUN 48
+
+// overlap of the arc a run of equal keys stands for: K minus the most frequent distance (calc_syncmer_overlap,
+// syncasm.c:477-582, and the arc.ls assignment :793-812).  One lane per short run; long runs are then taken by the
+// whole wave, sixty-four distances at a time.
+__global__ __launch_bounds__(64) void egr_mode_kernel(uint64_t n_runs, const uint64_t *ukeys, const uint32_t *counts, const uint64_t *run_off,
+                                                      const uint32_t *sdist, int K, uint32_t *run_ls, uint32_t *flags)
 {
-    uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= g.a.n_arc || g.a.arc_comp[i]) return;
-    const uint64_t v = g.a.arc_v[i], w = g.a.arc_w[i];
-    const uint64_t m1 = v >> 1, m2 = w >> 1, rc1 = v & 1ULL, rc2 = w & 1ULL;
-    const uint64_t *pos1 = g.occ + g.occ_off[m1], *pos2 = g.occ + g.occ_off[m2];
-    const uint64_t n1 = g.occ_off[m1 + 1] - g.occ_off[m1], n2 = g.occ_off[m2 + 1] - g.occ_off[m2];
-    MiniKh h;
-    h.init();
-    uint64_t p2 = 0;
-    for (uint64_t p1 = 0; p1 < n1; ++p1) {
-        const uint64_t r1 = pos1[p1] >> 32, i1 = (pos1[p1] >> 1) & 0x7FFFFFFFULL, c1 = pos1[p1] & 1ULL;
-        const uint64_t base = g.scm_off[r1 - g.sid0];
-        const int64_t l1 = g.m_pos[base + i1] >> 1;
-        while (p2 < n2 && (pos2[p2] >> 32) < r1) ++p2;
-        for (uint64_t t = p2; t < n2 && (pos2[t] >> 32) == r1; ++t) {
-            const uint64_t i2 = (pos2[t] >> 1) & 0x7FFFFFFFULL, c2 = pos2[t] & 1ULL;
-            const int64_t l2 = g.m_pos[base + i2] >> 1;
-            if (i1 == i2 + 1 && c1 != rc1 && c2 != rc2) h.add1((int32_t) (l1 - l2));
-            else if (i1 + 1 == i2 && c1 == rc1 && c2 == rc2) h.add1((int32_t) (l2 - l1));
+    __shared__ int32_t tk[64], tv[64];
+    const int lane = threadIdx.x;
+    const uint64_t i = (uint64_t) blockIdx.x * 64 + lane;
+    const bool valid = i < n_runs && ukeys[i] != EGR_INVALID;
+    const uint32_t c = valid? counts[i] : 0u;
+    const uint64_t o = valid? run_off[i] : 0;
+    auto to_ls = [&](int64_t l) -> uint32_t {          // scg_syncmer_consensus(beg = l) then MIN with the vertex length K
+        if (l < K) l = l < 0? K : K - l;
+        else l = 0;
+        return (uint32_t) l;
+    };
+    if (valid && c <= EGR_SMALL_RUN) {
+        MiniKh h;
+        h.init();
+        for (uint32_t t = 0; t < c; ++t) h.add1((int32_t) sdist[o + t]);
+        if (h.overflow) flags[1] = 1u;
+        else run_ls[i] = to_ls(h.mode());
+    }
+    uint64_t big = __ballot(valid && c > EGR_SMALL_RUN);
+    while (big) {
+        const int src = __builtin_ctzll(big);
+        big &= big - 1;
+        const uint32_t cc = (uint32_t) __builtin_amdgcn_readfirstlane((int32_t) __shfl(c, src));
+        const uint64_t oo = (uint64_t) (uint32_t) __builtin_amdgcn_readfirstlane((int32_t) (__shfl(o, src) >> 32)) << 32
+                          | (uint32_t) __builtin_amdgcn_readfirstlane((int32_t) __shfl(o, src));
+        WaveKh h;
+        h.init(tk, tv);
+        bool tail_new = false;                         // was the very last add call an insert?
+        for (uint32_t t0 = 0; t0 < cc && !h.overflow; t0 += 64) {
+            const bool in = t0 + lane < cc;
+            const int32_t d = in? (int32_t) sdist[oo + t0 + lane] : 0;
+            uint64_t rest = __ballot(in);
+            while (rest && !h.overflow) {
+                const int f = __builtin_ctzll(rest);
+                const int32_t x = __builtin_amdgcn_readfirstlane(__shfl(d, f));
+                const uint64_t eq = __ballot(in && d == x) & rest;
+                rest &= ~eq;
+                const bool fresh = h.add(x, (int32_t) __builtin_popcountll(eq));
+                tail_new = fresh && eq == (1ULL << f) && t0 + f == cc - 1;
+            }
+        }
+        if (!h.overflow && h.due() && !tail_new) h.resize(h.nb() + 1U);       // khashl grows at the call AFTER the insert that filled it
+        if (lane == src) {
+            if (h.overflow) flags[1] = 1u;
+            else run_ls[i] = to_ls(h.mode());
         }
     }
-    if (h.overflow) { g.a.flags[1] = 1u; return; }
-    int64_t l = h.mode();
-    if (l < g.K) l = l < 0? g.K : g.K - l;      // scg_syncmer_consensus(beg = l) then MIN with the vertex length K
-    else l = 0;
-    g.a.arc_ls[i] = (uint32_t) l;
-    const uint64_t cv = w ^ 1ULL, cw = v ^ 1ULL, p = g.a.idx_p[cv];
-    const uint32_t n = g.a.idx_n[cv];
-    for (uint32_t t = 0; t < n; ++t) if (g.a.arc_w[p + t] == cw) { g.a.arc_ls[p + t] = (uint32_t) l; break; }
 }
 
 }  // namespace oatk
