@@ -36,12 +36,13 @@ def parse_args():
     ap.add_argument("--workload", default="config2")
     ap.add_argument("--reads-per-gpu", type=int, default=0, help="override the number of reads each GPU owns")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-syncerr", action="store_true", help="skip the extra scan + count + error-correction measurement")
     ap.add_argument("--cpu-sample-reads", type=int, default=80000)
     ap.add_argument("--cpu-threads", type=int, default=8)
     return ap.parse_args()
 
 
-def cpu_baseline(readset, first, n_sample, k, s, threads):
+def cpu_baseline(readset, first, n_sample, k, s, threads, min_k_cov=30):
     """Reference scan + count (sr_read + collect_syncmer_from_reads of the compiled reference) on host cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import ref_lib
@@ -62,13 +63,25 @@ def cpu_baseline(readset, first, n_sample, k, s, threads):
         sc = ref_lib.ScmDb(db)
         dt = time.perf_counter() - t0
         n_scm = sc.n()
+        # the error-correction round of syncasm on the same databases (run_syncasm.c:109-124)
+        import ec_util
+        L = ref_lib.lib()
+        t1 = time.perf_counter()
+        g = L.refx_make_graph(db.handle, sc.handle, 0, 0.0)
+        L.refx_consensus(db.handle, g, 1, 1)
+        summ = ec_util.reference_ec(db, sc, g, 0.02, min_k_cov, 0.35, threads=threads)
+        dt_ec = time.perf_counter() - t1
+        L.refx_scg_destroy(g)
         sc.close()
         db.close()
     finally:
         os.unlink(path)
     return {"value": bases / dt / 1e9, "unit": "Gbases/s", "cores": threads, "kind": "reference",
             "sample": "first %d reads of the workload (%.2f Gbases) as FASTA through the compiled reference's sr_read + "
-                      "collect_syncmer_from_reads at -t %d, parse included; %.1f s wall, %d syncmers" % (n_sample, bases / 1e9, threads, dt, n_scm)}
+                      "collect_syncmer_from_reads at -t %d, parse included; %.1f s wall, %d syncmers" % (n_sample, bases / 1e9, threads, dt, n_scm),
+            "with_syncerr": {"value": bases / (dt + dt_ec) / 1e9, "unit": "Gbases/s",
+                             "sample": "the same, then make_syncmer_graph + scg_consensus + read_error_correction (-c %d); +%.1f s wall, %s error blocks"
+                                       % (min_k_cov, dt_ec, summ.get("total"))}}
 
 
 def main():
@@ -150,6 +163,37 @@ def main():
     for name in phase_ms:
         phase_ms[name] /= max(args.steps, 1)
 
+    # ---- the same batch through the error-correction round too (syncerr): scan + count + EC graph + read correction, all resident.
+    #      One GPU only: across GPUs the EC graph would need the merged arc table, which this round does not build. ----
+    syncerr = None
+    if world == 1 and not args.no_syncerr:
+        c = int(cfg.get("min_k_cov", 30))
+
+        def step_ec():
+            hip.scan_device(d_seq.data_ptr(), d_off.data_ptr(), d_len.data_ptr(), per_gpu, seq_bytes, K, S, sid0=first)
+            hip.count()
+            hip.ec_graph()
+            return hip.ec(0.02, c, 0.35)
+
+        hip.set_timing(False)
+        step_ec()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            st = step_ec()
+        fence()
+        dt_ec = (time.perf_counter() - t1) / max(args.steps, 1)
+        tg = time.perf_counter()
+        hip.ec_graph()
+        fence()
+        tg = time.perf_counter() - tg
+        syncerr = {"value": round(bases / dt_ec / 1e9, 3), "unit": "Gbases/s", "ms_per_step": round(dt_ec * 1e3, 3),
+                   "ms_ec_graph": round(tg * 1e3, 3),
+                   "workload": "scan + count + EC graph (make_syncmer_graph, hoco arc overlaps) + read_error_correction (-c %d, max_edist 0.02, a 0.35)" % c,
+                   "error_blocks": int(st[0] + st[5] + st[10]), "corrected": int(st[2] + st[7]), "uncorrected": int(st[1] + st[6]),
+                   "ambiguous": int(st[3] + st[4] + st[8] + st[9]), "blocks_past_first_tier": int(st[11])}
+        hip.set_timing(True)
+
     if rank == 0:
         # ---- roofline of the dominant kernel (by measured time) ----
         hoco = int(hip.fetch("HOCO_L").astype(np.uint64).sum())
@@ -172,7 +216,7 @@ def main():
                     "scan_achieved_GBs": round((alg_bytes["hpc"] + 28 * n_occ) / ((phase_ms["hpc"] + phase_ms["syncmer"]) / 1e3) / 1e9, 2)}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(rs, first, min(args.cpu_sample_reads, per_gpu), K, S, args.cpu_threads)
+            cpu = cpu_baseline(rs, first, min(args.cpu_sample_reads, per_gpu), K, S, args.cpu_threads, int(cfg.get("min_k_cov", 30)))
         out = {
             "metric": "HiFi Gbases/s through syncasm scan+count (closed syncmers, k=1001 s=31)",
             "value": round(total_bases * args.steps / dt / 1e9, 3), "unit": "Gbases/s",
@@ -183,7 +227,7 @@ def main():
                                    % (args.workload, per_gpu, cfg["mean_len"] // 1000),
                        "reads_per_gpu": per_gpu, "bases_per_gpu": bases, "genome_len": cfg["genome_len"],
                        "parallelism": "reads sharded by record, %d rank(s)" % world},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "syncerr": syncerr,
             "phases_ms": {k_: round(v, 4) for k_, v in phase_ms.items()},
             "syncmers": {"occurrences": n_occ, "distinct": info["n_scm"], "hoco_ratio": round(hoco / bases, 4)},
         }
