@@ -1,0 +1,123 @@
+"""GPU, BASELINE.json configs[1] at FULL size (200 k reads x ~15 kb, k = 1001, s = 31): properties that do not need an oracle
+run at that size -- conservation sums, orderings, run-to-run determinism of every resident result (the solver pulls blocks
+from a shared queue, so scheduling differs between runs), strand symmetry -- plus a bit-exact oracle check of reads sampled
+from the full batch."""
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from oatk_amd.synth import CONFIGS, ReadSet
+
+pytestmark = pytest.mark.gpu
+
+K, S = 1001, 31
+COMP = np.zeros(256, np.uint8)
+for a, b in zip(b"ACGTacgtNn", b"TGCAtgcaNn"):
+    COMP[a] = b
+
+
+@pytest.fixture(scope="module")
+def batch():
+    cfg = dict(CONFIGS["config2"])
+    rs = ReadSet(**cfg)
+    seq, off, lens = rs.slice(0, cfg["n_reads"])
+    return cfg, seq, off, lens
+
+
+def crc(a):
+    return zlib.crc32(np.ascontiguousarray(a).view(np.uint8))
+
+
+SCAN_BUFS = ["HOCO_L", "N_SCM", "SCM_OFF", "POS_MPOS", "POS_SMER", "POS_HASH"]
+COUNT_BUFS = ["POS_KID", "SCM_H", "SCM_S", "SCM_COV", "SCM_OCC_OFF", "SCM_OCC"]
+EC_BUFS = ["EC_N_SCM", "EC_SCM_OFF", "EC_KMER", "EC_MPOS", "EC_SMER", "EC_SCM_COV", "EC_SCM_DEL", "EC_SCM_OCC_OFF", "EC_SCM_OCC", "EC_ERR_DEL"]
+EG_BUFS = ["EG_IDX_N", "EG_ARC_V", "EG_ARC_W", "EG_ARC_LS", "EG_ARC_COV", "EG_ARC_COMP"]
+
+
+def test_full_size_pipeline_properties(hip, batch):
+    cfg, seq, off, lens = batch
+    n = len(off)
+    c = cfg["min_k_cov"]
+    sums = []
+    for rep in range(2):
+        hip.scan_host(seq, off, lens, K, S)
+        hip.count()
+        hip.ec_graph()
+        st = hip.ec(0.02, c, 0.35)
+        sums.append({b: crc(hip.fetch(b)) for b in SCAN_BUFS + COUNT_BUFS + EC_BUFS + EG_BUFS} | {"stats": st[:11].tolist()})
+    assert sums[0] == sums[1]                                     # nothing depends on scheduling
+
+    info = hip.info()
+    hoco_l, n_scm, scm_off = hip.fetch("HOCO_L"), hip.fetch("N_SCM"), hip.fetch("SCM_OFF")
+    m_pos = hip.fetch("POS_MPOS")
+    assert n == info["n_reads"] and int(n_scm.sum()) == info["n_occ"] == len(m_pos)
+    assert np.all(hoco_l <= lens) and np.all(hoco_l > 0)
+    assert np.array_equal(scm_off[1:] - scm_off[:-1], n_scm.astype(np.uint64))
+    # chains are ordered by position inside a read, and every k-mer fits its read
+    pos = (m_pos >> 1).astype(np.int64)
+    first = np.zeros(len(pos), bool)
+    first[scm_off[:-1][n_scm > 0].astype(np.int64)] = True
+    assert np.all((np.diff(pos) > 0) | first[1:])
+    assert np.all(pos + K <= np.repeat(hoco_l.astype(np.int64), n_scm))
+    # count: coverage is conserved; ids are dense; equal hashes got equal ids; the table is sorted by first appearance
+    cov, occ_off, occ, kid, h = hip.fetch("SCM_COV"), hip.fetch("SCM_OCC_OFF"), hip.fetch("SCM_OCC"), hip.fetch("POS_KID"), hip.fetch("POS_HASH")
+    assert int(cov.sum()) == info["n_occ"] and len(cov) == info["n_scm"]
+    assert np.array_equal(np.bincount((kid >> np.uint64(1)).astype(np.int64), minlength=len(cov)), cov)
+    assert np.array_equal(hip.fetch("SCM_H")[(kid >> np.uint64(1)).astype(np.int64)], h)
+    assert np.all(np.diff(occ.astype(np.int64))[np.ones(len(occ) - 1, bool) & ~np.isin(np.arange(1, len(occ)), occ_off[1:-1].astype(np.int64))] > 0)
+    # EC graph: symmetric (every arc has its complement with equal coverage and overlap), CSR consistent
+    av, aw, acov, als, idx_n = hip.fetch("EG_ARC_V"), hip.fetch("EG_ARC_W"), hip.fetch("EG_ARC_COV"), hip.fetch("EG_ARC_LS"), hip.fetch("EG_IDX_N")
+    assert int(idx_n.sum()) == len(av) and np.all(np.diff((av << np.uint64(32) | aw).astype(np.uint64).view(np.int64)) > 0)
+    fwd = dict(zip((av << np.uint64(32) | aw).tolist(), zip(acov.tolist(), als.tolist())))
+    samp = np.random.default_rng(1).integers(0, len(av), 20000)
+    for i in samp.tolist():
+        assert fwd[int((aw[i] ^ np.uint64(1)) << np.uint64(32) | (av[i] ^ np.uint64(1)))] == (int(acov[i]), int(als[i]))
+    assert int(acov.sum()) + int(acov[(aw ^ np.uint64(1)) == av].sum()) == 2 * (info["n_occ"] - int((n_scm > 0).sum()))
+    # error correction: conservation, the refreshed table is the histogram of the corrected chains, corrected entries point at live syncmers
+    st = np.array(sums[0]["stats"])
+    new_n, new_k, ecov, edel = hip.fetch("EC_N_SCM"), hip.fetch("EC_KMER"), hip.fetch("EC_SCM_COV"), hip.fetch("EC_SCM_DEL")
+    assert int(new_n.sum()) == len(new_k) == int(ecov.sum())
+    assert np.array_equal(np.bincount((new_k >> np.uint64(1)).astype(np.int64), minlength=len(ecov)), ecov)
+    assert int(st[0] + st[5] + st[10]) > 0 and int(st[2] + st[7]) > 0.9 * int(st[0] + st[5])      # HiFi-like errors are correctable
+    err_del = hip.fetch("EC_ERR_DEL")
+    assert not np.any(err_del[(new_k[(new_k & np.uint64(1)) == 1] >> np.uint64(1)).astype(np.int64)])
+    assert np.all(edel[ecov == 0] == 1)
+
+
+def test_full_size_sample_against_oracle(hip, batch):
+    cfg, seq, off, lens = batch
+    hip.scan_host(seq, off, lens, K, S)
+    n_scm, scm_off, hoco_l = hip.fetch("N_SCM"), hip.fetch("SCM_OFF"), hip.fetch("HOCO_L")
+    m_pos, s_mer, k_mer = hip.fetch("POS_MPOS"), hip.fetch("POS_SMER"), hip.fetch("POS_HASH")
+    pick = np.random.default_rng(7).choice(len(off), 96, replace=False)
+    reads = [seq[int(off[i]):int(off[i]) + int(lens[i])].tobytes() for i in pick]
+    want = O.scan(reads, K, S, mode=0)
+    assert np.array_equal(hoco_l[pick], want["hoco_l"]) and np.array_equal(n_scm[pick], want["n_scm"])
+    sel = np.concatenate([np.arange(int(scm_off[i]), int(scm_off[i + 1])) for i in pick])
+    assert np.array_equal(m_pos[sel], want["m_pos"]) and np.array_equal(s_mer[sel], want["s_mer"]) and np.array_equal(k_mer[sel], want["k_mer"])
+
+
+def test_strand_symmetry(hip, batch):
+    """a read and its reverse complement select the same k-mers: same hashes in reverse order, mirrored positions, flipped strands"""
+    cfg, seq, off, lens = batch
+    m = 20000
+    sub_end = int(off[m - 1]) + int((int(lens[m - 1]) + 63) // 64 * 64)
+    fwd = seq[:sub_end]
+    rc = np.zeros_like(fwd)
+    for i in range(m):
+        o, l = int(off[i]), int(lens[i])
+        rc[o:o + l] = COMP[fwd[o:o + l][::-1]]
+    res = []
+    for s in (fwd, rc):
+        hip.scan_host(s, off[:m], lens[:m], K, S)
+        res.append((hip.fetch("N_SCM"), hip.fetch("SCM_OFF"), hip.fetch("HOCO_L"), hip.fetch("POS_MPOS"), hip.fetch("POS_HASH"), hip.fetch("POS_SMER")))
+    (n0, o0, hl0, mp0, h0, s0), (n1, o1, hl1, mp1, h1, s1) = res
+    assert np.array_equal(n0, n1) and np.array_equal(hl0, hl1) and int(n0.sum()) > 0
+    # reverse every chain of the second scan
+    idx = np.concatenate([np.arange(int(o1[i + 1]) - 1, int(o1[i]) - 1, -1) for i in range(m)])
+    assert np.array_equal(h0, h1[idx]) and np.array_equal(s0 >> np.uint64(1), s1[idx] >> np.uint64(1))
+    hl = np.repeat(hl0.astype(np.int64), n0)
+    assert np.array_equal((mp0 >> 1).astype(np.int64), hl - K - (mp1[idx] >> 1).astype(np.int64))
+    assert np.array_equal(mp0 & 1, (mp1[idx] & 1) ^ 1)
