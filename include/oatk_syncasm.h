@@ -108,7 +108,9 @@ typedef struct {
  * make_syncmer_graph(sr_db, scm_db, 0, 0.) + scg_consensus(hoco) (run_syncasm.c:109-117).  Rewrites every read's
  * k_mer / m_pos / s_mer / n and the syncmer table's cov / del / m_pos exactly like the reference, marks the graph's
  * deleted vertices and arcs like find_error_syncmers(..., del_err = 1), and returns the block statistics in stats12
- * (layout of include/oatk_hip_ec.h).  The batch must still be resident in ctx (scan + count done on it). */
+ * (layout of include/oatk_hip_ec.h).  The batch must still be resident in ctx (scan + count done on it).
+ * asmg == NULL: the EC graph is built on the device too (oatk_hip_ec_graph) -- the caller then skips make_syncmer_graph,
+ * scg_consensus and scg_destroy of run_syncasm.c:109-132 altogether; only the reads and the syncmer table are written back. */
 int oatk_read_error_correction(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, oatk_syncmer_db_t *scm_db, oatk_asmg_t *asmg, double max_edist,
                                uint32_t err_mer_c, uint32_t max_err_c, uint32_t err_arc_c, double max_arc_f, uint64_t *stats12);
 

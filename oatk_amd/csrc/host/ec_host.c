@@ -7,6 +7,7 @@
  *   - every read: k_mer / m_pos / s_mer / n                      (syncerr.c:600-612)
  *   - syncmer table: cov, del, m_pos; c and h released           (update_syncmer_db, syncerr.c:769-814)
  *   - graph: deleted error syncmers and their arcs              (find_error_syncmers with del_err = 1, syncerr.c:748-752)
+ * With asmg == NULL the EC graph itself (run_syncasm.c:109-117) is built on the device as well and there is nothing to flatten.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -37,10 +38,21 @@ static void *fetch(oatk_hip_ctx *ctx, int which, uint64_t *bytes, int *rc)
 int oatk_read_error_correction(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, oatk_syncmer_db_t *scm_db, oatk_asmg_t *asmg, double max_edist,
                                uint32_t err_mer_c, uint32_t max_err_c, uint32_t err_arc_c, double max_arc_f, uint64_t *stats12)
 {
-    const uint64_t nv = asmg->n_vtx, na = asmg->n_arc;
-    uint64_t i, j;
+    uint64_t i, j, b;
+    int rc;
+    uint64_t *arc_v = 0, *arc_w = 0;
+    uint64_t nv = 0, na = 0;
+    if (!asmg) {
+        /* no host graph at all: make_syncmer_graph(sr_db, scm_db, 0, 0.) + the hoco arc overlaps are built on the device too */
+        rc = oatk_hip_ec_graph(ctx);
+        if (rc) return rc;
+        rc = oatk_hip_ec(ctx, 0, max_edist, err_mer_c, max_err_c, err_arc_c, max_arc_f);
+        if (rc) return rc;
+    } else {
+    nv = asmg->n_vtx, na = asmg->n_arc;
     /* asmg_t -> flat arrays */
-    uint64_t *idx_n = (uint64_t *) xmalloc(8 * 2 * nv), *arc_v = (uint64_t *) xmalloc(8 * na), *arc_w = (uint64_t *) xmalloc(8 * na);
+    uint64_t *idx_n = (uint64_t *) xmalloc(8 * 2 * nv);
+    arc_v = (uint64_t *) xmalloc(8 * na), arc_w = (uint64_t *) xmalloc(8 * na);
     uint64_t *arc_ls = (uint64_t *) xmalloc(8 * na);
     uint32_t *arc_cov = (uint32_t *) xmalloc(4 * na);
     uint8_t *arc_del = (uint8_t *) xmalloc(na);
@@ -52,12 +64,12 @@ int oatk_read_error_correction(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, oatk_sync
     oatk_ec_graph_t g;
     g.n_vtx = nv, g.n_arc = na, g.idx_p = asmg->idx_p, g.idx_n = idx_n, g.arc_v = arc_v, g.arc_w = arc_w, g.arc_ls = arc_ls;
     g.arc_cov = arc_cov, g.arc_del = arc_del;
-    int rc = oatk_hip_ec(ctx, &g, max_edist, err_mer_c, max_err_c, err_arc_c, max_arc_f);
+    rc = oatk_hip_ec(ctx, &g, max_edist, err_mer_c, max_err_c, err_arc_c, max_arc_f);
     free(idx_n); free(arc_ls); free(arc_cov); free(arc_del);
     if (rc) { free(arc_v); free(arc_w); return rc; }
+    }
     if (stats12) oatk_hip_ec_stats(ctx, stats12);
 
-    uint64_t b;
     uint32_t *new_n = (uint32_t *) fetch(ctx, OATK_BUF_EC_N_SCM, &b, &rc); if (rc) return rc;
     uint64_t *new_k = (uint64_t *) fetch(ctx, OATK_BUF_EC_KMER, &b, &rc); if (rc) return rc;
     uint32_t *new_m = (uint32_t *) fetch(ctx, OATK_BUF_EC_MPOS, &b, &rc); if (rc) return rc;
@@ -69,8 +81,10 @@ int oatk_read_error_correction(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, oatk_sync
     uint64_t *occ = (uint64_t *) fetch(ctx, OATK_BUF_EC_SCM_OCC, &b, &rc); if (rc) return rc;
 
     /* graph: what find_error_syncmers(..., del_err = 1) leaves behind -- every arc touching a marked syncmer */
-    for (i = 0; i < nv; ++i) if (err_del[i]) asmg->vtx[i].del = 1;
-    for (i = 0; i < na; ++i) if (err_del[arc_v[i] >> 1] || err_del[arc_w[i] >> 1]) asmg->arc[i].del = 1;
+    if (asmg) {
+        for (i = 0; i < nv; ++i) if (err_del[i]) asmg->vtx[i].del = 1;
+        for (i = 0; i < na; ++i) if (err_del[arc_v[i] >> 1] || err_del[arc_w[i] >> 1]) asmg->arc[i].del = 1;
+    }
     free(arc_v); free(arc_w);
 
     /* reads */

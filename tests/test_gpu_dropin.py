@@ -64,10 +64,11 @@ def test_gfa_identical_to_reference(hip, tmp_path, K, S, cov, do_ec, do_unzip):
     L.refx_srdb_destroy(db)
 
 
-@pytest.mark.parametrize("K,S,cov,err", [(1001, 31, 8, 0.0008), (301, 21, 6, 0.001)])
-def test_gfa_identical_with_all_three_device_functions(hip, tmp_path, K, S, cov, err):
+@pytest.mark.parametrize("K,S,cov,err,host_graph", [(1001, 31, 8, 0.0008, True), (301, 21, 6, 0.001, True), (1001, 31, 8, 0.0008, False),
+                                                    (301, 21, 6, 0.001, False)])
+def test_gfa_identical_with_all_three_device_functions(hip, tmp_path, K, S, cov, err, host_graph):
     """sr_read, collect_syncmer_from_reads AND read_error_correction on the device (through liboatk_host.so); the
-    reference only builds the EC graph in between and runs the rest of syncasm() afterwards"""
+    reference only builds the EC graph in between (host_graph) -- or not even that -- and runs the rest of syncasm() afterwards"""
     L, H = R.lib(), host_lib()
     L.refx_syncasm_tail.restype = C.c_int
     L.refx_syncasm_tail.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,
@@ -80,14 +81,17 @@ def test_gfa_identical_with_all_three_device_functions(hip, tmp_path, K, S, cov,
     out_ref, out_dev = str(tmp_path / "ref"), str(tmp_path / "dev")
     assert L.refx_syncasm(R._files_arg([fa]), 1, K, S, cov, 0.35, 1, 3, 4, out_ref.encode()) == 0
     db, scm = device_dbs(hip, reads, K, S)
-    g = L.refx_make_graph(db, scm, 0, 0.0)                                   # run_syncasm.c:109
-    L.refx_consensus(db, g, 1, 1)                                            # run_syncasm.c:117
-    asmg = C.cast(g, C.POINTER(C.c_void_p))[1]                               # scg_t.utg_asmg (syncasm.h:51-54)
     stats = np.zeros(12, np.uint64)
-    rc = H.oatk_read_error_correction(hip.h, db, scm, asmg, 0.02, cov, 10 * cov, cov, 0.35, stats.ctypes.data)
+    if host_graph:
+        g = L.refx_make_graph(db, scm, 0, 0.0)                               # run_syncasm.c:109
+        L.refx_consensus(db, g, 1, 1)                                        # run_syncasm.c:117
+        asmg = C.cast(g, C.POINTER(C.c_void_p))[1]                           # scg_t.utg_asmg (syncasm.h:51-54)
+        rc = H.oatk_read_error_correction(hip.h, db, scm, asmg, 0.02, cov, 10 * cov, cov, 0.35, stats.ctypes.data)
+        L.refx_scg_destroy(g)                                                # run_syncasm.c:132
+    else:
+        rc = H.oatk_read_error_correction(hip.h, db, scm, None, 0.02, cov, 10 * cov, cov, 0.35, stats.ctypes.data)
     assert rc == 0, hip.L.oatk_hip_last_error(hip.h)
     assert int(stats[2] + stats[7]) > 0                                      # blocks were corrected
-    L.refx_scg_destroy(g)                                                    # run_syncasm.c:132
     assert L.refx_syncasm_tail(db, scm, K, 100000, 10000, cov, 0.35, 0.3, 0, 3, 4, out_dev.encode()) == 0
     for suffix in (".utg.gfa", ".utg.final.gfa"):
         assert os.path.getsize(out_ref + suffix) > 100
