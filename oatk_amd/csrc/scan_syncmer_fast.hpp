@@ -10,15 +10,21 @@
 //      Open  at k-mer end E needs  M[E-w] <= every hash in (E-w, E-1]  -> in particular <= the D chunk minima after (E-w)'s chunk
 //    (D = w/8 - 1 = 120 chunks of 8 at K=1001).  Only the top 32 bits of the hashes take part; the bounds come from
 //    one wave-level prefix-min and suffix-min over 32-bit keys done with DPP row shifts + v_readlane (VALU only, no
-//    LDS round trips).  About one position in 480 survives; only those get the exact 64-bit window minimum, computed
-//    cooperatively by a wave from chunk minima + ragged ends, and the full Close/Open rule.
-//  * candidates are found with wave ballots (a scalar loop over the few set lanes), kept in per-wave, double-buffered
-//    LDS lists, so a tile needs three workgroup barriers instead of ten.
+//    LDS round trips).  About one position in 480 survives, and nearly every survivor IS a syncmer (closed syncmers have
+//    density 2/(w+1) = 1/486): the filter is almost the rule.
+//  * the exact rule is then finished by the very lane that found the candidate: the filter has already compared against
+//    the D whole chunks of the window, so only the w - 8 D = 8..15 ragged positions at the window's ends are left (a
+//    dozen LDS reads); the exact 64-bit chunk minima are consulted only when top words tie.  No candidate lists, no
+//    cooperative reduction; every wave writes its own records; a tile needs two workgroup barriers.  (The previous
+//    version -- candidates listed per wave, one WAVE per exact decision, wave 0 writing all records, three barriers --
+//    spent as many VALU issue slots on ~4 candidates per tile as on hashing the tile's 2048 s-mers; PMC: 106 VALU
+//    instructions per position, 41 of them the hash, and the kernel is VALU-issue bound.)
 //  * selected syncmers leave as (sid|ordinal|rev, s-mer code, pos) records; their 251-byte k-mers are hashed
 //    afterwards by kmer_hash_kernel (one lane per syncmer) instead of by a lone lane inside this kernel.
 #pragma once
 #include "common.hpp"
 #include "scan_syncmer.hpp"
+#include "scan_hpc.hpp"
 
 namespace oatk {
 
@@ -84,9 +90,7 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_fast_kernel(SynArgs a)
     __shared__ uint64_t cm_ring[NCH];           // chunk minima (64-bit, for the exact window minimum)
     __shared__ uint32_t pre32[NCH], suf32[NCH]; // per-wave-block inclusive prefix / suffix minima of the chunk minima's top 32 bits
     __shared__ uint32_t pb[PBW];                // packed bases, 16 per word, MSB-first
-    __shared__ uint32_t cand[2][NWAVE][SYF_SEG]; // k-mer ends of candidates: per wave, position order, double-buffered
-    __shared__ uint8_t surv[2][NWAVE][SYF_SEG];  // 0 none, 1 Close, 2 Open
-    __shared__ uint32_t w_cnt[2][NWAVE];
+    __shared__ uint32_t w_cnt[2][NWAVE];         // syncmers per wave of a tile, double-buffered (two barriers per tile)
 
     const uint32_t r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (a.n_nn[r] != 0) return;                 // reads with ambiguous bases take the general kernel
@@ -132,106 +136,8 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_fast_kernel(SynArgs a)
     };
     const uint32_t *m_hi = (const uint32_t *) m_ring;    // top word of entry e is m_hi[2e + 1]
 
-    uint32_t ord0 = 0, par = 0;                 // syncmers so far; parity of the candidate buffers
-
-    // One round: the selected waves list candidates from the selected lanes (sel_wave/sel_lo < 0 = all), every wave helps
-    // with the exact decisions, wave 0 writes the records.  Rounds consume buffers `par`, `par^1`, ... alternately; a buffer
-    // is rewritten two barriers after its last reader.
-    auto round = [&](uint32_t cmask, int32_t i0, int sel_wave, int sel_lo) {
-        uint32_t (*cd)[SYF_SEG] = cand[par];
-        uint8_t (*sv)[SYF_SEG] = surv[par];
-        uint32_t *wc = w_cnt[par];
-        // ---- list: a scalar walk over the lanes that have candidates ----
-        {
-            uint32_t mine = cmask;
-            if (sel_wave >= 0 && (int) wid != sel_wave) mine = 0;
-            if (sel_lo >= 0 && ((int) lane < sel_lo || (int) lane >= sel_lo + 8)) mine = 0;
-            uint64_t bal = __ballot(mine != 0);
-            uint32_t n = 0;
-            while (bal) {
-                const int l = __builtin_ctzll(bal);
-                bal &= bal - 1;
-                uint32_t mm = __builtin_amdgcn_readlane(mine, l);
-                const int32_t base = __builtin_amdgcn_readlane(i0, l);
-                while (mm) {
-                    const int o = __builtin_ctz(mm);
-                    mm &= mm - 1;
-                    if (n < (uint32_t) SYF_SEG && lane == 0) cd[wid][n] = (uint32_t) (base + o);
-                    ++n;
-                }
-            }
-            if (lane == 0) wc[wid] = n;         // may exceed SYF_SEG: the caller then falls back to lane-group rounds
-        }
-        __syncthreads();
-        uint32_t cw[NWAVE], nc = 0, over = 0;
-#pragma unroll
-        for (int ww = 0; ww < NWAVE; ++ww) { cw[ww] = wc[ww]; over |= cw[ww] > (uint32_t) SYF_SEG; nc += cw[ww]; }
-        if (over) return true;                  // nothing consumed yet; uniform across the workgroup
-        // ---- exact decision, one wave per candidate ----
-        for (uint32_t ci = wid; ci < nc; ci += NWAVE) {
-            uint32_t seg = 0, idx = ci;
-#pragma unroll
-            for (int ww = 0; ww < NWAVE - 1; ++ww) if (seg == (uint32_t) ww && idx >= cw[ww]) { idx -= cw[ww]; seg = ww + 1; }
-            const int32_t E = (int32_t) cd[seg][idx], lo = E - w, hi = E - 1;
-            const int32_t c_first = (lo + C - 1) / C, c_last = (hi + 1) / C - 1;
-            uint64_t v = UINT64_MAX;
-            for (int32_t cc = c_first + (int32_t) lane; cc <= c_last; cc += OATK_WAVE) {
-                uint64_t u = cm_ring[rch(cc)];
-                v = u < v? u : v;
-            }
-            const int32_t hd = c_first * C - lo, tl0 = (c_last + 1) * C, tl = hi - tl0 + 1;
-            if ((int32_t) lane < hd) { uint64_t u = m_ring[mi(lo + (int32_t) lane)]; v = u < v? u : v; }
-            if ((int32_t) lane >= 8 && (int32_t) lane - 8 < tl) { uint64_t u = m_ring[mi(tl0 + (int32_t) lane - 8)]; v = u < v? u : v; }
-            // (rare path: ~1 candidate per wave per tile.  A DPP reduction was tried here and mis-compiled in this
-            // context -- divergent producers of v -- so the reduction stays on ds_bpermute shuffles.)
-            uint64_t b = v;
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) { uint64_t o2 = __shfl_xor(b, d); b = o2 < b? o2 : b; }
-            if (lane == 0) {
-                const uint64_t yy = m_ring[mi(E)], f = m_ring[mi(lo)], x = m_ring[mi(lo - 1)];
-                bool cl = yy != UINT64_MAX && (yy < b || (yy == b && (x >= b || f == b)));
-                bool op = f != UINT64_MAX && f <= b && f <= yy;
-                sv[seg][idx] = (uint8_t) (cl && op? 0 : (cl? 1 : (op? 2 : 0)));
-            }
-        }
-        __syncthreads();
-        // ---- survivors -> records: wave 0 only (nobody else needs the running ordinal) ----
-        if (wid == 0) {
-            uint32_t nsurv = 0, my_rank[NWAVE], my_kind[NWAVE];
-#pragma unroll
-            for (int ww = 0; ww < NWAVE; ++ww) {
-                const uint32_t k = lane < cw[ww]? (uint32_t) sv[ww][lane] : 0u;
-                const uint64_t bl = __ballot(k != 0);
-                my_kind[ww] = k;
-                my_rank[ww] = nsurv + __builtin_popcountll(bl & ((1ULL << lane) - 1ULL));
-                nsurv += (uint32_t) __builtin_popcountll(bl);
-            }
-            if (nsurv) {
-                uint32_t gb = 0;
-                if (lane == 0) gb = atomicAdd(&a.shard_cnt[blockIdx.x & (OATK_REC_SHARDS - 1)], nsurv);
-                gb = __builtin_amdgcn_readfirstlane(gb);
-#pragma unroll
-                for (int ww = 0; ww < NWAVE; ++ww) {
-                    if (my_kind[ww]) {
-                        const int32_t E = (int32_t) cd[ww][lane], j = E - K + 1;
-                        uint64_t code = smer_code(my_kind[ww] == 2u? E - w : E);     // Open: first s-mer; Close: last s-mer
-                        const uint32_t rev = (uint32_t) (code & 1ULL);
-                        if (my_kind[ww] == 1u) code ^= 1ULL;                          // Close stores S ^ 1 (syncmer.c:345)
-                        const uint32_t loc = gb + my_rank[ww], ordn = ord0 + my_rank[ww];
-                        if (loc < a.region_cap) {
-                            const size_t slot = (size_t) (blockIdx.x & (OATK_REC_SHARDS - 1)) * a.region_cap + loc;
-                            a.rec_lo[slot] = sid << 32 | (uint64_t) ordn << 1 | rev;
-                            a.rec_smer[slot] = code;
-                            a.rec_mpos[slot] = (uint32_t) j << 1 | rev;
-                        }
-                    }
-                }
-            }
-            ord0 += nsurv;                      // meaningful in wave 0 only
-        }
-        par ^= 1u;
-        return false;
-    };
+    uint32_t ord0 = 0, par = 0;                 // syncmers so far; parity of the count buffer
+    const int HW = (w & (C - 1)) + C;           // window positions not covered by D whole chunks: w - C * D
 
     for (uint32_t I0 = 0; I0 < hl; I0 += T) {
         // ---- P1: s-mer hashes of this lane's chunk, chunk minimum, wave prefix/suffix minima ----
@@ -291,7 +197,7 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_fast_kernel(SynArgs a)
         __syncthreads();
 
         // ---- P3: filter on 32-bit keys (straight-line code: 64 <= D <= 127 means at most ONE whole block inside a range) ----
-        uint32_t cmask = 0;
+        uint32_t cmask = 0, backF_keep = 0, fwd0_keep = 0, fwd1_keep = 0;
         {
             // minimum of the chunk minima over chunks [lo, hi], hi - lo = D - 1: suffix of lo's block, prefix of hi's block and,
             // when the two are not adjacent, the one whole block between them.  Chunks before the read map to ring slots that
@@ -310,6 +216,7 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_fast_kernel(SynArgs a)
             const uint32_t fwd0 = range_min(ca0 + 1, ca0 + D);           // Open bound, first s-mers ending in chunk ca0
             const uint32_t fwd1 = range_min(ca0 + 2, ca0 + 1 + D);       // ... and in chunk ca0 + 1
             const uint32_t fbase = rpos(a_first);
+            backF_keep = backF, fwd0_keep = fwd0, fwd1_keep = fwd1;
             uint32_t hit = 0;
 #pragma unroll
             for (int o = 0; o < C; ++o) {
@@ -330,17 +237,82 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_fast_kernel(SynArgs a)
                 }
             }
         }
-        // ---- candidates -> exact decisions -> records ----
-        if (round(cmask, i0, -1, -1)) {
-            // a wave found more than SYF_SEG candidates (low-complexity sequence): redo wave by wave, eight lanes at a time,
-            // which keeps every list <= 64 entries and the ordinals in position order
-            for (int ww = 0; ww < NWAVE; ++ww)
-                for (int g = 0; g < OATK_WAVE; g += 8) {
-                    __syncthreads();
-                    round(cmask, i0, ww, g);
+        // ---- exact decision, by the lane that found the candidate.  The filter already proved that the D whole chunks
+        //      of the window hold nothing smaller (top 32 bits), so unless those top bits TIE only the HW ragged positions
+        //      at the two ends of the window remain to be looked at -- a dozen LDS reads.  A tie (probability ~2^-25 per
+        //      candidate on random sequence, common inside low-complexity repeats) takes the exact chunk minima as well. ----
+        uint32_t kinds = 0;                             // 2 bits per position of the chunk: 0 none, 1 Close, 2 Open
+        if (cmask) {
+            auto chunks_min = [&](int32_t c0, int32_t c1) -> uint64_t {
+                uint64_t v = UINT64_MAX;
+                for (int32_t cc = c0; cc <= c1; ++cc) { const uint64_t u = cm_ring[rch(cc)]; v = u < v? u : v; }
+                return v;
+            };
+            const int32_t a_first = i0 - w, ca0 = a_first >> 3;
+            const int sh = (-w) & (C - 1);
+            const uint32_t backF = backF_keep, fwd0 = fwd0_keep, fwd1 = fwd1_keep;
+            uint32_t mm = cmask;
+            while (mm) {
+                const int o = __builtin_ctz(mm);
+                mm &= mm - 1;
+                const int32_t E = i0 + o, lo = E - w;
+                const uint64_t yy = m_ring[mi(E)], f = m_ring[mi(lo)], x = m_ring[mi(lo - 1)];
+                const uint32_t yhi = (uint32_t) (yy >> 32), fhi = (uint32_t) (f >> 32);
+                const uint32_t fb = o + sh < C? fwd0 : fwd1;
+                bool cl = false, op = false;
+                if (yhi <= backF) {                     // Close: window = head [lo, lo + HW - o) + D chunks before `ch` + tail [i0, E)
+                    uint64_t b = UINT64_MAX;
+                    for (int t = 0; t < HW - o; ++t) { const uint64_t u = m_ring[mi(lo + t)]; b = u < b? u : b; }
+                    for (int t = 0; t < o; ++t) { const uint64_t u = m_ring[mi(i0 + t)]; b = u < b? u : b; }
+                    if (yhi == backF) { const uint64_t u = chunks_min(ch - D, ch - 1); b = u < b? u : b; }
+                    cl = yy != UINT64_MAX && (yy < b || (yy == b && (x >= b || f == b)));
                 }
-            __syncthreads();
+                if (fhi <= fb && fhi <= yhi) {          // Open: f must not exceed anything else in the window
+                    const int32_t ca = lo >> 3, tail0 = (ca + 1 + D) * C;
+                    uint64_t b = UINT64_MAX;
+                    for (int32_t q = lo + 1; q < (ca + 1) * C; ++q) { const uint64_t u = m_ring[mi(q)]; b = u < b? u : b; }
+                    for (int32_t q = tail0; q < E; ++q) { const uint64_t u = m_ring[mi(q)]; b = u < b? u : b; }
+                    if (fhi == fb) { const uint64_t u = chunks_min(ca + 1, ca + D); b = u < b? u : b; }
+                    op = f != UINT64_MAX && f <= b && f <= yy;
+                }
+                kinds |= (cl && op? 0u : (cl? 1u : (op? 2u : 0u))) << (2 * o);
+            }
+            (void) ca0;
         }
+        // ---- survivors -> records, every wave its own; ordinals need the counts of the waves before ----
+        const uint32_t ns = (uint32_t) __builtin_popcount((kinds | kinds >> 1) & 0x5555u);
+        const uint32_t incl = wave_incl_sum_dpp(ns, lane);
+        const uint32_t wtot = (uint32_t) __builtin_amdgcn_readlane((int) incl, 63);
+        if (lane == 0) w_cnt[par][wid] = wtot;
+        __syncthreads();
+        uint32_t before = 0, tot = 0;
+#pragma unroll
+        for (int ww = 0; ww < NWAVE; ++ww) { const uint32_t c = w_cnt[par][ww]; tot += c; before += ww < (int) wid? c : 0u; }
+        if (wtot) {
+            uint32_t gb = 0;
+            if (lane == 0) gb = atomicAdd(&a.shard_cnt[blockIdx.x & (OATK_REC_SHARDS - 1)], wtot);
+            gb = __builtin_amdgcn_readfirstlane(gb);
+            uint32_t rank = incl - ns, kk = kinds;
+            while (kk) {
+                const int o = __builtin_ctz(kk) >> 1;
+                const uint32_t kind = (kinds >> (2 * o)) & 3u;
+                kk &= ~(3u << (2 * o));
+                const int32_t E = i0 + o, j = E - K + 1;
+                uint64_t code = smer_code(kind == 2u? E - w : E);               // Open: first s-mer; Close: last s-mer
+                const uint32_t rev = (uint32_t) (code & 1ULL);
+                if (kind == 1u) code ^= 1ULL;                                    // Close stores S ^ 1 (syncmer.c:345)
+                const uint32_t loc = gb + rank, ordn = ord0 + before + rank;
+                if (loc < a.region_cap) {
+                    const size_t slot = (size_t) (blockIdx.x & (OATK_REC_SHARDS - 1)) * a.region_cap + loc;
+                    a.rec_lo[slot] = sid << 32 | (uint64_t) ordn << 1 | rev;
+                    a.rec_smer[slot] = code;
+                    a.rec_mpos[slot] = (uint32_t) j << 1 | rev;
+                }
+                ++rank;
+            }
+        }
+        ord0 += tot;
+        par ^= 1u;
     }
     if (tid == 0) a.n_scm[r] = ord0;            // tid 0 is in wave 0
 }
