@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "liboatk_hip.so")
+LIB_PATH = os.environ.get("OATK_HIP_LIB") or os.path.join(HERE, "lib", "liboatk_hip.so")   # override: development experiments only
 HOST_LIB_PATH = os.path.join(HERE, "lib", "liboatk_host.so")
 
 # names mirror include/oatk_hip.h

@@ -15,7 +15,9 @@
 //  * the exact rule is then finished by the very lane that found the candidate: the filter has already compared against
 //    the D whole chunks of the window, so only the w - 8 D = 8..15 ragged positions at the window's ends are left (a
 //    dozen LDS reads); the exact 64-bit chunk minima are consulted only when top words tie.  No candidate lists, no
-//    cooperative reduction; every wave writes its own records; a tile needs two workgroup barriers.  (The previous
+//    cooperative reduction; every wave writes its own records, one tile late, so that neither the other waves' counts
+//    nor the record-slot atomic is waited for.  A tile has two workgroup barriers, placed so that the s-mer hashing
+//    of the next tile (registers only) overlaps with the slower waves' decisions on this one.  (The previous
 //    version -- candidates listed per wave, one WAVE per exact decision, wave 0 writing all records, three barriers --
 //    spent as many VALU issue slots on ~4 candidates per tile as on hashing the tile's 2048 s-mers; PMC: 106 VALU
 //    instructions per position, 41 of them the hash, and the kernel is VALU-issue bound.)
@@ -139,6 +141,39 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_fast_kernel(SynArgs a)
     uint32_t ord0 = 0, par = 0;                 // syncmers so far; parity of the count buffer
     const int HW = (w & (C - 1)) + C;           // window positions not covered by D whole chunks: w - C * D
 
+    // syncmers of the previous tile, waiting for the other waves' counts and for their record slots
+    uint32_t pend_kinds = 0, pend_rank = 0, pend_wtot = 0, pend_gb = 0, pend_par = 0, pend_any = 0;
+    int32_t pend_i0 = 0;
+    auto flush = [&]() {                        // call after a barrier that follows the tile
+        if (!pend_any) return;
+        uint32_t before = 0, tot = 0;
+#pragma unroll
+        for (int ww = 0; ww < NWAVE; ++ww) { const uint32_t c = w_cnt[pend_par][ww]; tot += c; before += ww < (int) wid? c : 0u; }
+        if (pend_wtot) {
+            const uint32_t gb = __builtin_amdgcn_readfirstlane(pend_gb);
+            uint32_t rank = pend_rank, kk = pend_kinds;
+            while (kk) {
+                const int o = __builtin_ctz(kk) >> 1;
+                const uint32_t kind = (pend_kinds >> (2 * o)) & 3u;
+                kk &= ~(3u << (2 * o));
+                const int32_t E = pend_i0 + o, j = E - K + 1;
+                uint64_t code = smer_code(kind == 2u? E - w : E);               // Open: first s-mer; Close: last s-mer
+                const uint32_t rev = (uint32_t) (code & 1ULL);
+                if (kind == 1u) code ^= 1ULL;                                    // Close stores S ^ 1 (syncmer.c:345)
+                const uint32_t loc = gb + rank, ordn = ord0 + before + rank;
+                if (loc < a.region_cap) {
+                    const size_t slot = (size_t) (blockIdx.x & (OATK_REC_SHARDS - 1)) * a.region_cap + loc;
+                    a.rec_lo[slot] = sid << 32 | (uint64_t) ordn << 1 | rev;
+                    a.rec_smer[slot] = code;
+                    a.rec_mpos[slot] = (uint32_t) j << 1 | rev;
+                }
+                ++rank;
+            }
+        }
+        ord0 += tot;
+        pend_any = 0;
+    };
+
     for (uint32_t I0 = 0; I0 < hl; I0 += T) {
         // ---- P1: s-mer hashes of this lane's chunk, chunk minimum, wave prefix/suffix minima ----
         const int32_t i0 = (int32_t) (I0 + tid * C);
@@ -160,7 +195,6 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_fast_kernel(SynArgs a)
                     // (S31: an odd-length s-mer is never its own reverse complement, so no fw != rv test)
                     uint64_t mv = (S31 || fw != rv)? hash64(fw < rv? fw : rv, mask) : UINT64_MAX;
                     y[b] = mv;
-                    m_ring[mbase + b] = mv;
                     cmin = mv < cmin? mv : cmin;
                 }
             } else {                                    // first / last chunk of the read
@@ -173,7 +207,6 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_fast_kernel(SynArgs a)
                     uint64_t mv = UINT64_MAX;
                     if (i + 1 >= S && (uint32_t) i < hl && fw != rv) mv = hash64(fw < rv? fw : rv, mask);
                     y[b] = mv;
-                    m_ring[mbase + b] = mv;
                     cmin = mv < cmin? mv : cmin;
                 }
             }
@@ -188,6 +221,11 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_fast_kernel(SynArgs a)
 #else
             wave_prefix_suffix_min_u32((uint32_t) (cmin >> 32), lane, pre, suf);
 #endif
+            // everything above lives in registers: a wave that is done with the previous tile hashes ahead while the others
+            // still read that tile's windows from the ring.  Ring slots are only overwritten behind this barrier.
+            __syncthreads();
+#pragma unroll
+            for (int b = 0; b < C; ++b) m_ring[mbase + b] = y[b];
             const uint32_t cs = rch(ch);
             cm_ring[cs] = cmin;
             pre32[cs] = pre;
@@ -195,6 +233,7 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_fast_kernel(SynArgs a)
         }
         if (I0 + T < hl) load_bases(I0 + T);            // next tile's bases ride on this barrier
         __syncthreads();
+        flush();                                        // the previous tile's records
 
         // ---- P3: filter on 32-bit keys (straight-line code: 64 <= D <= 127 means at most ONE whole block inside a range) ----
         uint32_t cmask = 0, backF_keep = 0, fwd0_keep = 0, fwd1_keep = 0;
@@ -238,27 +277,25 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_fast_kernel(SynArgs a)
             }
         }
         // ---- exact decision, by the lane that found the candidate.  The filter already proved that the D whole chunks
-        //      of the window hold nothing smaller (top 32 bits), so unless those top bits TIE only the HW ragged positions
-        //      at the two ends of the window remain to be looked at -- a dozen LDS reads.  A tie (probability ~2^-25 per
-        //      candidate on random sequence, common inside low-complexity repeats) takes the exact chunk minima as well. ----
+        //      of the window hold nothing smaller (top 32 bits), so only the HW ragged positions at the two ends of the
+        //      window remain -- a dozen LDS reads of top words, one v_min each.  Top words that TIE (~2^-28 per candidate on
+        //      random sequence, common inside low-complexity repeats) send the position to the full 64-bit rule. ----
         uint32_t kinds = 0;                             // 2 bits per position of the chunk: 0 none, 1 Close, 2 Open
         if (cmask) {
-            auto chunks_min = [&](int32_t c0, int32_t c1) -> uint64_t {
-                uint64_t v = UINT64_MAX;
-                for (int32_t cc = c0; cc <= c1; ++cc) { const uint64_t u = cm_ring[rch(cc)]; v = u < v? u : v; }
-                return v;
-            };
-            const int32_t a_first = i0 - w, ca0 = a_first >> 3;
             const int sh = (-w) & (C - 1);
-            const uint32_t backF = backF_keep, fwd0 = fwd0_keep, fwd1 = fwd1_keep;
-            uint32_t mm = cmask;
-            while (mm) {
-                const int o = __builtin_ctz(mm);
-                mm &= mm - 1;
+            const uint32_t backF = backF_keep;
+            auto hi_at = [&](int32_t pos) -> uint32_t { return m_hi[2u * mi(pos) + 1u]; };
+            // the rule in full for one position (scan_syncmer.hpp states it; window = [E - w, E - 1]); rare
+            auto exact64 = [&](int o) -> uint32_t {
+                auto chunks_min = [&](int32_t c0, int32_t c1) -> uint64_t {
+                    uint64_t v = UINT64_MAX;
+                    for (int32_t cc = c0; cc <= c1; ++cc) { const uint64_t u = cm_ring[rch(cc)]; v = u < v? u : v; }
+                    return v;
+                };
                 const int32_t E = i0 + o, lo = E - w;
                 const uint64_t yy = m_ring[mi(E)], f = m_ring[mi(lo)], x = m_ring[mi(lo - 1)];
                 const uint32_t yhi = (uint32_t) (yy >> 32), fhi = (uint32_t) (f >> 32);
-                const uint32_t fb = o + sh < C? fwd0 : fwd1;
+                const uint32_t fb = o + sh < C? fwd0_keep : fwd1_keep;
                 bool cl = false, op = false;
                 if (yhi <= backF) {                     // Close: window = head [lo, lo + HW - o) + D chunks before `ch` + tail [i0, E)
                     uint64_t b = UINT64_MAX;
@@ -275,45 +312,46 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_fast_kernel(SynArgs a)
                     if (fhi == fb) { const uint64_t u = chunks_min(ca + 1, ca + D); b = u < b? u : b; }
                     op = f != UINT64_MAX && f <= b && f <= yy;
                 }
-                kinds |= (cl && op? 0u : (cl? 1u : (op? 2u : 0u))) << (2 * o);
+                return cl && op? 0u : (cl? 1u : (op? 2u : 0u));
+            };
+            uint32_t mm = cmask;
+            while (mm) {
+                const int o = __builtin_ctz(mm);
+                mm &= mm - 1;
+                const int32_t E = i0 + o, lo = E - w;
+                const uint32_t yhi = hi_at(E), fhi = hi_at(lo);
+                const uint32_t fb = o + sh < C? fwd0_keep : fwd1_keep;
+                bool cl = false, op = false, tie = false;
+                if (yhi <= backF) {
+                    uint32_t bh = backF;                // top word of the window minimum
+                    for (int t = 0; t < HW - o; ++t) { const uint32_t u = hi_at(lo + t); bh = u < bh? u : bh; }
+                    for (int t = 0; t < o; ++t) { const uint32_t u = hi_at(i0 + t); bh = u < bh? u : bh; }
+                    cl = yhi < bh, tie = yhi == bh;
+                }
+                if (fhi <= fb && fhi <= yhi) {
+                    const int32_t ca = lo >> 3, tail0 = (ca + 1 + D) * C;
+                    uint32_t rh = fb;                   // top word of the minimum of everything in the window but f
+                    for (int32_t q = lo + 1; q < (ca + 1) * C; ++q) { const uint32_t u = hi_at(q); rh = u < rh? u : rh; }
+                    for (int32_t q = tail0; q < E; ++q) { const uint32_t u = hi_at(q); rh = u < rh? u : rh; }
+                    op = fhi < rh && fhi < yhi, tie |= fhi <= rh && !op;
+                }
+                kinds |= (tie? exact64(o) : (cl && op? 0u : (cl? 1u : (op? 2u : 0u)))) << (2 * o);
             }
-            (void) ca0;
         }
-        // ---- survivors -> records, every wave its own; ordinals need the counts of the waves before ----
+        // ---- syncmers -> records, every wave its own.  Two things are only known a little later and neither is waited for:
+        //      the counts of the other waves (ordinals), exchanged through LDS across the NEXT tile's barrier, and the record
+        //      slots, from a returning atomic (an HBM round trip) that the next tile's hashing covers.  So a tile's records
+        //      are written one tile late (the packed-base ring still holds its bases then). ----
         const uint32_t ns = (uint32_t) __builtin_popcount((kinds | kinds >> 1) & 0x5555u);
         const uint32_t incl = wave_incl_sum_dpp(ns, lane);
         const uint32_t wtot = (uint32_t) __builtin_amdgcn_readlane((int) incl, 63);
         if (lane == 0) w_cnt[par][wid] = wtot;
-        __syncthreads();
-        uint32_t before = 0, tot = 0;
-#pragma unroll
-        for (int ww = 0; ww < NWAVE; ++ww) { const uint32_t c = w_cnt[par][ww]; tot += c; before += ww < (int) wid? c : 0u; }
-        if (wtot) {
-            uint32_t gb = 0;
-            if (lane == 0) gb = atomicAdd(&a.shard_cnt[blockIdx.x & (OATK_REC_SHARDS - 1)], wtot);
-            gb = __builtin_amdgcn_readfirstlane(gb);
-            uint32_t rank = incl - ns, kk = kinds;
-            while (kk) {
-                const int o = __builtin_ctz(kk) >> 1;
-                const uint32_t kind = (kinds >> (2 * o)) & 3u;
-                kk &= ~(3u << (2 * o));
-                const int32_t E = i0 + o, j = E - K + 1;
-                uint64_t code = smer_code(kind == 2u? E - w : E);               // Open: first s-mer; Close: last s-mer
-                const uint32_t rev = (uint32_t) (code & 1ULL);
-                if (kind == 1u) code ^= 1ULL;                                    // Close stores S ^ 1 (syncmer.c:345)
-                const uint32_t loc = gb + rank, ordn = ord0 + before + rank;
-                if (loc < a.region_cap) {
-                    const size_t slot = (size_t) (blockIdx.x & (OATK_REC_SHARDS - 1)) * a.region_cap + loc;
-                    a.rec_lo[slot] = sid << 32 | (uint64_t) ordn << 1 | rev;
-                    a.rec_smer[slot] = code;
-                    a.rec_mpos[slot] = (uint32_t) j << 1 | rev;
-                }
-                ++rank;
-            }
-        }
-        ord0 += tot;
+        pend_kinds = kinds, pend_rank = incl - ns, pend_i0 = i0, pend_wtot = wtot, pend_par = par, pend_any = 1u;
+        if (wtot && lane == 0) pend_gb = atomicAdd(&a.shard_cnt[blockIdx.x & (OATK_REC_SHARDS - 1)], wtot);
         par ^= 1u;
     }
+    __syncthreads();
+    flush();
     if (tid == 0) a.n_scm[r] = ord0;            // tid 0 is in wave 0
 }
 
