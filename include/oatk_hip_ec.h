@@ -51,8 +51,16 @@ int oatk_hip_debug_ec_tiers(oatk_hip_ctx *ctx, int cap_t0, int cap_t1);
  */
 enum {
     OATK_BUF_EC_N_SCM = 100, OATK_BUF_EC_SCM_OFF, OATK_BUF_EC_KMER, OATK_BUF_EC_MPOS, OATK_BUF_EC_SMER,
-    OATK_BUF_EC_SCM_COV, OATK_BUF_EC_SCM_DEL, OATK_BUF_EC_SCM_OCC_OFF, OATK_BUF_EC_SCM_OCC, OATK_BUF_EC_ERR_DEL
+    OATK_BUF_EC_SCM_COV, OATK_BUF_EC_SCM_DEL, OATK_BUF_EC_SCM_OCC_OFF, OATK_BUF_EC_SCM_OCC, OATK_BUF_EC_ERR_DEL,
+    OATK_BUF_EC_SCM_FWD,        /* u32[n_scm]  forward-strand occurrences per syncmer after correction (del = !fwd, syncerr.c:803-812) */
+    OATK_BUF_EC_VTX_SRC         /* u64[n_scm]  after oatk_hip_ec_mark: byte offset of the hoco string holding the vertex's k-mer, ~0 = none here */
 };
+
+/* oatk_hip_ec in two steps, for callers that need to act in between (sharded reads, below):
+ *   oatk_hip_ec_mark     find_error_syncmers (syncerr.c:679) on the resident graph; EC_ERR_DEL and EC_VTX_SRC become readable
+ *   oatk_hip_ec_correct  everything else of read_error_correction */
+int oatk_hip_ec_mark(oatk_hip_ctx *ctx, uint32_t err_mer_c, uint32_t max_err_c, uint32_t err_arc_c, double max_arc_f);
+int oatk_hip_ec_correct(oatk_hip_ctx *ctx, double max_edist);
 
 /* Builds the EC graph on the device from the resident scan + count instead of taking it from the host:
  * make_syncmer_graph(sr_db, scm_db, 0, 0.) (syncasm.c:203-299: one vertex per syncmer, one arc + its complement per pair of
@@ -65,6 +73,32 @@ enum {
  *   EG_IDX_P u64[2 n_scm] (valid where EG_IDX_N > 0)   EG_IDX_N u32[2 n_scm]
  *   EG_ARC_V u64[n_arc]  EG_ARC_W u64[n_arc]  EG_ARC_LS u32[n_arc]  EG_ARC_COV u32[n_arc]  EG_ARC_COMP u8[n_arc] */
 int oatk_hip_ec_graph(oatk_hip_ctx *ctx);
+
+/* ---- reads sharded by record over several GPUs (one context per GPU) --------------------------------------
+ * The EC graph is a property of ALL reads, so every shard builds the same graph from the adjacent pairs of all shards and
+ * corrects its own reads against it, in GLOBAL syncmer ids (ranks in the merged, sorted hash table -- what the reference's ids
+ * are, syncmer.c:1419-1438).  The exchange steps between the calls belong to the caller (oatk_amd/multi.py does them with
+ * torch.distributed over RCCL):
+ *
+ *   oatk_hip_ec_set_global(n_global, l2g, cov, s)   after the count tables were merged: local id -> global id, global coverage
+ *                                                   and s-mer codes (DEVICE pointers; copied)
+ *   oatk_hip_ec_pairs(&keys, &dist, &n)             this shard's adjacent pairs: canonical key (global ids) and distance, in
+ *                                                   (read, slot) order; entries with key ~0 (first slot of a read) are fillers
+ *        -- all-gather keys and dist in shard order --
+ *   oatk_hip_ec_graph_from_pairs(keys, dist, n)     the graph of all reads, resident
+ *   oatk_hip_ec_mark(...)                           identical marks on every shard
+ *        -- a live vertex this shard never saw (EC_ERR_DEL == 0, EC_VTX_SRC == ~0) needs its k-mer from a shard that did:
+ *           oatk_hip_ec_export_kmers there, oatk_hip_ec_import_kmers here --
+ *   oatk_hip_ec_correct(max_edist)                  chains (EC_KMER in global ids), EC_SCM_COV / EC_SCM_FWD of THIS shard's
+ *                                                   reads over global ids (sum them over the shards; del = !fwd)
+ * All pointers below are DEVICE pointers.  stride: bytes per exported k-mer, a multiple of 16, >= (k + 3) / 4 + 8. */
+int oatk_hip_ec_set_global(oatk_hip_ctx *ctx, uint64_t n_global, const uint32_t *d_l2g, const uint32_t *d_cov, const uint64_t *d_s);
+int oatk_hip_ec_pairs(oatk_hip_ctx *ctx, const void **d_keys, const void **d_dist, uint64_t *n_pairs);
+int oatk_hip_ec_graph_from_pairs(oatk_hip_ctx *ctx, const uint64_t *d_keys, const uint32_t *d_dist, uint64_t n_pairs);
+int oatk_hip_ec_export_kmers(oatk_hip_ctx *ctx, const uint32_t *d_ids, uint64_t n, uint8_t *d_out, uint32_t stride, uint8_t *d_rev);
+int oatk_hip_ec_import_kmers(oatk_hip_ctx *ctx, const uint32_t *d_ids, const uint8_t *d_rev, const uint8_t *d_kmers, uint64_t n, uint32_t stride);
+/* room kept behind the hoco strings for imported k-mers (default 1 MiB); call before the scan */
+int oatk_hip_ec_reserve_import(oatk_hip_ctx *ctx, uint64_t bytes);
 
 enum {
     OATK_BUF_EG_IDX_P = 120, OATK_BUF_EG_IDX_N, OATK_BUF_EG_ARC_V, OATK_BUF_EG_ARC_W, OATK_BUF_EG_ARC_LS, OATK_BUF_EG_ARC_COV,

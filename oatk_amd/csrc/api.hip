@@ -52,6 +52,7 @@ struct oatk_hip_ctx {
     float ms[OATK_T_COUNT_];
     uint64_t hash_mask = ~0ULL;
     bool force_general = false;   // test hook: run the general syncmer kernel even where the fast one applies
+    uint64_t import_reserve = 1u << 20;  // bytes kept free behind the hoco strings for k-mers imported from other shards (api_ec.inc)
     int ec_cap_t0 = 0, ec_cap_t1 = 0;   // test hook: block-length limits of the first two EC solver tiers (0 = default)
 
     // input (device view; owned only when uploaded through scan_host)
@@ -271,7 +272,7 @@ int oatk_hip_scan(oatk_hip_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off
 
     ENSURE(hoco_l, n_reads * 4); ENSURE(n_scm, n_reads * 4); ENSURE(n_nn, n_reads * 4); ENSURE(n_lrl, n_reads * 4);
     ENSURE(ho_rl, seq_bytes + 64);
-    ENSURE(hoco_s, seq_bytes / 4 + 128);
+    ENSURE(hoco_s, seq_bytes / 4 + 128 + 16 + ctx->import_reserve);
     ENSURE(nbits, seq_bytes / 8 + 128, true);          // all-zero invariant between scans; kernel B hands it back clean
     ENSURE(counters, 64);
     if (ctx->nn_cap == 0) ctx->nn_cap = 1u << 14;

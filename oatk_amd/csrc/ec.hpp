@@ -89,14 +89,22 @@ __global__ void ec_arc_del_kernel(EcGraph g)
 }
 
 // where each vertex's k-mer can be read: its first occurrence (syncasm.c:910-926; nothing is corrected yet)
-__global__ void ec_vtx_src_kernel(uint64_t n_vtx, const uint64_t *occ_off, const uint64_t *occ, uint64_t sid0, const uint64_t *off,
-                                  const uint64_t *scm_off, const uint32_t *m_pos, uint64_t *vtx_hs_off, uint32_t *vtx_mpos)
+// (sharded reads: `l2g` maps the shard's syncmer ids to the global ids the graph is built on; vertices this shard never saw
+// keep EC_NO_SRC until their k-mer is imported)
+#define EC_NO_SRC 0xFFFFFFFFFFFFFFFFULL
+__global__ void ec_vtx_src_kernel(uint64_t n_local, const uint64_t *occ_off, const uint64_t *occ, uint64_t sid0, const uint64_t *off,
+                                  const uint64_t *scm_off, const uint32_t *m_pos, const uint32_t *l2g, uint64_t *vtx_hs_off, uint32_t *vtx_mpos)
 {
     uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_vtx) return;
-    const uint64_t o = occ[occ_off[i]], rd = (o >> 32) - sid0, idx = (uint32_t) o >> 1;
-    vtx_hs_off[i] = off[rd] >> 2;
-    vtx_mpos[i] = m_pos[scm_off[rd] + idx];
+    if (i >= n_local) return;
+    const uint64_t o = occ[occ_off[i]], rd = (o >> 32) - sid0, idx = (uint32_t) o >> 1, v = l2g? l2g[i] : i;
+    vtx_hs_off[v] = off[rd] >> 2;
+    vtx_mpos[v] = m_pos[scm_off[rd] + idx];
+}
+__global__ void ec_remap_kernel(uint64_t n, const uint64_t *k_mer, const uint32_t *l2g, uint64_t *out)
+{
+    uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (uint64_t) l2g[k_mer[i] >> 1] << 1 | (k_mer[i] & 1ULL);
 }
 
 __device__ __forceinline__ uint32_t hoco_base(const uint8_t *hs, uint32_t p)
@@ -229,11 +237,13 @@ __global__ void ec_live_idx_kernel(uint64_t n_ovtx, const uint64_t *idx_p, const
     lidx_p[v] = (uint32_t) p, lidx_n[v] = n? (uint32_t) (live_off[idx_p[v] + n] - p) : 0u;
 }
 __global__ void ec_live_arc_kernel(uint64_t n_arc, const uint8_t *arc_del, const uint64_t *live_off, const uint64_t *arc_w, const uint32_t *arc_ls,
-                                   const uint64_t *vtx_hs_off, const uint32_t *vtx_mpos, const uint32_t *lidx_p, const uint32_t *lidx_n, EcLiveArc *larc)
+                                   const uint64_t *vtx_hs_off, const uint32_t *vtx_mpos, const uint32_t *lidx_p, const uint32_t *lidx_n, EcLiveArc *larc,
+                                   uint32_t *no_src)
 {
     uint64_t a = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n_arc || arc_del[a]) return;
     const uint64_t w = arc_w[a];
+    if (vtx_hs_off[w >> 1] == EC_NO_SRC) *no_src = 1u;          // sharded reads: the k-mer of a live vertex was never imported
     EcLiveArc x;
     x.w = (uint32_t) w, x.ls = arc_ls[a], x.hs16 = (uint32_t) (vtx_hs_off[w >> 1] >> 4), x.mpos = vtx_mpos[w >> 1];
     x.lp = lidx_p[w], x.ln = lidx_n[w], x.pad[0] = x.pad[1] = 0;

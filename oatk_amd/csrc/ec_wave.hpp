@@ -58,6 +58,29 @@ __device__ __forceinline__ int32_t ecw_uni(int32_t v) { return __builtin_amdgcn_
 __device__ __forceinline__ uint32_t ecw_uniu(uint32_t v) { return (uint32_t) __builtin_amdgcn_readfirstlane((int32_t) v); }
 __device__ __forceinline__ uint64_t ecw_uni64(uint64_t v) { return (uint64_t) ecw_uniu((uint32_t) (v >> 32)) << 32 | ecw_uniu((uint32_t) v); }
 
+// sharded reads: the k-mer of vertex ids[i] as a stand-alone hoco string (base 0 = first base as read, same byte layout),
+// `stride` bytes apart, with the strand it was read on -- what another shard needs to use this vertex (one wave per vertex)
+__global__ __launch_bounds__(64) void ecw_export_kmer_kernel(uint64_t n, const uint32_t *ids, const uint64_t *vtx_hs_off, const uint32_t *vtx_mpos,
+                                                             const uint8_t *hoco_s, int K, uint32_t stride, uint8_t *out, uint8_t *rev)
+{
+    const uint64_t i = blockIdx.x;
+    if (i >= n) return;
+    const uint32_t v = ids[i];
+    const uint64_t src = vtx_hs_off[v];
+    uint32_t *o = (uint32_t *) (out + i * stride);
+    const uint32_t mp = vtx_mpos[v];
+    for (uint32_t wi = threadIdx.x; wi < stride / 4; wi += 64)
+        o[wi] = src != EC_NO_SRC && (int) (wi << 4) < K? ecw_rev_in_bytes(ecw_src16(hoco_s + src, (mp >> 1) + (wi << 4))) : 0u;
+    if (threadIdx.x == 0) rev[i] = src != EC_NO_SRC? (uint8_t) (mp & 1u) : (uint8_t) 0xFF;
+}
+__global__ void ecw_import_kmer_kernel(uint64_t n, const uint32_t *ids, const uint8_t *rev, uint64_t base_off, uint32_t stride, uint64_t *vtx_hs_off, uint32_t *vtx_mpos)
+{
+    uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    vtx_hs_off[ids[i]] = base_off + i * stride;
+    vtx_mpos[ids[i]] = rev[i] & 1u;                            // position 0 on its own string
+}
+
 #ifdef ECW_PROF
 #define ECW_T(i) do { const unsigned long long _t = __builtin_readcyclecounter(); s.prof[i] += _t - s.t_last; s.t_last = _t; } while (0)
 #define ECW_C(i, v) do { s.prof[i] += (v); } while (0)
