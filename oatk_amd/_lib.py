@@ -19,7 +19,8 @@ BUF = {name: i for i, name in enumerate([
     "SCM_H", "SCM_S", "SCM_COV", "SCM_OCC_OFF", "SCM_OCC"])}
 # include/oatk_hip_ec.h
 BUF.update({name: 100 + i for i, name in enumerate([
-    "EC_N_SCM", "EC_SCM_OFF", "EC_KMER", "EC_MPOS", "EC_SMER", "EC_SCM_COV", "EC_SCM_DEL", "EC_SCM_OCC_OFF", "EC_SCM_OCC", "EC_ERR_DEL"])})
+    "EC_N_SCM", "EC_SCM_OFF", "EC_KMER", "EC_MPOS", "EC_SMER", "EC_SCM_COV", "EC_SCM_DEL", "EC_SCM_OCC_OFF", "EC_SCM_OCC", "EC_ERR_DEL",
+    "EC_SCM_FWD", "EC_VTX_SRC"])})
 BUF.update({name: 120 + i for i, name in enumerate([
     "EG_IDX_P", "EG_IDX_N", "EG_ARC_V", "EG_ARC_W", "EG_ARC_LS", "EG_ARC_COV", "EG_ARC_COMP"])})
 TIMERS = ["hpc", "syncmer", "syncmer_n", "scan_post", "count_place", "count_sort", "count_group", "kmer_hash"]
@@ -29,7 +30,9 @@ EXPORTS = [
     "oatk_hip_stream", "oatk_hip_sync", "oatk_hip_max_k", "oatk_hip_scan", "oatk_hip_scan_host", "oatk_hip_count",
     "oatk_hip_info", "oatk_hip_buffer", "oatk_hip_d2h", "oatk_hip_set_timing", "oatk_hip_get_timing",
     "oatk_hip_debug_hash_mask", "oatk_hip_debug_force_general",
-    "oatk_hip_ec_graph", "oatk_hip_ec", "oatk_hip_ec_stats", "oatk_hip_debug_ec_tiers",
+    "oatk_hip_ec_graph", "oatk_hip_ec", "oatk_hip_ec_stats", "oatk_hip_debug_ec_tiers", "oatk_hip_ec_mark", "oatk_hip_ec_correct",
+    "oatk_hip_ec_set_global", "oatk_hip_ec_pairs", "oatk_hip_ec_graph_from_pairs", "oatk_hip_ec_export_kmers", "oatk_hip_ec_import_kmers",
+    "oatk_hip_ec_reserve_import",
 ]
 
 
@@ -87,5 +90,13 @@ def load():
     L.oatk_hip_ec.argtypes = [vp, C.POINTER(EcGraph), C.c_double, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double]
     L.oatk_hip_ec_stats.argtypes = [vp, vp]
     L.oatk_hip_debug_ec_tiers.argtypes = [vp, C.c_int, C.c_int]
+    L.oatk_hip_ec_mark.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double]
+    L.oatk_hip_ec_correct.argtypes = [vp, C.c_double]
+    L.oatk_hip_ec_set_global.argtypes = [vp, C.c_uint64, vp, vp, vp]
+    L.oatk_hip_ec_pairs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_uint64)]
+    L.oatk_hip_ec_graph_from_pairs.argtypes = [vp, vp, vp, C.c_uint64]
+    L.oatk_hip_ec_export_kmers.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32, vp]
+    L.oatk_hip_ec_import_kmers.argtypes = [vp, vp, vp, vp, C.c_uint64, C.c_uint32]
+    L.oatk_hip_ec_reserve_import.argtypes = [vp, C.c_uint64]
     _lib = L
     return L

@@ -17,6 +17,7 @@ _DTYPES = {
     "SCM_COV": np.uint32, "SCM_OCC_OFF": np.uint64, "SCM_OCC": np.uint64,
     "EC_N_SCM": np.uint32, "EC_SCM_OFF": np.uint64, "EC_KMER": np.uint64, "EC_MPOS": np.uint32, "EC_SMER": np.uint64,
     "EC_SCM_COV": np.uint32, "EC_SCM_DEL": np.uint8, "EC_SCM_OCC_OFF": np.uint64, "EC_SCM_OCC": np.uint64, "EC_ERR_DEL": np.uint8,
+    "EC_SCM_FWD": np.uint32, "EC_VTX_SRC": np.uint64,
     "EG_IDX_P": np.uint64, "EG_IDX_N": np.uint32, "EG_ARC_V": np.uint64, "EG_ARC_W": np.uint64, "EG_ARC_LS": np.uint32,
     "EG_ARC_COV": np.uint32, "EG_ARC_COMP": np.uint8,
 }
@@ -104,6 +105,36 @@ class HipSyncasm:
         st = np.zeros(12, np.uint64)
         self._check(self.L.oatk_hip_ec_stats(self.h, st.ctypes.data), "oatk_hip_ec_stats")
         return st
+
+    def ec_stats(self):
+        st = np.zeros(12, np.uint64)
+        self._check(self.L.oatk_hip_ec_stats(self.h, st.ctypes.data), "oatk_hip_ec_stats")
+        return st
+
+    # the same in steps, and the calls for reads sharded over GPUs (device pointers as ints; oatk_amd/multi.py drives them)
+    def ec_mark(self, c, a):
+        self._check(self.L.oatk_hip_ec_mark(self.h, c, 10 * c, c, a), "oatk_hip_ec_mark")
+
+    def ec_correct(self, max_edist):
+        self._check(self.L.oatk_hip_ec_correct(self.h, max_edist), "oatk_hip_ec_correct")
+        return self.ec_stats()
+
+    def ec_set_global(self, n_global, d_l2g, d_cov, d_s):
+        self._check(self.L.oatk_hip_ec_set_global(self.h, n_global, d_l2g, d_cov, d_s), "oatk_hip_ec_set_global")
+
+    def ec_pairs(self):
+        k, d, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        self._check(self.L.oatk_hip_ec_pairs(self.h, C.byref(k), C.byref(d), C.byref(n)), "oatk_hip_ec_pairs")
+        return k.value, d.value, int(n.value)
+
+    def ec_graph_from_pairs(self, d_keys, d_dist, n):
+        self._check(self.L.oatk_hip_ec_graph_from_pairs(self.h, d_keys, d_dist, n), "oatk_hip_ec_graph_from_pairs")
+
+    def ec_export_kmers(self, d_ids, n, d_out, stride, d_rev):
+        self._check(self.L.oatk_hip_ec_export_kmers(self.h, d_ids, n, d_out, stride, d_rev), "oatk_hip_ec_export_kmers")
+
+    def ec_import_kmers(self, d_ids, d_rev, d_kmers, n, stride):
+        self._check(self.L.oatk_hip_ec_import_kmers(self.h, d_ids, d_rev, d_kmers, n, stride), "oatk_hip_ec_import_kmers")
 
     def info(self):
         i = _lib.Info()

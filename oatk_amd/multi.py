@@ -92,6 +92,108 @@ class CountMerger:
         return self.result
 
 
+def _staged(dist):
+    """gloo moves host memory only (the CPU tests, and two shards sharing one GPU); RCCL moves device memory"""
+    return dist.get_backend() == "gloo"
+
+
+def gather_var(t, dist):
+    """all_gather of tensors whose first dimension differs between ranks -> list of per-rank tensors (rank order)"""
+    dev = t.device
+    w = t.cpu() if _staged(dist) else t
+    n = torch.tensor([w.shape[0]], dtype=torch.int64, device=w.device)
+    sizes = [torch.zeros_like(n) for _ in range(dist.get_world_size())]
+    dist.all_gather(sizes, n)
+    sizes = [int(x.item()) for x in sizes]
+    pad = torch.zeros((max(max(sizes), 1),) + tuple(w.shape[1:]), dtype=w.dtype, device=w.device)
+    pad[: w.shape[0]] = w
+    out = [torch.empty_like(pad) for _ in sizes]
+    dist.all_gather(out, pad)
+    return [o[:k].to(dev) for o, k in zip(out, sizes)]
+
+
+def all_reduce(t, dist, op=None):
+    op = op if op is not None else dist.ReduceOp.SUM
+    if _staged(dist):
+        c = t.cpu()
+        dist.all_reduce(c, op=op)
+        return c.to(t.device)
+    dist.all_reduce(t, op=op)
+    return t
+
+
+class ShardedEc:
+    """The error-correction round of syncasm (run_syncasm.c:107-134) with reads sharded by record over GPUs: rank r owns a
+    contiguous range of read ids and a HipSyncasm context with its scan + count resident.  Every rank ends with the corrected
+    chains of ITS reads in global syncmer ids and with the refreshed global syncmer table -- bit-identical to one GPU holding
+    all reads (tests/test_gpu_sharded_ec.py).  Exchange steps (include/oatk_hip_ec.h lists the device calls between them):
+
+      1. count tables:  all_gather(sorted hashes) + all_reduce(coverage)                   (CountMerger)
+      2. adjacent pairs: all_gather((key, distance) lists) in rank order -- the graph is a property of all reads, every rank
+         builds the same one (12 bytes per syncmer occurrence; ~0.5 GB at 2 M reads, against 30 GB of reads)
+      3. k-mers of live vertices a rank never saw: owner = lowest rank that has one; all_gather of the few that are needed
+      4. refreshed table: all_reduce(coverage, forward-strand counts), block statistics
+    """
+
+    def __init__(self, hip, dist, device):
+        self.hip, self.dist, self.device = hip, dist, device
+        self.merger = CountMerger(hip, dist, device)
+        self.n_imported = 0
+
+    def _view(self, name, typestr, itemsize):
+        return self.merger._tensor(name, typestr, itemsize)
+
+    def run(self, max_edist, c, a):
+        hip, dist, dev = self.hip, self.dist, self.device
+        rank = dist.get_rank()
+        G, S, cov, l2g = self.merger.merge()
+        n_global = int(G.numel())
+        l2g32, cov32, s64 = l2g.to(torch.int32).contiguous(), cov.to(torch.int32).contiguous(), S.contiguous()
+        hip.ec_set_global(n_global, l2g32.data_ptr(), cov32.data_ptr(), s64.data_ptr())
+        # the graph of all reads, from everybody's adjacent pairs in read order
+        kp, dp, n = hip.ec_pairs()
+        if n:
+            keys = torch.as_tensor(_DevView(kp, n, "<i8"), device=dev)
+            dd = torch.as_tensor(_DevView(dp, n, "<i4"), device=dev)
+        else:
+            keys, dd = torch.zeros(0, dtype=torch.int64, device=dev), torch.zeros(0, dtype=torch.int32, device=dev)
+        keys_all = torch.cat(gather_var(keys, dist)).contiguous()
+        dist_all = torch.cat(gather_var(dd, dist)).contiguous()
+        hip.ec_graph_from_pairs(keys_all.data_ptr(), dist_all.data_ptr(), int(keys_all.numel()))
+        hip.ec_mark(c, a)
+        # live vertices without a k-mer on this rank
+        err_del = self._view("EC_ERR_DEL", "|u1", 1)
+        src = self._view("EC_VTX_SRC", "<i8", 8)
+        need = torch.nonzero((err_del == 0) & (src == -1)).flatten()
+        union = torch.unique(torch.cat(gather_var(need, dist)))
+        self.n_imported = 0
+        if union.numel():
+            big = dist.get_world_size()
+            owner = torch.where(src[union] != -1, torch.full_like(union, rank), torch.full_like(union, big))
+            owner = all_reduce(owner, dist, dist.ReduceOp.MIN)
+            if bool((owner == big).any()):
+                raise RuntimeError("a live syncmer occurs on no shard")
+            mine = union[owner == rank].to(torch.int32).contiguous()
+            stride = ((hip.info()["k"] + 3) // 4 + 8 + 15) // 16 * 16
+            out = torch.zeros((mine.numel(), stride), dtype=torch.uint8, device=dev)
+            rev = torch.zeros(mine.numel(), dtype=torch.uint8, device=dev)
+            hip.ec_export_kmers(mine.data_ptr(), int(mine.numel()), out.data_ptr(), stride, rev.data_ptr())
+            ids_all = torch.cat(gather_var(mine, dist))
+            rev_all = torch.cat(gather_var(rev, dist))
+            km_all = torch.cat(gather_var(out, dist))
+            lack = src[ids_all.long()] == -1
+            ids_i, rev_i, km_i = ids_all[lack].contiguous(), rev_all[lack].contiguous(), km_all[lack].contiguous()
+            hip.ec_import_kmers(ids_i.data_ptr(), rev_i.data_ptr(), km_i.data_ptr(), int(ids_i.numel()), stride)
+            self.n_imported = int(ids_i.numel())
+        st = hip.ec_correct(max_edist)
+        # the refreshed table of all reads
+        cov_g = all_reduce(self._view("EC_SCM_COV", "<i4", 4).to(torch.int64), dist)
+        fwd_g = all_reduce(self._view("EC_SCM_FWD", "<i4", 4).to(torch.int64), dist)
+        st_g = all_reduce(torch.from_numpy(st.astype(np.int64)).to(dev), dist)
+        return {"n_global": n_global, "hash": G, "cov": cov_g, "del": (fwd_g == 0).to(torch.uint8), "stats": st_g.cpu().numpy(),
+                "local_stats": st}
+
+
 def merge_numpy(h_u64, s_u64, cov, dist=None):
     """convenience for the CPU tests: numpy uint64 in, numpy out"""
     h = torch.from_numpy(h_u64.view(np.int64).copy())

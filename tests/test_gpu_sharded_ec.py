@@ -1,0 +1,88 @@
+"""GPU: the EC round with reads SHARDED by record (oatk_amd/multi.py: ShardedEc) equals the EC round of one context holding all
+reads -- chains (in global ids), refreshed coverage / deletion flags, block statistics.  Two processes share the one GPU of the
+test box and talk over gloo (RCCL refuses two ranks on one device); on a node the same code runs one rank per GPU over RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import adversarial as A
+import test_gpu_ec as E
+from oatk_amd import pack_reads
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, reads, bounds, K, S, c, outdir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oatk_amd import HipSyncasm
+    from oatk_amd.multi import ShardedEc
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    hip = HipSyncasm(0)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    seq, off, lens = pack_reads(reads[lo:hi])
+    hip.scan_host(seq, off, lens, K, S, sid0=lo)
+    hip.count()
+    sh = ShardedEc(hip, dist, dev)
+    res = sh.run(0.02, c, 0.35)
+    np.savez(os.path.join(outdir, "r%d.npz" % rank), n_scm=hip.fetch("EC_N_SCM"), k_mer=hip.fetch("EC_KMER"), m_pos=hip.fetch("EC_MPOS"),
+             s_mer=hip.fetch("EC_SMER"), occ=hip.fetch("EC_SCM_OCC"), occ_off=hip.fetch("EC_SCM_OCC_OFF"), cov=res["cov"].cpu().numpy(),
+             dele=res["del"].cpu().numpy(), stats=res["stats"], imported=sh.n_imported)
+    hip.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+CASES = [
+    # K, S, c, reads, shard boundaries as fractions
+    (301, 21, 6, lambda: A.hifi_like(300, 30000, 4000, seed=307, err=0.004), (0.0, 0.5, 1.0)),
+    (1001, 31, 6, lambda: E.sample_reads(E.genome_with_repeats(5, 50000), 260, 9000, 0.001, 6), (0.0, 0.35, 1.0)),
+    # a shard of a handful of reads sees few of the good syncmers: their k-mers must be imported
+    (101, 11, 5, lambda: E.sample_reads(E.genome_with_repeats(9, 9000, unit=600, copies=3), 300, 1500, 0.004, 10), (0.0, 0.02, 1.0)),
+]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_sharded_ec_equals_single_context(hip, tmp_path, case):
+    K, S, c, mk, frac = CASES[case]
+    reads = mk()
+    bounds = [int(round(f * len(reads))) for f in frac]
+    world = len(bounds) - 1
+    mp.spawn(_worker, args=(world, _free_port(), reads, bounds, K, S, c, str(tmp_path)), nprocs=world, join=True)
+    # one context, all reads
+    seq, off, lens = pack_reads(reads)
+    hip.scan_host(seq, off, lens, K, S)
+    hip.count()
+    hip.ec_graph()
+    st = hip.ec(0.02, c, 0.35)
+    want = {k: hip.fetch(k) for k in ["EC_N_SCM", "EC_KMER", "EC_MPOS", "EC_SMER", "EC_SCM_COV", "EC_SCM_DEL", "EC_SCM_OCC", "EC_SCM_OCC_OFF"]}
+    z = [np.load(os.path.join(str(tmp_path), "r%d.npz" % r)) for r in range(world)]
+    assert np.array_equal(np.concatenate([x["n_scm"] for x in z]), want["EC_N_SCM"])
+    for name, key in (("k_mer", "EC_KMER"), ("m_pos", "EC_MPOS"), ("s_mer", "EC_SMER")):
+        assert np.array_equal(np.concatenate([x[name] for x in z]), want[key]), name
+    for x in z:
+        assert np.array_equal(x["cov"], want["EC_SCM_COV"].astype(np.int64))
+        assert np.array_equal(x["dele"], want["EC_SCM_DEL"])
+        assert np.array_equal(x["stats"][:11], st[:11].astype(np.int64))
+    # occurrence lists: a syncmer's global list is the concatenation of the shards' lists in shard order
+    n = len(want["EC_SCM_COV"])
+    parts = [[x["occ"][int(x["occ_off"][i]):int(x["occ_off"][i + 1])] for x in z] for i in range(0, n, max(1, n // 400))]
+    got = np.concatenate([np.concatenate(p) for p in parts])
+    ref = np.concatenate([want["EC_SCM_OCC"][int(want["EC_SCM_OCC_OFF"][i]):int(want["EC_SCM_OCC_OFF"][i + 1])] for i in range(0, n, max(1, n // 400))])
+    assert np.array_equal(got, ref)
+    if case == 2:
+        assert sum(int(x["imported"]) for x in z) > 0
