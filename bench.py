@@ -8,7 +8,8 @@ hash; count = syncmer ID assignment) over one batch of synthetic HiFi reads that
 HBM when the timed region starts.  At N = 1 the workload is BASELINE.json configs[1] (200 k reads x 15 kb,
 k = 1001, s = 31, scan + count).  For N > 1 (launched by torch.distributed.run, one rank per GPU) reads are
 sharded by record: rank r owns reads [r*R, (r+1)*R) of an N*R-read set ("weak" scaling) and the per-GPU
-syncmer tables are merged over RCCL (oatk_amd/multi.py).
+syncmer tables are merged over RCCL (oatk_amd/multi.py).  The `syncerr` object reports the same batch through the
+error-correction round as well (scan + count + EC graph + read correction; sharded: oatk_amd/multi.py ShardedEc).
 
 Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel against the HBM roofline with its
 duration measured live by HIP events on the stream the kernels run on; `cpu_baseline` is the compiled
@@ -36,6 +37,7 @@ def parse_args():
     ap.add_argument("--workload", default="config2")
     ap.add_argument("--reads-per-gpu", type=int, default=0, help="override the number of reads each GPU owns")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; the contract) or gloo (development: several ranks on ONE GPU)")
     ap.add_argument("--no-syncerr", action="store_true", help="skip the extra scan + count + error-correction measurement")
     ap.add_argument("--cpu-sample-reads", type=int, default=80000)
     ap.add_argument("--cpu-threads", type=int, default=8)
@@ -97,8 +99,13 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "gloo":
+            local_rank = 0                  # development only: the ranks share GPU 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     dev = torch.device("cuda", local_rank)
 
@@ -164,35 +171,50 @@ def main():
         phase_ms[name] /= max(args.steps, 1)
 
     # ---- the same batch through the error-correction round too (syncerr): scan + count + EC graph + read correction, all resident.
-    #      One GPU only: across GPUs the EC graph would need the merged arc table, which this round does not build. ----
+    #      Across GPUs every rank builds the graph of ALL reads from the all-gathered adjacent pairs and corrects its own reads. ----
     syncerr = None
-    if world == 1 and not args.no_syncerr:
+    if not args.no_syncerr:
         c = int(cfg.get("min_k_cov", 30))
+        sharded = None
+        if world > 1:
+            from oatk_amd.multi import ShardedEc
+            sharded = ShardedEc(hip, dist, dev)
 
         def step_ec():
             hip.scan_device(d_seq.data_ptr(), d_off.data_ptr(), d_len.data_ptr(), per_gpu, seq_bytes, K, S, sid0=first)
             hip.count()
+            if sharded is not None:         # count-table merge, graph from everybody's pairs, correction in global ids (oatk_amd/multi.py)
+                return sharded.run(0.02, c, 0.35)["stats"]
             hip.ec_graph()
             return hip.ec(0.02, c, 0.35)
 
-        hip.set_timing(False)
-        step_ec()
-        fence()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            st = step_ec()
-        fence()
-        dt_ec = (time.perf_counter() - t1) / max(args.steps, 1)
-        tg = time.perf_counter()
-        hip.ec_graph()
-        fence()
-        tg = time.perf_counter() - tg
-        syncerr = {"value": round(bases / dt_ec / 1e9, 3), "unit": "Gbases/s", "ms_per_step": round(dt_ec * 1e3, 3),
-                   "ms_ec_graph": round(tg * 1e3, 3),
-                   "workload": "scan + count + EC graph (make_syncmer_graph, hoco arc overlaps) + read_error_correction (-c %d, max_edist 0.02, a 0.35)" % c,
-                   "error_blocks": int(st[0] + st[5] + st[10]), "corrected": int(st[2] + st[7]), "uncorrected": int(st[1] + st[6]),
-                   "ambiguous": int(st[3] + st[4] + st[8] + st[9]), "blocks_past_first_tier": int(st[11])}
+        try:                                # an extension of the headline measurement: it must never take the headline down
+            hip.set_timing(False)
+            step_ec()
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                st = step_ec()
+            fence()
+            dt_ec = (time.perf_counter() - t1) / max(args.steps, 1)
+            if dist is not None:
+                t = torch.tensor([dt_ec], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt_ec = float(t.item())
+            syncerr = {"value": round(total_bases / dt_ec / 1e9, 3), "unit": "Gbases/s", "ms_per_step": round(dt_ec * 1e3, 3),
+                       "workload": "scan + count + %sEC graph (make_syncmer_graph, hoco arc overlaps) + read_error_correction (-c %d, max_edist 0.02, a 0.35)"
+                                   % ("count-table merge + all-gather of adjacent pairs + " if world > 1 else "", c),
+                       "error_blocks": int(st[0] + st[5] + st[10]), "corrected": int(st[2] + st[7]), "uncorrected": int(st[1] + st[6]),
+                       "ambiguous": int(st[3] + st[4] + st[8] + st[9]), "blocks_past_first_tier": int(st[11])}
+            if sharded is not None:
+                syncerr["imported_kmers_rank0"] = sharded.n_imported
+        except Exception as ex:             # noqa: BLE001
+            syncerr = {"error": "%s: %s" % (type(ex).__name__, ex)}
         hip.set_timing(True)
+        # restore the scan + count state the rest of this report describes
+        hip.scan_device(d_seq.data_ptr(), d_off.data_ptr(), d_len.data_ptr(), per_gpu, seq_bytes, K, S, sid0=first)
+        hip.count()
+        fence()
 
     if rank == 0:
         # ---- roofline of the dominant kernel (by measured time) ----
