@@ -165,6 +165,8 @@ class ShardedEc:
         err_del = self._view("EC_ERR_DEL", "|u1", 1)
         src = self._view("EC_VTX_SRC", "<i8", 8)
         need = torch.nonzero((err_del == 0) & (src == -1)).flatten()
+        if hip.info()["n_occ"] == 0:            # a rank without syncmers corrects nothing and needs no k-mers
+            need = need[:0]
         union = torch.unique(torch.cat(gather_var(need, dist)))
         self.n_imported = 0
         if union.numel():
@@ -182,6 +184,8 @@ class ShardedEc:
             rev_all = torch.cat(gather_var(rev, dist))
             km_all = torch.cat(gather_var(out, dist))
             lack = src[ids_all.long()] == -1
+            if hip.info()["n_occ"] == 0:
+                lack = torch.zeros_like(lack)
             ids_i, rev_i, km_i = ids_all[lack].contiguous(), rev_all[lack].contiguous(), km_all[lack].contiguous()
             hip.ec_import_kmers(ids_i.data_ptr(), rev_i.data_ptr(), km_i.data_ptr(), int(ids_i.numel()), stride)
             self.n_imported = int(ids_i.numel())

@@ -53,6 +53,8 @@ CASES = [
     (1001, 31, 6, lambda: E.sample_reads(E.genome_with_repeats(5, 50000), 260, 9000, 0.001, 6), (0.0, 0.35, 1.0)),
     # a shard of a handful of reads sees few of the good syncmers: their k-mers must be imported
     (101, 11, 5, lambda: E.sample_reads(E.genome_with_repeats(9, 9000, unit=600, copies=3), 300, 1500, 0.004, 10), (0.0, 0.02, 1.0)),
+    # three shards, one of them empty
+    (101, 11, 5, lambda: E.sample_reads(E.genome_with_repeats(9, 9000, unit=600, copies=3), 300, 1500, 0.004, 10), (0.0, 0.4, 0.4, 1.0)),
 ]
 
 
