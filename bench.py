@@ -233,7 +233,7 @@ def main():
                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                     "algorithmic_bytes_per_launch": alg_bytes[dom], "avg_launch_ms": round(phase_ms[dom], 4),
-                    "note": "kernel B is integer-VALU bound (hash64 of every s-mer: ~50 VALU instructions per hoco base), see DESIGN.md 5",
+                    "note": "kernel B is integer-VALU issue bound (~104 VALU wave-instructions per 64 hoco positions, 41 of them roll + hash64; SIMDs 70-90 % busy), see DESIGN.md 5",
                     "scan_bytes_per_base": round((alg_bytes["hpc"] + 28 * n_occ) / bases, 4),
                     "scan_achieved_GBs": round((alg_bytes["hpc"] + 28 * n_occ) / ((phase_ms["hpc"] + phase_ms["syncmer"]) / 1e3) / 1e9, 2)}
         cpu = None
