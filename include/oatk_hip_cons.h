@@ -1,0 +1,30 @@
+/*
+ * include/oatk_hip_cons.h -- C ABI of the base-space syncmer consensus on the device (scg_syncmer_consensus, syncasm.c:888-1003).
+ *
+ * Call after oatk_hip_count (reads as scanned) or after oatk_hip_ec (corrected chains: corrected entries are skipped, :958-959).
+ * Reads sharded over GPUs are not supported yet: the totals of a syncmer are sums over all shards.
+ */
+#ifndef OATK_HIP_CONS_H
+#define OATK_HIP_CONS_H
+
+#include "oatk_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* For every syncmer that is not deleted and has coverage >= min_cov (and >= 1): the rounded mean run length at each of the k hoco
+ * positions of its FORWARD k-mer over its uncorrected occurrences -- the `b` of syncasm.c:994 -- their number, and the first of them
+ * (whose bases the reference prints, :912-936).  The reverse orientation is the mirror image.  Results stay resident:
+ *   CONS_SEL   u32[n_sel]       the syncmer ids, ascending          CONS_SLOT  u32[n_scm]   slot of a syncmer in CONS_SEL, ~0 = not selected
+ *   CONS_RL    u32[n_sel * k]   lround(total run length / CONS_MSEQ) per forward position
+ *   CONS_MSEQ  u32[n_sel]       occurrences that took part (0: every occurrence was corrected away, the reference prints N's)
+ *   CONS_FIRST u64[n_sel]       sid << 32 | idx << 1 | rev of the first of them, ~0 if none */
+int oatk_hip_consensus(oatk_hip_ctx *ctx, uint32_t min_cov);
+
+enum { OATK_BUF_CONS_SEL = 140, OATK_BUF_CONS_SLOT, OATK_BUF_CONS_RL, OATK_BUF_CONS_MSEQ, OATK_BUF_CONS_FIRST };
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -82,6 +82,7 @@ struct oatk_hip_ctx {
     DevBuf scm_h, scm_s, scm_cov, scm_occ_off, scm_occ;
     DevBuf tmp;           // rocprim temporary storage
     struct EcState *ec = nullptr;   // error-correction buffers (api_ec.inc)
+    struct ConsState *cons = nullptr;   // consensus buffers (api_cons.inc)
 };
 
 #define CK(call)                                                                                   \
@@ -123,6 +124,7 @@ static void t_collect(oatk_hip_ctx *ctx, int first, int last)
 }
 
 #include "api_ec.inc"
+#include "api_cons.inc"
 
 extern "C" {
 
@@ -169,6 +171,7 @@ void oatk_hip_destroy(oatk_hip_ctx *ctx)
                      &ctx->scm_occ_off, &ctx->scm_occ, &ctx->tmp};
     for (DevBuf *b : all) b->release();
     ec_state_free(ctx);
+    cons_state_free(ctx);
     for (int i = 0; i <= OATK_T_COUNT_; ++i) {
         (void) hipEventDestroy(ctx->ev[i][0]);
         (void) hipEventDestroy(ctx->ev[i][1]);
@@ -266,6 +269,8 @@ int oatk_hip_scan(oatk_hip_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off
     ctx->d_seq = d_seq, ctx->d_off = d_off, ctx->d_len = d_len;
     ctx->n_reads = n_reads, ctx->seq_bytes = seq_bytes, ctx->sid0 = sid0, ctx->K = k, ctx->S = s;
     ctx->scanned = ctx->counted = false;
+    if (ctx->ec) ctx->ec->done = ctx->ec->marked = ctx->ec->graph_resident = ctx->ec->global = false;     // results of the previous batch
+    if (ctx->cons) ctx->cons->done = false;
     ctx->retries = 0, ctx->collisions = 0;
     ctx->n_occ = ctx->tot_nn = ctx->tot_lrl = ctx->n_scm_total = 0;
     if (n_reads == 0) { ctx->scanned = true; return OATK_OK; }
@@ -536,7 +541,9 @@ int oatk_hip_buffer(oatk_hip_ctx *ctx, int which, const void **d_ptr, uint64_t *
                 case OATK_BUF_SCM_COV: p = ctx->scm_cov.p, b = ns * 4; break;
                 case OATK_BUF_SCM_OCC_OFF: p = ctx->scm_occ_off.p, b = (ns + 1) * 8; break;
                 case OATK_BUF_SCM_OCC: p = ctx->scm_occ.p, b = occ * 8; break;
-                default: return ec_buffer(ctx, which, d_ptr, bytes);     // error-correction results (api_ec.inc)
+                default:
+                    if (which >= OATK_BUF_CONS_SEL && which <= OATK_BUF_CONS_FIRST) return cons_buffer(ctx, which, d_ptr, bytes);
+                    return ec_buffer(ctx, which, d_ptr, bytes);     // error-correction results (api_ec.inc)
             }
     }
     *d_ptr = p, *bytes = b;

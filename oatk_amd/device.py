@@ -18,6 +18,7 @@ _DTYPES = {
     "EC_N_SCM": np.uint32, "EC_SCM_OFF": np.uint64, "EC_KMER": np.uint64, "EC_MPOS": np.uint32, "EC_SMER": np.uint64,
     "EC_SCM_COV": np.uint32, "EC_SCM_DEL": np.uint8, "EC_SCM_OCC_OFF": np.uint64, "EC_SCM_OCC": np.uint64, "EC_ERR_DEL": np.uint8,
     "EC_SCM_FWD": np.uint32, "EC_VTX_SRC": np.uint64,
+    "CONS_SEL": np.uint32, "CONS_SLOT": np.uint32, "CONS_RL": np.uint32, "CONS_MSEQ": np.uint32, "CONS_FIRST": np.uint64,
     "EG_IDX_P": np.uint64, "EG_IDX_N": np.uint32, "EG_ARC_V": np.uint64, "EG_ARC_W": np.uint64, "EG_ARC_LS": np.uint32,
     "EG_ARC_COV": np.uint32, "EG_ARC_COMP": np.uint8,
 }
@@ -135,6 +136,12 @@ class HipSyncasm:
 
     def ec_import_kmers(self, d_ids, d_rev, d_kmers, n, stride):
         self._check(self.L.oatk_hip_ec_import_kmers(self.h, d_ids, d_rev, d_kmers, n, stride), "oatk_hip_ec_import_kmers")
+
+    # ---- base-space consensus (include/oatk_hip_cons.h) ----
+    def consensus(self, min_cov=1):
+        """rounded mean run lengths of every live syncmer with coverage >= min_cov (scg_syncmer_consensus, syncasm.c:949-1001);
+        fetch CONS_SEL / CONS_SLOT / CONS_RL / CONS_MSEQ / CONS_FIRST"""
+        self._check(self.L.oatk_hip_consensus(self.h, min_cov), "oatk_hip_consensus")
 
     def info(self):
         i = _lib.Info()

@@ -118,6 +118,25 @@ orc_ecgraph_t *orc_ecgraph_build(uint64_t n_reads, const uint32_t *n_scm, const 
                                  const orc_count_view_t *c, int K);
 void orc_ecgraph_free(orc_ecgraph_t *g);
 
+/* base-space consensus of a syncmer (oracle/consensus.c): flat view of the reads (per-read arrays concatenated in read order) */
+typedef struct {
+    uint64_t sid0;
+    const uint64_t *scm_off;      /* [n_reads + 1] slots of the per-read chains                    */
+    const uint64_t *k_mer;        /* id << 1 | corrected                                            */
+    const uint32_t *m_pos;
+    const uint64_t *hs_off;       /* [n_reads] byte offset of the read's hoco_s                    */
+    const uint8_t *hoco_s;
+    const uint64_t *rl_off;       /* [n_reads] offset of the read's ho_rl                          */
+    const uint8_t *ho_rl;
+    const uint64_t *lrl_off;      /* [n_reads] offset of the read's ho_l_rl                        */
+    const uint32_t *ho_l_rl;
+} orc_reads_view_t;
+
+void orc_consensus_rl(const orc_reads_view_t *v, uint64_t n_occ, const uint64_t *occ, int K, uint64_t *tot_rl, uint32_t *m_seq, uint64_t *first_occ);
+/* `out` must hold |beg<0| + (K - beg) * (1 + max run length) characters; returns the length the reference returns */
+int64_t orc_consensus_string(const orc_reads_view_t *v, const uint64_t *tot_rl, uint32_t m_seq, uint64_t first_occ, int K, int rev, int64_t beg,
+                             int hoco_seq, char *out);
+
 int64_t orc_find_error_syncmers(const orc_graph_t *g, const uint32_t *scm_cov, uint8_t *scm_del, uint32_t err_mer_c,
                                 uint32_t max_err_c, uint32_t err_arc_c, double max_arc_f);
 

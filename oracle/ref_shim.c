@@ -304,3 +304,14 @@ done:
     scg_ra_v_destroy(ra_db);
     return ret;
 }
+
+/* ---- base-space consensus of one syncmer (syncasm.c:888-1003) ---- */
+int64_t refx_syncmer_consensus(sr_db_t *db, syncmer_db_t *s, uint64_t id, int rev, int64_t beg, int hoco_seq, char *out, int64_t cap)
+{
+    kstring_t ks = {0, 0, 0};
+    int64_t l = scg_syncmer_consensus(db, &s->a[id], rev, beg, &ks, hoco_seq);
+    int64_t n = (int64_t) ks.l < cap? (int64_t) ks.l : cap;
+    if (n > 0) memcpy(out, ks.s, (size_t) n);
+    free(ks.s);
+    return l;
+}

@@ -19,8 +19,8 @@ def declared(header, prefix):
 def test_hip_library_exports_every_declared_symbol():
     assert os.path.exists(_lib.LIB_PATH), "build with __graft_entry__.build()"
     L = ctypes.CDLL(_lib.LIB_PATH)
-    names = declared("oatk_hip.h", "oatk_hip_") + declared("oatk_hip_ec.h", "oatk_hip_")      # both headers are served by liboatk_hip.so
-    assert len(names) >= 19
+    names = declared("oatk_hip.h", "oatk_hip_") + declared("oatk_hip_ec.h", "oatk_hip_") + declared("oatk_hip_cons.h", "oatk_hip_")   # one library
+    assert len(names) >= 30
     for n in names:
         assert hasattr(L, n), n
     assert set(_lib.EXPORTS) <= set(names)
