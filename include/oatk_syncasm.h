@@ -114,6 +114,25 @@ typedef struct {
 int oatk_read_error_correction(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, oatk_syncmer_db_t *scm_db, oatk_asmg_t *asmg, double max_edist,
                                uint32_t err_mer_c, uint32_t max_err_c, uint32_t err_arc_c, double max_arc_f, uint64_t *stats12);
 
+/* ---- scg_syncmer_consensus (syncasm.c:888-1003) served from the device ----
+ * oatk_consensus_fetch runs oatk_hip_consensus (include/oatk_hip_cons.h) on the resident batch -- after the count, or after the
+ * error correction -- and copies the per-syncmer arrays to the host; oatk_scg_syncmer_consensus then appends to c_seq exactly what
+ * the reference's function appends for (syncmer id, rev, beg, hoco_seq) and returns what it returns, or -1 when the syncmer was not
+ * prepared (coverage below min_cov or deleted): the caller then runs its own routine.  oatk_kstring_t is kstring_t (kstring.h). */
+typedef struct { size_t l, m; char *s; } oatk_kstring_t;
+typedef struct {
+    uint64_t n_scm, n_sel;
+    int k;
+    uint32_t *slot;        /* [n_scm] index into the arrays below, ~0 = not prepared */
+    uint32_t *rl;          /* [n_sel * k] rounded mean run length per forward hoco position */
+    uint32_t *m_seq;       /* [n_sel] occurrences that took part */
+    uint64_t *first;       /* [n_sel] the first of them (sid << 32 | idx << 1 | rev), ~0 if none */
+} oatk_consensus_t;
+oatk_consensus_t *oatk_consensus_fetch(oatk_hip_ctx *ctx, uint32_t min_cov, int k, int *rc);
+void oatk_consensus_destroy(oatk_consensus_t *c);
+int64_t oatk_scg_syncmer_consensus(const oatk_consensus_t *cs, const oatk_sr_db_t *sr_db, uint64_t scm_id, int rev, int64_t beg,
+                                   oatk_kstring_t *c_seq, int hoco_seq);
+
 /* same destructors as the reference (syncmer.c:1047-1110) for objects that are not handed to it */
 void oatk_sr_db_clean(oatk_sr_db_t *sr_db);
 void oatk_syncmer_db_destroy(oatk_syncmer_db_t *scm_db);

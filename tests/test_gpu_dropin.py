@@ -118,3 +118,62 @@ def test_structs_equal_reference_structs(hip):
     for f in want_c:
         assert np.array_equal(np.asarray(got_c[f]), np.asarray(want_c[f])), f
     mine_scm.close(), mine_db.close(), ref_scm.close(), ref_db.close()
+
+
+class _KString(C.Structure):
+    _fields_ = [("l", C.c_size_t), ("m", C.c_size_t), ("s", C.c_void_p)]
+
+
+@pytest.mark.parametrize("K,S,cov,with_ec", [(101, 11, 4, False), (101, 11, 4, True), (301, 21, 4, True)])
+def test_syncmer_consensus_served_from_the_device(hip, K, S, cov, with_ec):
+    """scg_syncmer_consensus (syncasm.c:888) through liboatk_host.so: run-length totals from the MI355X, string assembly on the host,
+    against the compiled reference's function on the very same structs -- both strands, several `beg`, hoco and base space"""
+    import cons_util as CU
+    L, H = R.lib(), host_lib()
+    H.oatk_read_error_correction.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32,
+                                             C.c_double, C.c_void_p]
+    H.oatk_consensus_fetch.restype = C.c_void_p
+    H.oatk_consensus_fetch.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_int)]
+    H.oatk_consensus_destroy.argtypes = [C.c_void_p]
+    H.oatk_scg_syncmer_consensus.restype = C.c_int64
+    H.oatk_scg_syncmer_consensus.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int64, C.POINTER(_KString), C.c_int]
+    L.refx_syncmer_consensus.restype = C.c_int64
+    L.refx_syncmer_consensus.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int64, C.c_int, C.c_char_p, C.c_int64]
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    reads = CU.long_run_reads(K + 3, K)
+    db, scm = device_dbs(hip, reads, K, S)
+    if with_ec:
+        st = np.zeros(12, np.uint64)
+        assert H.oatk_read_error_correction(hip.h, db, scm, None, 0.02, cov, 10 * cov, cov, 0.35, st.ctypes.data) == 0
+        assert int(st[2] + st[7]) > 0
+    rc = C.c_int(0)
+    cs = H.oatk_consensus_fetch(hip.h, cov, K, C.byref(rc))
+    assert rc.value == 0 and cs
+    rscm = object.__new__(R.ScmDb)
+    rscm._h = scm
+    sc = rscm.flatten()
+    ids = np.nonzero((sc["cov"] >= cov) & (sc["del"] == 0))[0]
+    assert len(ids) > 20
+    buf = C.create_string_buffer(1 << 20)
+    served = 0
+    for i in ids.tolist():
+        for rev in (0, 1):
+            for beg in (0, 9, K - 1, -4):
+                for hoco in (0, 1):
+                    ks = _KString(0, 0, None)
+                    n = H.oatk_scg_syncmer_consensus(cs, db, i, rev, beg, C.byref(ks), hoco)
+                    got = C.string_at(ks.s, ks.l) if ks.l else b""
+                    libc.free(ks.s)
+                    nr = L.refx_syncmer_consensus(db, scm, i, rev, beg, hoco, buf, len(buf))
+                    assert n == nr and got == buf.raw[:nr], (i, rev, beg, hoco)
+                    served += 1
+    assert served == len(ids) * 16
+    # a syncmer below the threshold is not prepared: the caller keeps its own routine for it
+    low = np.nonzero(sc["cov"] < cov)[0]
+    if len(low):
+        ks = _KString(0, 0, None)
+        assert H.oatk_scg_syncmer_consensus(cs, db, int(low[0]), 0, 0, C.byref(ks), 0) == -1
+    H.oatk_consensus_destroy(cs)
+    L.refx_scmdb_destroy(scm)
+    L.refx_srdb_destroy(db)

@@ -29,6 +29,8 @@ for rep in range(a.reps):
     t_cnt, _ = T(hip.count)
     t_g, _ = T(hip.ec_graph)
     t_ec, st = T(lambda: hip.ec(0.02, a.c, 0.35))
+    t_cons, _ = T(lambda: hip.consensus(a.c))
+    n_sel = len(hip.fetch("CONS_SEL"))
     info = hip.info()
-    print("rep %d: %.2f Gbases  scan %.2f ms  count %.2f ms  graph %.2f ms  ec %.2f ms  -> %.2f Gbases/s  | occ %d scm %d  stats %s" % (
-        rep, bases / 1e9, t_scan, t_cnt, t_g, t_ec, bases / (t_scan + t_cnt + t_g + t_ec) / 1e6, info["n_occ"], info["n_scm"], st.tolist()), flush=True)
+    print("rep %d: %.2f Gbases  scan %.2f ms  count %.2f ms  graph %.2f ms  ec %.2f ms  consensus %.2f ms (%d syncmers)  -> %.2f Gbases/s  | occ %d scm %d  stats %s" % (
+        rep, bases / 1e9, t_scan, t_cnt, t_g, t_ec, t_cons, n_sel, bases / (t_scan + t_cnt + t_g + t_ec) / 1e6, info["n_occ"], info["n_scm"], st.tolist()), flush=True)
