@@ -10,7 +10,7 @@
 //   and every lane adds the run lengths of its 16 positions (t = lane + 64 q; coalesced 64-byte reads of ho_rl, ascending or,
 //   for a reverse occurrence, descending); run lengths behind the 255 escape are looked up in the sorted long-run list.
 //
-// Only the FORWARD orientation is stored: index t of a reverse request is index K-1-t (oracle/consensus.c proves it against the
+// Only the FORWARD orientation is stored: index t of a reverse request is index K-1-t (the CPU restatement used by the tests checks that against the
 // reference).  The string itself -- bases of the first uncorrected occurrence, 'N' padding for a negative `beg` -- is cheap host
 // work (liboatk_host: oatk_scg_syncmer_consensus).
 #pragma once
