@@ -88,20 +88,27 @@ __global__ __launch_bounds__(256) void cons_rl_kernel(ConsArgs a)
                 live &= live - 1;
                 const uint64_t ai = (uint64_t) (uint32_t) __builtin_amdgcn_readlane((int) (addr >> 32), i) << 32 | (uint32_t) __builtin_amdgcn_readlane((int) addr, i);
                 const uint32_t ri = (uint32_t) __builtin_amdgcn_readlane((int) r, i);
+                // all sixteen loads first (a test of each value right behind its load would serialise sixteen round trips)
+                uint32_t v[CONS_Q];
+                bool esc = false;
 #pragma unroll
                 for (int q = 0; q < CONS_Q; ++q) {
                     const int t = t0 + (int) lane + 64 * q;
-                    if (t < K) {
-                        const int po = ri? K - 1 - t : t;
-                        uint32_t v = a.ho_rl[ai + (uint64_t) po];
-                        if (v == 255u) {                             // the run length sits in the long-run list (syncmer.c: ho_l_rl)
-                            const uint64_t ki = (uint64_t) (uint32_t) __builtin_amdgcn_readlane((int) (key0 >> 32), i) << 32
-                                              | (uint32_t) __builtin_amdgcn_readlane((int) key0, i);
-                            v = cons_long_run(a, ki + (uint64_t) po);
-                        }
-                        acc[q] += v;
+                    v[q] = t < K? (uint32_t) a.ho_rl[ai + (uint64_t) (ri? K - 1 - t : t)] : 0u;
+                }
+#pragma unroll
+                for (int q = 0; q < CONS_Q; ++q) esc |= v[q] == 255u;
+                if (__any(esc)) {                                    // run lengths that sit in the long-run list (syncmer.c: ho_l_rl)
+                    const uint64_t ki = (uint64_t) (uint32_t) __builtin_amdgcn_readlane((int) (key0 >> 32), i) << 32
+                                      | (uint32_t) __builtin_amdgcn_readlane((int) key0, i);
+#pragma unroll
+                    for (int q = 0; q < CONS_Q; ++q) {
+                        const int t = t0 + (int) lane + 64 * q;
+                        if (v[q] == 255u) v[q] = cons_long_run(a, ki + (uint64_t) (ri? K - 1 - t : t));
                     }
                 }
+#pragma unroll
+                for (int q = 0; q < CONS_Q; ++q) acc[q] += v[q];
             }
         }
 #pragma unroll
