@@ -21,6 +21,9 @@ BUF = {name: i for i, name in enumerate([
 BUF.update({name: 100 + i for i, name in enumerate([
     "EC_N_SCM", "EC_SCM_OFF", "EC_KMER", "EC_MPOS", "EC_SMER", "EC_SCM_COV", "EC_SCM_DEL", "EC_SCM_OCC_OFF", "EC_SCM_OCC", "EC_ERR_DEL",
     "EC_SCM_FWD", "EC_VTX_SRC"])})
+# include/oatk_hip_ingest.h
+BUF.update({name: 160 + i for i, name in enumerate(["INGEST_SEQ", "INGEST_OFF", "INGEST_LEN", "INGEST_HDR"])})
+FMT_AUTO, FMT_FASTA, FMT_FASTQ = 0, 1, 2
 # include/oatk_hip_cons.h
 BUF.update({name: 140 + i for i, name in enumerate(["CONS_SEL", "CONS_SLOT", "CONS_RL", "CONS_MSEQ", "CONS_FIRST"])})
 BUF.update({name: 120 + i for i, name in enumerate([
@@ -34,7 +37,7 @@ EXPORTS = [
     "oatk_hip_debug_hash_mask", "oatk_hip_debug_force_general",
     "oatk_hip_ec_graph", "oatk_hip_ec", "oatk_hip_ec_stats", "oatk_hip_debug_ec_tiers", "oatk_hip_ec_mark", "oatk_hip_ec_correct",
     "oatk_hip_ec_set_global", "oatk_hip_ec_pairs", "oatk_hip_ec_graph_from_pairs", "oatk_hip_ec_export_kmers", "oatk_hip_ec_import_kmers",
-    "oatk_hip_ec_reserve_import", "oatk_hip_consensus",
+    "oatk_hip_ec_reserve_import", "oatk_hip_consensus", "oatk_hip_ingest", "oatk_hip_ingest_host", "oatk_hip_scan_ingested",
 ]
 
 
@@ -101,5 +104,8 @@ def load():
     L.oatk_hip_ec_import_kmers.argtypes = [vp, vp, vp, vp, C.c_uint64, C.c_uint32]
     L.oatk_hip_ec_reserve_import.argtypes = [vp, C.c_uint64]
     L.oatk_hip_consensus.argtypes = [vp, C.c_uint32]
+    L.oatk_hip_ingest.argtypes = [vp, vp, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.oatk_hip_ingest_host.argtypes = [vp, vp, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.oatk_hip_scan_ingested.argtypes = [vp, C.c_uint64, C.c_int, C.c_int]
     _lib = L
     return L

@@ -83,6 +83,7 @@ struct oatk_hip_ctx {
     DevBuf tmp;           // rocprim temporary storage
     struct EcState *ec = nullptr;   // error-correction buffers (api_ec.inc)
     struct ConsState *cons = nullptr;   // consensus buffers (api_cons.inc)
+    struct IngState *ing = nullptr;     // record scan buffers (api_ingest.inc)
 };
 
 #define CK(call)                                                                                   \
@@ -125,6 +126,7 @@ static void t_collect(oatk_hip_ctx *ctx, int first, int last)
 
 #include "api_ec.inc"
 #include "api_cons.inc"
+#include "api_ingest.inc"
 
 extern "C" {
 
@@ -172,6 +174,7 @@ void oatk_hip_destroy(oatk_hip_ctx *ctx)
     for (DevBuf *b : all) b->release();
     ec_state_free(ctx);
     cons_state_free(ctx);
+    ing_state_free(ctx);
     for (int i = 0; i <= OATK_T_COUNT_; ++i) {
         (void) hipEventDestroy(ctx->ev[i][0]);
         (void) hipEventDestroy(ctx->ev[i][1]);
@@ -514,6 +517,7 @@ int oatk_hip_info(oatk_hip_ctx *ctx, oatk_hip_info_t *out)
 int oatk_hip_buffer(oatk_hip_ctx *ctx, int which, const void **d_ptr, uint64_t *bytes)
 {
     if (!ctx) return OATK_E_NODEV;
+    if (which >= OATK_BUF_INGEST_SEQ && which <= OATK_BUF_INGEST_HDR) return ing_buffer(ctx, which, d_ptr, bytes);      // precedes any scan
     if (!ctx->scanned) { ctx->err = "no resident scan"; return OATK_E_STATE; }
     const uint64_t n = ctx->n_reads, occ = ctx->n_occ, ns = ctx->n_scm_total;
     const void *p = nullptr;
@@ -543,6 +547,7 @@ int oatk_hip_buffer(oatk_hip_ctx *ctx, int which, const void **d_ptr, uint64_t *
                 case OATK_BUF_SCM_OCC: p = ctx->scm_occ.p, b = occ * 8; break;
                 default:
                     if (which >= OATK_BUF_CONS_SEL && which <= OATK_BUF_CONS_FIRST) return cons_buffer(ctx, which, d_ptr, bytes);
+                    if (which >= OATK_BUF_INGEST_SEQ && which <= OATK_BUF_INGEST_HDR) return ing_buffer(ctx, which, d_ptr, bytes);
                     return ec_buffer(ctx, which, d_ptr, bytes);     // error-correction results (api_ec.inc)
             }
     }

@@ -18,6 +18,7 @@ _DTYPES = {
     "EC_N_SCM": np.uint32, "EC_SCM_OFF": np.uint64, "EC_KMER": np.uint64, "EC_MPOS": np.uint32, "EC_SMER": np.uint64,
     "EC_SCM_COV": np.uint32, "EC_SCM_DEL": np.uint8, "EC_SCM_OCC_OFF": np.uint64, "EC_SCM_OCC": np.uint64, "EC_ERR_DEL": np.uint8,
     "EC_SCM_FWD": np.uint32, "EC_VTX_SRC": np.uint64,
+    "INGEST_SEQ": np.uint8, "INGEST_OFF": np.uint64, "INGEST_LEN": np.uint32, "INGEST_HDR": np.uint64,
     "CONS_SEL": np.uint32, "CONS_SLOT": np.uint32, "CONS_RL": np.uint32, "CONS_MSEQ": np.uint32, "CONS_FIRST": np.uint64,
     "EG_IDX_P": np.uint64, "EG_IDX_N": np.uint32, "EG_ARC_V": np.uint64, "EG_ARC_W": np.uint64, "EG_ARC_LS": np.uint32,
     "EG_ARC_COV": np.uint32, "EG_ARC_COMP": np.uint8,
@@ -136,6 +137,25 @@ class HipSyncasm:
 
     def ec_import_kmers(self, d_ids, d_rev, d_kmers, n, stride):
         self._check(self.L.oatk_hip_ec_import_kmers(self.h, d_ids, d_rev, d_kmers, n, stride), "oatk_hip_ec_import_kmers")
+
+    # ---- FASTA / FASTQ text -> packed read stream on the device (include/oatk_hip_ingest.h) ----
+    def ingest_host(self, text, fmt=0, final=True):
+        """text: bytes / uint8 array with the (inflated) content of a FASTA or four-line FASTQ file, or a chunk of one (final=False).
+        Returns (n_reads, consumed bytes); the packed stream stays resident: scan_ingested() / fetch('INGEST_*')"""
+        t = np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray, memoryview)) else np.ascontiguousarray(text, dtype=np.uint8)
+        self._keep_text = t
+        n, used = C.c_uint64(), C.c_uint64()
+        self._check(self.L.oatk_hip_ingest_host(self.h, t.ctypes.data if t.size else None, t.size, fmt, 1 if final else 0, C.byref(n), C.byref(used)),
+                    "oatk_hip_ingest_host")
+        return int(n.value), int(used.value)
+
+    def ingest_device(self, d_text, n_bytes, fmt=0, final=True):
+        n, used = C.c_uint64(), C.c_uint64()
+        self._check(self.L.oatk_hip_ingest(self.h, d_text, n_bytes, fmt, 1 if final else 0, C.byref(n), C.byref(used)), "oatk_hip_ingest")
+        return int(n.value), int(used.value)
+
+    def scan_ingested(self, k, s, sid0=0):
+        self._check(self.L.oatk_hip_scan_ingested(self.h, sid0, k, s), "oatk_hip_scan_ingested")
 
     # ---- base-space consensus (include/oatk_hip_cons.h) ----
     def consensus(self, min_cov=1):

@@ -1,0 +1,135 @@
+"""GPU: the device-side FASTA / FASTQ record scan (oatk_hip_ingest) -- the reads it finds equal kseq's reading of the same text
+(restated in kseq_like below and, end to end, the compiled reference's sr_read of the same FILE), for wrapped and unwrapped FASTA,
+CRLF, blank lines, junk before the first header, a last line without newline, four-line FASTQ with quality lines that begin
+with '@' / '+', and a text fed in chunks."""
+import numpy as np
+import pytest
+
+import adversarial as A
+import ref_lib as R
+from oatk_amd import OatkHipError, pack_reads
+
+pytestmark = pytest.mark.gpu
+
+
+def kseq_like(text: bytes):
+    """(name, seq) records the way kseq_read (kseq.h:192-235) reads FASTA / four-line FASTQ"""
+    out, lines, i = [], text.split(b"\n"), 0
+    if lines and lines[-1] == b"":
+        lines.pop()
+    lines = [ln[:-1] if ln.endswith(b"\r") else ln for ln in lines]
+    while i < len(lines) and not (lines[i][:1] in (b">", b"@")):
+        i += 1
+    while i < len(lines):
+        name, fq = lines[i][1:].split()[0] if lines[i][1:].split() else b"", lines[i][:1] == b"@"
+        i += 1
+        seq = b""
+        while i < len(lines) and lines[i][:1] not in (b">", b"@", b"+"):
+            seq += lines[i]
+            i += 1
+        if i < len(lines) and lines[i][:1] == b"+":
+            i += 1
+            q = 0
+            while i < len(lines) and q < len(seq):
+                q += len(lines[i])
+                i += 1
+        out.append((name, seq))
+    return out
+
+
+def device_reads(hip, text, fmt=0):
+    n, used = hip.ingest_host(text, fmt, True)
+    seq, off, lens = hip.fetch("INGEST_SEQ"), hip.fetch("INGEST_OFF"), hip.fetch("INGEST_LEN")
+    assert n == len(off) == len(lens) and used == len(text)
+    assert np.all(off % 64 == 0)
+    return [seq[int(o):int(o) + int(l)].tobytes() for o, l in zip(off, lens)]
+
+
+def fasta(reads, width=0, eol=b"\n", last_eol=True, blank_every=0, head=b">"):
+    t = b""
+    for i, r in enumerate(reads):
+        t += head + b"read%d some comment" % i + eol
+        body = [r[j:j + width] for j in range(0, len(r), width)] if width else [r]
+        for j, ln in enumerate(body):
+            t += ln + eol
+            if blank_every and j % blank_every == 1:
+                t += eol
+    return t if last_eol else t[:-len(eol)]
+
+
+def fastq(reads, eol=b"\n", seed=0):
+    rng = np.random.default_rng(seed)
+    t = b""
+    for i, r in enumerate(reads):
+        q = bytes(rng.choice(np.frombuffer(b"@+>I5~!", np.uint8), len(r)).tolist())       # quality lines starting with '@', '+', '>'
+        t += b"@m84/%d/ccs" % i + eol + r + eol + b"+" + eol + q + eol
+    return t
+
+
+READS = A.hifi_like(40, 20000, 3000, seed=11) + [b"acgtnACGTN" * 30, b"A" * 700, b"C"]
+
+
+@pytest.mark.parametrize("variant", ["plain", "wrap60", "wrap70_crlf", "blank_lines", "no_last_eol", "junk_first", "at_headers"])
+def test_fasta_variants(hip, variant):
+    t = {"plain": lambda: fasta(READS), "wrap60": lambda: fasta(READS, 60), "wrap70_crlf": lambda: fasta(READS, 70, b"\r\n"),
+         "blank_lines": lambda: fasta(READS, 50, blank_every=3), "no_last_eol": lambda: fasta(READS, 80, last_eol=False),
+         "junk_first": lambda: b"\n\n# produced by something\n" + fasta(READS, 61), "at_headers": lambda: fasta(READS, 0, head=b"@")}[variant]()
+    got = device_reads(hip, t, 1)                       # FASTA stated: a file of '@' headers is FASTA to kseq if no '+' line follows
+    want = [s for _, s in kseq_like(t)]
+    assert got == want and got == READS
+
+
+def test_fastq_four_line(hip):
+    for eol in (b"\n", b"\r\n"):
+        t = fastq(READS, eol)
+        assert device_reads(hip, t) == READS == [s for _, s in kseq_like(t)]
+    with pytest.raises(OatkHipError):                   # wrapped FASTQ is refused, not misread
+        bad = b"@r0\nACGTACGT\nACGT\n+\nIIIIIIII\nIIII\n@r1\nAC\n+\nII\n@r2\nAC\n+\nII\n"
+        hip.ingest_host(bad, 2, True)
+
+
+@pytest.mark.parametrize("kind", ["fasta", "fastq"])
+def test_chunked_text_gives_the_same_reads(hip, kind):
+    t = fasta(READS, 64) if kind == "fasta" else fastq(READS)
+    rng = np.random.default_rng(5)
+    got, pos, carry = [], 0, b""
+    cuts = sorted(rng.integers(1, len(t) - 1, 9).tolist()) + [len(t)]
+    for c in cuts:
+        chunk = carry + t[pos:c]
+        final = c == len(t)
+        n, used = hip.ingest_host(chunk, 1 if kind == "fasta" else 2, final)
+        seq, off, lens = hip.fetch("INGEST_SEQ"), hip.fetch("INGEST_OFF"), hip.fetch("INGEST_LEN")
+        got += [seq[int(o):int(o) + int(l)].tobytes() for o, l in zip(off, lens)]
+        carry, pos = chunk[used:], c
+        assert final or used <= len(chunk)
+    assert got == READS
+
+
+@pytest.mark.skipif(not R.available(), reason="oracle/_ref not built")
+def test_file_through_device_ingest_equals_reference_sr_read(hip, tmp_path):
+    """the FILE the reference reads with kseq, read by the device instead: scan results identical member by member"""
+    K, S = 301, 21
+    reads = A.hifi_like(120, 30000, 4000, seed=21)
+    path = str(tmp_path / "reads.fa")
+    with open(path, "wb") as f:
+        f.write(fasta(reads, 70))
+    db = R.SrDb([path], K, S, 2)
+    want = db.flatten()
+    n, _ = hip.ingest_host(open(path, "rb").read())
+    assert n == len(reads)
+    hip.scan_ingested(K, S)
+    got = hip.fetch_scan(hip.fetch("INGEST_OFF"))
+    for f in ["hoco_l", "n_scm", "hoco_s", "ho_rl", "ho_l_rl", "m_pos", "s_mer", "k_mer"]:
+        assert np.array_equal(got[f], want[f]), f
+    # and the same as scanning the reads handed over as a packed stream
+    seq, off, lens = pack_reads(reads)
+    hip.scan_host(seq, off, lens, K, S)
+    again = hip.fetch_scan(off)
+    for f in ["hoco_l", "n_scm", "m_pos", "s_mer", "k_mer"]:
+        assert np.array_equal(again[f], got[f]), f
+    db.close()
+
+
+def test_empty_and_headers_only(hip):
+    assert hip.ingest_host(b"", 0, True) == (0, 0)
+    assert device_reads(hip, b">a\n>b\nACGT\n>c\n", 1) == [b"", b"ACGT", b""]
