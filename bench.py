@@ -39,6 +39,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; the contract) or gloo (development: several ranks on ONE GPU)")
     ap.add_argument("--no-syncerr", action="store_true", help="skip the extra scan + count + error-correction measurement")
+    ap.add_argument("--no-ingest", action="store_true", help="skip the FASTA-text-to-syncmers measurement (device record scan, PCIe included)")
+    ap.add_argument("--ingest-reads", type=int, default=50000)
     ap.add_argument("--cpu-sample-reads", type=int, default=80000)
     ap.add_argument("--cpu-threads", type=int, default=8)
     return ap.parse_args()
@@ -233,6 +235,55 @@ def main():
         hip.count()
         fence()
 
+    # ---- from the TEXT of a FASTA file to syncmers: host -> device copy of the text (PCIe), record scan on the device
+    #      (include/oatk_hip_ingest.h), scan.  Rank 0, a bounded sample; the reference's reader does 0.4 Gbases/s here. ----
+    ingest = None
+    if rank == 0 and not args.no_ingest:
+        try:
+            n_ing = min(args.ingest_reads, per_gpu)
+            sq, of, ln = rs.slice(first, n_ing)
+            parts = []
+            for i in range(n_ing):
+                parts.append(b">r%d\n" % i)
+                parts.append(sq[int(of[i]):int(of[i]) + int(ln[i])].tobytes())
+                parts.append(b"\n")
+            text = torch.from_numpy(np.frombuffer(b"".join(parts), dtype=np.uint8).copy()).pin_memory()
+            del parts, sq
+            ing_bases = int(ln.sum())
+            best = None
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                d_text = text.to(dev, non_blocking=True)
+                torch.cuda.synchronize()
+                t_copy = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                n_found, _ = hip.ingest_device(d_text.data_ptr(), int(d_text.numel()), 1, True)
+                hip.sync()
+                t_ing = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                hip.scan_ingested(K, S, sid0=first)
+                hip.count()
+                hip.sync()
+                t_sc = time.perf_counter() - t0
+                assert n_found == n_ing
+                tot = t_copy + t_ing + t_sc
+                if best is None or tot < best[0]:
+                    best = (tot, t_copy, t_ing, t_sc)
+            ingest = {"value": round(ing_bases / best[0] / 1e9, 3), "unit": "Gbases/s",
+                      "workload": "text of an unwrapped FASTA file with %d reads (%.2f GB) in pinned host memory -> PCIe copy -> record scan on the device -> scan + count"
+                                  % (n_ing, text.numel() / 1e9),
+                      "ms_h2d": round(best[1] * 1e3, 3), "h2d_GBs": round(text.numel() / best[1] / 1e9, 2),
+                      "ms_record_scan": round(best[2] * 1e3, 3), "record_scan_GBs_of_text": round(text.numel() / best[2] / 1e9, 2),
+                      "ms_scan_count": round(best[3] * 1e3, 3)}
+            del text, d_text
+        except Exception as ex:             # noqa: BLE001
+            ingest = {"error": "%s: %s" % (type(ex).__name__, ex)}
+        # restore the scan + count state the rest of this report describes
+        hip.scan_device(d_seq.data_ptr(), d_off.data_ptr(), d_len.data_ptr(), per_gpu, seq_bytes, K, S, sid0=first)
+        hip.count()
+        hip.sync()
+
     if rank == 0:
         # ---- roofline of the dominant kernel (by measured time) ----
         hoco = int(hip.fetch("HOCO_L").astype(np.uint64).sum())
@@ -267,7 +318,7 @@ def main():
                                    % (args.workload, per_gpu, cfg["mean_len"] // 1000),
                        "reads_per_gpu": per_gpu, "bases_per_gpu": bases, "genome_len": cfg["genome_len"],
                        "parallelism": "reads sharded by record, %d rank(s)" % world},
-            "roofline": roofline, "cpu_baseline": cpu, "syncerr": syncerr,
+            "roofline": roofline, "cpu_baseline": cpu, "syncerr": syncerr, "ingest": ingest,
             "phases_ms": {k_: round(v, 4) for k_, v in phase_ms.items()},
             "syncmers": {"occurrences": n_occ, "distinct": info["n_scm"], "hoco_ratio": round(hoco / bases, 4)},
         }
