@@ -134,3 +134,22 @@ def test_fast_kernel_k_range(hip, K, S):
     reads = A.hifi_like(30, 30000, 9000, seed=K) + A.reads(K, S, seed=3, scale=0.3)[:30]
     got, _ = run_hip(hip, reads, K, S)
     compare_scan(got, O.scan(reads, K, S, mode=1))
+
+
+@pytest.mark.parametrize("K,S", [(1001, 31), (561, 31), (1060, 31)])
+def test_long_low_complexity_reads(hip, K, S):
+    """many tiles of tandem repeats inside long reads: equal s-mer hashes everywhere, so the top-word filter of the fast kernel
+    ties constantly and the exact 64-bit rule (chunk minima included) decides -- at the edges of the fast kernel's K - S range too"""
+    rng = np.random.default_rng(K)
+    w = K - S
+    reads = []
+    for unit_len in (2, 3, 7, S, S + 1, 64, w - 1, w, w + 1, K, 2048, 4096, 5000):
+        unit = A.rand_nohp(rng, unit_len)
+        rep = (unit * (26000 // unit_len + 2))[:26000]
+        reads.append(A.rand_nohp(rng, 2500) + rep + A.rand_nohp(rng, 1800))
+        reads.append(rep[:9000] + A.rand_dna(rng, 3000) + rep[:7000])
+    reads.append(A.rand_dna(rng, 40000))
+    got, _ = run_hip(hip, reads, K, S)
+    want = O.scan(reads, K, S, mode=0)
+    compare_scan(got, want)
+    assert int(got["n_scm"].sum()) > 1000
