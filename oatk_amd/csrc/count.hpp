@@ -101,6 +101,7 @@ struct GroupArgs {
     uint32_t *head_idx;           // sorted index of the group head (filled by a max-scan)
     uint32_t *newclus;            // 1 where a new syncmer (cluster) starts; starts as a copy of head
     uint32_t *flags;              // [0] some group holds different k-mers, [1] s-mer mismatch, [2] too many clusters
+    uint64_t *loc;                // where the k-mer of sorted record i lives: (32-bit word index of its read's hoco string) << 32 | pos << 1 | rev
 };
 
 __global__ void mark_heads_kernel(GroupArgs a)
@@ -111,25 +112,33 @@ __global__ void mark_heads_kernel(GroupArgs a)
     a.head[i] = h;
     a.newclus[i] = h;
     a.head_idx[i] = h? i : 0u;
+    // the gathers verify_group would otherwise chain in front of every k-mer read, done here once, a lane per record
+    const uint32_t p = a.perm[i];
+    a.loc[i] = ((a.off[(a.pos_lo[p] >> 32) - a.sid0] >> 4) << 32) | a.pos_mpos[p];
 }
 
-// one wave per sorted record that is not a group head: is its k-mer identical to the head's?
+// half a wave per sorted record that is not a group head: is its k-mer identical to the head's?  (32 lanes x 32 bases cover
+// k <= 1024 in one step; two records per wave keep all lanes busy)
 __global__ __launch_bounds__(256) void verify_group_kernel(GroupArgs a, uint32_t *bad_head)
 {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (i >= a.n_rec || a.head[i]) return;
-    const uint32_t hidx = a.head_idx[i];
-    const uint32_t p = a.perm[i], q = a.perm[hidx];
-    const uint64_t lo_p = a.pos_lo[p], lo_q = a.pos_lo[q];
-    const uint32_t *hs_p = (const uint32_t *) (a.hoco_s + (a.off[(lo_p >> 32) - a.sid0] >> 2));
-    const uint32_t *hs_q = (const uint32_t *) (a.hoco_s + (a.off[(lo_q >> 32) - a.sid0] >> 2));
-    const uint32_t mp = a.pos_mpos[p], mq = a.pos_mpos[q];
-    const int nw = (a.K + 31) / 32;
+    const uint32_t hl = threadIdx.x & 31;
+    const uint32_t i = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
+    const bool live = i < a.n_rec && !a.head[i];
     bool diff = false;
-    for (int wd = (int) lane; wd < nw; wd += 64)
-        diff |= kmer_word_global(hs_p, mp >> 1, mp & 1u, a.K, wd) != kmer_word_global(hs_q, mq >> 1, mq & 1u, a.K, wd);
-    if (__any(diff) && lane == 0) {
+    uint32_t hidx = 0;
+    if (live) {
+        hidx = a.head_idx[i];
+        const uint64_t lp = a.loc[i], lq = a.loc[hidx];
+        const uint32_t *hs32 = (const uint32_t *) a.hoco_s;
+        const uint32_t *hs_p = hs32 + (lp >> 32), *hs_q = hs32 + (lq >> 32);
+        const uint32_t mp = (uint32_t) lp, mq = (uint32_t) lq;
+        const int nw = (a.K + 31) / 32;
+        for (int wd = (int) hl; wd < nw; wd += 32)
+            diff |= kmer_word_global(hs_p, mp >> 1, mp & 1u, a.K, wd) != kmer_word_global(hs_q, mq >> 1, mq & 1u, a.K, wd);
+    }
+    const uint64_t bad = __ballot(diff);
+    const uint32_t mine = (uint32_t) (threadIdx.x & 32? bad >> 32 : bad);
+    if (mine && hl == 0) {
         a.flags[0] = 1u;
         bad_head[hidx] = 1u;
     }

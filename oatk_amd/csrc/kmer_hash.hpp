@@ -32,11 +32,19 @@ __global__ __launch_bounds__(64) void kmer_hash_kernel(KmerHashArgs a)
     const int stride = NW + 1;
     const uint32_t nrec = a.n_rec - base < 64u? a.n_rec - base : 64u;
     const uint32_t items = nrec * (uint32_t) NW;
-    for (uint32_t it = lane; it < items; it += 64u) {
-        const uint32_t rr = it / (uint32_t) NW, wd = it - rr * (uint32_t) NW;
-        const uint32_t rec = base + rr;
-        const uint32_t mp = a.rec_mpos[rec];
-        const uint32_t *hs = (const uint32_t *) (a.hoco_s + (a.off[(a.rec_lo[rec] >> 32) - a.sid0] >> 2));
+    // where record `lane` lives: fetched once, handed to the lanes that read its words by ds_bpermute (three dependent gathers
+    // in front of every word otherwise)
+    uint32_t my_mp = 0, my_hsw = 0;
+    if (lane < nrec) {
+        my_mp = a.rec_mpos[base + lane];
+        my_hsw = (uint32_t) (a.off[(a.rec_lo[base + lane] >> 32) - a.sid0] >> 4);      // 32-bit word index of the read's hoco string
+    }
+    const uint32_t *hs32 = (const uint32_t *) a.hoco_s;
+    for (uint32_t it = lane; it < ((items + 63u) & ~63u); it += 64u) {
+        const uint32_t rr0 = it / (uint32_t) NW, rr = rr0 < nrec? rr0 : 0u, wd = it - rr0 * (uint32_t) NW;
+        const uint32_t mp = __shfl(my_mp, (int) rr);
+        const uint32_t *hs = hs32 + __shfl(my_hsw, (int) rr);
+        if (it >= items) continue;
         uint64_t word = bswap64(kmer_word_global(hs, mp >> 1, mp & 1u, K, (int) wd));
         kmix[rr * (uint32_t) stride + wd] = (int) wd < nfull? murmur_mix_word(word) : word;
     }
