@@ -342,7 +342,7 @@ int oatk_hip_scan(oatk_hip_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off
         kh.n_rec = (uint32_t) ctx->n_occ, kh.K = ctx->K;
         const int nw = ((ctx->K - 1) / 4 + 1 + 7) / 8;
         t_begin(ctx, OATK_T_KMER_HASH);
-        hipLaunchKernelGGL(oatk::kmer_hash_kernel, dim3((unsigned) ((ctx->n_occ + 63) / 64)), dim3(64), (size_t) 64 * (nw + 1) * 8, ctx->stream, kh);
+        hipLaunchKernelGGL(oatk::kmer_hash_kernel, dim3((unsigned) ((ctx->n_occ + KMH_REC - 1) / KMH_REC)), dim3(64), (size_t) KMH_REC * (nw + 1) * 8, ctx->stream, kh);
         t_end(ctx, OATK_T_KMER_HASH);
     }
 

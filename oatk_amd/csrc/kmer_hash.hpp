@@ -22,15 +22,17 @@ struct KmerHashArgs {
     int K;
 };
 
+#define KMH_REC 16                // records per wave: most lanes idle in the short chain phase, but four times the waves fit a CU's LDS (64: 1.12 ms, 32: 0.75, 16: 0.56, 8: 0.67)
+
 __global__ __launch_bounds__(64) void kmer_hash_kernel(KmerHashArgs a)
 {
-    extern __shared__ uint64_t kmix[];          // 64 records x (NW + 1)
+    extern __shared__ uint64_t kmix[];          // KMH_REC records x (NW + 1)
     const uint32_t lane = threadIdx.x;
-    const uint32_t base = blockIdx.x * 64u;
+    const uint32_t base = blockIdx.x * (uint32_t) KMH_REC;
     const int K = a.K;
     const int nbytes = (K - 1) / 4 + 1, nfull = nbytes >> 3, nrem = nbytes & 7, NW = nfull + (nrem? 1 : 0);
     const int stride = NW + 1;
-    const uint32_t nrec = a.n_rec - base < 64u? a.n_rec - base : 64u;
+    const uint32_t nrec = a.n_rec - base < (uint32_t) KMH_REC? a.n_rec - base : (uint32_t) KMH_REC;
     const uint32_t items = nrec * (uint32_t) NW;
     // where record `lane` lives: fetched once, handed to the lanes that read its words by ds_bpermute (three dependent gathers
     // in front of every word otherwise)
