@@ -19,6 +19,7 @@
 
 #include <stddef.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include "oatk_hip.h"
 
@@ -113,6 +114,11 @@ typedef struct {
  * scg_consensus and scg_destroy of run_syncasm.c:109-132 altogether; only the reads and the syncmer table are written back. */
 int oatk_read_error_correction(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, oatk_syncmer_db_t *scm_db, oatk_asmg_t *asmg, double max_edist,
                                uint32_t err_mer_c, uint32_t max_err_c, uint32_t err_arc_c, double max_arc_f, uint64_t *stats12);
+
+/* sr_db_stat (syncmer.c:867): the two sorts and the tabulation on the device (include/oatk_hip_stat.h), the peak finder and the report
+ * here; fills sr_db->stats (allocated if NULL) and prints the reference's nine lines to fo (may be NULL).  Works on the batch resident
+ * in ctx at whatever stage it is -- after sr_read (run_syncasm.c:88) or after read_error_correction (:131). */
+int oatk_sr_db_stat(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, FILE *fo, int verbose);
 
 /* ---- scg_syncmer_consensus (syncasm.c:888-1003) served from the device ----
  * oatk_consensus_fetch runs oatk_hip_consensus (include/oatk_hip_cons.h) on the resident batch -- after the count, or after the

@@ -37,7 +37,7 @@ EXPORTS = [
     "oatk_hip_debug_hash_mask", "oatk_hip_debug_force_general",
     "oatk_hip_ec_graph", "oatk_hip_ec", "oatk_hip_ec_stats", "oatk_hip_debug_ec_tiers", "oatk_hip_ec_mark", "oatk_hip_ec_correct",
     "oatk_hip_ec_set_global", "oatk_hip_ec_pairs", "oatk_hip_ec_graph_from_pairs", "oatk_hip_ec_export_kmers", "oatk_hip_ec_import_kmers",
-    "oatk_hip_ec_reserve_import", "oatk_hip_consensus", "oatk_hip_ingest", "oatk_hip_ingest_host", "oatk_hip_scan_ingested",
+    "oatk_hip_ec_reserve_import", "oatk_hip_consensus", "oatk_hip_ingest", "oatk_hip_ingest_host", "oatk_hip_scan_ingested", "oatk_hip_stat",
 ]
 
 
@@ -45,6 +45,13 @@ class EcGraph(C.Structure):
     """oatk_ec_graph_t (include/oatk_hip_ec.h): the reference's asmg_t flattened, host pointers"""
     _fields_ = [("n_vtx", C.c_uint64), ("n_arc", C.c_uint64), ("idx_p", C.c_void_p), ("idx_n", C.c_void_p), ("arc_v", C.c_void_p),
                 ("arc_w", C.c_void_p), ("arc_ls", C.c_void_p), ("arc_cov", C.c_void_p), ("arc_del", C.c_void_p)]
+
+
+class StatRaw(C.Structure):
+    """oatk_stat_raw_t (include/oatk_hip_stat.h)"""
+    _fields_ = [("n_reads", C.c_uint64), ("n_syncmers", C.c_uint64), ("sum_dist", C.c_int64), ("n_dist", C.c_uint64),
+                ("smer_unique", C.c_uint64), ("kmer_unique", C.c_uint64), ("smer_cnt", C.c_int64 * 1001), ("kmer_cnt", C.c_int64 * 1001),
+                ("smer_no_singleton", C.c_int64), ("kmer_no_singleton", C.c_int64)]
 
 
 class Info(C.Structure):
@@ -107,5 +114,6 @@ def load():
     L.oatk_hip_ingest.argtypes = [vp, vp, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.oatk_hip_ingest_host.argtypes = [vp, vp, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.oatk_hip_scan_ingested.argtypes = [vp, C.c_uint64, C.c_int, C.c_int]
+    L.oatk_hip_stat.argtypes = [vp, C.POINTER(StatRaw)]
     _lib = L
     return L

@@ -84,6 +84,7 @@ struct oatk_hip_ctx {
     struct EcState *ec = nullptr;   // error-correction buffers (api_ec.inc)
     struct ConsState *cons = nullptr;   // consensus buffers (api_cons.inc)
     struct IngState *ing = nullptr;     // record scan buffers (api_ingest.inc)
+    struct StatState *stat = nullptr;   // scan statistics buffers (api_stat.inc)
 };
 
 #define CK(call)                                                                                   \
@@ -127,6 +128,7 @@ static void t_collect(oatk_hip_ctx *ctx, int first, int last)
 #include "api_ec.inc"
 #include "api_cons.inc"
 #include "api_ingest.inc"
+#include "api_stat.inc"
 
 extern "C" {
 
@@ -175,6 +177,7 @@ void oatk_hip_destroy(oatk_hip_ctx *ctx)
     ec_state_free(ctx);
     cons_state_free(ctx);
     ing_state_free(ctx);
+    stat_state_free(ctx);
     for (int i = 0; i <= OATK_T_COUNT_; ++i) {
         (void) hipEventDestroy(ctx->ev[i][0]);
         (void) hipEventDestroy(ctx->ev[i][1]);

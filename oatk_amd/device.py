@@ -157,6 +157,14 @@ class HipSyncasm:
     def scan_ingested(self, k, s, sid0=0):
         self._check(self.L.oatk_hip_scan_ingested(self.h, sid0, k, s), "oatk_hip_scan_ingested")
 
+    # ---- scan statistics (include/oatk_hip_stat.h) ----
+    def stat_raw(self):
+        """multiplicity histograms of s-mers / k-mers and the distance sum of sr_db_stat (syncmer.c:867), at the batch's current stage"""
+        r = _lib.StatRaw()
+        self._check(self.L.oatk_hip_stat(self.h, C.byref(r)), "oatk_hip_stat")
+        return {"n_reads": r.n_reads, "n_syncmers": r.n_syncmers, "sum_dist": r.sum_dist, "n_dist": r.n_dist, "smer_unique": r.smer_unique,
+                "kmer_unique": r.kmer_unique, "smer_cnt": np.array(r.smer_cnt, np.int64), "kmer_cnt": np.array(r.kmer_cnt, np.int64)}
+
     # ---- base-space consensus (include/oatk_hip_cons.h) ----
     def consensus(self, min_cov=1):
         """rounded mean run lengths of every live syncmer with coverage >= min_cov (scg_syncmer_consensus, syncasm.c:949-1001);

@@ -177,3 +177,56 @@ def test_syncmer_consensus_served_from_the_device(hip, K, S, cov, with_ec):
     H.oatk_consensus_destroy(cs)
     L.refx_scmdb_destroy(scm)
     L.refx_srdb_destroy(db)
+
+
+@pytest.mark.parametrize("K,S,cov", [(101, 11, 4), (301, 21, 5)])
+def test_sr_db_stat_from_the_device(hip, K, S, cov):
+    """sr_db_stat (syncmer.c:867) through liboatk_host.so at its two call sites -- after sr_read (k-mers are still hashes,
+    run_syncasm.c:88) and after read_error_correction (:131) -- against the compiled reference on the very same structs"""
+    L, H = R.lib(), host_lib()
+    H.oatk_sr_db_stat.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    H.oatk_read_error_correction.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32,
+                                             C.c_double, C.c_void_p]
+    H.oatk_sr_read_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+    H.oatk_sr_db_new.restype = C.c_void_p
+    H.oatk_collect_syncmer_from_reads.restype = C.c_void_p
+    H.oatk_collect_syncmer_from_reads.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+
+    class StatT(C.Structure):             # sr_stat_t, syncmer.h:72-77
+        _fields_ = [("syncmer_n", C.c_uint64), ("per_read", C.c_double), ("avg_dist", C.c_double), ("smer_avg", C.c_double), ("kmer_avg", C.c_double),
+                    ("smer_unique", C.c_int), ("smer_singleton", C.c_int), ("smer_hom", C.c_int), ("smer_het", C.c_int),
+                    ("kmer_unique", C.c_int), ("kmer_singleton", C.c_int), ("kmer_hom", C.c_int), ("kmer_het", C.c_int)]
+
+    class SrDbT(C.Structure):
+        _fields_ = [("n", C.c_size_t), ("m", C.c_size_t), ("a", C.c_void_p), ("k", C.c_int), ("s", C.c_int), ("stats", C.POINTER(StatT))]
+
+    def snapshot(db):
+        st = C.cast(db, C.POINTER(SrDbT)).contents.stats.contents
+        return [getattr(st, f[0]) for f in StatT._fields_]
+
+    def check(db):
+        assert H.oatk_sr_db_stat(hip.h, db, None, 0) == 0
+        mine = snapshot(db)
+        i8, d5 = np.zeros(8, np.int32), np.zeros(5, np.float64)
+        L.refx_srdb_stat(db, i8.ctypes.data, d5.ctypes.data)             # overwrites db->stats with the reference's own
+        ref = snapshot(db)
+        assert mine == ref, (mine, ref)                                   # doubles bit for bit: sums of integers below 2^53
+        return mine
+
+    reads = A.hifi_like(400, 20000, 2500 if K < 300 else 5000, seed=K, err=0.002)
+    seq, off, lens = pack_reads(reads)
+    db = H.oatk_sr_db_new(K, S)
+    assert H.oatk_sr_read_packed(hip.h, db, seq.ctypes.data, off.ctypes.data, lens.ctypes.data, len(reads), seq.size, None) == 0
+    a = check(db)                                                         # after sr_read
+    assert a[0] > 1000 and a[11] > 0                                      # a k-mer coverage peak was found
+    rc = C.c_int(0)
+    scm = H.oatk_collect_syncmer_from_reads(hip.h, db, C.byref(rc))
+    assert rc.value == 0 and scm
+    b = check(db)                                                         # after the count: same numbers, k-mers are ids now
+    assert a == b
+    st = np.zeros(12, np.uint64)
+    assert H.oatk_read_error_correction(hip.h, db, scm, None, 0.02, cov, 10 * cov, cov, 0.35, st.ctypes.data) == 0
+    c = check(db)                                                         # after the correction (run_syncasm.c:131)
+    assert c != b and int(st[2] + st[7]) > 0
+    L.refx_scmdb_destroy(scm)
+    L.refx_srdb_destroy(db)
