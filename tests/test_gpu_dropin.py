@@ -230,3 +230,33 @@ def test_sr_db_stat_from_the_device(hip, K, S, cov):
     assert c != b and int(st[2] + st[7]) > 0
     L.refx_scmdb_destroy(scm)
     L.refx_srdb_destroy(db)
+
+
+def test_gfa_identical_at_scale(hip, tmp_path):
+    """20 k synthetic HiFi reads x 15 kb (0.3 Gbases, ~300x of a 1 Mb genome, the bench's generator), k = 1001, -c 30: scan, count,
+    EC graph and error correction on the MI355X (no host graph), the compiled reference's syncasm() for the rest -- both GFA files
+    byte-identical to a pure reference run.  Every solver tier, 80 k error blocks, long-run escapes and coverage in the hundreds."""
+    from oatk_amd.synth import ReadSet
+    L, H = R.lib(), host_lib()
+    L.refx_syncasm_tail.restype = C.c_int
+    L.refx_syncasm_tail.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,
+                                    C.c_int, C.c_char_p]
+    H.oatk_read_error_correction.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32,
+                                             C.c_double, C.c_void_p]
+    K, S, cov, n = 1001, 31, 30, 20000
+    rs = ReadSet(1_000_000, n, 15000)
+    reads = rs.as_list(0, n)
+    fa = str(tmp_path / "reads.fa")
+    R.write_fasta(reads, fa)
+    out_ref, out_dev = str(tmp_path / "ref"), str(tmp_path / "dev")
+    assert L.refx_syncasm(R._files_arg([fa]), 1, K, S, cov, 0.35, 1, 3, 16, out_ref.encode()) == 0
+    db, scm = device_dbs(hip, reads, K, S)
+    stats = np.zeros(12, np.uint64)
+    assert H.oatk_read_error_correction(hip.h, db, scm, None, 0.02, cov, 10 * cov, cov, 0.35, stats.ctypes.data) == 0
+    assert int(stats[0] + stats[5]) > 50000 and int(stats[11]) > 0          # blocks past the first solver tier too
+    assert L.refx_syncasm_tail(db, scm, K, 100000, 10000, cov, 0.35, 0.3, 0, 3, 16, out_dev.encode()) == 0
+    for suffix in (".utg.gfa", ".utg.final.gfa"):
+        assert os.path.getsize(out_ref + suffix) > 100000
+        assert filecmp.cmp(out_ref + suffix, out_dev + suffix, shallow=False), suffix
+    L.refx_scmdb_destroy(scm)
+    L.refx_srdb_destroy(db)
