@@ -115,6 +115,11 @@ typedef struct {
 int oatk_read_error_correction(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, oatk_syncmer_db_t *scm_db, oatk_asmg_t *asmg, double max_edist,
                                uint32_t err_mer_c, uint32_t max_err_c, uint32_t err_arc_c, double max_arc_f, uint64_t *stats12);
 
+/* sstream_open + the sstream_read loop (sstream.c:70-103, syncmer.c:519-543) without kseq: the files (plain or gzip'ed FASTA / four-line
+ * FASTQ, read one after the other) are inflated into host memory and their TEXT is handed to the device reader
+ * (include/oatk_hip_ingest.h), which leaves the packed read stream resident: follow with oatk_hip_scan_ingested. */
+int oatk_ingest_files(oatk_hip_ctx *ctx, char **files, int n_files, uint64_t *n_reads);
+
 /* sr_db_stat (syncmer.c:867): the two sorts and the tabulation on the device (include/oatk_hip_stat.h), the peak finder and the report
  * here; fills sr_db->stats (allocated if NULL) and prints the reference's nine lines to fo (may be NULL).  Works on the batch resident
  * in ctx at whatever stage it is -- after sr_read (run_syncasm.c:88) or after read_error_correction (:131). */

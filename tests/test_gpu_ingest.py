@@ -133,3 +133,28 @@ def test_file_through_device_ingest_equals_reference_sr_read(hip, tmp_path):
 def test_empty_and_headers_only(hip):
     assert hip.ingest_host(b"", 0, True) == (0, 0)
     assert device_reads(hip, b">a\n>b\nACGT\n>c\n", 1) == [b"", b"ACGT", b""]
+
+
+def test_files_plain_and_gzip_through_the_host_helper(hip, tmp_path):
+    """oatk_ingest_files (liboatk_host.so): several files, plain and gzip'ed, FASTA without a final newline -- one stream of records"""
+    import ctypes as C
+    import gzip
+    from test_gpu_dropin import host_lib
+    H = host_lib()
+    H.oatk_ingest_files.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_uint64)]
+    a, b, c = READS[:15], READS[15:30], READS[30:]
+    p1, p2, p3 = str(tmp_path / "a.fa"), str(tmp_path / "b.fa.gz"), str(tmp_path / "c.fa")
+    open(p1, "wb").write(fasta(a, 70, last_eol=False))
+    gzip.open(p2, "wb").write(fasta(b, 0))
+    open(p3, "wb").write(fasta(c, 61, b"\r\n"))
+    files = (C.c_char_p * 3)(p1.encode(), p2.encode(), p3.encode())
+    n = C.c_uint64()
+    assert H.oatk_ingest_files(hip.h, files, 3, C.byref(n)) == 0 and n.value == len(READS)
+    seq, off, lens = hip.fetch("INGEST_SEQ"), hip.fetch("INGEST_OFF"), hip.fetch("INGEST_LEN")
+    assert [seq[int(o):int(o) + int(l)].tobytes() for o, l in zip(off, lens)] == READS
+    q = str(tmp_path / "r.fastq.gz")
+    gzip.open(q, "wb").write(fastq(READS))
+    files = (C.c_char_p * 1)(q.encode())
+    assert H.oatk_ingest_files(hip.h, files, 1, C.byref(n)) == 0 and n.value == len(READS)
+    seq, off, lens = hip.fetch("INGEST_SEQ"), hip.fetch("INGEST_OFF"), hip.fetch("INGEST_LEN")
+    assert [seq[int(o):int(o) + int(l)].tobytes() for o, l in zip(off, lens)] == READS
