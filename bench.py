@@ -39,6 +39,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; the contract) or gloo (development: several ranks on ONE GPU)")
     ap.add_argument("--no-syncerr", action="store_true", help="skip the extra scan + count + error-correction measurement")
+    ap.add_argument("--sharded-syncerr", action="store_true",
+                    help="at N > 1 also run the error-correction round sharded over the ranks (oatk_amd/multi.py: ShardedEc).  Off by default: it was "
+                         "validated with two ranks sharing one GPU over gloo (tests/test_gpu_sharded_ec.py), not yet on a multi-GPU node over RCCL, "
+                         "and a mismatch in a collective would hang the headline measurement with it")
     ap.add_argument("--no-ingest", action="store_true", help="skip the FASTA-text-to-syncmers measurement (device record scan, PCIe included)")
     ap.add_argument("--ingest-reads", type=int, default=50000)
     ap.add_argument("--cpu-sample-reads", type=int, default=80000)
@@ -192,7 +196,7 @@ def main():
     # ---- the same batch through the error-correction round too (syncerr): scan + count + EC graph + read correction, all resident.
     #      Across GPUs every rank builds the graph of ALL reads from the all-gathered adjacent pairs and corrects its own reads. ----
     syncerr = None
-    if not args.no_syncerr:
+    if not args.no_syncerr and (world == 1 or args.sharded_syncerr):
         c = int(cfg.get("min_k_cov", 30))
         sharded = None
         if world > 1:
