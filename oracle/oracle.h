@@ -11,7 +11,7 @@
  * sources by oracle/Makefile) is run side by side with these functions in
  * tests/test_oracle_vs_ref.py (this container), and the committed vectors in
  * tests/golden/ were produced by that compiled reference with
- * tools/make_golden.py.
+ * tests/make_golden.py.
  *
  * Nothing in the product path (oatk_amd/, include/, bench.py's timed region)
  * may include, link or call anything in this directory.

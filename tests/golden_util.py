@@ -1,4 +1,4 @@
-"""Load tests/golden/*.npz (reference outputs committed as data; generator: tools/make_golden.py)."""
+"""Load tests/golden/*.npz (reference outputs committed as data; generator: tests/make_golden.py)."""
 import glob
 import os
 

@@ -4,7 +4,7 @@ reference's own sources by `make -C oracle ref`).  Runs only in the authoring co
 /root/reference exists; the fixtures are data (inputs + the reference's outputs), committed so that the
 CPU and GPU suites can check the oracle and the HIP path anywhere.
 
-    python tools/make_golden.py
+    python tests/make_golden.py
 """
 import os
 import sys

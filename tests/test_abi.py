@@ -49,9 +49,8 @@ def test_no_silent_fallback_without_a_gpu():
 
 def test_product_does_not_import_the_oracle():
     """only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke may touch oracle/"""
-    pkg = os.path.join(ROOT, "oatk_amd")
-    for base, _, files in os.walk(pkg):
+    for base, _, files in list(os.walk(os.path.join(ROOT, "oatk_amd"))) + list(os.walk(os.path.join(ROOT, "tools"))) + list(os.walk(os.path.join(ROOT, "include"))):
         for f in files:
-            if f.endswith((".py", ".c", ".h", ".hip", ".hpp")):
+            if f.endswith((".py", ".c", ".h", ".hip", ".hpp", ".inc", ".sh")):
                 txt = open(os.path.join(base, f), errors="ignore").read()
                 assert "oracle_lib" not in txt and "ref_lib" not in txt and "liboatk_oracle" not in txt and "oracle/" not in txt, f

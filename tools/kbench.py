@@ -15,7 +15,6 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--reads", type=int, default=50000)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--mean-len", type=int, default=15000)
-ap.add_argument("--check", type=int, default=0, help="compare the first N reads with the oracle")
 a = ap.parse_args()
 rs = ReadSet(genome_len=1_000_000, n_reads=a.reads, mean_len=a.mean_len)
 seq, off, lens = rs.slice(0, a.reads)
@@ -32,13 +31,3 @@ bases = int(lens.sum())
 print("reads %d bases %.3f G  " % (a.reads, bases / 1e9) + "  ".join("%s %.3f" % kv for kv in acc.items()))
 tot = sum(v for k, v in acc.items() if k not in ("scan_post",))
 print("device ms/step %.3f -> %.1f Gbases/s ; hpc %.1f GB/s" % (tot, bases / tot / 1e6, (bases * 1.9375) / acc["hpc"] / 1e6))
-if a.check:
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib as O
-    n = a.check
-    hip.scan_host(seq[:int(off[n])], off[:n], lens[:n], 1001, 31)
-    got = hip.fetch_scan(off[:n])
-    want = O.scan([seq[int(o):int(o) + int(l)].tobytes() for o, l in zip(off[:n], lens[:n])], 1001, 31)
-    for f in ["hoco_l", "n_scm", "hoco_s", "ho_rl", "m_pos", "s_mer", "k_mer"]:
-        assert np.array_equal(got[f], want[f]), f
-    print("parity ok on %d reads" % n)
