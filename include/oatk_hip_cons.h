@@ -22,7 +22,13 @@ extern "C" {
  *   CONS_FIRST u64[n_sel]       sid << 32 | idx << 1 | rev of the first of them, ~0 if none */
 int oatk_hip_consensus(oatk_hip_ctx *ctx, uint32_t min_cov);
 
-enum { OATK_BUF_CONS_SEL = 140, OATK_BUF_CONS_SLOT, OATK_BUF_CONS_RL, OATK_BUF_CONS_MSEQ, OATK_BUF_CONS_FIRST };
+/* The same for a caller-chosen list of syncmer ids (DEVICE pointer, ascending).  With reads sharded over GPUs (oatk_hip_ec_set_global ...
+ * oatk_hip_ec_correct done) the ids are global and the results cover THIS shard's occurrences only: add CONS_TOT (u64[n * k], the totals
+ * before the division) and CONS_MSEQ over the shards, then round(total / count) is the reference's value; the bases come from the shard
+ * of lowest rank whose CONS_FIRST is not ~0 (oatk_amd/multi.py: ShardedEc.consensus). */
+int oatk_hip_consensus_ids(oatk_hip_ctx *ctx, const uint32_t *d_ids, uint64_t n);
+
+enum { OATK_BUF_CONS_SEL = 140, OATK_BUF_CONS_SLOT, OATK_BUF_CONS_RL, OATK_BUF_CONS_MSEQ, OATK_BUF_CONS_FIRST, OATK_BUF_CONS_TOT };
 
 #ifdef __cplusplus
 }

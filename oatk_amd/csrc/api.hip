@@ -551,7 +551,7 @@ int oatk_hip_buffer(oatk_hip_ctx *ctx, int which, const void **d_ptr, uint64_t *
                 case OATK_BUF_SCM_OCC_OFF: p = ctx->scm_occ_off.p, b = (ns + 1) * 8; break;
                 case OATK_BUF_SCM_OCC: p = ctx->scm_occ.p, b = occ * 8; break;
                 default:
-                    if (which >= OATK_BUF_CONS_SEL && which <= OATK_BUF_CONS_FIRST) return cons_buffer(ctx, which, d_ptr, bytes);
+                    if (which >= OATK_BUF_CONS_SEL && which <= OATK_BUF_CONS_TOT) return cons_buffer(ctx, which, d_ptr, bytes);
                     if (which >= OATK_BUF_INGEST_SEQ && which <= OATK_BUF_INGEST_HDR) return ing_buffer(ctx, which, d_ptr, bytes);
                     return ec_buffer(ctx, which, d_ptr, bytes);     // error-correction results (api_ec.inc)
             }

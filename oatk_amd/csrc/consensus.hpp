@@ -32,6 +32,7 @@ struct ConsArgs {
     const uint32_t *lrl_val;
     uint64_t n_lrl;
     int K;
+    unsigned long long *cons_tot; // [n_sel * K] total run length per forward position (what shards add up)
     uint32_t *cons_rl;            // [n_sel * K] lround(mean run length) per forward position
     uint32_t *m_seq;              // [n_sel] occurrences that took part
     uint64_t *first_occ;          // [n_sel] the first of them, ~0 if none
@@ -121,8 +122,10 @@ __global__ __launch_bounds__(256) void cons_rl_kernel(ConsArgs a)
         }
         __syncthreads();
         const uint32_t m = s_m;
-        for (uint32_t i = tid; i < CONS_Q * 64 && t0 + (int) i < K; i += 256)
+        for (uint32_t i = tid; i < CONS_Q * 64 && t0 + (int) i < K; i += 256) {
             a.cons_rl[s * (uint64_t) K + (uint64_t) (t0 + (int) i)] = m? (uint32_t) lround((double) tot[i] / (double) m) : 0u;
+            a.cons_tot[s * (uint64_t) K + (uint64_t) (t0 + (int) i)] = tot[i];
+        }
         if (tid == 0 && t0 == 0) {
             a.m_seq[s] = m;
             a.first_occ[s] = s_first == ~0ULL? ~0ULL : a.occ[o0 + s_first];

@@ -19,7 +19,7 @@ _DTYPES = {
     "EC_SCM_COV": np.uint32, "EC_SCM_DEL": np.uint8, "EC_SCM_OCC_OFF": np.uint64, "EC_SCM_OCC": np.uint64, "EC_ERR_DEL": np.uint8,
     "EC_SCM_FWD": np.uint32, "EC_VTX_SRC": np.uint64,
     "INGEST_SEQ": np.uint8, "INGEST_OFF": np.uint64, "INGEST_LEN": np.uint32, "INGEST_HDR": np.uint64,
-    "CONS_SEL": np.uint32, "CONS_SLOT": np.uint32, "CONS_RL": np.uint32, "CONS_MSEQ": np.uint32, "CONS_FIRST": np.uint64,
+    "CONS_SEL": np.uint32, "CONS_SLOT": np.uint32, "CONS_RL": np.uint32, "CONS_MSEQ": np.uint32, "CONS_FIRST": np.uint64, "CONS_TOT": np.uint64,
     "EG_IDX_P": np.uint64, "EG_IDX_N": np.uint32, "EG_ARC_V": np.uint64, "EG_ARC_W": np.uint64, "EG_ARC_LS": np.uint32,
     "EG_ARC_COV": np.uint32, "EG_ARC_COMP": np.uint8,
 }
@@ -170,6 +170,10 @@ class HipSyncasm:
         """rounded mean run lengths of every live syncmer with coverage >= min_cov (scg_syncmer_consensus, syncasm.c:949-1001);
         fetch CONS_SEL / CONS_SLOT / CONS_RL / CONS_MSEQ / CONS_FIRST"""
         self._check(self.L.oatk_hip_consensus(self.h, min_cov), "oatk_hip_consensus")
+
+    def consensus_ids(self, d_ids, n):
+        """the same for a device array of ids; with sharded reads the results (CONS_TOT, CONS_MSEQ) are this shard's share"""
+        self._check(self.L.oatk_hip_consensus_ids(self.h, d_ids, n), "oatk_hip_consensus_ids")
 
     def info(self):
         i = _lib.Info()

@@ -194,8 +194,33 @@ class ShardedEc:
         cov_g = all_reduce(self._view("EC_SCM_COV", "<i4", 4).to(torch.int64), dist)
         fwd_g = all_reduce(self._view("EC_SCM_FWD", "<i4", 4).to(torch.int64), dist)
         st_g = all_reduce(torch.from_numpy(st.astype(np.int64)).to(dev), dist)
-        return {"n_global": n_global, "hash": G, "cov": cov_g, "del": (fwd_g == 0).to(torch.uint8), "stats": st_g.cpu().numpy(),
-                "local_stats": st}
+        self.last = {"n_global": n_global, "hash": G, "cov": cov_g, "del": (fwd_g == 0).to(torch.uint8), "stats": st_g.cpu().numpy(),
+                     "local_stats": st}
+        return self.last
+
+    def consensus(self, min_cov):
+        """scg_syncmer_consensus' rounded mean run lengths (syncasm.c:949-1001) for every live syncmer with GLOBAL coverage >= min_cov,
+        after run(): every rank adds up its own occurrences (oatk_hip_consensus_ids), totals and counts are all-reduced.  Returns ids,
+        rl [n, k], m_seq and, per id, the lowest rank that holds an uncorrected occurrence (its CONS_FIRST names the read whose bases
+        the reference prints; -1 where there is none)."""
+        hip, dist, dev = self.hip, self.dist, self.device
+        cov, dele = self.last["cov"], self.last["del"]
+        ids = torch.nonzero((dele == 0) & (cov >= max(int(min_cov), 1))).flatten().to(torch.int32).contiguous()
+        n, K = int(ids.numel()), hip.info()["k"]
+        hip.consensus_ids(ids.data_ptr(), n)
+        if n:
+            tot = self._view("CONS_TOT", "<i8", 8).reshape(n, K).clone()
+            m = self._view("CONS_MSEQ", "<i4", 4).to(torch.int64)
+            first = self._view("CONS_FIRST", "<i8", 8).clone()
+        else:
+            tot, m, first = torch.zeros((0, K), dtype=torch.int64, device=dev), torch.zeros(0, dtype=torch.int64, device=dev), torch.zeros(0, dtype=torch.int64, device=dev)
+        tot, m = all_reduce(tot, dist), all_reduce(m, dist)
+        big = dist.get_world_size()
+        owner = all_reduce(torch.where(first != -1, torch.full_like(first, dist.get_rank()), torch.full_like(first, big)), dist, dist.ReduceOp.MIN)
+        owner = torch.where(owner == big, torch.full_like(owner, -1), owner)
+        rl = torch.floor(tot.to(torch.float64) / m.clamp(min=1).to(torch.float64).unsqueeze(1) + 0.5).to(torch.int64)     # lround of a quotient >= 0
+        rl = torch.where(m.unsqueeze(1) > 0, rl, torch.zeros_like(rl))
+        return {"ids": ids, "rl": rl, "m_seq": m, "owner": owner, "first_local": first}
 
 
 def merge_numpy(h_u64, s_u64, cov, dist=None):

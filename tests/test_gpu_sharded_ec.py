@@ -39,9 +39,12 @@ def _worker(rank, world, port, reads, bounds, K, S, c, outdir):
     hip.count()
     sh = ShardedEc(hip, dist, dev)
     res = sh.run(0.02, c, 0.35)
+    cons = sh.consensus(c)
     np.savez(os.path.join(outdir, "r%d.npz" % rank), n_scm=hip.fetch("EC_N_SCM"), k_mer=hip.fetch("EC_KMER"), m_pos=hip.fetch("EC_MPOS"),
              s_mer=hip.fetch("EC_SMER"), occ=hip.fetch("EC_SCM_OCC"), occ_off=hip.fetch("EC_SCM_OCC_OFF"), cov=res["cov"].cpu().numpy(),
-             dele=res["del"].cpu().numpy(), stats=res["stats"], imported=sh.n_imported)
+             dele=res["del"].cpu().numpy(), stats=res["stats"], imported=sh.n_imported,
+             c_ids=cons["ids"].cpu().numpy(), c_rl=cons["rl"].cpu().numpy(), c_m=cons["m_seq"].cpu().numpy(), c_owner=cons["owner"].cpu().numpy(),
+             c_first=cons["first_local"].cpu().numpy())
     hip.close()
     dist.barrier()
     dist.destroy_process_group()
@@ -88,3 +91,13 @@ def test_sharded_ec_equals_single_context(hip, tmp_path, case):
     assert np.array_equal(got, ref)
     if case == 2:
         assert sum(int(x["imported"]) for x in z) > 0
+    # base-space consensus: totals summed over the shards round to the single-context values; the first uncorrected occurrence
+    # is the first one of the lowest rank that has any
+    hip.consensus(c)
+    sel, rl, ms, fo = hip.fetch("CONS_SEL"), hip.fetch("CONS_RL").reshape(-1, K), hip.fetch("CONS_MSEQ"), hip.fetch("CONS_FIRST")
+    for x in z:
+        assert np.array_equal(x["c_ids"].astype(np.uint32), sel) and np.array_equal(x["c_rl"], rl.astype(np.int64))
+        assert np.array_equal(x["c_m"], ms.astype(np.int64))
+    owner = z[0]["c_owner"]
+    first = np.array([z[int(o)]["c_first"][i] if o >= 0 else -1 for i, o in enumerate(owner)], dtype=np.int64)
+    assert np.array_equal(first.view(np.uint64), fo) and len(sel) > 0
