@@ -46,19 +46,22 @@ def merge_syncmer_tables(h, s, cov, dist=None, group=None):
         all_h, all_s = hk, s
     order = torch.argsort(all_h, stable=True)
     sh, ss = all_h[order], all_s[order]
-    G, inverse = torch.unique_consecutive(sh, return_inverse=True)
-    # the same k-mer must carry the same s-mer everywhere (syncmer.c:1370-1376); equal hash with different s-mers
-    # across GPUs is either that fatal condition or a true 64-bit hash collision -- both need the sequences
-    smin = torch.full((G.numel(),), torch.iinfo(torch.int64).max, dtype=torch.int64, device=dev).scatter_reduce(0, inverse, ss, "amin")
-    smax = torch.full((G.numel(),), torch.iinfo(torch.int64).min, dtype=torch.int64, device=dev).scatter_reduce(0, inverse, ss, "amax")
-    if bool((smin != smax).any()):
-        raise RuntimeError("equal k-mer hash with different s-mers across shards: sequence-level merge required")
+    new = torch.ones(sh.numel(), dtype=torch.bool, device=dev)
+    if sh.numel() > 1:
+        new[1:] = sh[1:] != sh[:-1]
+        # the same k-mer must carry the same s-mer everywhere (syncmer.c:1370-1376); equal hash with different s-mers
+        # across GPUs is either that fatal condition or a true 64-bit hash collision -- both need the sequences
+        if bool(((~new[1:]) & (ss[1:] != ss[:-1])).any()):
+            raise RuntimeError("equal k-mer hash with different s-mers across shards: sequence-level merge required")
+    G, S = sh[new], ss[new]
     l2g = torch.searchsorted(G, hk)
-    dense = torch.zeros(G.numel(), dtype=torch.int64, device=dev)
-    dense.index_add_(0, l2g, cov.to(torch.int64))
+    # a local table holds every hash once, so its rows land on distinct global rows: a plain scatter, then the count-table
+    # all-reduce over xGMI (32-bit counts: half the bytes of the index type)
+    dense = torch.zeros(G.numel(), dtype=torch.int32, device=dev)
+    dense[l2g] = cov.to(torch.int32)
     if world > 1:
-        dist.all_reduce(dense, group=group)         # the count-table all-reduce over xGMI
-    return G ^ _BIAS, smin, dense, l2g
+        dist.all_reduce(dense, group=group)
+    return G ^ _BIAS, S, dense.to(torch.int64), l2g
 
 
 class _DevView:
