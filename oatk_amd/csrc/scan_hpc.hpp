@@ -95,6 +95,7 @@ __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
 
     lut[tid] = (uint8_t) nt4_code(tid);
     for (uint32_t i = tid; i < HPC_RING / 16; i += HPC_NT) ring_hs[i] = 0;
+    for (uint32_t i = tid; i < HPC_RING / 16; i += HPC_NT) ring_rl4[i] = make_uint4(0, 0, 0, 0);      // runs of one base (most) never write their 0
     if (tid == 0) s_nn = 0, s_lrl = 0;
 
     // move finished 64-position groups [g0, g1) from the LDS ring to HBM as 16-byte stores
@@ -105,6 +106,7 @@ __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
             uint32_t hr = (g * 64u) & (HPC_RING - 1);
             if (q < 4u) {
                 ((uint4 *) out_rl)[g * 4u + q] = ring_rl4[hr / 16u + q];
+                ring_rl4[hr / 16u + q] = make_uint4(0, 0, 0, 0);
             } else {
                 uint4 v = ring_hs4[hr / 64u];
                 ring_hs4[hr / 64u] = make_uint4(0, 0, 0, 0);
@@ -205,39 +207,62 @@ __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
         // ---- a run is finished when the next one starts: this lane finishes one run per start it holds ----
         if (smask) {
             // hoco index of the run finished by the k-th start of this lane: (n + k) - 1; the very first start of a
-            // read (position 0) finishes nothing
-            uint64_t codes = 0;
-            uint32_t k = 0, special = 0;
-            int32_t prev = ls;
+            // read (position 0) finishes nothing.  Three out of four positions are starts and most runs are one base long, so
+            // nothing here walks the sixteen positions:
+            //   codes  : the 2-bit code of the byte BEFORE every position, folded to sixteen fields, then the fields of the few
+            //            positions that are NOT starts are squeezed out (a loop over ~4 clear bits)
+            //   lengths: the ring is all zero (min(rl, 256) - 1 of a one-base run); only starts whose previous byte is not a
+            //            start finish a longer run (a loop over ~3 set bits)
             const uint64_t cls64 = (uint64_t) cy << 32 | cx;
-#pragma unroll
-            for (int b = 0; b < HPC_BPT; ++b) {
-                if ((smask >> b) & 1u) {
-                    const int32_t i = (int32_t) (b0 + b);
-                    if (i > 0) {
-                        const uint32_t rl = (uint32_t) (i - prev);
-                        const uint32_t pc = b? (uint32_t) (cls64 >> (4 * (b - 1))) & 7u : up;
-                        const uint32_t h = n + k - 1u;
-                        ring_rl[h & (HPC_RING - 1)] = (uint8_t) ((rl > 256u? 256u : rl) - 1u);
-                        codes = codes << 2 | (pc & 3u);
-                        special |= (rl > 255u) | (pc == 4u);
-                    }
-                    prev = i;
-                    ++k;
-                }
+            const uint64_t prevc = cls64 << 4 | up;                        // class of the byte before position b, nibble b
+            uint32_t fin = smask;                                          // starts that finish a run
+            if (b0 == 0) fin &= ~1u;
+            const uint32_t kfin = (uint32_t) __builtin_popcount(fin);
+            uint32_t special = 0;
+            {   // an ambiguous byte (class 4) before a finishing start?
+                const uint64_t is4 = (prevc >> 2) & ~(prevc >> 1) & ~prevc & 0x1111111111111111ULL;
+                uint64_t spread = fin;                                     // bit b -> bit 4 b
+                spread = (spread | spread << 24) & 0x000000ff000000ffULL;
+                spread = (spread | spread << 12) & 0x000f000f000f000fULL;
+                spread = (spread | spread << 6) & 0x0303030303030303ULL;
+                spread = (spread | spread << 3) & 0x1111111111111111ULL;
+                special = (is4 & spread) != 0;
             }
-            const uint32_t kfin = k - (b0 == 0? 1u : 0u);            // runs this lane finished
             if (kfin) {
+                uint64_t x = prevc & 0x3333333333333333ULL;                // low two bits of every nibble -> sixteen 2-bit fields
+                x = (x | x >> 2) & 0x0f0f0f0f0f0f0f0fULL;
+                x = (x | x >> 4) & 0x00ff00ff00ff00ffULL;
+                x = (x | x >> 8) & 0x0000ffff0000ffffULL;
+                uint32_t f2 = (uint32_t) (x | x >> 16);
+                uint32_t drop = ~fin & 0xffffu;                            // squeeze out the fields of non-finishing positions, top down
+                while (drop) {
+                    const int z = 31 - __builtin_clz(drop);
+                    drop &= ~(1u << z);
+                    const uint32_t lowm = (1u << (2 * z)) - 1u;
+                    f2 = (f2 & lowm) | ((f2 >> 2) & ~lowm);
+                }
+                // first finished run in the top field: reverse the order of the sixteen fields
+                uint32_t rv = __builtin_bitreverse32(f2);
+                rv = ((rv >> 1) & 0x55555555u) | ((rv & 0x55555555u) << 1);
                 const uint32_t hfirst = n - 1u + (b0 == 0? 1u : 0u);
-                // left-align the kfin codes, then drop them at bit offset 2*(hfirst % 16) of the MSB-first word stream
-                const uint64_t al = codes << (64u - 2u * kfin);
                 const uint32_t off = (hfirst & 15u) * 2u;
-                const uint64_t sh = al >> off;
+                const uint64_t sh = ((uint64_t) rv << 32) >> off;
                 const uint32_t w0 = (hfirst & (HPC_RING - 1)) >> 4;
                 const uint32_t hiw = (uint32_t) (sh >> 32), low = (uint32_t) sh;
                 if (hiw) atomicOr(&ring_hs[w0], hiw);
                 if (low) atomicOr(&ring_hs[(w0 + 1) & (HPC_RING / 16 - 1)], low);
-                // codes beyond 64 - off bits cannot exist: kfin <= 16 -> 32 bits, off <= 30
+                // runs longer than one base: finishing starts whose previous byte is not a start
+                uint32_t lng = fin & ~(smask << 1 | (uint32_t) (ls == (int32_t) b0 - 1));
+                while (lng) {
+                    const int b = __builtin_ctz(lng);
+                    lng &= lng - 1;
+                    const uint32_t below = smask & ((1u << b) - 1u);
+                    const int32_t prev = below? (int32_t) (b0 + 31 - __builtin_clz(below)) : ls;
+                    const uint32_t rl = (uint32_t) ((int32_t) (b0 + b) - prev);
+                    const uint32_t h = n + (uint32_t) __builtin_popcount(below) - 1u;
+                    ring_rl[h & (HPC_RING - 1)] = (uint8_t) ((rl > 256u? 256u : rl) - 1u);
+                    special |= rl > 255u;
+                }
             }
             if (special) {                                             // ambiguous bases / very long runs: walk again, slowly
                 uint32_t k2 = 0;
