@@ -187,7 +187,9 @@ __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
         const int32_t lpos = smask? (int32_t) (b0 + 31 - __builtin_clz(smask)) : -1;
         // ---- workgroup scan: run starts before this lane, and the position of the latest one ----
         const uint32_t icnt = wave_incl_sum_dpp(cnt, lane);
-        const int32_t imax = wave_incl_max_dpp(lpos, lane);
+        // latest start at or before this lane: positions grow with the lane, so when every lane holds a start (always, outside
+        // homopolymers of 16+ bases and the tail of the read) it is the lane's own
+        const int32_t imax = __ballot(lpos < 0)? wave_incl_max_dpp(lpos, lane) : lpos;
         if (lane == 63) w_cnt[wid] = icnt, w_max[wid] = imax;
         __syncthreads();
         uint32_t n = nstart + icnt - cnt;
