@@ -115,6 +115,14 @@ typedef struct {
 int oatk_read_error_correction(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, oatk_syncmer_db_t *scm_db, oatk_asmg_t *asmg, double max_edist,
                                uint32_t err_mer_c, uint32_t max_err_c, uint32_t err_arc_c, double max_arc_f, uint64_t *stats12);
 
+/* make_syncmer_graph(sr_db, scm_db, min_k_cov, min_a_cov_f) (syncasm.c:203-299, run_syncasm.c:138) on the device, from the batch resident
+ * in ctx (after oatk_read_error_correction: the corrected reads): returns what the reference stores in scg->utg_asmg -- one vertex per
+ * surviving syncmer, filtered arcs in (v, w) order with symmetry flags and link ids, the index -- allocated so that the reference's
+ * asmg_destroy frees it, and updates scm_db->a[i].del like syncasm.c:228.  NULL with *rc == 0 when the table is empty (syncasm.c:205).
+ * The caller wraps it: scg->scm_db = scm_db; scg->utg_asmg = g; scg_scm_utg_index(scg). */
+oatk_asmg_t *oatk_make_syncmer_asmg(oatk_hip_ctx *ctx, oatk_syncmer_db_t *scm_db, uint32_t min_k_cov, double min_a_cov_f, int *rc);
+void oatk_asmg_destroy(oatk_asmg_t *g);
+
 /* sstream_open + the sstream_read loop (sstream.c:70-103, syncmer.c:519-543) without kseq: the files (plain or gzip'ed FASTA / four-line
  * FASTQ, read one after the other) are inflated into host memory and their TEXT is handed to the device reader
  * (include/oatk_hip_ingest.h), which leaves the packed read stream resident: follow with oatk_hip_scan_ingested. */

@@ -22,6 +22,8 @@ _DTYPES = {
     "CONS_SEL": np.uint32, "CONS_SLOT": np.uint32, "CONS_RL": np.uint32, "CONS_MSEQ": np.uint32, "CONS_FIRST": np.uint64, "CONS_TOT": np.uint64,
     "EG_IDX_P": np.uint64, "EG_IDX_N": np.uint32, "EG_ARC_V": np.uint64, "EG_ARC_W": np.uint64, "EG_ARC_LS": np.uint32,
     "EG_ARC_COV": np.uint32, "EG_ARC_COMP": np.uint8,
+    "AG_SCM_DEL": np.uint8, "AG_VTX_SCM": np.uint32, "AG_VTX_COV": np.uint32, "AG_IDX_P": np.uint64, "AG_IDX_N": np.uint32,
+    "AG_ARC_V": np.uint64, "AG_ARC_W": np.uint64, "AG_ARC_COV": np.uint32, "AG_ARC_COMP": np.uint8, "AG_ARC_LINK": np.uint64,
 }
 
 
@@ -196,6 +198,28 @@ class HipSyncasm:
 
     def debug_force_general(self, on=True):
         self.L.oatk_hip_debug_force_general(self.h, 1 if on else 0)
+
+    # ---- assembly graph (include/oatk_hip_graph.h) ----
+    def asm_graph(self, min_k_cov, min_a_cov_f):
+        """make_syncmer_graph(sr_db, scm_db, min_k_cov, min_a_cov_f) + asmg_finalize (run_syncasm.c:138); returns (n_vtx, n_arc)"""
+        nv, na = C.c_uint64(), C.c_uint64()
+        self._check(self.L.oatk_hip_asm_graph(self.h, min_k_cov, min_a_cov_f, C.byref(nv), C.byref(na)), "oatk_hip_asm_graph")
+        return int(nv.value), int(na.value)
+
+    def asm_pairs(self):
+        k, n = C.c_void_p(), C.c_uint64()
+        self._check(self.L.oatk_hip_asm_pairs(self.h, C.byref(k), C.byref(n)), "oatk_hip_asm_pairs")
+        return k.value, int(n.value)
+
+    def asm_graph_from_pairs(self, d_keys, n, n_scm, d_cov, d_del, min_k_cov, min_a_cov_f):
+        nv, na = C.c_uint64(), C.c_uint64()
+        self._check(self.L.oatk_hip_asm_graph_from_pairs(self.h, d_keys, n, n_scm, d_cov, d_del, min_k_cov, min_a_cov_f, C.byref(nv), C.byref(na)),
+                    "oatk_hip_asm_graph_from_pairs")
+        return int(nv.value), int(na.value)
+
+    def fetch_asm_graph(self):
+        names = ["SCM_DEL", "VTX_SCM", "VTX_COV", "IDX_P", "IDX_N", "ARC_V", "ARC_W", "ARC_COV", "ARC_COMP", "ARC_LINK"]
+        return {n.lower(): self.fetch("AG_" + n) for n in names}
 
     def debug_hash_mask(self, mask):
         self.L.oatk_hip_debug_hash_mask(self.h, C.c_uint64(mask & 0xFFFFFFFFFFFFFFFF))

@@ -118,6 +118,22 @@ orc_ecgraph_t *orc_ecgraph_build(uint64_t n_reads, const uint32_t *n_scm, const 
                                  const orc_count_view_t *c, int K);
 void orc_ecgraph_free(orc_ecgraph_t *g);
 
+/* the assembly graph of the (corrected) reads (oracle/asmgraph.c): make_syncmer_graph(…, min_k_cov, min_a_cov_f) + asmg_finalize(g, 1);
+ * vertices are the surviving syncmers in order, scm_del is updated in place like syncasm.c:228 does */
+typedef struct {
+    uint64_t n_vtx, n_arc;
+    uint32_t *vtx_scm, *vtx_cov;
+    uint64_t *arc_v, *arc_w, *arc_link;
+    uint32_t *arc_cov;
+    uint8_t *arc_comp;
+    uint64_t *idx_p, *idx_n;
+    int multi_arc;
+} orc_asmgraph_t;
+
+orc_asmgraph_t *orc_asmgraph_build(uint64_t n_reads, const uint32_t *n_scm, const uint64_t *k_mer, const uint32_t *m_pos,
+                                   uint64_t n_syncmers, const uint32_t *scm_cov, uint8_t *scm_del, uint32_t min_k_cov, double min_a_cov_f);
+void orc_asmgraph_free(orc_asmgraph_t *g);
+
 /* base-space consensus of a syncmer (oracle/consensus.c): flat view of the reads (per-read arrays concatenated in read order) */
 typedef struct {
     uint64_t sid0;

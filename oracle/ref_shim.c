@@ -179,6 +179,15 @@ void refx_graph_flatten(scg_t *g, uint64_t *vtx_len, uint8_t *vtx_del, uint32_t 
     if (idx_n) memcpy(idx_n, a->idx_n, sizeof(uint64_t) * a->n_vtx * 2);
 }
 
+/* the rest of asmg_t: per vertex the syncmer count and first syncmer (vtx.n, vtx.a[0]), per arc ln and link_id */
+void refx_graph_flatten2(scg_t *g, uint64_t *vtx_n, uint64_t *vtx_a0, uint64_t *arc_ln, uint64_t *arc_link)
+{
+    asmg_t *a = g->utg_asmg;
+    uint64_t i;
+    for (i = 0; i < a->n_vtx; ++i) vtx_n[i] = a->vtx[i].n, vtx_a0[i] = a->vtx[i].n? a->vtx[i].a[0] : UINT64_MAX;
+    for (i = 0; i < a->n_arc; ++i) arc_ln[i] = a->arc[i].ln, arc_link[i] = a->arc[i].link_id;
+}
+
 /* ---- EC: read_error_correction (syncerr.c:819) ---- */
 void refx_ec(sr_db_t *db, scg_t *g, double max_edist, uint32_t err_mer_c, uint32_t max_err_c, uint32_t err_arc_c,
         double max_arc_f, int n_threads)
@@ -232,7 +241,20 @@ int refx_syncasm(char **files, int n_files, int k, int s, int min_k_cov, double 
  * Lets a test feed sr_db / scm_db built by ANOTHER implementation (this repo's device path) into the reference's own
  * graph construction, error correction, cleaning, unzipping and GFA output, and compare the GFA bytes.  Only calls
  * public reference functions, in the order run_syncasm.c does. */
+static int syncasm_tail(sr_db_t *sr_db, syncmer_db_t *scm_db, asmg_t *given_asmg, int k, int bubble_size, int tip_size, int min_k_cov,
+        double min_a_cov_f, double weak_cross, int do_ec, int do_unzip, int n_threads, const char *out);
 int refx_syncasm_tail(sr_db_t *sr_db, syncmer_db_t *scm_db, int k, int bubble_size, int tip_size, int min_k_cov,
+        double min_a_cov_f, double weak_cross, int do_ec, int do_unzip, int n_threads, const char *out)
+{
+    return syncasm_tail(sr_db, scm_db, 0, k, bubble_size, tip_size, min_k_cov, min_a_cov_f, weak_cross, do_ec, do_unzip, n_threads, out);
+}
+/* the same from run_syncasm.c:160 on, with the assembly graph of :138 (scg->utg_asmg) supplied by the caller; takes ownership of it */
+int refx_syncasm_tail_graph(sr_db_t *sr_db, syncmer_db_t *scm_db, asmg_t *asmg, int k, int bubble_size, int tip_size, int min_k_cov,
+        double min_a_cov_f, double weak_cross, int do_unzip, int n_threads, const char *out)
+{
+    return syncasm_tail(sr_db, scm_db, asmg, k, bubble_size, tip_size, min_k_cov, min_a_cov_f, weak_cross, 0, do_unzip, n_threads, out);
+}
+static int syncasm_tail(sr_db_t *sr_db, syncmer_db_t *scm_db, asmg_t *given_asmg, int k, int bubble_size, int tip_size, int min_k_cov,
         double min_a_cov_f, double weak_cross, int do_ec, int do_unzip, int n_threads, const char *out)
 {
     scg_t *scg = 0;
@@ -247,7 +269,10 @@ int refx_syncasm_tail(sr_db_t *sr_db, syncmer_db_t *scm_db, int k, int bubble_si
         sr_db_stat(sr_db, nul, 0);
         scg_destroy(scg); scg = 0;
     }
-    scg = make_syncmer_graph(sr_db, scm_db, min_k_cov, min_a_cov_f);  /* :138 */
+    if (given_asmg) {                                              /* the assembly graph was built elsewhere: wrap it the way syncasm.c:208-296 does */
+        scg = (scg_t *) calloc(1, sizeof(scg_t));
+        scg->scm_db = scm_db, scg->utg_asmg = given_asmg;          /* the syncmer index is rebuilt by process_mergeable_unitigs below */
+    } else scg = make_syncmer_graph(sr_db, scm_db, min_k_cov, min_a_cov_f);  /* :138 */
     if (!scg || scg_is_empty(scg)) { ret = 1; goto done; }
     process_mergeable_unitigs(scg);                                /* :161 */
     snprintf(path, sizeof(path), "%s.utg.gfa", out);

@@ -141,10 +141,59 @@ def ec_case(name, reads, K, S, c, a=0.35, max_edist=0.02):
     db.close()
 
 
+def flatten_asm(g):
+    """make_syncmer_graph(…, c, a) of the reference as arrays: vertices (syncmer, cov), arcs with flags and link ids, index"""
+    import ctypes as C
+    import ec_util as E
+    Gd = E.flatten_graph(g)
+    nv, na = Gd["n_vtx"], Gd["n_arc"]
+    vn, va0, aln, alink = np.zeros(max(nv, 1), np.uint64), np.zeros(max(nv, 1), np.uint64), np.zeros(max(na, 1), np.uint64), np.zeros(max(na, 1), np.uint64)
+    R.lib().refx_graph_flatten2(g, *[C.c_void_p(x.ctypes.data) for x in (vn, va0, aln, alink)])
+    assert (vn[:nv] == 1).all() and (aln[:na] == 0).all() and (Gd["arc_ls"][:na] == 0).all() and (Gd["arc_del"][:na] == 0).all() and (Gd["vtx_del"] == 0).all()
+    return {"vtx_scm": (va0[:nv] >> np.uint64(1)).astype(np.uint32), "vtx_cov": Gd["vtx_cov"], "arc_v": Gd["arc_v"][:na], "arc_w": Gd["arc_w"][:na],
+            "arc_cov": Gd["arc_cov"][:na], "arc_comp": Gd["arc_comp"][:na], "arc_link": alink[:na], "idx_p": Gd["idx_p"], "idx_n": Gd["idx_n"]}
+
+
+def asmgraph_case(name, reads, K, S, c, a=0.35, max_edist=0.02):
+    """the assembly graph, make_syncmer_graph(sr_db, scm_db, c, a) (run_syncasm.c:138): `raw_*` built from the uncorrected databases,
+    `ec_*` after the error correction of the golden case `name` (whose out_* arrays are this graph's input chains)"""
+    import ec_util as E
+    L = R.lib()
+    out = {}
+    for tag in ("raw", "ec"):
+        db = R.SrDb.from_reads(reads, K, S, threads=2)
+        scm = R.ScmDb(db)
+        if tag == "ec":
+            g, _ = E.ref_graph(db, scm)
+            E.reference_ec(db, scm, g, max_edist, c, a)
+            L.refx_scg_destroy(g)
+            gold = np.load(os.path.join(GOLD, name + ".npz"))
+            assert np.array_equal(db.flatten()["k_mer"], gold["out_k_mer"])
+        g = L.refx_make_graph(db.handle, scm.handle, c, a)
+        F = flatten_asm(g)
+        for k, v in F.items():
+            out[tag + "_" + k] = v
+        out[tag + "_scm_del"] = scm.flatten()["del"]
+        print("%-28s %-3s vertices=%d arcs=%d dropped syncmers=%d" % ("asmgraph_" + name, tag, len(F["vtx_scm"]), len(F["arc_v"]), int(out[tag + "_scm_del"].sum())))
+        L.refx_scg_destroy(g)
+        scm.close()
+        db.close()
+    np.savez_compressed(os.path.join(GOLD, "asmgraph_" + name + ".npz"), c=c, a=a, **out)
+
+
+def asmgraph_cases():
+    import test_gpu_ec as T
+    asmgraph_case("ec_diploid_k101", T.diploid_reads(101, 6000, 150, 500, 1200, 0.006), 101, 11, 4)
+    asmgraph_case("ec_repeats_k301", T.sample_reads(T.genome_with_repeats(7, 25000, unit=1500, copies=4), 320, 4000, 0.003, 8), 301, 21, 5)
+    asmgraph_case("ec_hifi_k1001", A.hifi_like(120, 30000, 9000, seed=1009, err=0.0008), 1001, 31, 6)
+
+
 def main():
     if not R.available():
         sys.exit("oracle/_ref/liboatk_ref.so missing: run `make -C oracle ref` (needs /root/reference)")
     os.makedirs(GOLD, exist_ok=True)
+    if "--asmgraph-only" in sys.argv:        # adds asmgraph_*.npz next to existing ec_*.npz without rewriting those
+        return asmgraph_cases()
     for (K, S) in [(101, 11), (61, 15), (33, 31), (25, 5), (64, 16)]:
         scan_count_case("adversarial_k%d_s%d" % (K, S), A.reads(K, S, scale=0.5), K, S)
     scan_count_case("adversarial_k1001_s31", A.reads(1001, 31, scale=0.5), 1001, 31)
@@ -155,6 +204,7 @@ def main():
     ec_case("ec_diploid_k101", T.diploid_reads(101, 6000, 150, 500, 1200, 0.006), 101, 11, 4)
     ec_case("ec_repeats_k301", T.sample_reads(T.genome_with_repeats(7, 25000, unit=1500, copies=4), 320, 4000, 0.003, 8), 301, 21, 5)
     ec_case("ec_hifi_k1001", A.hifi_like(120, 30000, 9000, seed=1009, err=0.0008), 1001, 31, 6)
+    asmgraph_cases()
 
 
 if __name__ == "__main__":

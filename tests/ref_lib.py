@@ -51,6 +51,7 @@ def lib():
         L.refx_find_error_syncmers.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_int]
         L.refx_graph_dims.argtypes = [vp, vp, vp, vp]
         L.refx_graph_flatten.argtypes = [vp] * 14
+        L.refx_graph_flatten2.argtypes = [vp] * 5
         L.refx_ec.argtypes = [vp, vp, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_int]
         L.refx_wf_ed.argtypes = [C.c_int32, C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, C.c_int32, vp]
         L.refx_wf_new.restype = vp

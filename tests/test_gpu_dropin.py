@@ -100,6 +100,39 @@ def test_gfa_identical_with_all_three_device_functions(hip, tmp_path, K, S, cov,
     L.refx_srdb_destroy(db)
 
 
+@pytest.mark.parametrize("K,S,cov,err,do_ec,do_unzip", [(1001, 31, 8, 0.0008, 1, 3), (301, 21, 6, 0.001, 1, 3), (1001, 31, 8, 0.0008, 0, 0),
+                                                       (301, 21, 6, 0.001, 0, 3)])
+def test_gfa_identical_with_the_assembly_graph_from_the_device(hip, tmp_path, K, S, cov, err, do_ec, do_unzip):
+    """sr_read, collect_syncmer_from_reads, the whole error-correction round AND make_syncmer_graph(sr_db, scm_db, c, a) (run_syncasm.c:138)
+    on the device: the reference receives its asmg_t ready-made (oatk_make_syncmer_asmg) and starts at the unitigging (:160)"""
+    L, H = R.lib(), host_lib()
+    L.refx_syncasm_tail_graph.restype = C.c_int
+    L.refx_syncasm_tail_graph.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
+                                          C.c_int, C.c_char_p]
+    H.oatk_read_error_correction.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32,
+                                             C.c_double, C.c_void_p]
+    H.oatk_make_syncmer_asmg.restype = C.c_void_p
+    H.oatk_make_syncmer_asmg.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_double, C.POINTER(C.c_int)]
+    reads = A.hifi_like(260, 50000, 9000 if K > 500 else (5000 if K > 200 else 2000), seed=K + 9, err=err)
+    fa = str(tmp_path / "reads.fa")
+    R.write_fasta(reads, fa)
+    out_ref, out_dev = str(tmp_path / "ref"), str(tmp_path / "dev")
+    assert L.refx_syncasm(R._files_arg([fa]), 1, K, S, cov, 0.35, do_ec, do_unzip, 4, out_ref.encode()) == 0
+    db, scm = device_dbs(hip, reads, K, S)
+    if do_ec:
+        stats = np.zeros(12, np.uint64)
+        assert H.oatk_read_error_correction(hip.h, db, scm, None, 0.02, cov, 10 * cov, cov, 0.35, stats.ctypes.data) == 0
+    rc = C.c_int(0)
+    asmg = H.oatk_make_syncmer_asmg(hip.h, scm, cov, 0.35, C.byref(rc))
+    assert rc.value == 0 and asmg, hip.L.oatk_hip_last_error(hip.h)
+    assert L.refx_syncasm_tail_graph(db, scm, asmg, K, 100000, 10000, cov, 0.35, 0.3, do_unzip, 4, out_dev.encode()) == 0   # frees asmg
+    for suffix in (".utg.gfa", ".utg.final.gfa"):
+        assert os.path.getsize(out_ref + suffix) > 100
+        assert filecmp.cmp(out_ref + suffix, out_dev + suffix, shallow=False), suffix
+    L.refx_scmdb_destroy(scm)
+    L.refx_srdb_destroy(db)
+
+
 def test_structs_equal_reference_structs(hip):
     """member-by-member: reference flatteners applied to OUR sr_db / scm_db vs the reference's own"""
     K, S = 1001, 31
