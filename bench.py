@@ -231,6 +231,15 @@ def main():
                        "ambiguous": int(st[3] + st[4] + st[8] + st[9]), "blocks_past_first_tier": int(st[11])}
             if sharded is not None:
                 syncerr["imported_kmers_rank0"] = sharded.n_imported
+            else:                           # the assembly graph of the corrected reads (run_syncasm.c:138), not part of `value`
+                hip.asm_graph(c, 0.35)
+                fence()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    nv, na = hip.asm_graph(c, 0.35)
+                fence()
+                syncerr["asm_graph"] = {"ms": round((time.perf_counter() - t1) / max(args.steps, 1) * 1e3, 3), "n_vtx": nv, "n_arc": na,
+                                        "workload": "make_syncmer_graph(-c %d, a 0.35) + asmg_finalize on the corrected chains" % c}
         except Exception as ex:             # noqa: BLE001
             syncerr = {"error": "%s: %s" % (type(ex).__name__, ex)}
         hip.set_timing(True)
