@@ -226,6 +226,20 @@ class ShardedEc:
         return {"ids": ids, "rl": rl, "m_seq": m, "owner": owner, "first_local": first}
 
 
+    def asm_graph(self, min_k_cov, min_a_cov_f):
+        """make_syncmer_graph(sr_db, scm_db, min_k_cov, min_a_cov_f) (run_syncasm.c:138) of ALL reads after run(): the canonical keys of
+        every rank's corrected chains are all-gathered (8 bytes per syncmer occurrence; their order does not matter to a counter), the
+        coverage and deletion marks are the all-reduced ones of run(); every rank ends with the same resident graph (AG_* buffers, global
+        ids).  Returns (n_vtx, n_arc)."""
+        hip, dist, dev = self.hip, self.dist, self.device
+        kp, n = hip.asm_pairs()
+        keys = torch.as_tensor(_DevView(kp, n, "<i8"), device=dev) if n else torch.zeros(0, dtype=torch.int64, device=dev)
+        keys_all = torch.cat(gather_var(keys, dist)).contiguous()
+        cov32, del8 = self.last["cov"].to(torch.int32).contiguous(), self.last["del"].contiguous()
+        return hip.asm_graph_from_pairs(keys_all.data_ptr(), int(keys_all.numel()), self.last["n_global"], cov32.data_ptr(), del8.data_ptr(),
+                                        int(min_k_cov), float(min_a_cov_f))
+
+
 def merge_numpy(h_u64, s_u64, cov, dist=None):
     """convenience for the CPU tests: numpy uint64 in, numpy out"""
     h = torch.from_numpy(h_u64.view(np.int64).copy())

@@ -40,6 +40,10 @@ def _worker(rank, world, port, reads, bounds, K, S, c, outdir):
     sh = ShardedEc(hip, dist, dev)
     res = sh.run(0.02, c, 0.35)
     cons = sh.consensus(c)
+    nv, na = sh.asm_graph(c, 0.35)
+    ag = hip.fetch_asm_graph()
+    assert nv == len(ag["vtx_scm"]) and na == len(ag["arc_v"])
+    np.savez(os.path.join(outdir, "ag%d.npz" % rank), **ag)
     np.savez(os.path.join(outdir, "r%d.npz" % rank), n_scm=hip.fetch("EC_N_SCM"), k_mer=hip.fetch("EC_KMER"), m_pos=hip.fetch("EC_MPOS"),
              s_mer=hip.fetch("EC_SMER"), occ=hip.fetch("EC_SCM_OCC"), occ_off=hip.fetch("EC_SCM_OCC_OFF"), cov=res["cov"].cpu().numpy(),
              dele=res["del"].cpu().numpy(), stats=res["stats"], imported=sh.n_imported,
@@ -101,3 +105,15 @@ def test_sharded_ec_equals_single_context(hip, tmp_path, case):
     owner = z[0]["c_owner"]
     first = np.array([z[int(o)]["c_first"][i] if o >= 0 else -1 for i, o in enumerate(owner)], dtype=np.int64)
     assert np.array_equal(first.view(np.uint64), fo) and len(sel) > 0
+    # the assembly graph of all reads (run_syncasm.c:138): every rank holds the graph the single context builds
+    nv, na = hip.asm_graph(c, 0.35)
+    want_g = hip.fetch_asm_graph()
+    assert nv > 0 and na > 0
+    for r in range(world):
+        got_g = np.load(os.path.join(str(tmp_path), "ag%d.npz" % r))
+        for k, v in want_g.items():
+            if k == "idx_p":
+                has = want_g["idx_n"] > 0
+                assert np.array_equal(got_g[k][has], v[has]), k
+            else:
+                assert np.array_equal(got_g[k], v), (r, k)
