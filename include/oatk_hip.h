@@ -131,6 +131,9 @@ int oatk_hip_get_timing(oatk_hip_ctx *ctx, float *ms, int n);
 int oatk_hip_debug_hash_mask(oatk_hip_ctx *ctx, uint64_t mask);
 /* test hook: 1 = always use the general syncmer kernel (scan_syncmer.hpp), 0 = use the fast path where it applies */
 int oatk_hip_debug_force_general(oatk_hip_ctx *ctx, int on);
+/* Test hook: syncmers the fast scan kernel collects per read in LDS before it writes their records (1..512; 0 = default 512).
+ * Results never depend on it. */
+int oatk_hip_debug_list_cap(oatk_hip_ctx *ctx, int cap);
 
 #ifdef __cplusplus
 }

@@ -52,6 +52,7 @@ struct oatk_hip_ctx {
     float ms[OATK_T_COUNT_];
     uint64_t hash_mask = ~0ULL;
     bool force_general = false;   // test hook: run the general syncmer kernel even where the fast one applies
+    int list_cap = 0;             // test hook: syncmers the fast kernel collects per read before writing records (0 = default)
     uint64_t import_reserve = 1u << 20;  // bytes kept free behind the hoco strings for k-mers imported from other shards (api_ec.inc)
     int ec_cap_t0 = 0, ec_cap_t1 = 0;   // test hook: block-length limits of the first two EC solver tiers (0 = default)
 
@@ -215,6 +216,13 @@ int oatk_hip_debug_force_general(oatk_hip_ctx *ctx, int on)
     ctx->force_general = on != 0;
     return OATK_OK;
 }
+int oatk_hip_debug_list_cap(oatk_hip_ctx *ctx, int cap)
+{
+    if (!ctx) return OATK_E_NODEV;
+    if (cap < 0 || cap > oatk::SYF_LIST) { ctx->err = "oatk_hip_debug_list_cap: 0 <= cap <= 512"; return OATK_E_ARG; }
+    ctx->list_cap = cap;
+    return OATK_OK;
+}
 int oatk_hip_debug_hash_mask(oatk_hip_ctx *ctx, uint64_t mask)
 {
     if (!ctx) return OATK_E_NODEV;
@@ -248,7 +256,7 @@ static int launch_scan_kernels(oatk_hip_ctx *ctx)
     SynArgs s;
     s.hoco_s = ctx->hoco_s.as<uint8_t>(), s.nbits = ctx->nbits.as<uint32_t>(), s.off = ctx->d_off;
     s.hoco_l = ctx->hoco_l.as<uint32_t>(), s.n_nn = ctx->n_nn.as<uint32_t>(), s.sid0 = ctx->sid0;
-    s.K = ctx->K, s.S = ctx->S, s.want_n = 0, s.n_scm = ctx->n_scm.as<uint32_t>();
+    s.K = ctx->K, s.S = ctx->S, s.want_n = 0, s.n_scm = ctx->n_scm.as<uint32_t>(), s.list_cap = ctx->list_cap? ctx->list_cap : SYF_LIST;
     s.rec_hash = nullptr, s.rec_lo = ctx->raw_lo.as<uint64_t>(), s.rec_smer = ctx->raw_smer.as<uint64_t>();
     s.rec_mpos = ctx->raw_mpos.as<uint32_t>(), s.region_cap = ctx->region_cap, s.shard_cnt = ctx->shard_cnt.as<uint32_t>();
     const bool small = ctx->K + 8 * SYN_NT + 8 + 64 <= 4096;

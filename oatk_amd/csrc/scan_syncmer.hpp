@@ -39,6 +39,7 @@ struct SynArgs {
     uint64_t sid0;
     int K, S;
     int want_n;               // 1: process only reads with ambiguous bases; 0: only reads without
+    int list_cap;             // fast kernel: syncmers collected per read before records are written (<= SYF_LIST)
     uint32_t *n_scm;          // per read
     uint64_t *rec_hash, *rec_lo, *rec_smer;
     uint32_t *rec_mpos;

@@ -34,6 +34,7 @@ constexpr int SYF_C = 8;                 // positions per lane per tile (one chu
 constexpr int SYF_T = SYN_NT * SYF_C;    // 2048 positions per tile
 constexpr int SYF_BLK = 64;              // chunks per wave = block of the prefix/suffix minima
 constexpr int SYF_SEG = 64;              // candidate slots per wave per round
+constexpr int SYF_LIST = 512;            // syncmers a read collects in LDS before they become records
 
 // ring size (positions) the fast kernel needs for this K, or 0 if it does not apply
 static inline int syncmer_fast_ring(int K, int S)
@@ -93,6 +94,9 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_fast_kernel(SynArgs a)
     __shared__ uint32_t pre32[NCH], suf32[NCH]; // per-wave-block inclusive prefix / suffix minima of the chunk minima's top 32 bits
     __shared__ uint32_t pb[PBW];                // packed bases, 16 per word, MSB-first
     __shared__ uint32_t w_cnt[2][NWAVE];         // syncmers per wave of a tile, double-buffered (two barriers per tile)
+    __shared__ uint32_t sl_e[SYF_LIST];          // syncmers of the read so far, in position order: k-mer end ...
+    __shared__ uint8_t sl_k[SYF_LIST];           // ... and kind (1 Close, 2 Open); written out when the read is done (or the list is full)
+    __shared__ uint32_t s_gb;                    // record slots of the list being written out
 
     const uint32_t r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (a.n_nn[r] != 0) return;                 // reads with ambiguous bases take the general kernel
@@ -131,47 +135,84 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_fast_kernel(SynArgs a)
         uint32_t w2 = pb[p2];
         return sh? (hi << sh) | ((uint64_t) w2 >> (32u - sh)) : hi;
     };
-    auto smer_code = [&](int32_t e) -> uint64_t {
-        uint64_t X = get64(e - S + 1) & (~0ULL << (64 - 2 * S));
-        uint64_t fw = X >> (64 - 2 * S), rv = revcomp32(X) & mask;
-        return fw < rv? fw << 1 : rv << 1 | 1ULL;
-    };
     const uint32_t *m_hi = (const uint32_t *) m_ring;    // top word of entry e is m_hi[2e + 1]
 
-    uint32_t ord0 = 0, par = 0;                 // syncmers so far; parity of the count buffer
+    uint32_t ord0 = 0, par = 0;                 // syncmers already turned into records; parity of the count buffer
+    uint32_t sl_n = 0;                          // syncmers in the list (the same value in every thread)
     const int HW = (w & (C - 1)) + C;           // window positions not covered by D whole chunks: w - C * D
 
-    // syncmers of the previous tile, waiting for the other waves' counts and for their record slots
-    uint32_t pend_kinds = 0, pend_rank = 0, pend_wtot = 0, pend_gb = 0, pend_par = 0, pend_any = 0;
+    // s-mer code of a record from the read's packed bases in HBM (the LDS base ring only holds the last tiles)
+    auto get64g = [&](int32_t t) -> uint64_t {
+        const uint32_t wi = (uint32_t) t >> 4, sh = ((uint32_t) t & 15u) * 2u;
+        const uint64_t hi = (uint64_t) __builtin_bswap32(ghs[wi]) << 32 | __builtin_bswap32(ghs[wi + 1]);
+        const uint32_t w2 = __builtin_bswap32(ghs[wi + 2]);            // the slab has slack behind the last read
+        return sh? (hi << sh) | ((uint64_t) w2 >> (32u - sh)) : hi;
+    };
+    auto write_record = [&](int32_t E, uint32_t kind, uint32_t loc, uint32_t ordn) {
+        const int32_t e = kind == 2u? E - w : E, j = E - K + 1;        // Open: first s-mer; Close: last s-mer
+        const uint64_t X = get64g(e - S + 1) & (~0ULL << (64 - 2 * S));
+        const uint64_t fw = X >> (64 - 2 * S), rv = revcomp32(X) & mask;
+        uint64_t code = fw < rv? fw << 1 : rv << 1 | 1ULL;
+        const uint32_t rev = (uint32_t) (code & 1ULL);
+        if (kind == 1u) code ^= 1ULL;                                    // Close stores S ^ 1 (syncmer.c:345)
+        if (loc < a.region_cap) {
+            const size_t slot = (size_t) (blockIdx.x & (OATK_REC_SHARDS - 1)) * a.region_cap + loc;
+            a.rec_lo[slot] = sid << 32 | (uint64_t) ordn << 1 | rev;
+            a.rec_smer[slot] = code;
+            a.rec_mpos[slot] = (uint32_t) j << 1 | rev;
+        }
+    };
+    // the list -> records, all threads; the entries must be visible (a barrier since the last append).  One slot atomic per call.
+    auto emit_list = [&]() {
+        if (sl_n) {
+            if (tid == 0) s_gb = atomicAdd(&a.shard_cnt[blockIdx.x & (OATK_REC_SHARDS - 1)], sl_n);
+            __syncthreads();
+            const uint32_t gb = s_gb;
+            for (uint32_t i = tid; i < sl_n; i += SYN_NT) write_record((int32_t) sl_e[i], sl_k[i], gb + i, ord0 + i);
+            __syncthreads();                    // the list may be refilled, s_gb rewritten
+        }
+        ord0 += sl_n, sl_n = 0;
+    };
+
+    // Syncmers of the previous tile: once the other waves' counts are known (across the next tile's barrier) every wave appends
+    // its own to the list at a position that follows from the counts alone -- no atomics, and the list comes out in position
+    // order, so an entry's index is its ordinal.  Records are written when the read is done: one slot atomic per read instead of
+    // one per wave and tile, and the k-mer codes are computed by 256 lanes at once instead of by lone lanes between two barriers.
+    uint32_t pend_kinds = 0, pend_rank = 0, pend_wtot = 0, pend_par = 0, pend_any = 0;
     int32_t pend_i0 = 0;
     auto flush = [&]() {                        // call after a barrier that follows the tile
         if (!pend_any) return;
         uint32_t before = 0, tot = 0;
 #pragma unroll
         for (int ww = 0; ww < NWAVE; ++ww) { const uint32_t c = w_cnt[pend_par][ww]; tot += c; before += ww < (int) wid? c : 0u; }
-        if (pend_wtot) {
-            const uint32_t gb = __builtin_amdgcn_readfirstlane(pend_gb);
-            uint32_t rank = pend_rank, kk = pend_kinds;
+        pend_any = 0;
+        if (tot == 0) return;
+        if (sl_n + tot > (uint32_t) a.list_cap) emit_list();               // uniform: sl_n and tot are the same in every thread
+        if (tot > (uint32_t) a.list_cap) {                                  // a tile with more syncmers than the list holds: straight to records
+            if (tid == 0) s_gb = atomicAdd(&a.shard_cnt[blockIdx.x & (OATK_REC_SHARDS - 1)], tot);
+            __syncthreads();
+            uint32_t rank = before + pend_rank, kk = pend_kinds;
             while (kk) {
                 const int o = __builtin_ctz(kk) >> 1;
                 const uint32_t kind = (pend_kinds >> (2 * o)) & 3u;
                 kk &= ~(3u << (2 * o));
-                const int32_t E = pend_i0 + o, j = E - K + 1;
-                uint64_t code = smer_code(kind == 2u? E - w : E);               // Open: first s-mer; Close: last s-mer
-                const uint32_t rev = (uint32_t) (code & 1ULL);
-                if (kind == 1u) code ^= 1ULL;                                    // Close stores S ^ 1 (syncmer.c:345)
-                const uint32_t loc = gb + rank, ordn = ord0 + before + rank;
-                if (loc < a.region_cap) {
-                    const size_t slot = (size_t) (blockIdx.x & (OATK_REC_SHARDS - 1)) * a.region_cap + loc;
-                    a.rec_lo[slot] = sid << 32 | (uint64_t) ordn << 1 | rev;
-                    a.rec_smer[slot] = code;
-                    a.rec_mpos[slot] = (uint32_t) j << 1 | rev;
-                }
+                write_record(pend_i0 + o, kind, s_gb + rank, ord0 + rank);
                 ++rank;
             }
+            __syncthreads();
+            ord0 += tot;
+            return;
         }
-        ord0 += tot;
-        pend_any = 0;
+        if (pend_wtot) {
+            uint32_t idx = sl_n + before + pend_rank, kk = pend_kinds;
+            while (kk) {
+                const int o = __builtin_ctz(kk) >> 1;
+                sl_e[idx] = (uint32_t) (pend_i0 + o), sl_k[idx] = (uint8_t) ((pend_kinds >> (2 * o)) & 3u);
+                kk &= ~(3u << (2 * o));
+                ++idx;
+            }
+        }
+        sl_n += tot;
     };
 
     for (uint32_t I0 = 0; I0 < hl; I0 += T) {
@@ -193,7 +234,11 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_fast_kernel(SynArgs a)
                     fw = (fw << 2 | c) & mask;
                     rv = rv >> 2 | (3ULL ^ c) << (2 * S - 2);
                     // (S31: an odd-length s-mer is never its own reverse complement, so no fw != rv test)
+#ifdef OATK_EXP_NOHASH
+                    uint64_t mv = (fw < rv? fw : rv) * 0x9E3779B97F4A7C15ULL;
+#else
                     uint64_t mv = (S31 || fw != rv)? hash64(fw < rv? fw : rv, mask) : UINT64_MAX;
+#endif
                     y[b] = mv;
                     cmin = mv < cmin? mv : cmin;
                 }
@@ -237,6 +282,7 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_fast_kernel(SynArgs a)
 
         // ---- P3: filter on 32-bit keys (straight-line code: 64 <= D <= 127 means at most ONE whole block inside a range) ----
         uint32_t cmask = 0, backF_keep = 0, fwd0_keep = 0, fwd1_keep = 0;
+#ifndef OATK_EXP_NOFILTER
         {
             // minimum of the chunk minima over chunks [lo, hi], hi - lo = D - 1: suffix of lo's block, prefix of hi's block and,
             // when the two are not adjacent, the one whole block between them.  Chunks before the read map to ring slots that
@@ -276,17 +322,16 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_fast_kernel(SynArgs a)
                 }
             }
         }
-        // ---- exact decision, by the lane that found the candidate.  The filter already proved that the D whole chunks
-        //      of the window hold nothing smaller (top 32 bits), so only the HW ragged positions at the two ends of the
-        //      window remain -- a dozen LDS reads of top words, one v_min each.  Top words that TIE (~2^-28 per candidate on
-        //      random sequence, common inside low-complexity repeats) send the position to the full 64-bit rule. ----
+#endif
+        // ---- exact decision.  The filter already proved that the D whole chunks of the window hold nothing smaller (top 32
+        //      bits), so only the HW ragged positions at the two ends of the window remain -- a dozen top words each for Close
+        //      and Open.  Top words that TIE (~2^-28 per candidate on random sequence, common inside low-complexity repeats) send
+        //      the position to the full 64-bit rule. ----
         uint32_t kinds = 0;                             // 2 bits per position of the chunk: 0 none, 1 Close, 2 Open
-        if (cmask) {
-            const int sh = (-w) & (C - 1);
-            const uint32_t backF = backF_keep;
-            auto hi_at = [&](int32_t pos) -> uint32_t { return m_hi[2u * mi(pos) + 1u]; };
-            // the rule in full for one position (scan_syncmer.hpp states it; window = [E - w, E - 1]); rare
-            auto exact64 = [&](int o) -> uint32_t {
+        // the rule in full for one position (scan_syncmer.hpp states it; window = [E - w, E - 1]); rare
+        auto exact64 = [&](int o) -> uint32_t {
+                const int sh = (-w) & (C - 1);
+                const uint32_t backF = backF_keep;
                 auto chunks_min = [&](int32_t c0, int32_t c1) -> uint64_t {
                     uint64_t v = UINT64_MAX;
                     for (int32_t cc = c0; cc <= c1; ++cc) { const uint64_t u = cm_ring[rch(cc)]; v = u < v? u : v; }
@@ -313,29 +358,68 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_fast_kernel(SynArgs a)
                     op = f != UINT64_MAX && f <= b && f <= yy;
                 }
                 return cl && op? 0u : (cl? 1u : (op? 2u : 0u));
-            };
-            uint32_t mm = cmask;
-            while (mm) {
-                const int o = __builtin_ctz(mm);
-                mm &= mm - 1;
-                const int32_t E = i0 + o, lo = E - w;
-                const uint32_t yhi = hi_at(E), fhi = hi_at(lo);
-                const uint32_t fb = o + sh < C? fwd0_keep : fwd1_keep;
-                bool cl = false, op = false, tie = false;
-                if (yhi <= backF) {
-                    uint32_t bh = backF;                // top word of the window minimum
-                    for (int t = 0; t < HW - o; ++t) { const uint32_t u = hi_at(lo + t); bh = u < bh? u : bh; }
-                    for (int t = 0; t < o; ++t) { const uint32_t u = hi_at(i0 + t); bh = u < bh? u : bh; }
-                    cl = yhi < bh, tie = yhi == bh;
+        };
+        // The wave decides its candidates TOGETHER, one after the other (there is about one per wave and tile): lanes 0-15 fetch the
+        // ragged positions of the Close window, lanes 16-31 those of the Open window, lanes 32 / 33 the two hashes in question -- one
+        // LDS read per lane, one row-wise DPP min, and the rest is scalar.  (A lone lane walking the same thirty positions cost the
+        // wave ~200 issue slots per candidate; this costs ~40.)
+        uint32_t tiemask = 0;
+        {
+            const int sh = (-w) & (C - 1);
+            const uint32_t wbase = I0 + (uint32_t) __builtin_amdgcn_readfirstlane((int) wid) * (OATK_WAVE * C);
+            uint64_t cand = __ballot(cmask != 0);
+#ifdef OATK_EXP_NODECIDE
+            cand = 0;
+#endif
+            while (cand) {
+                const int L = __builtin_ctzll(cand);
+                cand &= cand - 1;
+                uint32_t mm = (uint32_t) __builtin_amdgcn_readlane((int) cmask, L);
+                const uint32_t cbackF = (uint32_t) __builtin_amdgcn_readlane((int) backF_keep, L);
+                const uint32_t cf0 = (uint32_t) __builtin_amdgcn_readlane((int) fwd0_keep, L), cf1 = (uint32_t) __builtin_amdgcn_readlane((int) fwd1_keep, L);
+                const int32_t ci0 = (int32_t) (wbase + (uint32_t) L * C);
+                uint32_t res = 0, ties = 0;
+                while (mm) {
+                    const int o = __builtin_ctz(mm);
+                    mm &= mm - 1;
+                    const int32_t E = ci0 + o, lo = E - w;
+                    const int32_t ca = lo >> 3, n1 = (ca + 1) * C - lo - 1, tail0 = (ca + 1 + D) * C, n2 = E - tail0;
+                    const int32_t t = (int32_t) (lane & 15u);
+                    int32_t pos = E;
+                    bool valid = false;
+                    if (lane < 16) valid = t < HW, pos = t < HW - o? lo + t : ci0 + (t - (HW - o));          // Close: head [lo, lo + HW - o) + tail [i0, E)
+                    else if (lane < 32) valid = t < n1 + n2, pos = t < n1? lo + 1 + t : tail0 + (t - n1);     // Open: rest of f's chunk + [tail0, E)
+                    else if (lane == 33) pos = lo;
+                    const uint32_t u = m_hi[2u * mi(pos) + 1u];
+                    const uint32_t yhi = (uint32_t) __builtin_amdgcn_readlane((int) u, 32), fhi = (uint32_t) __builtin_amdgcn_readlane((int) u, 33);
+                    uint32_t v = valid? u : 0xFFFFFFFFu, x;
+                    x = dpp_u32<OATK_DPP_ROW_SHR(1)>(v, v); v = x < v? x : v;
+                    x = dpp_u32<OATK_DPP_ROW_SHR(2)>(v, v); v = x < v? x : v;
+                    x = dpp_u32<OATK_DPP_ROW_SHR(4)>(v, v); v = x < v? x : v;
+                    x = dpp_u32<OATK_DPP_ROW_SHR(8)>(v, v); v = x < v? x : v;
+                    const uint32_t cmin = (uint32_t) __builtin_amdgcn_readlane((int) v, 15), omin = (uint32_t) __builtin_amdgcn_readlane((int) v, 31);
+                    const uint32_t fb = o + sh < C? cf0 : cf1;
+                    bool cl = false, op = false, tie = false;
+                    if (yhi <= cbackF) {
+                        const uint32_t bh = cmin < cbackF? cmin : cbackF;                // top word of the window minimum
+                        cl = yhi < bh, tie = yhi == bh;
+                    }
+                    if (fhi <= fb && fhi <= yhi) {
+                        const uint32_t rh = omin < fb? omin : fb;                        // top word of the minimum of everything in the window but f
+                        op = fhi < rh && fhi < yhi, tie |= fhi <= rh && !op;
+                    }
+                    ties |= (uint32_t) tie << o;
+                    res |= (tie? 0u : (cl && op? 0u : (cl? 1u : (op? 2u : 0u)))) << (2 * o);
                 }
-                if (fhi <= fb && fhi <= yhi) {
-                    const int32_t ca = lo >> 3, tail0 = (ca + 1 + D) * C;
-                    uint32_t rh = fb;                   // top word of the minimum of everything in the window but f
-                    for (int32_t q = lo + 1; q < (ca + 1) * C; ++q) { const uint32_t u = hi_at(q); rh = u < rh? u : rh; }
-                    for (int32_t q = tail0; q < E; ++q) { const uint32_t u = hi_at(q); rh = u < rh? u : rh; }
-                    op = fhi < rh && fhi < yhi, tie |= fhi <= rh && !op;
-                }
-                kinds |= (tie? exact64(o) : (cl && op? 0u : (cl? 1u : (op? 2u : 0u)))) << (2 * o);
+                if ((int) lane == L) kinds = res, tiemask = ties;
+            }
+        }
+        if (tiemask) {                                  // top words tied: the full 64-bit rule, by the lane itself (rare)
+            uint32_t tm = tiemask;
+            while (tm) {
+                const int o = __builtin_ctz(tm);
+                tm &= tm - 1;
+                kinds |= exact64(o) << (2 * o);
             }
         }
         // ---- syncmers -> records, every wave its own.  Two things are only known a little later and neither is waited for:
@@ -347,11 +431,12 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_fast_kernel(SynArgs a)
         const uint32_t wtot = (uint32_t) __builtin_amdgcn_readlane((int) incl, 63);
         if (lane == 0) w_cnt[par][wid] = wtot;
         pend_kinds = kinds, pend_rank = incl - ns, pend_i0 = i0, pend_wtot = wtot, pend_par = par, pend_any = 1u;
-        if (wtot && lane == 0) pend_gb = atomicAdd(&a.shard_cnt[blockIdx.x & (OATK_REC_SHARDS - 1)], wtot);
         par ^= 1u;
     }
     __syncthreads();
     flush();
+    __syncthreads();
+    emit_list();
     if (tid == 0) a.n_scm[r] = ord0;            // tid 0 is in wave 0
 }
 

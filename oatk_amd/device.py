@@ -196,6 +196,9 @@ class HipSyncasm:
         self.L.oatk_hip_get_timing(self.h, ms, len(_lib.TIMERS))
         return dict(zip(_lib.TIMERS, [float(x) for x in ms]))
 
+    def debug_list_cap(self, cap):
+        self._check(self.L.oatk_hip_debug_list_cap(self.h, cap), "oatk_hip_debug_list_cap")
+
     def debug_force_general(self, on=True):
         self.L.oatk_hip_debug_force_general(self.h, 1 if on else 0)
 

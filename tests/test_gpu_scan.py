@@ -129,6 +129,23 @@ def test_general_kernel_still_matches_at_k1001(hip):
     compare_scan(got2, want)
 
 
+@pytest.mark.parametrize("cap", [1, 3, 16])
+def test_fast_kernel_record_list_overflows(hip, cap):
+    """the fast kernel collects a read's syncmers in LDS and writes the records when the read is done; with room for only
+    `cap` of them the list is written out in the middle of the read, and tiles with more syncmers than that go straight to
+    records -- the same records either way"""
+    reads = A.reads(1001, 31, seed=31, scale=0.6) + A.hifi_like(40, 60000, 20000, seed=8) + [A.hifi_like(1, 400000, 300000, seed=5)[0]]
+    want = O.scan(reads, 1001, 31, mode=0)
+    hip.debug_list_cap(cap)
+    try:
+        got, _ = run_hip(hip, reads, 1001, 31)
+    finally:
+        hip.debug_list_cap(0)
+    compare_scan(got, want)
+    with pytest.raises(RuntimeError):
+        hip.debug_list_cap(513)
+
+
 @pytest.mark.parametrize("K,S", [(550, 31), (1500, 21), (1976, 31), (1977, 31)])
 def test_fast_kernel_k_range(hip, K, S):
     reads = A.hifi_like(30, 30000, 9000, seed=K) + A.reads(K, S, seed=3, scale=0.3)[:30]
