@@ -310,12 +310,12 @@ def main():
         dom = max(("hpc", "syncmer"), key=lambda k_: phase_ms.get(k_, 0.0))
         dur_s = phase_ms[dom] / 1e3
         achieved = alg_bytes[dom] / dur_s / 1e9 if dur_s > 0 else 0.0
-        roofline = {"bound": "hbm", "kernel": {"hpc": "oatk::hpc_pack_kernel", "syncmer": "oatk::syncmer_fast_kernel<4096, true>"}[dom],
+        roofline = {"bound": "hbm", "kernel": {"hpc": "oatk::hpc_pack_kernel", "syncmer": "oatk::syncmer_fast_kernel<4096, true, 256, (-(K-S))&7>"}[dom],
                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5),
-                    "traffic": pmc_traffic({"hpc": "oatk::hpc_pack_kernel", "syncmer": "void oatk::syncmer_fast_kernel<4096, true>"}[dom], args.workload, per_gpu),
+                    "traffic": pmc_traffic({"hpc": "oatk::hpc_pack_kernel", "syncmer": "void oatk::syncmer_fast_kernel<4096, true"}[dom], args.workload, per_gpu),
                     "algorithmic_bytes_per_launch": alg_bytes[dom], "avg_launch_ms": round(phase_ms[dom], 4),
-                    "note": "kernel B is integer-VALU issue bound (~104 VALU wave-instructions per 64 hoco positions, 41 of them roll + hash64; SIMDs 70-90 % busy), see DESIGN.md 5",
+                    "note": "kernel B is integer-VALU issue bound (PMC: 90 VALU wave-instructions per 64 hoco positions, 41 of them roll + hash64; waves issue during 38 % of their residency at 10 waves per CU, i.e. the SIMDs' issue ports are ~97 % busy), see DESIGN.md 5",
                     "scan_bytes_per_base": round((alg_bytes["hpc"] + 28 * n_occ) / bases, 4),
                     "scan_achieved_GBs": round((alg_bytes["hpc"] + 28 * n_occ) / ((phase_ms["hpc"] + phase_ms["syncmer"]) / 1e3) / 1e9, 2)}
         cpu = None

@@ -262,7 +262,19 @@ static int launch_scan_kernels(oatk_hip_ctx *ctx)
     const bool small = ctx->K + 8 * SYN_NT + 8 + 64 <= 4096;
     const int fast_ring = ctx->force_general? 0 : syncmer_fast_ring(ctx->K, ctx->S);
     t_begin(ctx, OATK_T_SYNCMER);
-    if (fast_ring == 4096 && ctx->S == 31) hipLaunchKernelGGL((syncmer_fast_kernel<4096, true>), dim3((unsigned) n), dim3(SYN_NT), 0, ctx->stream, s);
+    if (fast_ring == 4096 && ctx->S == 31) {
+        const dim3 g((unsigned) n), b(SYN_NT);
+        switch ((-(ctx->K - ctx->S)) & 7) {        // one instantiation per alignment of the window start against the chunks of 8
+            case 0: hipLaunchKernelGGL((syncmer_fast_kernel<4096, true, SYN_NT, 0>), g, b, 0, ctx->stream, s); break;
+            case 1: hipLaunchKernelGGL((syncmer_fast_kernel<4096, true, SYN_NT, 1>), g, b, 0, ctx->stream, s); break;
+            case 2: hipLaunchKernelGGL((syncmer_fast_kernel<4096, true, SYN_NT, 2>), g, b, 0, ctx->stream, s); break;
+            case 3: hipLaunchKernelGGL((syncmer_fast_kernel<4096, true, SYN_NT, 3>), g, b, 0, ctx->stream, s); break;
+            case 4: hipLaunchKernelGGL((syncmer_fast_kernel<4096, true, SYN_NT, 4>), g, b, 0, ctx->stream, s); break;
+            case 5: hipLaunchKernelGGL((syncmer_fast_kernel<4096, true, SYN_NT, 5>), g, b, 0, ctx->stream, s); break;
+            case 6: hipLaunchKernelGGL((syncmer_fast_kernel<4096, true, SYN_NT, 6>), g, b, 0, ctx->stream, s); break;
+            default: hipLaunchKernelGGL((syncmer_fast_kernel<4096, true, SYN_NT, 7>), g, b, 0, ctx->stream, s); break;
+        }
+    }
     else if (fast_ring == 4096) hipLaunchKernelGGL((syncmer_fast_kernel<4096, false>), dim3((unsigned) n), dim3(SYN_NT), 0, ctx->stream, s);
     else if (small) hipLaunchKernelGGL((syncmer_kernel<8, 4096, false>), dim3((unsigned) n), dim3(SYN_NT), 0, ctx->stream, s);
     else hipLaunchKernelGGL((syncmer_kernel<16, 8192, false>), dim3((unsigned) n), dim3(SYN_NT), 0, ctx->stream, s);

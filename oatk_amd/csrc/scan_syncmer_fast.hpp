@@ -81,10 +81,11 @@ __device__ __forceinline__ void wave_prefix_suffix_min_u32(uint32_t v, uint32_t 
     suf = sadd < s? sadd : s;
 }
 
-template <int R, bool S31>
-__global__ __launch_bounds__(SYN_NT) void syncmer_fast_kernel(SynArgs a)
+// SH: (-(K - S)) & 7 when known at compile time (the offsets of the Open filter's eight reads become immediates), -1 otherwise
+template <int R, bool S31, int NT = SYN_NT, int SH = -1>
+__global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
 {
-    constexpr int C = SYF_C, T = SYF_T, NCH = R / C, NWAVE = SYN_NT / OATK_WAVE;
+    constexpr int C = SYF_C, T = NT * SYF_C, NCH = R / C, NWAVE = NT / OATK_WAVE;
     constexpr int PBW = 512;                    // packed-base ring: 8192 positions, so the next tile's bases can be fetched early
     static_assert((R & (R - 1)) == 0, "power-of-two ring: index arithmetic is one AND (a 3200-slot ring raised occupancy from 3 to 4\n"
                   "workgroups per CU but its modulo arithmetic cost more issue slots than the occupancy returned)");
@@ -120,9 +121,9 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_fast_kernel(SynArgs a)
         }
     };
 
-    for (uint32_t i = tid; i < R + R / 32; i += SYN_NT) m_ring[i] = UINT64_MAX;
-    for (uint32_t i = tid; i < NCH; i += SYN_NT) cm_ring[i] = UINT64_MAX, pre32[i] = suf32[i] = 0xFFFFFFFFu;
-    for (uint32_t i = tid; i < PBW; i += SYN_NT) pb[i] = 0;
+    for (uint32_t i = tid; i < R + R / 32; i += NT) m_ring[i] = UINT64_MAX;
+    for (uint32_t i = tid; i < NCH; i += NT) cm_ring[i] = UINT64_MAX, pre32[i] = suf32[i] = 0xFFFFFFFFu;
+    for (uint32_t i = tid; i < PBW; i += NT) pb[i] = 0;
     __syncthreads();
     load_bases(0);
     __syncthreads();
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_fast_kernel(SynArgs a)
             if (tid == 0) s_gb = atomicAdd(&a.shard_cnt[blockIdx.x & (OATK_REC_SHARDS - 1)], sl_n);
             __syncthreads();
             const uint32_t gb = s_gb;
-            for (uint32_t i = tid; i < sl_n; i += SYN_NT) write_record((int32_t) sl_e[i], sl_k[i], gb + i, ord0 + i);
+            for (uint32_t i = tid; i < sl_n; i += NT) write_record((int32_t) sl_e[i], sl_k[i], gb + i, ord0 + i);
             __syncthreads();                    // the list may be refilled, s_gb rewritten
         }
         ord0 += sl_n, sl_n = 0;
@@ -234,11 +235,7 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_fast_kernel(SynArgs a)
                     fw = (fw << 2 | c) & mask;
                     rv = rv >> 2 | (3ULL ^ c) << (2 * S - 2);
                     // (S31: an odd-length s-mer is never its own reverse complement, so no fw != rv test)
-#ifdef OATK_EXP_NOHASH
-                    uint64_t mv = (fw < rv? fw : rv) * 0x9E3779B97F4A7C15ULL;
-#else
                     uint64_t mv = (S31 || fw != rv)? hash64(fw < rv? fw : rv, mask) : UINT64_MAX;
-#endif
                     y[b] = mv;
                     cmin = mv < cmin? mv : cmin;
                 }
@@ -282,7 +279,6 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_fast_kernel(SynArgs a)
 
         // ---- P3: filter on 32-bit keys (straight-line code: 64 <= D <= 127 means at most ONE whole block inside a range) ----
         uint32_t cmask = 0, backF_keep = 0, fwd0_keep = 0, fwd1_keep = 0;
-#ifndef OATK_EXP_NOFILTER
         {
             // minimum of the chunk minima over chunks [lo, hi], hi - lo = D - 1: suffix of lo's block, prefix of hi's block and,
             // when the two are not adjacent, the one whole block between them.  Chunks before the read map to ring slots that
@@ -296,17 +292,18 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_fast_kernel(SynArgs a)
             };
             const int32_t a_first = i0 - w;             // first s-mer of the k-mer that ends at i0
             const int32_t ca0 = a_first >> 3;
-            const int sh = (-w) & (C - 1);              // = a_first & 7, the same for every lane
+            const int sh = SH >= 0? SH : ((-w) & (C - 1));   // = a_first & 7, the same for every lane
             const uint32_t backF = range_min(ch - D, ch - 1);            // Close bound
             const uint32_t fwd0 = range_min(ca0 + 1, ca0 + D);           // Open bound, first s-mers ending in chunk ca0
             const uint32_t fwd1 = range_min(ca0 + 2, ca0 + 1 + D);       // ... and in chunk ca0 + 1
-            const uint32_t fbase = rpos(a_first);
+            // the eight first s-mers sit in chunks ca0 (from offset sh) and ca0 + 1: two base addresses, constant offsets
+            const uint32_t bA = 2u * mi(ca0 * C) + 1u, bB = 2u * mi((ca0 + 1) * C) + 1u;
             backF_keep = backF, fwd0_keep = fwd0, fwd1_keep = fwd1;
             uint32_t hit = 0;
 #pragma unroll
             for (int o = 0; o < C; ++o) {
-                const uint32_t fp = (fbase + (uint32_t) o) & (uint32_t) (R - 1);
-                const uint32_t fhi = m_hi[2u * (fp + (fp >> 5)) + 1u];
+                const int q = o + sh;
+                const uint32_t fhi = q < C? m_hi[bA + 2u * (uint32_t) q] : m_hi[bB + 2u * (uint32_t) (q - C)];
                 const uint32_t yhi = (uint32_t) (y[o] >> 32);
                 const uint32_t fb = o + sh < C? fwd0 : fwd1;
                 // (a MAX sentinel passes only when its whole window is MAX; the exact rule rejects it)
@@ -322,7 +319,6 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_fast_kernel(SynArgs a)
                 }
             }
         }
-#endif
         // ---- exact decision.  The filter already proved that the D whole chunks of the window hold nothing smaller (top 32
         //      bits), so only the HW ragged positions at the two ends of the window remain -- a dozen top words each for Close
         //      and Open.  Top words that TIE (~2^-28 per candidate on random sequence, common inside low-complexity repeats) send
@@ -330,7 +326,7 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_fast_kernel(SynArgs a)
         uint32_t kinds = 0;                             // 2 bits per position of the chunk: 0 none, 1 Close, 2 Open
         // the rule in full for one position (scan_syncmer.hpp states it; window = [E - w, E - 1]); rare
         auto exact64 = [&](int o) -> uint32_t {
-                const int sh = (-w) & (C - 1);
+                const int sh = SH >= 0? SH : ((-w) & (C - 1));
                 const uint32_t backF = backF_keep;
                 auto chunks_min = [&](int32_t c0, int32_t c1) -> uint64_t {
                     uint64_t v = UINT64_MAX;
@@ -365,12 +361,9 @@ __global__ __launch_bounds__(SYN_NT) void syncmer_fast_kernel(SynArgs a)
         // wave ~200 issue slots per candidate; this costs ~40.)
         uint32_t tiemask = 0;
         {
-            const int sh = (-w) & (C - 1);
+            const int sh = SH >= 0? SH : ((-w) & (C - 1));
             const uint32_t wbase = I0 + (uint32_t) __builtin_amdgcn_readfirstlane((int) wid) * (OATK_WAVE * C);
             uint64_t cand = __ballot(cmask != 0);
-#ifdef OATK_EXP_NODECIDE
-            cand = 0;
-#endif
             while (cand) {
                 const int L = __builtin_ctzll(cand);
                 cand &= cand - 1;

@@ -146,12 +146,18 @@ class ShardedEc:
     def _view(self, name, typestr, itemsize):
         return self.merger._tensor(name, typestr, itemsize)
 
+    def _ready(self):
+        """tensors made by torch (its current stream) are about to be read by the HIP context (its own, non-blocking stream)"""
+        if self.device.type == "cuda":
+            torch.cuda.current_stream(self.device).synchronize()
+
     def run(self, max_edist, c, a):
         hip, dist, dev = self.hip, self.dist, self.device
         rank = dist.get_rank()
         G, S, cov, l2g = self.merger.merge()
         n_global = int(G.numel())
         l2g32, cov32, s64 = l2g.to(torch.int32).contiguous(), cov.to(torch.int32).contiguous(), S.contiguous()
+        self._ready()
         hip.ec_set_global(n_global, l2g32.data_ptr(), cov32.data_ptr(), s64.data_ptr())
         # the graph of all reads, from everybody's adjacent pairs in read order
         kp, dp, n = hip.ec_pairs()
@@ -162,6 +168,7 @@ class ShardedEc:
             keys, dd = torch.zeros(0, dtype=torch.int64, device=dev), torch.zeros(0, dtype=torch.int32, device=dev)
         keys_all = torch.cat(gather_var(keys, dist)).contiguous()
         dist_all = torch.cat(gather_var(dd, dist)).contiguous()
+        self._ready()
         hip.ec_graph_from_pairs(keys_all.data_ptr(), dist_all.data_ptr(), int(keys_all.numel()))
         hip.ec_mark(c, a)
         # live vertices without a k-mer on this rank
@@ -182,6 +189,7 @@ class ShardedEc:
             stride = ((hip.info()["k"] + 3) // 4 + 8 + 15) // 16 * 16
             out = torch.zeros((mine.numel(), stride), dtype=torch.uint8, device=dev)
             rev = torch.zeros(mine.numel(), dtype=torch.uint8, device=dev)
+            self._ready()
             hip.ec_export_kmers(mine.data_ptr(), int(mine.numel()), out.data_ptr(), stride, rev.data_ptr())
             ids_all = torch.cat(gather_var(mine, dist))
             rev_all = torch.cat(gather_var(rev, dist))
@@ -190,6 +198,7 @@ class ShardedEc:
             if hip.info()["n_occ"] == 0:
                 lack = torch.zeros_like(lack)
             ids_i, rev_i, km_i = ids_all[lack].contiguous(), rev_all[lack].contiguous(), km_all[lack].contiguous()
+            self._ready()
             hip.ec_import_kmers(ids_i.data_ptr(), rev_i.data_ptr(), km_i.data_ptr(), int(ids_i.numel()), stride)
             self.n_imported = int(ids_i.numel())
         st = hip.ec_correct(max_edist)
@@ -210,6 +219,7 @@ class ShardedEc:
         cov, dele = self.last["cov"], self.last["del"]
         ids = torch.nonzero((dele == 0) & (cov >= max(int(min_cov), 1))).flatten().to(torch.int32).contiguous()
         n, K = int(ids.numel()), hip.info()["k"]
+        self._ready()
         hip.consensus_ids(ids.data_ptr(), n)
         if n:
             tot = self._view("CONS_TOT", "<i8", 8).reshape(n, K).clone()
@@ -236,6 +246,7 @@ class ShardedEc:
         keys = torch.as_tensor(_DevView(kp, n, "<i8"), device=dev) if n else torch.zeros(0, dtype=torch.int64, device=dev)
         keys_all = torch.cat(gather_var(keys, dist)).contiguous()
         cov32, del8 = self.last["cov"].to(torch.int32).contiguous(), self.last["del"].contiguous()
+        self._ready()
         return hip.asm_graph_from_pairs(keys_all.data_ptr(), int(keys_all.numel()), self.last["n_global"], cov32.data_ptr(), del8.data_ptr(),
                                         int(min_k_cov), float(min_a_cov_f))
 

@@ -22,8 +22,12 @@ hip = HipSyncasm(0)
 hip.set_timing(True)
 acc = {}
 for it in range(a.steps + 1):
-    hip.scan_host(seq, off, lens, 1001, 31)
-    hip.count()
+    try:
+        hip.scan_host(seq, off, lens, 1001, 31)
+        hip.count()
+    except Exception as ex:        # experimental builds with phases compiled out produce garbage the count refuses; the timers still hold
+        if it == 1:
+            print("(%s)" % str(ex)[:80])
     if it:
         for k, v in hip.timing().items():
             acc[k] = acc.get(k, 0) + v / a.steps
