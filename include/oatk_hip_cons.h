@@ -28,7 +28,19 @@ int oatk_hip_consensus(oatk_hip_ctx *ctx, uint32_t min_cov);
  * of lowest rank whose CONS_FIRST is not ~0 (oatk_amd/multi.py: ShardedEc.consensus). */
 int oatk_hip_consensus_ids(oatk_hip_ctx *ctx, const uint32_t *d_ids, uint64_t n);
 
+/* What calc_syncmer_overlap (syncasm.c:477-582) tabulates, for EVERY pair of syncmers adjacent on a read, in one pass over the resident
+ * chains (after oatk_hip_ec: the corrected ones, pairs with a corrected member left out as :499 / :511 do).  Per pair, under its canonical
+ * key ((v << 32 | w) with v <= w, or the complementary pair's; v, w = syncmer id << 1 | strand): the distinct distances between the two
+ * syncmers in the order the reference's walk meets them first, their counts, and whether the walk's last add_ovl_count call was a repeat
+ * (a khashl table grows at the call AFTER the insert that filled it, so this decides the final bucket order, khashl.h:199).  Replaying
+ * kh_put for the distinct distances in this order -- plus one more put of any of them when the flag is set -- leaves the reference's own
+ * table in exactly the state its walk would, so the mode and its tie-break (:558-571) come out identical.
+ *   OVL_KEY  u64[n_pairs]  ascending      OVL_OFF u64[n_pairs + 1]      OVL_DIST i32[n_entries]   OVL_CNT u32[n_entries]   OVL_TAIL u8[n_pairs]
+ * Returns OATK_E_SPLIT when a pair has more than 64 distinct distances. */
+int oatk_hip_overlap_hist(oatk_hip_ctx *ctx, uint64_t *n_pairs, uint64_t *n_entries);
+
 enum { OATK_BUF_CONS_SEL = 140, OATK_BUF_CONS_SLOT, OATK_BUF_CONS_RL, OATK_BUF_CONS_MSEQ, OATK_BUF_CONS_FIRST, OATK_BUF_CONS_TOT };
+enum { OATK_BUF_OVL_KEY = 150, OATK_BUF_OVL_OFF, OATK_BUF_OVL_DIST, OATK_BUF_OVL_CNT, OATK_BUF_OVL_TAIL };
 
 #ifdef __cplusplus
 }

@@ -152,6 +152,33 @@ void oatk_consensus_destroy(oatk_consensus_t *c);
 int64_t oatk_scg_syncmer_consensus(const oatk_consensus_t *cs, const oatk_sr_db_t *sr_db, uint64_t scm_id, int rev, int64_t beg,
                                    oatk_kstring_t *c_seq, int hoco_seq);
 
+/* calc_syncmer_overlap (syncasm.c:477-582) and scg_unitig_consensus (:1004-1046) served from the device's pair tables
+ * (include/oatk_hip_cons.h: oatk_hip_overlap_hist).  oatk_overlap_fetch builds the tables of ALL adjacent pairs from the batch resident in
+ * ctx (after oatk_read_error_correction: the corrected reads) and copies them to the host.  A maintainer can either keep the reference's
+ * own khashl table and refill it -- oatk_overlap_lookup gives the distinct distances of m1 -> m2 in the order the reference's walk would
+ * insert them, their counts, and whether one more put of an existing key is due -- or use the replica here:
+ * oatk_calc_syncmer_overlap returns what the reference returns, `hm` being the table a caller keeps across calls (NULL = fresh), whose
+ * size carries over exactly like the reference's (kh_clear keeps the buckets, so the tie-break of a later pair depends on it).
+ * oatk_scg_unitig_consensus appends the unitig's sequence to c_seq and returns its length, or -1 if one of its syncmers has no prepared
+ * consensus (c_seq is then partial: reset it and run the original routine). */
+typedef struct {
+    uint64_t n_pairs, n_entries;
+    uint64_t *key;         /* [n_pairs] canonical oriented pairs, ascending: v << 32 | w with v <= w, else the complementary pair's */
+    uint64_t *off;         /* [n_pairs + 1] */
+    int32_t *dist;         /* [n_entries] distinct distances in first-appearance order */
+    uint32_t *cnt;         /* [n_entries] */
+    uint8_t *tail;         /* [n_pairs] the walk's last add_ovl_count call was a repeat */
+} oatk_overlap_t;
+typedef struct { uint32_t bits, count; uint32_t *used; int32_t *keys, *vals; } oatk_ovl_table_t;     /* khashl<int,int>, identity hash */
+oatk_overlap_t *oatk_overlap_fetch(oatk_hip_ctx *ctx, int *rc);
+void oatk_overlap_destroy(oatk_overlap_t *o);
+int oatk_overlap_lookup(const oatk_overlap_t *o, uint64_t v, uint64_t w, const int32_t **dist, const uint32_t **cnt, int *tail_repeat);
+oatk_ovl_table_t *oatk_ovl_table_new(void);
+void oatk_ovl_table_destroy(oatk_ovl_table_t *h);
+int oatk_calc_syncmer_overlap(const oatk_overlap_t *o, uint64_t v, uint64_t w, oatk_ovl_table_t *hm);
+int64_t oatk_scg_unitig_consensus(const oatk_consensus_t *cs, const oatk_overlap_t *o, const oatk_sr_db_t *sr_db, const uint64_t *v, uint64_t n,
+                                  oatk_kstring_t *c_seq, int hoco_seq);
+
 /* same destructors as the reference (syncmer.c:1047-1110) for objects that are not handed to it */
 void oatk_sr_db_clean(oatk_sr_db_t *sr_db);
 void oatk_syncmer_db_destroy(oatk_syncmer_db_t *scm_db);

@@ -26,6 +26,7 @@ BUF.update({name: 160 + i for i, name in enumerate(["INGEST_SEQ", "INGEST_OFF", 
 FMT_AUTO, FMT_FASTA, FMT_FASTQ = 0, 1, 2
 # include/oatk_hip_cons.h
 BUF.update({name: 140 + i for i, name in enumerate(["CONS_SEL", "CONS_SLOT", "CONS_RL", "CONS_MSEQ", "CONS_FIRST", "CONS_TOT"])})
+BUF.update({name: 150 + i for i, name in enumerate(["OVL_KEY", "OVL_OFF", "OVL_DIST", "OVL_CNT", "OVL_TAIL"])})
 BUF.update({name: 120 + i for i, name in enumerate([
     "EG_IDX_P", "EG_IDX_N", "EG_ARC_V", "EG_ARC_W", "EG_ARC_LS", "EG_ARC_COV", "EG_ARC_COMP"])})
 # include/oatk_hip_graph.h
@@ -41,7 +42,7 @@ EXPORTS = [
     "oatk_hip_ec_graph", "oatk_hip_ec", "oatk_hip_ec_stats", "oatk_hip_debug_ec_tiers", "oatk_hip_ec_mark", "oatk_hip_ec_correct",
     "oatk_hip_ec_set_global", "oatk_hip_ec_pairs", "oatk_hip_ec_graph_from_pairs", "oatk_hip_ec_export_kmers", "oatk_hip_ec_import_kmers",
     "oatk_hip_ec_reserve_import", "oatk_hip_consensus", "oatk_hip_consensus_ids", "oatk_hip_ingest", "oatk_hip_ingest_host", "oatk_hip_scan_ingested", "oatk_hip_stat",
-    "oatk_hip_asm_graph", "oatk_hip_asm_pairs", "oatk_hip_asm_graph_from_pairs",
+    "oatk_hip_asm_graph", "oatk_hip_asm_pairs", "oatk_hip_asm_graph_from_pairs", "oatk_hip_overlap_hist",
 ]
 
 
@@ -121,6 +122,7 @@ def load():
     L.oatk_hip_ingest_host.argtypes = [vp, vp, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.oatk_hip_scan_ingested.argtypes = [vp, C.c_uint64, C.c_int, C.c_int]
     L.oatk_hip_stat.argtypes = [vp, C.POINTER(StatRaw)]
+    L.oatk_hip_overlap_hist.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.oatk_hip_asm_graph.argtypes = [vp, C.c_uint32, C.c_double, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.oatk_hip_asm_pairs.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
     L.oatk_hip_asm_graph_from_pairs.argtypes = [vp, vp, C.c_uint64, C.c_uint64, vp, vp, C.c_uint32, C.c_double, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]

@@ -25,7 +25,9 @@ namespace oatk {
 // of a read carries no pair.  Entries are produced in (read, slot) order, which is the order calc_syncmer_overlap meets
 // the pairs of one arc in (it walks the occurrences of the arc's first syncmer, syncasm.c:497-556; the slot of that
 // syncmer is the pair's first or second slot, and two pairs of one arc never share it).
-__global__ void egr_pair_keys_kernel(uint64_t n_reads, const uint64_t *scm_off, const uint64_t *k_mer, const uint32_t *m_pos, uint64_t *keys, uint32_t *dist)
+// skip_corrected: pairs with an error-corrected member (low bit of k_mer) become fillers, as calc_syncmer_overlap ignores them (syncasm.c:499, :511)
+__global__ void egr_pair_keys_kernel(uint64_t n_reads, const uint64_t *scm_off, const uint64_t *k_mer, const uint32_t *m_pos, uint64_t *keys, uint32_t *dist,
+                                     int skip_corrected = 0)
 {
     uint64_t r = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
@@ -37,7 +39,7 @@ __global__ void egr_pair_keys_kernel(uint64_t n_reads, const uint64_t *scm_off, 
     for (uint64_t j = 1; j < n; ++j) {
         const uint64_t v1 = (k_mer[o + j] >> 1) << 1 | (m_pos[o + j] & 1u);
         const uint32_t p1 = m_pos[o + j] >> 1;
-        keys[o + j] = v0 <= v1? v0 << 32 | v1 : (v1 ^ 1ULL) << 32 | (v0 ^ 1ULL);
+        keys[o + j] = skip_corrected && ((k_mer[o + j - 1] | k_mer[o + j]) & 1ULL)? EGR_INVALID : (v0 <= v1? v0 << 32 | v1 : (v1 ^ 1ULL) << 32 | (v0 ^ 1ULL));
         dist[o + j] = p1 - p0;
         v0 = v1, p0 = p1;
     }

@@ -1,0 +1,68 @@
+// oatk_amd/csrc/ovlhist.hpp -- what calc_syncmer_overlap (syncasm.c:477-582) tabulates, for every pair of adjacent syncmers at once.
+//
+// The reference answers "how far apart are syncmers m1 and m2 on the reads" by walking the occurrence list of m1, finding m2 next to
+// it on the same read and counting the distances in a khashl<int,int>; scg_consensus asks this for every pair of neighbours inside
+// every unitig and for every arc, four times per assembly.  All answers are already sitting in the sorted (key, distance) list the EC
+// graph is built from (ecgraph.hpp): a run of equal keys is the multiset of one pair.  This file reduces each run to the distinct
+// distances IN THE ORDER OF THEIR FIRST APPEARANCE with their counts -- which is all a khashl table's final layout depends on -- plus
+// one bit: whether the last add_ovl_count call of the run was a repeat (khashl grows at the call AFTER the insert that filled the
+// table, khashl.h:199, so a trailing repeat can still change the bucket order).  Pairs with an error-corrected member do not take part
+// (syncasm.c:499, :511).
+#pragma once
+#include "common.hpp"
+#include "ecgraph.hpp"
+
+namespace oatk {
+
+#define OVH_MAX 64        // distinct distances per pair the kernel keeps (the EC graph's own limit is 48)
+
+// one wave per run of equal keys.  n_out == nullptr: write the entries at out_off[run]; otherwise only count them.
+__global__ __launch_bounds__(64) void ovh_kernel(uint64_t n_runs, const uint64_t *ukeys, const uint32_t *counts, const uint64_t *run_off,
+                                                 const uint32_t *sdist, uint32_t *n_out, const uint64_t *out_off, int32_t *o_dist, uint32_t *o_cnt,
+                                                 uint8_t *o_tail, uint32_t *flags)
+{
+    __shared__ int32_t hk[OVH_MAX];
+    __shared__ uint32_t hc[OVH_MAX];
+    const int lane = threadIdx.x;
+    const uint64_t run = blockIdx.x;
+    if (run >= n_runs) return;
+    if (ukeys[run] == EGR_INVALID) { if (n_out && lane == 0) n_out[run] = 0; return; }
+    const uint32_t cc = counts[run];
+    const uint64_t oo = run_off[run];
+    uint32_t nd = 0;
+    bool overflow = false;
+    for (uint32_t t0 = 0; t0 < cc && !overflow; t0 += 64) {
+        const bool in = t0 + lane < cc;
+        const int32_t d = in? (int32_t) sdist[oo + t0 + lane] : 0;
+        uint64_t rest = __ballot(in);
+        for (uint32_t j = 0; j < nd && rest; ++j) {                      // distances seen in earlier chunks
+            const uint64_t eq = __ballot(in && d == hk[j]) & rest;
+            if (eq && lane == 0) hc[j] += (uint32_t) __builtin_popcountll(eq);
+            rest &= ~eq;
+        }
+        while (rest) {                                                   // new ones, in the order of their first appearance
+            const int f = __builtin_ctzll(rest);
+            const int32_t x = __builtin_amdgcn_readfirstlane(__shfl(d, f));
+            const uint64_t eq = __ballot(in && d == x) & rest;
+            rest &= ~eq;
+            if (nd == OVH_MAX) { overflow = true; break; }
+            if (lane == 0) hk[nd] = x, hc[nd] = (uint32_t) __builtin_popcountll(eq);
+            ++nd;
+        }
+        __syncthreads();                                                 // lane 0's LDS writes before the next chunk's reads
+    }
+    __syncthreads();
+    if (overflow) { if (lane == 0) flags[1] = 1u; nd = 0; }
+    if (n_out) { if (lane == 0) n_out[run] = nd; return; }
+    const uint64_t w0 = out_off[run];
+    if ((uint32_t) lane < nd) o_dist[w0 + lane] = hk[lane], o_cnt[w0 + lane] = hc[lane];
+    if (lane == 0 && nd) {
+        // the last call was a repeat unless the last distance of the run occurs exactly once (then the call inserted it)
+        const int32_t last = (int32_t) sdist[oo + cc - 1];
+        uint32_t c = 0;
+        for (uint32_t j = 0; j < nd; ++j) if (hk[j] == last) c = hc[j];
+        o_tail[run] = c > 1;
+    }
+}
+
+} // namespace oatk

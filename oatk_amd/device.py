@@ -22,6 +22,7 @@ _DTYPES = {
     "CONS_SEL": np.uint32, "CONS_SLOT": np.uint32, "CONS_RL": np.uint32, "CONS_MSEQ": np.uint32, "CONS_FIRST": np.uint64, "CONS_TOT": np.uint64,
     "EG_IDX_P": np.uint64, "EG_IDX_N": np.uint32, "EG_ARC_V": np.uint64, "EG_ARC_W": np.uint64, "EG_ARC_LS": np.uint32,
     "EG_ARC_COV": np.uint32, "EG_ARC_COMP": np.uint8,
+    "OVL_KEY": np.uint64, "OVL_OFF": np.uint64, "OVL_DIST": np.int32, "OVL_CNT": np.uint32, "OVL_TAIL": np.uint8,
     "AG_SCM_DEL": np.uint8, "AG_VTX_SCM": np.uint32, "AG_VTX_COV": np.uint32, "AG_IDX_P": np.uint64, "AG_IDX_N": np.uint32,
     "AG_ARC_V": np.uint64, "AG_ARC_W": np.uint64, "AG_ARC_COV": np.uint32, "AG_ARC_COMP": np.uint8, "AG_ARC_LINK": np.uint64,
 }
@@ -172,6 +173,12 @@ class HipSyncasm:
         """rounded mean run lengths of every live syncmer with coverage >= min_cov (scg_syncmer_consensus, syncasm.c:949-1001);
         fetch CONS_SEL / CONS_SLOT / CONS_RL / CONS_MSEQ / CONS_FIRST"""
         self._check(self.L.oatk_hip_consensus(self.h, min_cov), "oatk_hip_consensus")
+
+    def overlap_hist(self):
+        """pair-distance tables of every adjacent syncmer pair (calc_syncmer_overlap's tabulation, syncasm.c:477-556); returns (n_pairs, n_entries)"""
+        np_, ne = C.c_uint64(), C.c_uint64()
+        self._check(self.L.oatk_hip_overlap_hist(self.h, C.byref(np_), C.byref(ne)), "oatk_hip_overlap_hist")
+        return int(np_.value), int(ne.value)
 
     def consensus_ids(self, d_ids, n):
         """the same for a device array of ids; with sharded reads the results (CONS_TOT, CONS_MSEQ) are this shard's share"""

@@ -330,6 +330,31 @@ done:
     return ret;
 }
 
+/* ---- unitigs and their consensus (syncasm.c:1048-1061, :1004-1046) ---- */
+void refx_process_unitigs(scg_t *g) { process_mergeable_unitigs(g); }
+/* per vertex of the (unitig) graph: number of syncmers, deleted flag; `a` receives the oriented syncmer lists back to back (may be NULL) */
+uint64_t refx_utg_lists(scg_t *g, uint64_t *n, uint8_t *del, uint64_t *a)
+{
+    asmg_t *u = g->utg_asmg;
+    uint64_t i, tot = 0;
+    for (i = 0; i < u->n_vtx; ++i) {
+        if (n) n[i] = u->vtx[i].n;
+        if (del) del[i] = u->vtx[i].del;
+        if (a) memcpy(a + tot, u->vtx[i].a, sizeof(uint64_t) * u->vtx[i].n);
+        tot += u->vtx[i].n;
+    }
+    return tot;
+}
+/* scg_unitig_consensus of the syncmer list v[0..n): returns the length, the string in out (up to cap bytes) */
+int64_t refx_unitig_consensus(sr_db_t *db, scg_t *g, uint64_t *v, uint64_t n, int hoco_seq, char *out, int64_t cap)
+{
+    kstring_t c = {0, 0, 0};
+    int64_t l = scg_unitig_consensus(db, v, n, scg_a_scm(g), &c, hoco_seq);
+    if (out && l > 0) memcpy(out, c.s, l < cap? l : cap);
+    free(c.s);
+    return l;
+}
+
 /* ---- base-space consensus of one syncmer (syncasm.c:888-1003) ---- */
 int64_t refx_syncmer_consensus(sr_db_t *db, syncmer_db_t *s, uint64_t id, int rev, int64_t beg, int hoco_seq, char *out, int64_t cap)
 {
