@@ -179,6 +179,24 @@ int oatk_calc_syncmer_overlap(const oatk_overlap_t *o, uint64_t v, uint64_t w, o
 int64_t oatk_scg_unitig_consensus(const oatk_consensus_t *cs, const oatk_overlap_t *o, const oatk_sr_db_t *sr_db, const uint64_t *v, uint64_t n,
                                   oatk_kstring_t *c_seq, int hoco_seq);
 
+/* scg_read_alignment (alignment.c:596-691) on the device (include/oatk_hip_align.h): `g` is the reference's scg_t with its unitig graph
+ * and syncmer -> unitig index as they are at the time of the call, `ra_v` the previous alignments (read when for_unzip, replaced by the
+ * new ones).  The reads aligned are the chains resident in ctx, which must be the whole of sr_db.  Layout-compatible mirrors of syncasm.h:51-80.
+ * *n_skipped reads (indices in *skipped, malloc'ed, no particular order) exceeded the device routine's per-read limits (160 unitig hits,
+ * 128 fragments, 6 equally good predecessors, 48 fragments in a chain) and got no alignment: the caller runs the original routine for
+ * them (none on HiFi data so far). */
+typedef struct {
+    oatk_syncmer_db_t *scm_db;
+    oatk_asmg_t *utg_asmg;
+    void *scm_u;           /* uint128_t *: scm_id[49] | scm_rev[1] | utg_id[42] | utg_pos[36] */
+    void **idx_u;          /* uint128_t **: [n_scm + 1] into scm_u */
+} oatk_scg_t;
+typedef struct { uint64_t uid, u_beg, u_end; uint32_t s_beg, s_end; } oatk_ra_frg_t;
+typedef struct { uint64_t sid; uint32_t n; oatk_ra_frg_t *a; double s; } oatk_scg_ra_t;
+typedef struct { size_t n, m; oatk_scg_ra_t *a; } oatk_scg_ra_v;
+int oatk_scg_read_alignment(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, oatk_scg_ra_v *ra_v, oatk_scg_t *g, int for_unzip, uint64_t *n_skipped,
+                            uint32_t **skipped);
+
 /* same destructors as the reference (syncmer.c:1047-1110) for objects that are not handed to it */
 void oatk_sr_db_clean(oatk_sr_db_t *sr_db);
 void oatk_syncmer_db_destroy(oatk_syncmer_db_t *scm_db);

@@ -88,6 +88,7 @@ struct oatk_hip_ctx {
     struct StatState *stat = nullptr;   // scan statistics buffers (api_stat.inc)
     struct AgState *ag = nullptr;       // assembly graph buffers (api_graph.inc)
     struct OvlState *ovl = nullptr;     // pair-distance tables (api_ovl.inc)
+    struct RaState *ra = nullptr;       // read alignment buffers (api_align.inc)
 };
 
 #define CK(call)                                                                                   \
@@ -132,6 +133,7 @@ static void t_collect(oatk_hip_ctx *ctx, int first, int last)
 #include "api_graph.inc"
 #include "api_cons.inc"
 #include "api_ovl.inc"
+#include "api_align.inc"
 #include "api_ingest.inc"
 #include "api_stat.inc"
 
@@ -185,6 +187,7 @@ void oatk_hip_destroy(oatk_hip_ctx *ctx)
     stat_state_free(ctx);
     ag_state_free(ctx);
     ovl_state_free(ctx);
+    ra_state_free(ctx);
     for (int i = 0; i <= OATK_T_COUNT_; ++i) {
         (void) hipEventDestroy(ctx->ev[i][0]);
         (void) hipEventDestroy(ctx->ev[i][1]);
@@ -305,6 +308,7 @@ int oatk_hip_scan(oatk_hip_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off
     if (ctx->cons) ctx->cons->done = false;
     if (ctx->ag) ctx->ag->done = false;
     if (ctx->ovl) ctx->ovl->done = false;
+    if (ctx->ra) ctx->ra->done = false;
     ctx->retries = 0, ctx->collisions = 0;
     ctx->n_occ = ctx->tot_nn = ctx->tot_lrl = ctx->n_scm_total = 0;
     if (n_reads == 0) { ctx->scanned = true; return OATK_OK; }
@@ -582,6 +586,7 @@ int oatk_hip_buffer(oatk_hip_ctx *ctx, int which, const void **d_ptr, uint64_t *
                     if (which >= OATK_BUF_CONS_SEL && which <= OATK_BUF_CONS_TOT) return cons_buffer(ctx, which, d_ptr, bytes);
                     if (which >= OATK_BUF_AG_SCM_DEL && which <= OATK_BUF_AG_ARC_LINK) return ag_buffer(ctx, which, d_ptr, bytes);
                     if (which >= OATK_BUF_OVL_KEY && which <= OATK_BUF_OVL_TAIL) return ovl_buffer(ctx, which, d_ptr, bytes);
+                    if (which >= OATK_BUF_RA_ALN_SID && which <= OATK_BUF_RA_SKIPPED) return ra_buffer(ctx, which, d_ptr, bytes);
                     if (which >= OATK_BUF_INGEST_SEQ && which <= OATK_BUF_INGEST_HDR) return ing_buffer(ctx, which, d_ptr, bytes);
                     return ec_buffer(ctx, which, d_ptr, bytes);     // error-correction results (api_ec.inc)
             }

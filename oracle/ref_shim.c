@@ -243,6 +243,11 @@ int refx_syncasm(char **files, int n_files, int k, int s, int min_k_cov, double 
  * public reference functions, in the order run_syncasm.c does. */
 static int syncasm_tail(sr_db_t *sr_db, syncmer_db_t *scm_db, asmg_t *given_asmg, int k, int bubble_size, int tip_size, int min_k_cov,
         double min_a_cov_f, double weak_cross, int do_ec, int do_unzip, int n_threads, const char *out);
+/* who aligns the reads in the tail: the reference's scg_read_alignment, or a routine of the same signature supplied by a test */
+typedef void (*refx_aligner_t)(sr_db_t *, scg_ra_v *, scg_t *, int, int);
+static refx_aligner_t tail_aligner = 0;
+void refx_set_aligner(refx_aligner_t f) { tail_aligner = f; }
+#define TAIL_ALIGN(db, v, g, t, u) do { if (tail_aligner) tail_aligner(db, v, g, t, u); else scg_read_alignment(db, v, g, t, u); } while (0)
 int refx_syncasm_tail(sr_db_t *sr_db, syncmer_db_t *scm_db, int k, int bubble_size, int tip_size, int min_k_cov,
         double min_a_cov_f, double weak_cross, int do_ec, int do_unzip, int n_threads, const char *out)
 {
@@ -295,15 +300,15 @@ static int syncasm_tail(sr_db_t *sr_db, syncmer_db_t *scm_db, asmg_t *given_asmg
         uint32_t max_n_scm = (uint32_t) ceil(30000.0 / k);
         while (updated != 0 && round < do_unzip) {
             ++round;
-            scg_read_alignment(sr_db, ra_db, scg, n_threads, 1);
+            TAIL_ALIGN(sr_db, ra_db, scg, n_threads, 1);
             scg_update_utg_cov(scg);
             updated = scg_multiplex(scg, ra_db, max_n_scm, 10, .3);
         }
-        scg_read_alignment(sr_db, ra_db, scg, n_threads, 1);
+        TAIL_ALIGN(sr_db, ra_db, scg, n_threads, 1);
         scg_ra_arc_coverage(scg, sr_db, ra_db, 0, 0);
         asmg_remove_weak_crosslink(scg->utg_asmg, weak_cross, 10, 0, 0);
         scg_demultiplex(scg);
-        scg_read_alignment(sr_db, ra_db, scg, n_threads, 0);
+        TAIL_ALIGN(sr_db, ra_db, scg, n_threads, 0);
         scg_ra_utg_coverage(scg, sr_db, ra_db, 0);
         scg_ra_arc_coverage(scg, sr_db, ra_db, 1, 0);
         scg_consensus(sr_db, scg, 0, 0, 0);
@@ -318,7 +323,7 @@ static int syncasm_tail(sr_db_t *sr_db, syncmer_db_t *scm_db, asmg_t *given_asmg
         }
         process_mergeable_unitigs(scg);
     }
-    scg_read_alignment(sr_db, ra_db, scg, n_threads, 0);           /* :295-303 */
+    TAIL_ALIGN(sr_db, ra_db, scg, n_threads, 0);           /* :295-303 */
     scg_ra_utg_coverage(scg, sr_db, ra_db, 0);
     scg_ra_arc_coverage(scg, sr_db, ra_db, 1, 0);
     snprintf(path, sizeof(path), "%s.utg.final.gfa", out);
@@ -354,6 +359,29 @@ int64_t refx_unitig_consensus(sr_db_t *db, scg_t *g, uint64_t *v, uint64_t n, in
     free(c.s);
     return l;
 }
+
+/* ---- read -> unitig alignment (alignment.c:596-691) ---- */
+scg_ra_v *refx_ra_new(void) { return (scg_ra_v *) calloc(1, sizeof(scg_ra_v)); }
+void refx_ra_destroy(scg_ra_v *v) { scg_ra_v_destroy(v); }
+void refx_read_alignment(sr_db_t *db, scg_ra_v *v, scg_t *g, int n_threads, int for_unzip) { scg_read_alignment(db, v, g, n_threads, for_unzip); }
+void refx_ra_dims(scg_ra_v *v, uint64_t *n_aln, uint64_t *n_frg)
+{
+    uint64_t i, f = 0;
+    for (i = 0; i < v->n; ++i) f += v->a[i].n;
+    *n_aln = v->n, *n_frg = f;
+}
+void refx_ra_flatten(scg_ra_v *v, uint64_t *sid, uint32_t *n, double *s, uint64_t *uid, uint64_t *u_beg, uint64_t *u_end, uint32_t *s_beg, uint32_t *s_end)
+{
+    uint64_t i, j, f = 0;
+    for (i = 0; i < v->n; ++i) {
+        sid[i] = v->a[i].sid, n[i] = v->a[i].n, s[i] = v->a[i].s;
+        for (j = 0; j < v->a[i].n; ++j, ++f)
+            uid[f] = v->a[i].a[j].uid, u_beg[f] = v->a[i].a[j].u_beg, u_end[f] = v->a[i].a[j].u_end, s_beg[f] = v->a[i].a[j].s_beg, s_end[f] = v->a[i].a[j].s_end;
+    }
+}
+/* graph surgery between alignment rounds, as run_syncasm.c:209-232 does it */
+void refx_update_utg_cov(scg_t *g) { scg_update_utg_cov(g); }
+int refx_multiplex(scg_t *g, scg_ra_v *v, uint32_t max_n_scm, double min_n_r, double min_d_f) { return scg_multiplex(g, v, max_n_scm, min_n_r, min_d_f); }
 
 /* ---- base-space consensus of one syncmer (syncasm.c:888-1003) ---- */
 int64_t refx_syncmer_consensus(sr_db_t *db, syncmer_db_t *s, uint64_t id, int rev, int64_t beg, int hoco_seq, char *out, int64_t cap)

@@ -1,0 +1,98 @@
+"""GPU parity of the read -> unitig alignment (oatk_hip_read_alignment through liboatk_host.so's oatk_scg_read_alignment) against the
+COMPILED REFERENCE's scg_read_alignment (alignment.c:596-691) on the same graph: after unitigging, and through rounds of multiplexing
+with the for_unzip filter (run_syncasm.c:209-232).  Bit-exact: which reads align, every alignment's fragments, order, scores."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import adversarial as A
+import ref_lib as R
+import test_gpu_ec as T
+from test_gpu_dropin import device_dbs, host_lib
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not R.available(), reason="oracle/_ref not built")]
+
+
+def setup_libs():
+    L, H = R.lib(), host_lib()
+    vp = C.c_void_p
+    H.oatk_read_error_correction.argtypes = [vp, vp, vp, vp, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, vp]
+    H.oatk_scg_read_alignment.argtypes = [vp, vp, vp, vp, C.c_int, C.POINTER(C.c_uint64), C.POINTER(vp)]
+    L.refx_ra_new.restype = vp
+    L.refx_ra_destroy.argtypes = [vp]
+    L.refx_read_alignment.argtypes = [vp, vp, vp, C.c_int, C.c_int]
+    L.refx_ra_dims.argtypes = [vp, vp, vp]
+    L.refx_ra_flatten.argtypes = [vp] * 9
+    L.refx_process_unitigs.argtypes = [vp]
+    L.refx_update_utg_cov.argtypes = [vp]
+    L.refx_multiplex.argtypes = [vp, vp, C.c_uint32, C.c_double, C.c_double]
+    return L, H
+
+
+def flatten(L, v):
+    na, nf = C.c_uint64(), C.c_uint64()
+    L.refx_ra_dims(v, C.byref(na), C.byref(nf))
+    na, nf = na.value, nf.value
+    out = {"sid": np.zeros(na, np.uint64), "n": np.zeros(na, np.uint32), "s": np.zeros(na, np.float64), "uid": np.zeros(nf, np.uint64),
+           "u_beg": np.zeros(nf, np.uint64), "u_end": np.zeros(nf, np.uint64), "s_beg": np.zeros(nf, np.uint32), "s_end": np.zeros(nf, np.uint32)}
+    L.refx_ra_flatten(v, *[out[k].ctypes.data for k in ("sid", "n", "s", "uid", "u_beg", "u_end", "s_beg", "s_end")])
+    return out
+
+
+def both(L, H, hip, db, g, v_ref, v_dev, for_unzip):
+    L.refx_read_alignment(db, v_ref, g, 3, for_unzip)
+    nsk = C.c_uint64(0)
+    rc = H.oatk_scg_read_alignment(hip.h, db, v_dev, g, for_unzip, C.byref(nsk), None)
+    assert rc == 0, hip.L.oatk_hip_last_error(hip.h)
+    assert nsk.value == 0
+    want, got = flatten(L, v_ref), flatten(L, v_dev)
+    for k in want:
+        assert len(got[k]) == len(want[k]), k
+        assert np.array_equal(got[k], want[k]), k
+    return want
+
+
+CASES = [
+    (1001, 31, 8, lambda: A.hifi_like(260, 50000, 9000, seed=1010, err=0.0008)),
+    (301, 21, 6, lambda: A.hifi_like(300, 30000, 4000, seed=307, err=0.002)),
+    (101, 11, 4, lambda: T.diploid_reads(101, 6000, 150, 500, 1200, 0.006)),
+    (301, 21, 5, lambda: T.sample_reads(T.genome_with_repeats(7, 25000, unit=1500, copies=4), 320, 4000, 0.003, 8)),
+    (101, 11, 5, lambda: T.sample_reads(T.genome_with_repeats(9, 9000, unit=600, copies=3), 300, 1500, 0.004, 10)),
+    (1001, 31, 6, lambda: T.sample_reads(T.genome_with_repeats(5, 50000), 260, 9000, 0.001, 6)),
+]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_read_alignment_matches_reference(hip, case):
+    K, S, c, mk = CASES[case]
+    L, H = setup_libs()
+    db, scm = device_dbs(hip, mk(), K, S)
+    st = np.zeros(12, np.uint64)
+    assert H.oatk_read_error_correction(hip.h, db, scm, None, 0.02, c, 10 * c, c, 0.35, st.ctypes.data) == 0
+    g = L.refx_make_graph(db, scm, c, 0.35)                 # run_syncasm.c:138
+    assert g
+    v_ref, v_dev = L.refx_ra_new(), L.refx_ra_new()
+    w = both(L, H, hip, db, g, v_ref, v_dev, 0)             # one syncmer per vertex: every read maps along its own chain
+    assert len(w["sid"]) > 10
+    L.refx_process_unitigs(g)                               # :160
+    w = both(L, H, hip, db, g, v_ref, v_dev, 0)
+    assert len(w["sid"]) > 10 and w["n"].max() >= 1
+    # the unzip rounds: align with the previous round's filter, update coverage, multiplex (run_syncasm.c:219-232)
+    max_n_scm = int(math.ceil(30000.0 / K))
+    rounds = 0
+    for _ in range(3):
+        w = both(L, H, hip, db, g, v_ref, v_dev, 1)
+        L.refx_update_utg_cov(g)
+        rounds += 1
+        if L.refx_multiplex(g, v_ref, max_n_scm, 10.0, 0.3) == 0:
+            break
+    both(L, H, hip, db, g, v_ref, v_dev, 1)
+    both(L, H, hip, db, g, v_ref, v_dev, 0)
+    assert rounds >= 1
+    L.refx_ra_destroy(v_ref)
+    L.refx_ra_destroy(v_dev)                                # the reference's destructor frees what liboatk_host allocated
+    L.refx_scg_destroy(g)
+    L.refx_scmdb_destroy(scm)
+    L.refx_srdb_destroy(db)

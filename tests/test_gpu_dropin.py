@@ -133,6 +133,58 @@ def test_gfa_identical_with_the_assembly_graph_from_the_device(hip, tmp_path, K,
     L.refx_srdb_destroy(db)
 
 
+@pytest.mark.parametrize("K,S,cov,err,n_reads,scale", [(1001, 31, 8, 0.0008, 260, False), (301, 21, 6, 0.001, 260, False), (1001, 31, 30, 0.0, 20000, True)])
+def test_gfa_identical_with_everything_but_the_graph_surgery_on_the_device(hip, tmp_path, K, S, cov, err, n_reads, scale):
+    """sr_read, collect_syncmer_from_reads, the error-correction round, make_syncmer_graph AND every scg_read_alignment call of the unzip
+    rounds and the final coverage pass (run_syncasm.c:219-303) on the device; the reference does the unitigging, cleaning, multiplexing and
+    the GFA output in between, and both GFA files still equal a pure reference run byte for byte"""
+    L, H = R.lib(), host_lib()
+    vp = C.c_void_p
+    L.refx_syncasm_tail_graph.restype = C.c_int
+    L.refx_syncasm_tail_graph.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_char_p]
+    H.oatk_read_error_correction.argtypes = [vp, vp, vp, vp, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, vp]
+    H.oatk_make_syncmer_asmg.restype = vp
+    H.oatk_make_syncmer_asmg.argtypes = [vp, vp, C.c_uint32, C.c_double, C.POINTER(C.c_int)]
+    H.oatk_scg_read_alignment.argtypes = [vp, vp, vp, vp, C.c_int, C.POINTER(C.c_uint64), C.POINTER(vp)]
+    if scale:
+        from oatk_amd.synth import ReadSet
+        reads = ReadSet(1_000_000, n_reads, 15000).as_list(0, n_reads)
+    else:
+        reads = A.hifi_like(n_reads, 50000, 9000 if K > 500 else 5000, seed=K + 21, err=err)
+    fa = str(tmp_path / "reads.fa")
+    R.write_fasta(reads, fa)
+    out_ref, out_dev = str(tmp_path / "ref"), str(tmp_path / "dev")
+    assert L.refx_syncasm(R._files_arg([fa]), 1, K, S, cov, 0.35, 1, 3, 8, out_ref.encode()) == 0
+    db, scm = device_dbs(hip, reads, K, S)
+    stats = np.zeros(12, np.uint64)
+    assert H.oatk_read_error_correction(hip.h, db, scm, None, 0.02, cov, 10 * cov, cov, 0.35, stats.ctypes.data) == 0
+    rc = C.c_int(0)
+    asmg = H.oatk_make_syncmer_asmg(hip.h, scm, cov, 0.35, C.byref(rc))
+    assert rc.value == 0 and asmg
+    calls, problems = [], []
+
+    def aligner(db_, v, g, n_threads, for_unzip):          # same signature as scg_read_alignment (alignment.c:596)
+        nsk = C.c_uint64(0)
+        r = H.oatk_scg_read_alignment(hip.h, db_, v, g, for_unzip, C.byref(nsk), None)
+        calls.append(for_unzip)
+        if r != 0 or nsk.value:
+            problems.append((r, nsk.value))
+
+    cb = C.CFUNCTYPE(None, vp, vp, vp, C.c_int, C.c_int)(aligner)
+    L.refx_set_aligner.argtypes = [vp]
+    L.refx_set_aligner(cb)
+    try:
+        assert L.refx_syncasm_tail_graph(db, scm, asmg, K, 100000, 10000, cov, 0.35, 0.3, 3, 8, out_dev.encode()) == 0
+    finally:
+        L.refx_set_aligner(None)
+    assert not problems and len(calls) >= 4 and 1 in calls and 0 in calls
+    for suffix in (".utg.gfa", ".utg.final.gfa"):
+        assert os.path.getsize(out_ref + suffix) > 100
+        assert filecmp.cmp(out_ref + suffix, out_dev + suffix, shallow=False), suffix
+    L.refx_scmdb_destroy(scm)
+    L.refx_srdb_destroy(db)
+
+
 def test_structs_equal_reference_structs(hip):
     """member-by-member: reference flatteners applied to OUR sr_db / scm_db vs the reference's own"""
     K, S = 1001, 31
