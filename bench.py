@@ -240,6 +240,23 @@ def main():
                 fence()
                 syncerr["asm_graph"] = {"ms": round((time.perf_counter() - t1) / max(args.steps, 1) * 1e3, 3), "n_vtx": nv, "n_arc": na,
                                         "workload": "make_syncmer_graph(-c %d, a 0.35) + asmg_finalize on the corrected chains" % c}
+                # every corrected read against that graph, one syncmer per vertex (scg_read_alignment before the unitigging)
+                ag = hip.fetch_asm_graph()
+                n_scm_all = len(ag["scm_del"])
+                su_off = np.zeros(n_scm_all + 1, np.uint64)
+                su_off[1:] = np.cumsum(ag["scm_del"] == 0)
+                graph = {"n_scm": n_scm_all, "su_off": su_off, "su_uid": np.arange(nv, dtype=np.uint64) << np.uint64(1), "su_pos": np.zeros(nv, np.uint32),
+                         "utg_n": np.ones(nv, np.uint32), "idx_p": ag["idx_p"], "idx_n": ag["idx_n"].astype(np.uint64), "arc_w": ag["arc_w"],
+                         "arc_ln": np.zeros(na, np.uint64), "arc_del": np.zeros(na, np.uint8)}
+                hip.read_alignment(graph)
+                fence()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    n_aln, n_frg, ast = hip.read_alignment(graph)
+                fence()
+                syncerr["read_alignment"] = {"ms": round((time.perf_counter() - t1) / max(args.steps, 1) * 1e3, 3), "alignments": n_aln, "fragments": n_frg,
+                                             "reads_aligned": int(ast[0]), "reads_over_limits": int(ast[2]),
+                                             "workload": "scg_read_alignment of the %d corrected reads against the %d-vertex graph (graph upload included)" % (per_gpu, nv)}
         except Exception as ex:             # noqa: BLE001
             syncerr = {"error": "%s: %s" % (type(ex).__name__, ex)}
         hip.set_timing(True)

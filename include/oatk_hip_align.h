@@ -41,6 +41,10 @@ typedef struct {
  *   RA_SKIPPED  u32[stats3[2]]  read indices */
 int oatk_hip_read_alignment(oatk_hip_ctx *ctx, const oatk_ra_graph_t *g, const int64_t *old_ra, uint64_t *n_aln, uint64_t *n_frg, uint64_t *stats3);
 
+/* Test hook: 1 = count, scan, run the routine a second time writing in place (the path taken when the output pool of the normal,
+ * single-run path is too small), 0 = default.  Results never depend on it. */
+int oatk_hip_debug_align_two_pass(oatk_hip_ctx *ctx, int on);
+
 enum {
     OATK_BUF_RA_ALN_SID = 200, OATK_BUF_RA_ALN_OFF, OATK_BUF_RA_ALN_S, OATK_BUF_RA_FRG_UID, OATK_BUF_RA_FRG_UBEG, OATK_BUF_RA_FRG_UEND,
     OATK_BUF_RA_FRG_SBEG, OATK_BUF_RA_FRG_SEND, OATK_BUF_RA_SKIPPED

@@ -26,6 +26,8 @@ BUF.update({name: 160 + i for i, name in enumerate(["INGEST_SEQ", "INGEST_OFF", 
 FMT_AUTO, FMT_FASTA, FMT_FASTQ = 0, 1, 2
 # include/oatk_hip_cons.h
 BUF.update({name: 140 + i for i, name in enumerate(["CONS_SEL", "CONS_SLOT", "CONS_RL", "CONS_MSEQ", "CONS_FIRST", "CONS_TOT"])})
+# include/oatk_hip_align.h
+BUF.update({name: 200 + i for i, name in enumerate(["RA_ALN_SID", "RA_ALN_OFF", "RA_ALN_S", "RA_FRG_UID", "RA_FRG_UBEG", "RA_FRG_UEND", "RA_FRG_SBEG", "RA_FRG_SEND", "RA_SKIPPED"])})
 BUF.update({name: 150 + i for i, name in enumerate(["OVL_KEY", "OVL_OFF", "OVL_DIST", "OVL_CNT", "OVL_TAIL"])})
 BUF.update({name: 120 + i for i, name in enumerate([
     "EG_IDX_P", "EG_IDX_N", "EG_ARC_V", "EG_ARC_W", "EG_ARC_LS", "EG_ARC_COV", "EG_ARC_COMP"])})
@@ -42,7 +44,7 @@ EXPORTS = [
     "oatk_hip_ec_graph", "oatk_hip_ec", "oatk_hip_ec_stats", "oatk_hip_debug_ec_tiers", "oatk_hip_ec_mark", "oatk_hip_ec_correct",
     "oatk_hip_ec_set_global", "oatk_hip_ec_pairs", "oatk_hip_ec_graph_from_pairs", "oatk_hip_ec_export_kmers", "oatk_hip_ec_import_kmers",
     "oatk_hip_ec_reserve_import", "oatk_hip_consensus", "oatk_hip_consensus_ids", "oatk_hip_ingest", "oatk_hip_ingest_host", "oatk_hip_scan_ingested", "oatk_hip_stat",
-    "oatk_hip_asm_graph", "oatk_hip_asm_pairs", "oatk_hip_asm_graph_from_pairs", "oatk_hip_overlap_hist",
+    "oatk_hip_asm_graph", "oatk_hip_asm_pairs", "oatk_hip_asm_graph_from_pairs", "oatk_hip_overlap_hist", "oatk_hip_read_alignment", "oatk_hip_debug_align_two_pass",
 ]
 
 
@@ -50,6 +52,12 @@ class EcGraph(C.Structure):
     """oatk_ec_graph_t (include/oatk_hip_ec.h): the reference's asmg_t flattened, host pointers"""
     _fields_ = [("n_vtx", C.c_uint64), ("n_arc", C.c_uint64), ("idx_p", C.c_void_p), ("idx_n", C.c_void_p), ("arc_v", C.c_void_p),
                 ("arc_w", C.c_void_p), ("arc_ls", C.c_void_p), ("arc_cov", C.c_void_p), ("arc_del", C.c_void_p)]
+
+
+class RaGraph(C.Structure):
+    """oatk_ra_graph_t (include/oatk_hip_align.h): what scg_read_alignment reads from scg_t, flattened, host pointers"""
+    _fields_ = [("n_scm", C.c_uint64), ("n_utg", C.c_uint64), ("n_arc", C.c_uint64), ("su_off", C.c_void_p), ("su_uid", C.c_void_p), ("su_pos", C.c_void_p),
+                ("utg_n", C.c_void_p), ("idx_p", C.c_void_p), ("idx_n", C.c_void_p), ("arc_w", C.c_void_p), ("arc_ln", C.c_void_p), ("arc_del", C.c_void_p)]
 
 
 class StatRaw(C.Structure):
@@ -122,6 +130,8 @@ def load():
     L.oatk_hip_ingest_host.argtypes = [vp, vp, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.oatk_hip_scan_ingested.argtypes = [vp, C.c_uint64, C.c_int, C.c_int]
     L.oatk_hip_stat.argtypes = [vp, C.POINTER(StatRaw)]
+    L.oatk_hip_debug_align_two_pass.argtypes = [vp, C.c_int]
+    L.oatk_hip_read_alignment.argtypes = [vp, C.POINTER(RaGraph), vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), vp]
     L.oatk_hip_overlap_hist.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.oatk_hip_asm_graph.argtypes = [vp, C.c_uint32, C.c_double, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.oatk_hip_asm_pairs.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]

@@ -8,6 +8,7 @@
 // merge sort here), the chaining loop's early exit, the order predecessors are recorded and walked in.
 #pragma once
 #include "common.hpp"
+#include "scan_hpc.hpp"
 
 namespace oatk {
 
@@ -17,12 +18,25 @@ constexpr int RA_PREV = 6;        // recorded predecessors per fragment
 constexpr int RA_DEPTH = 48;      // fragments per alignment
 constexpr uint64_t RA_NONE = 0xFFFFFFFFFFFFFFFEULL;
 
-struct RaScm { uint64_t uid, next; uint32_t u_pos, s_pos; };
-struct RaFrg {
-    uint64_t uid;
-    uint32_t u_beg, u_end, s_beg, s_end, s_cnt;
-    int32_t score0, score;
-    uint16_t prev_n, prev[RA_PREV];
+// A lane's working arrays, element i of every lane next to each other: lanes that walk their arrays in step touch consecutive words
+// (the routine is bound by memory transactions per lane, not by arithmetic; arrays of structs per lane made every access its own line).
+template <typename T>
+struct RaCol {
+    T *p;                 // already offset by the lane
+    uint64_t stride;      // lanes in the grid
+    __device__ T &operator[](uint32_t i) const { return p[(uint64_t) i * stride]; }
+};
+struct RaHits { RaCol<uint64_t> uid, next; RaCol<uint32_t> u_pos, s_pos; };
+struct RaFrgs {
+    RaCol<uint64_t> uid;
+    RaCol<uint32_t> u_beg, u_end, s_beg, s_end, s_cnt;
+    RaCol<int32_t> score0, score;
+    RaCol<uint16_t> prev_n, prev;         // prev[i * RA_PREV + k]
+    __device__ void copy(uint32_t dst, const RaFrgs &o, uint32_t src) const
+    {
+        uid[dst] = o.uid[src], u_beg[dst] = o.u_beg[src], u_end[dst] = o.u_end[src], s_beg[dst] = o.s_beg[src], s_end[dst] = o.s_end[src];
+        s_cnt[dst] = o.s_cnt[src], score0[dst] = o.score0[src], score[dst] = o.score[src], prev_n[dst] = o.prev_n[src];
+    }
 };
 
 struct RaArgs {
@@ -34,17 +48,44 @@ struct RaArgs {
     const uint64_t *idx_p, *idx_n, *arc_w, *arc_ln;
     const uint8_t *arc_del;
     const int64_t *old_ra;                    // may be null
-    RaScm *scm_slab;                          // [threads * RA_MAXS]
-    RaFrg *frg_slab;                          // [threads * RA_MAXF]
+    uint8_t *slab;                            // working arrays of all lanes, column by column (ra_slab_bytes)
     uint32_t *cnt_aln, *cnt_frg;              // [n_reads] pass 1
     uint8_t *skipped;                         // [n_reads]
     const uint64_t *aln_off, *frg_off;        // [n_reads + 1] pass 2
+    unsigned long long *pool_used;            // [0] alignments, [1] fragments taken from the pool, [2] it ran short
+    uint64_t pool_cap_a, pool_cap_f;
+    uint64_t *pool_a, *pool_f;                // [n_reads] where a read's block starts in the pool
     uint32_t *o_sid;
     uint64_t *o_off;                          // [n_aln + 1]
     double *o_s;
     uint64_t *o_uid;
     uint32_t *o_ubeg, *o_uend, *o_sbeg, *o_send;
 };
+
+// bytes of working arrays per lane: hits, fragments as collected, fragments in sorted order, the sorted order itself
+constexpr uint64_t RA_LANE_BYTES = (uint64_t) RA_MAXS * 24 + 2 * ((uint64_t) RA_MAXF * (8 + 5 * 4 + 2 * 4 + 2 + 2 * RA_PREV)) + (uint64_t) RA_MAXF * 2;
+static inline uint64_t ra_slab_bytes(uint64_t lanes) { return lanes * RA_LANE_BYTES + 256; }
+
+struct RaWork { RaHits S; RaFrgs F, G; RaCol<uint16_t> P; };
+__device__ inline RaWork ra_work(uint8_t *slab, uint64_t tid, uint64_t nthr)
+{
+    RaWork w;
+    uint8_t *q = slab;
+    auto col64 = [&](uint64_t n) { RaCol<uint64_t> c = {(uint64_t *) q + tid, nthr}; q += n * nthr * 8; return c; };
+    auto col32 = [&](uint64_t n) { RaCol<uint32_t> c = {(uint32_t *) q + tid, nthr}; q += n * nthr * 4; return c; };
+    auto coli32 = [&](uint64_t n) { RaCol<int32_t> c = {(int32_t *) q + tid, nthr}; q += n * nthr * 4; return c; };
+    auto col16 = [&](uint64_t n) { RaCol<uint16_t> c = {(uint16_t *) q + tid, nthr}; q += n * nthr * 2; return c; };
+    w.S.uid = col64(RA_MAXS), w.S.next = col64(RA_MAXS);                           // 8-byte columns first: everything stays aligned
+    w.F.uid = col64(RA_MAXF), w.G.uid = col64(RA_MAXF);
+    w.S.u_pos = col32(RA_MAXS), w.S.s_pos = col32(RA_MAXS);
+    for (RaFrgs *f : {&w.F, &w.G}) {
+        f->u_beg = col32(RA_MAXF), f->u_end = col32(RA_MAXF), f->s_beg = col32(RA_MAXF), f->s_end = col32(RA_MAXF), f->s_cnt = col32(RA_MAXF);
+        f->score0 = coli32(RA_MAXF), f->score = coli32(RA_MAXF);
+    }
+    for (RaFrgs *f : {&w.F, &w.G}) f->prev_n = col16(RA_MAXF), f->prev = col16((uint64_t) RA_MAXF * RA_PREV);
+    w.P = col16(RA_MAXF);
+    return w;
+}
 
 // asmg_arc1 (graph.h:193-205): the first arc v -> w that is not deleted
 __device__ inline int64_t ra_arc_ln(const RaArgs &a, uint64_t v, uint64_t w)
@@ -54,182 +95,260 @@ __device__ inline int64_t ra_arc_ln(const RaArgs &a, uint64_t v, uint64_t w)
     return -1;
 }
 
-template <bool WRITE>
+// Depth-first walk over the recorded predecessors from every fragment of maximal score; a chain's fragments come out earliest first.
+// WR: write alignments from slot wa / fragments from slot wf on (offsets stored relative to f_base); otherwise only count.  Returns true
+// when a chain is longer than the stack.
+template <bool WR>
+__device__ inline bool ra_backtrace(const RaArgs &a, uint16_t *st_mem, const RaFrgs &G, uint32_t nf, int64_t max_score, uint64_t n, uint64_t r,
+                                    uint32_t tot_a, uint64_t wa, uint64_t wf, uint64_t f_base, uint32_t &n_a, uint32_t &n_fr)
+{
+    // the walk's stack lives in LDS (st_mem, 2 * RA_DEPTH * 256 entries per workgroup), one column per lane: an array in registers indexed by a per-lane depth turns every access into a
+    // loop over all its elements (measured: the walk took three times as long as everything before it)
+    struct Col { uint16_t *p; __device__ uint16_t &operator[](int i) const { return p[i * 256]; } };
+    const Col st_node = {st_mem + threadIdx.x}, st_child = {st_mem + RA_DEPTH * 256 + threadIdx.x};
+    n_a = 0, n_fr = 0;
+    for (uint32_t j = 0; j < nf; ++j) {
+        if (G.score[j] < max_score) continue;
+        int d = 0;
+        st_node[0] = (uint16_t) j, st_child[0] = 0;
+        while (d >= 0) {
+            const uint32_t f = st_node[d];
+            const uint32_t pn = G.prev_n[f];
+            if (pn == 0) {                                                         // a chain is complete: its fragments are st_node[d .. 0]
+                uint64_t s = 0;
+                for (int t = d; t >= 0; --t) s += G.s_cnt[st_node[t]];
+                if (!((double) s / (double) n < 0.9)) {                            // min_a_frac (:161, :547)
+                    if (WR) {
+                        a.o_sid[wa] = (uint32_t) r, a.o_off[wa] = wf - f_base, a.o_s[wa] = 1.0 / (double) tot_a + (double) max_score;
+                        for (int t = d; t >= 0; --t, ++wf) {
+                            const uint32_t q = st_node[t];
+                            a.o_uid[wf] = G.uid[q], a.o_ubeg[wf] = G.u_beg[q], a.o_uend[wf] = G.u_end[q], a.o_sbeg[wf] = G.s_beg[q], a.o_send[wf] = G.s_end[q];
+                        }
+                        ++wa;
+                    }
+                    ++n_a, n_fr += (uint32_t) d + 1;
+                }
+                --d;
+            } else if (st_child[d] < pn) {
+                if (d + 1 == RA_DEPTH) return true;
+                const uint16_t c = G.prev[f * RA_PREV + st_child[d]++];
+                ++d;
+                st_node[d] = c, st_child[d] = 0;
+            } else --d;
+        }
+    }
+    return false;
+}
+
+// Everything of scg_ra_analysis_thread up to the chained fragments for read r.  Returns 0: nothing to report, 1: the fragments G[0 .. nf) in
+// sorted order with their best scores and predecessors are ready and max_score passes the read's threshold, 2: the read is over the limits.
+template <int MODE>
+__device__ inline int ra_prepare(const RaArgs &a, uint64_t r, const RaWork &w, uint32_t &nf, int64_t &max_score, uint64_t &n)
+{
+    const RaHits &S = w.S;
+    const RaFrgs &F = w.F, &G = w.G;
+    const RaCol<uint16_t> &P = w.P;
+    const int64_t old = a.old_ra? a.old_ra[r] : 1;
+    if ((old & 1) == 0) return 0;                                              // alignment.c:225
+    const uint64_t co = a.chain_off[r];
+    n = a.chain_off[r + 1] - co;
+    if (n == 0) return 0;
+    if (MODE == 1 && (a.skipped[r] || a.cnt_aln[r] == 0)) return 0;
+    bool over = false;
+    // ---- every position of every syncmer of the read on the unitigs (alignment.c:233-251), kept sorted by unitig, read position, unitig
+    //      position as they arrive (sr_scm_cmpfunc :93-107; the order is total, so inserting in place equals sorting afterwards) ----
+    uint32_t ns = 0;
+    for (uint64_t j = 0; j < n && !over; ++j) {
+        const uint64_t s = a.k_mer[co + j] >> 1;
+        for (uint64_t k = a.su_off[s]; k < a.su_off[s + 1]; ++k) {
+            if (ns == RA_MAXS) { over = true; break; }
+            const uint64_t x = a.su_uid[k], u = x >> 1, t = (x & 1ULL) ^ (a.m_pos[co + j] & 1u);
+            const uint32_t p = a.su_pos[k];
+            const uint64_t xu = u << 1 | t;
+            const uint32_t xp = t? a.utg_n[u] - p - 1u : p, xs = (uint32_t) j;
+            uint32_t i = ns;
+            while (i > 0) {
+                const uint64_t yu = S.uid[i - 1];
+                bool gt = yu > xu;
+                if (yu == xu) { const uint32_t ys = S.s_pos[i - 1]; gt = ys != xs? ys > xs : S.u_pos[i - 1] > xp; }
+                if (!gt) break;
+                S.uid[i] = yu, S.s_pos[i] = S.s_pos[i - 1], S.u_pos[i] = S.u_pos[i - 1], --i;
+            }
+            S.uid[i] = xu, S.s_pos[i] = xs, S.u_pos[i] = xp;
+            ++ns;
+        }
+    }
+    if (over) return 2;
+    if (ns == 0) return 0;
+    for (uint32_t i = 0; i < ns; ++i) S.next[i] = RA_NONE;
+    // ---- fragments, unitig by unitig (:259-342) ----
+    nf = 0;
+    for (uint32_t j = 0; j < ns && !over; ) {
+        const uint64_t u = S.uid[j];
+        uint32_t p = j;
+        while (++p < ns && S.uid[p] == u) {}
+        // next mapping position of every hit: the closest larger unitig position among the hits of the next read position (:279-292)
+        {
+            uint32_t g0 = j, g1 = j;                                           // [g0, g1): hits of one read position
+            while (g1 < p && S.s_pos[g1] == S.s_pos[g0]) ++g1;
+            while (g1 < p) {
+                uint32_t g2 = g1;
+                while (g2 < p && S.s_pos[g2] == S.s_pos[g1]) ++g2;
+                uint32_t s1 = g0, t1 = g1;
+                while (s1 < g1) {
+                    const uint32_t up = S.u_pos[s1];
+                    while (t1 < g2 && S.u_pos[t1] <= up) ++t1;
+                    if (t1 < g2 && S.u_pos[t1] > up) S.next[s1] = (uint64_t) t1 << 1;
+                    ++s1;
+                }
+                g0 = g1, g1 = g2;
+            }
+        }
+        // walk the links into fragments (:295-326)
+        for (uint32_t k = j; k < p && !over; ++k) {
+            uint32_t s = k;
+            if (S.next[s] & 1ULL) continue;                                    // not a starting point
+            const uint32_t u_beg = S.u_pos[s], s_beg = S.s_pos[s];
+            uint32_t s_cnt = 1;
+            int64_t u_gap = 0, s_gap = 0;
+            for (;;) {
+                const uint64_t nx = S.next[s], t = nx >> 1;
+                if (t == 0x7FFFFFFFFFFFFFFFULL) break;
+                const int64_t du = (int64_t) S.u_pos[(uint32_t) t] - (int64_t) S.u_pos[s], ds = (int64_t) S.s_pos[(uint32_t) t] - (int64_t) S.s_pos[s];
+                u_gap += (du < 0? -du : du) - 1, s_gap += (ds < 0? -ds : ds) - 1;
+                S.next[s] = nx | 1ULL;
+                ++s_cnt;
+                s = (uint32_t) t;
+            }
+            if (s_cnt == 1) continue;                                          // singletons come below
+            S.next[s] |= 1ULL;
+            if (s_gap > u_gap) u_gap = s_gap;
+            if (u_gap < 0) u_gap = 0;
+            const int64_t score = (int64_t) s_cnt - u_gap;                     // match_score = gap_penalty = 1 (:159-160)
+            if (score >= 0) {
+                if (nf == RA_MAXF) { over = true; break; }
+                F.uid[nf] = u, F.s_beg[nf] = s_beg, F.s_end[nf] = S.s_pos[s], F.s_cnt[nf] = s_cnt, F.u_beg[nf] = u_beg, F.u_end[nf] = S.u_pos[s];
+                F.score0[nf] = F.score[nf] = (int32_t) score, F.prev_n[nf] = 0;
+                ++nf;
+            }
+        }
+        for (uint32_t k = j; k < p && !over; ++k) {                            // :329-336
+            if (S.next[k] != RA_NONE) continue;
+            if (nf == RA_MAXF) { over = true; break; }
+            const uint32_t sp = S.s_pos[k], up = S.u_pos[k];
+            F.uid[nf] = u, F.s_beg[nf] = F.s_end[nf] = sp, F.s_cnt[nf] = 1, F.u_beg[nf] = F.u_end[nf] = up, F.score0[nf] = F.score[nf] = 1, F.prev_n[nf] = 0;
+            ++nf;
+        }
+        j = p;
+    }
+    if (over) return 2;
+    if (nf == 0) return 0;
+    // stable sort by the read interval (sr_frg_cmpfunc :109-119 under glibc's merge sort): the order first, then the fragments moved once
+    for (uint32_t i = 0; i < nf; ++i) {
+        const uint32_t xb = F.s_beg[i], xe = F.s_end[i];
+        uint32_t j = i;
+        while (j > 0) {
+            const uint32_t y = P[j - 1], yb = F.s_beg[y];
+            const bool gt = yb != xb? yb > xb : F.s_end[y] > xe;
+            if (!gt) break;
+            P[j] = (uint16_t) y, --j;
+        }
+        P[j] = (uint16_t) i;
+    }
+    for (uint32_t i = 0; i < nf; ++i) G.copy(i, F, P[i]);
+    // ---- chaining across arcs: no clipping, no gap, no overlap beyond the arc's (:440-476) ----
+    for (uint32_t j = 0; j < nf && !over; ++j) {
+        const uint64_t fu = G.uid[j];
+        const int64_t p = G.s_end[j];
+        if ((int64_t) a.utg_n[fu >> 1] - (int64_t) G.u_end[j] - 1 > 0) continue;
+        const int64_t score = G.score[j];
+        for (uint32_t k = j + 1; k < nf; ++k) {
+            if (G.u_beg[k] > 0) continue;
+            const int64_t ln = ra_arc_ln(a, fu, G.uid[k]);
+            if (ln < 0) continue;
+            const int64_t u_ovl = ln < p + 1? ln : p + 1, p1 = G.s_beg[k];
+            if (p1 > p + 1) break;
+            if (p1 + u_ovl != p + 1) continue;
+            const int64_t score1 = score + G.score0[k] - u_ovl, sk = G.score[k];
+            uint32_t pn = G.prev_n[k];
+            if (score1 <= score || score1 < sk || (score1 == sk && pn == 0)) continue;
+            if (score1 > sk) G.score[k] = (int32_t) score1, pn = 0;
+            if (pn == RA_PREV) { over = true; break; }
+            G.prev[k * RA_PREV + pn] = (uint16_t) j;
+            G.prev_n[k] = (uint16_t) (pn + 1);
+        }
+    }
+    if (over) return 2;
+    max_score = 0;
+    for (uint32_t j = 0; j < nf; ++j) { const int32_t sc = G.score[j]; if (sc > max_score) max_score = sc; }
+    if (max_score < (old >> 1)) return 0;                                      // :505
+    return 1;
+}
+
+// MODE 0: count a read's alignments and fragments; 1: write them at the scanned offsets (a second run of the whole routine);
+//      2: count, take room in a pool and write there (the normal path; 0 + 1 is the fallback when the pool is short).  The pool is
+//      handed out per WAVE -- the lanes' needs are summed with DPP and one lane asks -- because 200 k lanes asking one by one serialise
+//      on the two counters (measured: as long as the whole routine again).
+template <int MODE>
 __global__ __launch_bounds__(256) void ra_kernel(RaArgs a)
 {
     const uint64_t tid = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x, nthr = (uint64_t) gridDim.x * blockDim.x;
-    RaScm *S = a.scm_slab + tid * RA_MAXS;
-    RaFrg *F = a.frg_slab + tid * RA_MAXF;
-    for (uint64_t r = tid; r < a.n_reads; r += nthr) {
-        if (!WRITE) a.cnt_aln[r] = 0, a.cnt_frg[r] = 0, a.skipped[r] = 0;
-        const int64_t old = a.old_ra? a.old_ra[r] : 1;
-        if ((old & 1) == 0) continue;                                              // alignment.c:225
-        const uint64_t co = a.chain_off[r], n = a.chain_off[r + 1] - co;
-        if (n == 0) continue;
-        if (WRITE && (a.skipped[r] || a.cnt_aln[r] == 0)) continue;
-        bool over = false;
-        // ---- every position of every syncmer of the read on the unitigs (alignment.c:233-251) ----
-        uint32_t ns = 0;
-        for (uint64_t j = 0; j < n && !over; ++j) {
-            const uint64_t s = a.k_mer[co + j] >> 1;
-            for (uint64_t k = a.su_off[s]; k < a.su_off[s + 1]; ++k) {
-                if (ns == RA_MAXS) { over = true; break; }
-                const uint64_t x = a.su_uid[k], u = x >> 1, t = (x & 1ULL) ^ (a.m_pos[co + j] & 1u);
-                const uint32_t p = a.su_pos[k];
-                S[ns].uid = u << 1 | t, S[ns].u_pos = t? a.utg_n[u] - p - 1u : p, S[ns].s_pos = (uint32_t) j, S[ns].next = RA_NONE;
-                ++ns;
-            }
-        }
-        if (over) { if (!WRITE) a.skipped[r] = 1; continue; }
-        if (ns == 0) continue;
-        // sort by unitig, read position, unitig position (sr_scm_cmpfunc :93-107; the order is total)
-        for (uint32_t i = 1; i < ns; ++i) {
-            const RaScm x = S[i];
-            uint32_t j = i;
-            while (j > 0) {
-                const RaScm &y = S[j - 1];
-                const bool gt = y.uid != x.uid? y.uid > x.uid : (y.s_pos != x.s_pos? y.s_pos > x.s_pos : y.u_pos > x.u_pos);
-                if (!gt) break;
-                S[j] = y, --j;
-            }
-            S[j] = x;
-        }
-        // ---- fragments, unitig by unitig (:259-342) ----
-        uint32_t nf = 0;
-        for (uint32_t j = 0; j < ns && !over; ) {
-            const uint64_t u = S[j].uid;
-            uint32_t p = j;
-            while (++p < ns && S[p].uid == u) {}
-            // next mapping position of every hit: the closest larger unitig position among the hits of the next read position (:279-292)
-            {
-                uint32_t g0 = j, g1 = j;                                           // [g0, g1): hits of one read position
-                while (g1 < p && S[g1].s_pos == S[g0].s_pos) ++g1;
-                while (g1 < p) {
-                    uint32_t g2 = g1;
-                    while (g2 < p && S[g2].s_pos == S[g1].s_pos) ++g2;
-                    uint32_t s1 = g0, t1 = g1;
-                    while (s1 < g1) {
-                        while (t1 < g2 && S[t1].u_pos <= S[s1].u_pos) ++t1;
-                        if (t1 < g2 && S[t1].u_pos > S[s1].u_pos) S[s1].next = (uint64_t) t1 << 1;
-                        ++s1;
-                    }
-                    g0 = g1, g1 = g2;
-                }
-            }
-            // walk the links into fragments (:295-326)
-            for (uint32_t k = j; k < p && !over; ++k) {
-                uint32_t s = k;
-                if (S[s].next & 1ULL) continue;                                    // not a starting point
-                const uint32_t u_beg = S[s].u_pos, s_beg = S[s].s_pos;
-                uint32_t s_cnt = 1;
-                int64_t u_gap = 0, s_gap = 0;
-                for (;;) {
-                    const uint64_t t = S[s].next >> 1;
-                    if (t == 0x7FFFFFFFFFFFFFFFULL) break;
-                    const int64_t du = (int64_t) S[t].u_pos - (int64_t) S[s].u_pos, ds = (int64_t) S[t].s_pos - (int64_t) S[s].s_pos;
-                    u_gap += (du < 0? -du : du) - 1, s_gap += (ds < 0? -ds : ds) - 1;
-                    S[s].next |= 1ULL;
-                    ++s_cnt;
-                    s = (uint32_t) t;
-                }
-                if (s_cnt == 1) continue;                                          // singletons come below
-                S[s].next |= 1ULL;
-                if (s_gap > u_gap) u_gap = s_gap;
-                if (u_gap < 0) u_gap = 0;
-                const int64_t score = (int64_t) s_cnt - u_gap;                     // match_score = gap_penalty = 1 (:159-160)
-                if (score >= 0) {
-                    if (nf == RA_MAXF) { over = true; break; }
-                    RaFrg &f = F[nf++];
-                    f.uid = u, f.s_beg = s_beg, f.s_end = S[s].s_pos, f.s_cnt = s_cnt, f.u_beg = u_beg, f.u_end = S[s].u_pos;
-                    f.score0 = f.score = (int32_t) score, f.prev_n = 0;
-                }
-            }
-            for (uint32_t k = j; k < p && !over; ++k) {                            // :329-336
-                if (S[k].next != RA_NONE) continue;
-                if (nf == RA_MAXF) { over = true; break; }
-                RaFrg &f = F[nf++];
-                f.uid = u, f.s_beg = f.s_end = S[k].s_pos, f.s_cnt = 1, f.u_beg = f.u_end = S[k].u_pos, f.score0 = f.score = 1, f.prev_n = 0;
-            }
-            j = p;
-        }
-        if (over) { if (!WRITE) a.skipped[r] = 1; continue; }
-        if (nf == 0) continue;
-        // stable sort by the read interval (sr_frg_cmpfunc :109-119 under glibc's merge sort)
-        for (uint32_t i = 1; i < nf; ++i) {
-            const RaFrg x = F[i];
-            uint32_t j = i;
-            while (j > 0) {
-                const RaFrg &y = F[j - 1];
-                const bool gt = y.s_beg != x.s_beg? y.s_beg > x.s_beg : y.s_end > x.s_end;
-                if (!gt) break;
-                F[j] = y, --j;
-            }
-            F[j] = x;
-        }
-        // ---- chaining across arcs: no clipping, no gap, no overlap beyond the arc's (:440-476) ----
-        for (uint32_t j = 0; j < nf && !over; ++j) {
-            const RaFrg &f = F[j];
-            const int64_t p = f.s_end;
-            if ((int64_t) a.utg_n[f.uid >> 1] - (int64_t) f.u_end - 1 > 0) continue;
-            const int64_t score = f.score;
-            for (uint32_t k = j + 1; k < nf; ++k) {
-                RaFrg &f1 = F[k];
-                if (f1.u_beg > 0) continue;
-                const int64_t ln = ra_arc_ln(a, f.uid, f1.uid);
-                if (ln < 0) continue;
-                const int64_t u_ovl = ln < p + 1? ln : p + 1, p1 = f1.s_beg;
-                if (p1 > p + 1) break;
-                if (p1 + u_ovl != p + 1) continue;
-                const int64_t score1 = score + f1.score0 - u_ovl;
-                if (score1 <= score || score1 < f1.score || (score1 == f1.score && f1.prev_n == 0)) continue;
-                if (score1 > f1.score) f1.score = (int32_t) score1, f1.prev_n = 0;
-                if (f1.prev_n == RA_PREV) { over = true; break; }
-                f1.prev[f1.prev_n++] = (uint16_t) j;
-            }
-        }
-        if (over) { if (!WRITE) a.skipped[r] = 1; continue; }
+    const uint32_t lane = threadIdx.x & 63u;
+    __shared__ uint16_t st_mem[2 * RA_DEPTH * 256];
+    const RaWork w = ra_work(a.slab, tid, nthr);
+    for (uint64_t base = tid - lane; base < a.n_reads; base += nthr) {                 // the same trip count in every lane of a wave
+        const uint64_t r = base + lane;
+        uint32_t nf = 0, n_a = 0, n_fr = 0;
         int64_t max_score = 0;
-        for (uint32_t j = 0; j < nf; ++j) if (F[j].score > max_score) max_score = F[j].score;
-        if (max_score < (old >> 1)) continue;                                      // :505
-        // ---- all chains of maximal score, predecessors first (aln_frg_backtrace :132-157), kept when they cover 90 % of the read ----
-        uint32_t n_a = 0, n_fr = 0;
-        const uint32_t tot_a = WRITE? a.cnt_aln[r] : 0;
-        uint64_t wa = WRITE? a.aln_off[r] : 0, wf = WRITE? a.frg_off[r] : 0;
-        uint16_t st_node[RA_DEPTH], st_child[RA_DEPTH];
-        for (uint32_t j = 0; j < nf && !over; ++j) {
-            if (F[j].score < max_score) continue;
-            int d = 0;
-            st_node[0] = (uint16_t) j, st_child[0] = 0;
-            while (d >= 0) {
-                const RaFrg &f = F[st_node[d]];
-                if (f.prev_n == 0) {                                               // a chain is complete: its fragments are st_node[d .. 0]
-                    uint64_t s = 0;
-                    for (int t = d; t >= 0; --t) s += F[st_node[t]].s_cnt;
-                    if (!((double) s / (double) n < 0.9)) {                        // min_a_frac (:161, :547)
-                        if (WRITE) {
-                            a.o_sid[wa] = (uint32_t) r, a.o_off[wa] = wf, a.o_s[wa] = 1.0 / (double) tot_a + (double) max_score;
-                            for (int t = d; t >= 0; --t, ++wf) {
-                                const RaFrg &q = F[st_node[t]];
-                                a.o_uid[wf] = q.uid, a.o_ubeg[wf] = q.u_beg, a.o_uend[wf] = q.u_end, a.o_sbeg[wf] = q.s_beg, a.o_send[wf] = q.s_end;
-                            }
-                            ++wa;
-                        }
-                        ++n_a, n_fr += (uint32_t) d + 1;
-                    }
-                    --d;
-                } else if (st_child[d] < f.prev_n) {
-                    if (d + 1 == RA_DEPTH) { over = true; break; }
-                    const uint16_t c = f.prev[st_child[d]++];
-                    ++d;
-                    st_node[d] = c, st_child[d] = 0;
-                } else --d;
+        uint64_t n = 0;
+        int st = 0;
+        if (r < a.n_reads) {
+            if (MODE != 1) a.cnt_aln[r] = 0, a.cnt_frg[r] = 0, a.skipped[r] = 0;
+            st = ra_prepare<MODE>(a, r, w, nf, max_score, n);
+            if (MODE == 1) {
+                if (st == 1) ra_backtrace<true>(a, st_mem, w.G, nf, max_score, n, r, a.cnt_aln[r], a.aln_off[r], a.frg_off[r], 0, n_a, n_fr);
+            } else {
+                if (st == 1 && ra_backtrace<false>(a, st_mem, w.G, nf, max_score, n, r, 0, 0, 0, 0, n_a, n_fr)) st = 2;
+                if (st == 2) a.skipped[r] = 1, n_a = n_fr = 0;
+                else a.cnt_aln[r] = n_a, a.cnt_frg[r] = n_fr;
             }
         }
-        if (!WRITE) {
-            if (over) a.skipped[r] = 1;
-            else a.cnt_aln[r] = n_a, a.cnt_frg[r] = n_fr;
+        if (MODE == 2) {                                                           // every lane of the wave is here
+            const uint32_t ia = wave_incl_sum_dpp(n_a, lane), ifr = wave_incl_sum_dpp(n_fr, lane);
+            const uint32_t ta = (uint32_t) __builtin_amdgcn_readlane((int) ia, 63), tf = (uint32_t) __builtin_amdgcn_readlane((int) ifr, 63);
+            uint64_t wa = 0, wf = 0;
+            if (ta) {
+                if (lane == 0) wa = atomicAdd(&a.pool_used[0], (unsigned long long) ta), wf = atomicAdd(&a.pool_used[1], (unsigned long long) tf);
+                wa = (uint64_t) (uint32_t) __builtin_amdgcn_readfirstlane((int) (wa >> 32)) << 32 | (uint32_t) __builtin_amdgcn_readfirstlane((int) wa);
+                wf = (uint64_t) (uint32_t) __builtin_amdgcn_readfirstlane((int) (wf >> 32)) << 32 | (uint32_t) __builtin_amdgcn_readfirstlane((int) wf);
+                if (wa + ta > a.pool_cap_a || wf + tf > a.pool_cap_f) { if (lane == 0) a.pool_used[2] = 1ULL; }
+                else if (n_a) {
+                    const uint64_t pa = wa + ia - n_a, pf = wf + ifr - n_fr;
+                    uint32_t x, y;
+                    a.pool_a[r] = pa, a.pool_f[r] = pf;
+                    ra_backtrace<true>(a, st_mem, w.G, nf, max_score, n, r, n_a, pa, pf, pf, x, y);
+                }
+            }
         }
     }
 }
+
+// pool -> read order (MODE 2): one lane per read moves its block; fragment offsets become absolute
+struct RaOut { uint32_t *sid; uint64_t *off; double *s; uint64_t *uid; uint32_t *ubeg, *uend, *sbeg, *send; };
+__global__ void ra_gather_kernel(uint64_t n_reads, const uint32_t *cnt_aln, const uint32_t *cnt_frg, const uint64_t *pool_a, const uint64_t *pool_f,
+                                 const uint64_t *aln_off, const uint64_t *frg_off, RaOut src, RaOut dst)
+{
+    uint64_t r = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint32_t na = cnt_aln[r], nf = cnt_frg[r];
+    if (na == 0) return;
+    const uint64_t pa = pool_a[r], pf = pool_f[r], A = aln_off[r], Fo = frg_off[r];
+    for (uint32_t i = 0; i < na; ++i) dst.sid[A + i] = src.sid[pa + i], dst.s[A + i] = src.s[pa + i], dst.off[A + i] = Fo + src.off[pa + i];
+    for (uint32_t i = 0; i < nf; ++i) {
+        dst.uid[Fo + i] = src.uid[pf + i], dst.ubeg[Fo + i] = src.ubeg[pf + i], dst.uend[Fo + i] = src.uend[pf + i];
+        dst.sbeg[Fo + i] = src.sbeg[pf + i], dst.send[Fo + i] = src.send[pf + i];
+    }
+}
+
 
 } // namespace oatk

@@ -52,6 +52,7 @@ struct oatk_hip_ctx {
     float ms[OATK_T_COUNT_];
     uint64_t hash_mask = ~0ULL;
     bool force_general = false;   // test hook: run the general syncmer kernel even where the fast one applies
+    bool ra_two_pass = false;     // test hook: the read alignment counts, scans and runs again instead of writing into its pool
     int list_cap = 0;             // test hook: syncmers the fast kernel collects per read before writing records (0 = default)
     uint64_t import_reserve = 1u << 20;  // bytes kept free behind the hoco strings for k-mers imported from other shards (api_ec.inc)
     int ec_cap_t0 = 0, ec_cap_t1 = 0;   // test hook: block-length limits of the first two EC solver tiers (0 = default)
@@ -220,6 +221,12 @@ int oatk_hip_debug_force_general(oatk_hip_ctx *ctx, int on)
 {
     if (!ctx) return OATK_E_NODEV;
     ctx->force_general = on != 0;
+    return OATK_OK;
+}
+int oatk_hip_debug_align_two_pass(oatk_hip_ctx *ctx, int on)
+{
+    if (!ctx) return OATK_E_NODEV;
+    ctx->ra_two_pass = on != 0;
     return OATK_OK;
 }
 int oatk_hip_debug_list_cap(oatk_hip_ctx *ctx, int cap)

@@ -22,6 +22,8 @@ _DTYPES = {
     "CONS_SEL": np.uint32, "CONS_SLOT": np.uint32, "CONS_RL": np.uint32, "CONS_MSEQ": np.uint32, "CONS_FIRST": np.uint64, "CONS_TOT": np.uint64,
     "EG_IDX_P": np.uint64, "EG_IDX_N": np.uint32, "EG_ARC_V": np.uint64, "EG_ARC_W": np.uint64, "EG_ARC_LS": np.uint32,
     "EG_ARC_COV": np.uint32, "EG_ARC_COMP": np.uint8,
+    "RA_ALN_SID": np.uint32, "RA_ALN_OFF": np.uint64, "RA_ALN_S": np.float64, "RA_FRG_UID": np.uint64, "RA_FRG_UBEG": np.uint32,
+    "RA_FRG_UEND": np.uint32, "RA_FRG_SBEG": np.uint32, "RA_FRG_SEND": np.uint32, "RA_SKIPPED": np.uint32,
     "OVL_KEY": np.uint64, "OVL_OFF": np.uint64, "OVL_DIST": np.int32, "OVL_CNT": np.uint32, "OVL_TAIL": np.uint8,
     "AG_SCM_DEL": np.uint8, "AG_VTX_SCM": np.uint32, "AG_VTX_COV": np.uint32, "AG_IDX_P": np.uint64, "AG_IDX_N": np.uint32,
     "AG_ARC_V": np.uint64, "AG_ARC_W": np.uint64, "AG_ARC_COV": np.uint32, "AG_ARC_COMP": np.uint8, "AG_ARC_LINK": np.uint64,
@@ -173,6 +175,20 @@ class HipSyncasm:
         """rounded mean run lengths of every live syncmer with coverage >= min_cov (scg_syncmer_consensus, syncasm.c:949-1001);
         fetch CONS_SEL / CONS_SLOT / CONS_RL / CONS_MSEQ / CONS_FIRST"""
         self._check(self.L.oatk_hip_consensus(self.h, min_cov), "oatk_hip_consensus")
+
+    def read_alignment(self, graph, old_ra=None):
+        """scg_read_alignment (alignment.c:596) of the resident chains against a unitig graph given as a dict of host arrays shaped like
+        oatk_ra_graph_t; returns (n_aln, n_frg, stats[3])"""
+        dts = (("su_off", np.uint64), ("su_uid", np.uint64), ("su_pos", np.uint32), ("utg_n", np.uint32), ("idx_p", np.uint64), ("idx_n", np.uint64),
+               ("arc_w", np.uint64), ("arc_ln", np.uint64), ("arc_del", np.uint8))
+        keep = {k: np.ascontiguousarray(graph[k], dtype=dt) for k, dt in dts}
+        g = _lib.RaGraph(int(graph["n_scm"]), len(keep["utg_n"]), len(keep["arc_w"]), *[keep[k].ctypes.data for k, _ in dts])
+        o = None if old_ra is None else np.ascontiguousarray(old_ra, dtype=np.int64)
+        na, nf = C.c_uint64(), C.c_uint64()
+        st = np.zeros(3, np.uint64)
+        self._check(self.L.oatk_hip_read_alignment(self.h, C.byref(g), None if o is None else o.ctypes.data, C.byref(na), C.byref(nf), st.ctypes.data),
+                    "oatk_hip_read_alignment")
+        return int(na.value), int(nf.value), st
 
     def overlap_hist(self):
         """pair-distance tables of every adjacent syncmer pair (calc_syncmer_overlap's tabulation, syncasm.c:477-556); returns (n_pairs, n_entries)"""

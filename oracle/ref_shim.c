@@ -379,6 +379,21 @@ void refx_ra_flatten(scg_ra_v *v, uint64_t *sid, uint32_t *n, double *s, uint64_
             uid[f] = v->a[i].a[j].uid, u_beg[f] = v->a[i].a[j].u_beg, u_end[f] = v->a[i].a[j].u_end, s_beg[f] = v->a[i].a[j].s_beg, s_end[f] = v->a[i].a[j].s_end;
     }
 }
+/* the inverse of refx_ra_flatten */
+scg_ra_v *refx_ra_build(uint64_t n_aln, uint64_t *sid, uint32_t *n, double *s, uint64_t *uid, uint64_t *u_beg, uint64_t *u_end, uint32_t *s_beg, uint32_t *s_end)
+{
+    scg_ra_v *v = (scg_ra_v *) calloc(1, sizeof(scg_ra_v));
+    uint64_t i, j, f = 0;
+    v->n = v->m = n_aln;
+    v->a = (scg_ra_t *) calloc(n_aln? n_aln : 1, sizeof(scg_ra_t));
+    for (i = 0; i < n_aln; ++i) {
+        v->a[i].sid = sid[i], v->a[i].n = n[i], v->a[i].s = s[i];
+        v->a[i].a = (ra_frg_t *) calloc(n[i]? n[i] : 1, sizeof(ra_frg_t));
+        for (j = 0; j < n[i]; ++j, ++f)
+            v->a[i].a[j].uid = uid[f], v->a[i].a[j].u_beg = u_beg[f], v->a[i].a[j].u_end = u_end[f], v->a[i].a[j].s_beg = s_beg[f], v->a[i].a[j].s_end = s_end[f];
+    }
+    return v;
+}
 /* graph surgery between alignment rounds, as run_syncasm.c:209-232 does it */
 void refx_update_utg_cov(scg_t *g) { scg_update_utg_cov(g); }
 int refx_multiplex(scg_t *g, scg_ra_v *v, uint32_t max_n_scm, double min_n_r, double min_d_f) { return scg_multiplex(g, v, max_n_scm, min_n_r, min_d_f); }

@@ -43,15 +43,30 @@ def flatten(L, v):
 
 def both(L, H, hip, db, g, v_ref, v_dev, for_unzip):
     L.refx_read_alignment(db, v_ref, g, 3, for_unzip)
-    nsk = C.c_uint64(0)
-    rc = H.oatk_scg_read_alignment(hip.h, db, v_dev, g, for_unzip, C.byref(nsk), None)
-    assert rc == 0, hip.L.oatk_hip_last_error(hip.h)
-    assert nsk.value == 0
-    want, got = flatten(L, v_ref), flatten(L, v_dev)
-    for k in want:
-        assert len(got[k]) == len(want[k]), k
-        assert np.array_equal(got[k], want[k]), k
+    want = flatten(L, v_ref)
+    # the device routine twice on copies of the previous alignments: writing into its pool (normal) and counting first, then running again
+    for two_pass in (1, 0):
+        hip._check(hip.L.oatk_hip_debug_align_two_pass(hip.h, two_pass), "oatk_hip_debug_align_two_pass")
+        v = v_dev if two_pass == 0 else clone(L, H, v_dev)
+        nsk = C.c_uint64(0)
+        rc = H.oatk_scg_read_alignment(hip.h, db, v, g, for_unzip, C.byref(nsk), None)
+        assert rc == 0, hip.L.oatk_hip_last_error(hip.h)
+        assert nsk.value == 0
+        got = flatten(L, v)
+        for k in want:
+            assert len(got[k]) == len(want[k]), (k, two_pass)
+            assert np.array_equal(got[k], want[k]), (k, two_pass)
+        if two_pass:
+            L.refx_ra_destroy(v)
     return want
+
+
+def clone(L, H, v):
+    """a deep copy of a scg_ra_v (the for_unzip filter reads the previous alignments, and the call replaces them)"""
+    f = flatten(L, v)
+    L.refx_ra_build.restype = C.c_void_p
+    L.refx_ra_build.argtypes = [C.c_uint64] + [C.c_void_p] * 8
+    return L.refx_ra_build(len(f["sid"]), *[f[k].ctypes.data for k in ("sid", "n", "s", "uid", "u_beg", "u_end", "s_beg", "s_end")])
 
 
 CASES = [
