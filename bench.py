@@ -80,6 +80,20 @@ def cpu_baseline(readset, first, n_sample, k, s, threads, min_k_cov=30):
         summ = ec_util.reference_ec(db, sc, g, 0.02, min_k_cov, 0.35, threads=threads)
         dt_ec = time.perf_counter() - t1
         L.refx_scg_destroy(g)
+        # the assembly graph of the corrected reads and one alignment of all reads against it (run_syncasm.c:138, alignment.c:596)
+        import ctypes as C
+        L.refx_ra_new.restype = C.c_void_p
+        L.refx_ra_destroy.argtypes = [C.c_void_p]
+        L.refx_read_alignment.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        t2 = time.perf_counter()
+        g = L.refx_make_graph(db.handle, sc.handle, min_k_cov, 0.35)
+        dt_graph = time.perf_counter() - t2
+        v = L.refx_ra_new()
+        t2 = time.perf_counter()
+        L.refx_read_alignment(db.handle, v, g, threads, 0)
+        dt_aln = time.perf_counter() - t2
+        L.refx_ra_destroy(v)
+        L.refx_scg_destroy(g)
         sc.close()
         db.close()
     finally:
@@ -89,7 +103,10 @@ def cpu_baseline(readset, first, n_sample, k, s, threads, min_k_cov=30):
                       "collect_syncmer_from_reads at -t %d, parse included; %.1f s wall, %d syncmers" % (n_sample, bases / 1e9, threads, dt, n_scm),
             "with_syncerr": {"value": bases / (dt + dt_ec) / 1e9, "unit": "Gbases/s",
                              "sample": "the same, then make_syncmer_graph + scg_consensus + read_error_correction (-c %d); +%.1f s wall, %s error blocks"
-                                       % (min_k_cov, dt_ec, summ.get("total"))}}
+                                       % (min_k_cov, dt_ec, summ.get("total"))},
+            "asm_graph_ms": round(dt_graph * 1e3, 1), "read_alignment_ms": round(dt_aln * 1e3, 1),
+            "after_syncerr": "make_syncmer_graph(-c %d, a 0.35) on the corrected sample, then scg_read_alignment of its %d reads against that graph at -t %d"
+                             % (min_k_cov, n_sample, threads)}
 
 
 def pmc_traffic(kernel_name, workload, per_gpu):
