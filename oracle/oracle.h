@@ -134,6 +134,23 @@ orc_asmgraph_t *orc_asmgraph_build(uint64_t n_reads, const uint32_t *n_scm, cons
                                    uint64_t n_syncmers, const uint32_t *scm_cov, uint8_t *scm_del, uint32_t min_k_cov, double min_a_cov_f);
 void orc_asmgraph_free(orc_asmgraph_t *g);
 
+/* read -> unitig alignment (oracle/align.c): what scg_read_alignment reads of scg_t, flattened, and what it leaves in scg_ra_v */
+typedef struct {
+    uint64_t n_scm, n_utg, n_arc;
+    const uint64_t *su_off, *su_uid;      /* [n_scm + 1] into su_uid / su_pos; utg << 1 | strand */
+    const uint32_t *su_pos, *utg_n;
+    const uint64_t *idx_p, *idx_n, *arc_w, *arc_ln;
+    const uint8_t *arc_del;
+} orc_ra_graph_t;
+typedef struct {
+    uint64_t n_aln, n_frg, m_aln, m_frg, n_mapped, n_unique;
+    uint64_t *sid; uint32_t *n; double *s;                                  /* per alignment */
+    uint64_t *uid, *u_beg, *u_end; uint32_t *s_beg, *s_end;                 /* per fragment */
+} orc_ra_out_t;
+orc_ra_out_t *orc_read_alignment(uint64_t n_reads, const uint32_t *n_scm, const uint64_t *k_mer, const uint32_t *m_pos, const orc_ra_graph_t *g,
+                                 const int64_t *old_ra);
+void orc_ra_out_free(orc_ra_out_t *o);
+
 /* base-space consensus of a syncmer (oracle/consensus.c): flat view of the reads (per-read arrays concatenated in read order) */
 typedef struct {
     uint64_t sid0;

@@ -394,6 +394,25 @@ scg_ra_v *refx_ra_build(uint64_t n_aln, uint64_t *sid, uint32_t *n, double *s, u
     }
     return v;
 }
+/* what scg_ra_analysis_thread reads of scg_t, as flat arrays (tests feed them to the oracle and to the device) */
+void refx_ra_graph_dims(scg_t *g, uint64_t *n_scm, uint64_t *n_su, uint64_t *n_utg, uint64_t *n_arc)
+{
+    *n_scm = scg_n_scm(g), *n_su = (uint64_t) (g->idx_u[scg_n_scm(g)] - g->idx_u[0]), *n_utg = g->utg_asmg->n_vtx, *n_arc = g->utg_asmg->n_arc;
+}
+void refx_ra_graph_flatten(scg_t *g, uint64_t *su_off, uint64_t *su_uid, uint32_t *su_pos, uint32_t *utg_n, uint64_t *idx_p, uint64_t *idx_n,
+        uint64_t *arc_w, uint64_t *arc_ln, uint8_t *arc_del)
+{
+    asmg_t *u = g->utg_asmg;
+    uint64_t i, ns = scg_n_scm(g), nsu = (uint64_t) (g->idx_u[ns] - g->idx_u[0]);
+    for (i = 0; i <= ns; ++i) su_off[i] = (uint64_t) (g->idx_u[i] - g->idx_u[0]);
+    for (i = 0; i < nsu; ++i) {
+        uint128_t x = g->idx_u[0][i];
+        su_uid[i] = scm_utg_uid(x) << 1 | scm_utg_rev(x), su_pos[i] = (uint32_t) scm_utg_pos(x);
+    }
+    for (i = 0; i < u->n_vtx; ++i) utg_n[i] = (uint32_t) u->vtx[i].n;
+    memcpy(idx_p, u->idx_p, 8 * 2 * u->n_vtx); memcpy(idx_n, u->idx_n, 8 * 2 * u->n_vtx);
+    for (i = 0; i < u->n_arc; ++i) arc_w[i] = u->arc[i].w, arc_ln[i] = u->arc[i].ln, arc_del[i] = u->arc[i].del;
+}
 /* graph surgery between alignment rounds, as run_syncasm.c:209-232 does it */
 void refx_update_utg_cov(scg_t *g) { scg_update_utg_cov(g); }
 int refx_multiplex(scg_t *g, scg_ra_v *v, uint32_t max_n_scm, double min_n_r, double min_d_f) { return scg_multiplex(g, v, max_n_scm, min_n_r, min_d_f); }

@@ -188,12 +188,39 @@ def asmgraph_cases():
     asmgraph_case("ec_hifi_k1001", A.hifi_like(120, 30000, 9000, seed=1009, err=0.0008), 1001, 31, 6)
 
 
+def align_case(name, reads, K, S, c):
+    """read -> unitig alignment (scg_read_alignment, alignment.c:596): the corrected chains, and per stage of the reference's pipeline
+    (one syncmer per vertex, after unitigging, unzip rounds with multiplexing, final) the flattened graph, the old_ra filter and the
+    alignments the compiled reference produced"""
+    import test_oracle_align as TA
+    import align_util as AU
+    chains, stages = TA.reference_stages(reads, K, S, c)
+    out = {"K": K, "S": S, "c": c, "n_scm": chains[0], "k_mer": chains[1], "m_pos": chains[2], "n_stages": len(stages),
+           "n_scm_table": stages[0][1]["n_scm"], "stage_names": np.array([st[0] for st in stages])}
+    for i, (nm, graph, old, want) in enumerate(stages):
+        for k, _ in AU.GRAPH_FIELDS:
+            out["s%d_%s" % (i, k)] = graph[k]
+        out["s%d_old_ra" % i] = old
+        for k in AU.OUT_FIELDS:
+            out["s%d_out_%s" % (i, k)] = want[k]
+        print("%-28s %-9s unitigs=%d arcs=%d alignments=%d fragments=%d" % ("align_" + name, nm, len(graph["utg_n"]), len(graph["arc_w"]), len(want["sid"]), len(want["uid"])))
+    np.savez_compressed(os.path.join(GOLD, "align_" + name + ".npz"), **out)
+
+
+def align_cases():
+    import test_gpu_ec as T
+    align_case("repeats_k301", T.sample_reads(T.genome_with_repeats(7, 25000, unit=1500, copies=4), 320, 4000, 0.003, 8), 301, 21, 5)
+    align_case("diploid_k101", T.diploid_reads(101, 6000, 150, 500, 1200, 0.006), 101, 11, 4)
+
+
 def main():
     if not R.available():
         sys.exit("oracle/_ref/liboatk_ref.so missing: run `make -C oracle ref` (needs /root/reference)")
     os.makedirs(GOLD, exist_ok=True)
     if "--asmgraph-only" in sys.argv:        # adds asmgraph_*.npz next to existing ec_*.npz without rewriting those
         return asmgraph_cases()
+    if "--align-only" in sys.argv:
+        return align_cases()
     for (K, S) in [(101, 11), (61, 15), (33, 31), (25, 5), (64, 16)]:
         scan_count_case("adversarial_k%d_s%d" % (K, S), A.reads(K, S, scale=0.5), K, S)
     scan_count_case("adversarial_k1001_s31", A.reads(1001, 31, scale=0.5), 1001, 31)
@@ -205,6 +232,7 @@ def main():
     ec_case("ec_repeats_k301", T.sample_reads(T.genome_with_repeats(7, 25000, unit=1500, copies=4), 320, 4000, 0.003, 8), 301, 21, 5)
     ec_case("ec_hifi_k1001", A.hifi_like(120, 30000, 9000, seed=1009, err=0.0008), 1001, 31, 6)
     asmgraph_cases()
+    align_cases()
 
 
 if __name__ == "__main__":

@@ -12,7 +12,8 @@ import ref_lib as R
 import test_gpu_ec as T
 from test_gpu_dropin import device_dbs, host_lib
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not R.available(), reason="oracle/_ref not built")]
+pytestmark = pytest.mark.gpu
+needs_ref = pytest.mark.skipif(not R.available(), reason="oracle/_ref not built")
 
 
 def setup_libs():
@@ -79,6 +80,7 @@ CASES = [
 ]
 
 
+@needs_ref
 @pytest.mark.parametrize("case", range(len(CASES)))
 def test_read_alignment_matches_reference(hip, case):
     K, S, c, mk = CASES[case]
@@ -111,3 +113,81 @@ def test_read_alignment_matches_reference(hip, case):
     L.refx_scg_destroy(g)
     L.refx_scmdb_destroy(scm)
     L.refx_srdb_destroy(db)
+
+
+GOLDEN = {
+    "align_repeats_k301": (301, 21, 5, lambda: T.sample_reads(T.genome_with_repeats(7, 25000, unit=1500, copies=4), 320, 4000, 0.003, 8)),
+    "align_diploid_k101": (101, 11, 4, lambda: T.diploid_reads(101, 6000, 150, 500, 1200, 0.006)),
+}
+
+
+@pytest.mark.parametrize("two_pass", [0, 1])
+@pytest.mark.parametrize("case", sorted(GOLDEN))
+def test_read_alignment_matches_golden(hip, case, two_pass):
+    """the committed vectors of the compiled reference (tests/golden/align_*.npz: every stage of its pipeline, multi-mapping reads
+    included) through the C ABI: device scan + count + EC must reproduce the golden chains, then every stage's alignments"""
+    import align_util as AU
+    import golden_util as G
+    from oatk_amd import pack_reads
+    K, S, c, mk = GOLDEN[case]
+    g = G.load(case)
+    hip.scan_host(*pack_reads(mk()), K, S)
+    hip.count()
+    hip.ec_graph()
+    hip.ec(0.02, c, 0.35)
+    assert np.array_equal(hip.fetch("EC_KMER"), g["k_mer"]) and np.array_equal(hip.fetch("EC_MPOS"), g["m_pos"])
+    hip._check(hip.L.oatk_hip_debug_align_two_pass(hip.h, two_pass), "oatk_hip_debug_align_two_pass")
+    try:
+        multi = 0
+        for st in range(int(g["n_stages"])):
+            pre = "s%d_" % st
+            graph = {k: g[pre + k] for k, _ in AU.GRAPH_FIELDS}
+            graph["n_scm"] = int(g["n_scm_table"])
+            got = AU.device_align(hip, graph, g[pre + "old_ra"])
+            assert got["skipped"] == 0
+            AU.assert_same(got, {k: g[pre + "out_" + k] for k in AU.OUT_FIELDS}, (case, st))
+            multi += got["n_mapped"] - got["n_unique"]
+    finally:
+        hip._check(hip.L.oatk_hip_debug_align_two_pass(hip.h, 0), "oatk_hip_debug_align_two_pass")
+    assert multi > 0 or case != "align_repeats_k301"
+
+
+def test_read_alignment_matches_oracle_at_scale_and_reports_reads_over_the_limits(hip):
+    """20 k reads against the one-syncmer-per-vertex graph of their own corrected chains (the densest chaining case) vs oracle/align.c;
+    then a graph in which one syncmer sits on 200 unitigs: reads that carry it exceed the per-read limits and are reported, not aligned"""
+    import align_util as AU
+    from oatk_amd import pack_reads
+    from oatk_amd.synth import ReadSet
+    K, S, c, n = 1001, 31, 30, 20000
+    hip.scan_host(*pack_reads(ReadSet(1_000_000, n, 15000).as_list(0, n)), K, S)
+    hip.count()
+    hip.ec_graph()
+    hip.ec(0.02, c, 0.35)
+    nv, na = hip.asm_graph(c, 0.35)
+    ag = hip.fetch_asm_graph()
+    ns = len(ag["scm_del"])
+    su_off = np.zeros(ns + 1, np.uint64)
+    su_off[1:] = np.cumsum(ag["scm_del"] == 0)
+    graph = {"n_scm": ns, "su_off": su_off, "su_uid": np.arange(nv, dtype=np.uint64) << np.uint64(1), "su_pos": np.zeros(nv, np.uint32),
+             "utg_n": np.ones(nv, np.uint32), "idx_p": ag["idx_p"], "idx_n": ag["idx_n"].astype(np.uint64), "arc_w": ag["arc_w"],
+             "arc_ln": np.zeros(na, np.uint64), "arc_del": np.zeros(na, np.uint8)}
+    chains = hip.fetch("EC_N_SCM"), hip.fetch("EC_KMER"), hip.fetch("EC_MPOS")
+    got = AU.device_align(hip, graph)
+    want = AU.oracle_align(*chains, graph)
+    AU.assert_same(got, want)
+    assert got["skipped"] == 0 and len(got["sid"]) > 0.9 * n and (got["n_mapped"], got["n_unique"]) == (want["n_mapped"], want["n_unique"])
+    # one popular syncmer on 200 extra single-syncmer unitigs
+    pop = int(ag["vtx_scm"][0])
+    extra = 200
+    su_uid = np.concatenate([graph["su_uid"][:1], (np.arange(nv, nv + extra, dtype=np.uint64) << np.uint64(1)), graph["su_uid"][1:]])
+    su_off2 = su_off.copy()
+    su_off2[pop + 1:] += np.uint64(extra)
+    g2 = dict(graph, su_off=su_off2, su_uid=su_uid, su_pos=np.zeros(nv + extra, np.uint32), utg_n=np.ones(nv + extra, np.uint32),
+              idx_p=np.concatenate([graph["idx_p"], np.zeros(2 * extra, np.uint64)]), idx_n=np.concatenate([graph["idx_n"], np.zeros(2 * extra, np.uint64)]))
+    got2 = AU.device_align(hip, g2)
+    carriers = np.unique(np.repeat(np.arange(n), chains[0])[(chains[1] >> np.uint64(1)) == pop])
+    assert got2["skipped"] == len(carriers) > 0
+    assert np.array_equal(np.sort(hip.fetch("RA_SKIPPED")), carriers.astype(np.uint32))
+    want2 = AU.oracle_align(*chains, g2)
+    keep = ~np.isin(want2["sid"], carriers)
+    assert np.array_equal(got2["sid"], want2["sid"][keep]) and np.array_equal(got2["s"], want2["s"][keep])
