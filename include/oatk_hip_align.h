@@ -16,7 +16,9 @@
 extern "C" {
 #endif
 
-/* HOST pointers.  n_scm must equal the number of syncmers of the resident count. */
+/* HOST pointers.  n_scm must equal the number of syncmers of the resident count -- with reads sharded over GPUs (oatk_hip_ec_set_global ...
+ * oatk_hip_ec_correct done) the size of the GLOBAL table: reads align independently, so every shard aligns its own against the same graph
+ * in global ids and the results are simply concatenated in shard order (RA_ALN_SID counts from the shard's first read). */
 typedef struct {
     uint64_t n_scm, n_utg, n_arc;
     const uint64_t *su_off;    /* [n_scm + 1] scg->idx_u as offsets into the two arrays below (syncasm.c:116-181)                 */

@@ -251,6 +251,13 @@ class ShardedEc:
                                         int(min_k_cov), float(min_a_cov_f))
 
 
+    def read_alignment(self, graph, old_ra=None):
+        """scg_read_alignment (alignment.c:596) with sharded reads: no exchange at all -- the graph (dict shaped like oatk_ra_graph_t, global
+        syncmer ids, e.g. built from asm_graph()'s result) is the same on every rank and a read aligns on its own; the alignments of all
+        reads are the ranks' results in rank order.  Returns this rank's (n_aln, n_frg, stats3)."""
+        return self.hip.read_alignment(graph, old_ra)
+
+
 def merge_numpy(h_u64, s_u64, cov, dist=None):
     """convenience for the CPU tests: numpy uint64 in, numpy out"""
     h = torch.from_numpy(h_u64.view(np.int64).copy())

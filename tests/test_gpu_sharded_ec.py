@@ -44,6 +44,8 @@ def _worker(rank, world, port, reads, bounds, K, S, c, outdir):
     ag = hip.fetch_asm_graph()
     assert nv == len(ag["vtx_scm"]) and na == len(ag["arc_v"])
     np.savez(os.path.join(outdir, "ag%d.npz" % rank), **ag)
+    sh.read_alignment(vertex_graph(ag, nv, na))
+    np.savez(os.path.join(outdir, "ra%d.npz" % rank), **{k: hip.fetch("RA_" + k) for k in RA_NAMES})
     np.savez(os.path.join(outdir, "r%d.npz" % rank), n_scm=hip.fetch("EC_N_SCM"), k_mer=hip.fetch("EC_KMER"), m_pos=hip.fetch("EC_MPOS"),
              s_mer=hip.fetch("EC_SMER"), occ=hip.fetch("EC_SCM_OCC"), occ_off=hip.fetch("EC_SCM_OCC_OFF"), cov=res["cov"].cpu().numpy(),
              dele=res["del"].cpu().numpy(), stats=res["stats"], imported=sh.n_imported,
@@ -52,6 +54,19 @@ def _worker(rank, world, port, reads, bounds, K, S, c, outdir):
     hip.close()
     dist.barrier()
     dist.destroy_process_group()
+
+
+RA_NAMES = ["ALN_SID", "ALN_OFF", "ALN_S", "FRG_UID", "FRG_UBEG", "FRG_UEND", "FRG_SBEG", "FRG_SEND"]
+
+
+def vertex_graph(ag, nv, na):
+    """the assembly graph (one syncmer per vertex) as scg_read_alignment reads it"""
+    ns = len(ag["scm_del"])
+    su_off = np.zeros(ns + 1, np.uint64)
+    su_off[1:] = np.cumsum(ag["scm_del"] == 0)
+    return {"n_scm": ns, "su_off": su_off, "su_uid": np.arange(nv, dtype=np.uint64) << np.uint64(1), "su_pos": np.zeros(nv, np.uint32),
+            "utg_n": np.ones(nv, np.uint32), "idx_p": ag["idx_p"], "idx_n": ag["idx_n"].astype(np.uint64), "arc_w": ag["arc_w"],
+            "arc_ln": np.zeros(na, np.uint64), "arc_del": np.zeros(na, np.uint8)}
 
 
 CASES = [
@@ -117,3 +132,12 @@ def test_sharded_ec_equals_single_context(hip, tmp_path, case):
                 assert np.array_equal(got_g[k][has], v[has]), k
             else:
                 assert np.array_equal(got_g[k], v), (r, k)
+    # read alignment: every shard aligns its own reads against the same graph; the results concatenate
+    hip.read_alignment(vertex_graph(want_g, nv, na))
+    want_ra = {k: hip.fetch("RA_" + k) for k in RA_NAMES}
+    zr = [np.load(os.path.join(str(tmp_path), "ra%d.npz" % r)) for r in range(world)]
+    assert np.array_equal(np.concatenate([x["ALN_SID"] + np.uint32(bounds[r]) for r, x in enumerate(zr)]), want_ra["ALN_SID"])
+    assert np.array_equal(np.concatenate([x["ALN_S"] for x in zr]), want_ra["ALN_S"]) and len(want_ra["ALN_SID"]) > 0
+    for k in RA_NAMES[3:]:
+        assert np.array_equal(np.concatenate([x[k] for x in zr]), want_ra[k]), k
+    assert np.array_equal(np.concatenate([np.diff(x["ALN_OFF"]) for x in zr]), np.diff(want_ra["ALN_OFF"]))
