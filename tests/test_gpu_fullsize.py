@@ -121,3 +121,81 @@ def test_strand_symmetry(hip, batch):
     hl = np.repeat(hl0.astype(np.int64), n0)
     assert np.array_equal((mp0 >> 1).astype(np.int64), hl - K - (mp1[idx] >> 1).astype(np.int64))
     assert np.array_equal(mp0 & 1, (mp1[idx] & 1) ^ 1)
+
+
+def test_full_size_graph_tables_and_alignment_properties(hip, batch):
+    """the rows behind the error correction at full size: the assembly graph is symmetric and indexed consistently, the pair tables add up to
+    the uncorrected adjacencies, every read aligns along its own corrected chain on the one-syncmer-per-vertex graph, and the two output
+    paths of the aligner (pool + gather, count + second run) agree"""
+    cfg, seq, off, lens = batch
+    n, c = len(off), cfg["min_k_cov"]
+    hip.scan_host(seq, off, lens, K, S)
+    hip.count()
+    hip.ec_graph()
+    hip.ec(0.02, c, 0.35)
+    n_scm, k_mer, m_pos = hip.fetch("EC_N_SCM"), hip.fetch("EC_KMER"), hip.fetch("EC_MPOS")
+    cov, dele = hip.fetch("EC_SCM_COV"), hip.fetch("EC_SCM_DEL")
+
+    # ---- assembly graph (make_syncmer_graph -c 30 -a 0.35 + asmg_finalize) ----
+    nv, na = hip.asm_graph(c, 0.35)
+    g = hip.fetch_asm_graph()
+    keep = (dele == 0) & (cov >= c)
+    assert nv == int(keep.sum()) and np.array_equal(g["vtx_scm"], np.nonzero(keep)[0].astype(np.uint32)) and np.array_equal(g["vtx_cov"], cov[keep])
+    assert np.array_equal(g["scm_del"], (~keep).astype(np.uint8))
+    v, w = g["arc_v"], g["arc_w"]
+    key = v << np.uint64(32) | w
+    assert na == len(v) and np.all(key[1:] > key[:-1])                                  # (v, w) order, no duplicate arcs
+    ckey = (w ^ np.uint64(1)) << np.uint64(32) | (v ^ np.uint64(1))
+    ci = np.searchsorted(key, ckey)
+    assert np.array_equal(key[ci], ckey)                                                # every arc has its complement ...
+    assert np.array_equal(g["arc_cov"][ci], g["arc_cov"]) and np.array_equal(g["arc_link"][ci], g["arc_link"])    # ... same coverage, same link
+    self_c = ci == np.arange(na)
+    assert np.array_equal(g["arc_comp"][ci][~self_c] ^ 1, g["arc_comp"][~self_c]) and np.all(g["arc_comp"][self_c] == 1)
+    assert int(g["arc_link"].max()) + 1 == len(np.unique(g["arc_link"])) == (na + int(self_c.sum())) // 2
+    idx_n = np.bincount(v.astype(np.int64), minlength=2 * nv)
+    assert np.array_equal(g["idx_n"], idx_n.astype(np.uint32))
+    has = idx_n > 0
+    assert np.array_equal(g["idx_p"][has], (np.cumsum(idx_n) - idx_n)[has].astype(np.uint64))
+    assert np.all(g["arc_cov"] >= 0.35 * np.minimum(g["vtx_cov"][(v >> np.uint64(1)).astype(np.int64)], g["vtx_cov"][(w >> np.uint64(1)).astype(np.int64)]))
+
+    # ---- pair tables (calc_syncmer_overlap): counts add up to the adjacent pairs without a corrected member ----
+    np_, ne = hip.overlap_hist()
+    okey, ooff, odist, ocnt = hip.fetch("OVL_KEY"), hip.fetch("OVL_OFF"), hip.fetch("OVL_DIST"), hip.fetch("OVL_CNT")
+    first = np.zeros(len(k_mer), bool)
+    first[(np.cumsum(n_scm, dtype=np.int64) - n_scm)[n_scm > 0]] = True
+    corr = (k_mer & np.uint64(1)).astype(bool)
+    pair_ok = ~first & ~corr
+    pair_ok[1:] &= ~corr[:-1]
+    assert int(ocnt.sum()) == int(pair_ok.sum()) and np_ == len(okey) and np.all(okey[1:] > okey[:-1]) and int(ooff[-1]) == ne == len(odist)
+    assert np.all(odist > 0) and np.all(ocnt > 0)
+    d_all = (m_pos[1:] >> 1).astype(np.int64) - (m_pos[:-1] >> 1).astype(np.int64)
+    assert int((odist.astype(np.int64) * ocnt).sum()) == int(d_all[pair_ok[1:]].sum())    # and so do the distances
+
+    # ---- read alignment against the graph with one syncmer per vertex ----
+    su_off = np.zeros(len(dele) + 1, np.uint64)
+    su_off[1:] = np.cumsum(g["scm_del"] == 0)
+    graph = {"n_scm": len(dele), "su_off": su_off, "su_uid": np.arange(nv, dtype=np.uint64) << np.uint64(1), "su_pos": np.zeros(nv, np.uint32),
+             "utg_n": np.ones(nv, np.uint32), "idx_p": g["idx_p"], "idx_n": g["idx_n"].astype(np.uint64), "arc_w": w,
+             "arc_ln": np.zeros(na, np.uint64), "arc_del": np.zeros(na, np.uint8)}
+    res = []
+    for two_pass in (0, 1):
+        hip._check(hip.L.oatk_hip_debug_align_two_pass(hip.h, two_pass), "oatk_hip_debug_align_two_pass")
+        n_aln, n_frg, st = hip.read_alignment(graph)
+        res.append((n_aln, n_frg, st.tolist(), [crc(hip.fetch("RA_" + b)) for b in ("ALN_SID", "ALN_OFF", "ALN_S", "FRG_UID", "FRG_UBEG", "FRG_UEND", "FRG_SBEG", "FRG_SEND")]))
+    hip._check(hip.L.oatk_hip_debug_align_two_pass(hip.h, 0), "oatk_hip_debug_align_two_pass")
+    assert res[0] == res[1]
+    n_aln, n_frg, st = res[0][:3]
+    assert st[2] == 0 and st[0] > 0.99 * n and st[1] <= st[0]
+    sid, aoff, uid = hip.fetch("RA_ALN_SID"), hip.fetch("RA_ALN_OFF"), hip.fetch("RA_FRG_UID")
+    sb, se = hip.fetch("RA_FRG_SBEG"), hip.fetch("RA_FRG_SEND")
+    assert np.all(sid[1:] >= sid[:-1]) and int(aoff[-1]) == n_frg == len(uid)
+    # on this graph a fragment is one syncmer of the read, on the vertex of that syncmer in the read's orientation
+    assert np.array_equal(sb, se)
+    starts = np.cumsum(n_scm, dtype=np.int64) - n_scm
+    slot = np.repeat(starts[sid.astype(np.int64)], np.diff(aoff).astype(np.int64)) + sb
+    vtx_of = np.full(len(dele), -1, np.int64)
+    vtx_of[g["vtx_scm"].astype(np.int64)] = np.arange(nv)
+    want_uid = (vtx_of[(k_mer[slot] >> np.uint64(1)).astype(np.int64)] << 1 | (m_pos[slot] & 1)).astype(np.uint64)
+    assert np.array_equal(uid, want_uid)
+    per_aln = np.diff(aoff).astype(np.int64)
+    assert np.all(per_aln >= np.ceil(0.9 * n_scm[sid.astype(np.int64)] - 1e-9))         # min_a_frac
