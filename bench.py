@@ -257,6 +257,16 @@ def main():
                 fence()
                 syncerr["asm_graph"] = {"ms": round((time.perf_counter() - t1) / max(args.steps, 1) * 1e3, 3), "n_vtx": nv, "n_arc": na,
                                         "workload": "make_syncmer_graph(-c %d, a 0.35) + asmg_finalize on the corrected chains" % c}
+                # what scg_consensus needs of the reads: run-length totals of every live syncmer, distance tables of every adjacent pair
+                for name, fn, what in (("consensus", lambda: hip.consensus(c), "oatk_hip_consensus(-c %d): scg_syncmer_consensus' sums for every live syncmer" % c),
+                                       ("overlap_hist", hip.overlap_hist, "oatk_hip_overlap_hist: calc_syncmer_overlap's tables for every adjacent pair")):
+                    fn()
+                    fence()
+                    t1 = time.perf_counter()
+                    for _ in range(args.steps):
+                        fn()
+                    fence()
+                    syncerr[name] = {"ms": round((time.perf_counter() - t1) / max(args.steps, 1) * 1e3, 3), "workload": what}
                 # every corrected read against that graph, one syncmer per vertex (scg_read_alignment before the unitigging)
                 ag = hip.fetch_asm_graph()
                 n_scm_all = len(ag["scm_del"])
