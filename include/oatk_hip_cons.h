@@ -38,6 +38,11 @@ int oatk_hip_consensus_ids(oatk_hip_ctx *ctx, const uint32_t *d_ids, uint64_t n)
  *   OVL_KEY  u64[n_pairs]  ascending      OVL_OFF u64[n_pairs + 1]      OVL_DIST i32[n_entries]   OVL_CNT u32[n_entries]   OVL_TAIL u8[n_pairs]
  * Returns OATK_E_SPLIT when a pair has more than 64 distinct distances. */
 int oatk_hip_overlap_hist(oatk_hip_ctx *ctx, uint64_t *n_pairs, uint64_t *n_entries);
+/* With reads sharded over GPUs (after oatk_hip_ec_correct, global ids) the table of a pair is made of all shards' adjacencies: every shard lists its
+ * pairs (canonical key -- ~0 for fillers -- and distance, in (read, slot) order; DEVICE pointers), the caller all-gathers both lists in shard
+ * order, which is the order of one context holding all reads, and any shard builds the same tables from the whole. */
+int oatk_hip_overlap_pairs(oatk_hip_ctx *ctx, const void **d_keys, const void **d_dist, uint64_t *n);
+int oatk_hip_overlap_hist_from_pairs(oatk_hip_ctx *ctx, const uint64_t *d_keys, const uint32_t *d_dist, uint64_t n, uint64_t *n_pairs, uint64_t *n_entries);
 
 enum { OATK_BUF_CONS_SEL = 140, OATK_BUF_CONS_SLOT, OATK_BUF_CONS_RL, OATK_BUF_CONS_MSEQ, OATK_BUF_CONS_FIRST, OATK_BUF_CONS_TOT };
 enum { OATK_BUF_OVL_KEY = 150, OATK_BUF_OVL_OFF, OATK_BUF_OVL_DIST, OATK_BUF_OVL_CNT, OATK_BUF_OVL_TAIL };

@@ -196,6 +196,16 @@ class HipSyncasm:
         self._check(self.L.oatk_hip_overlap_hist(self.h, C.byref(np_), C.byref(ne)), "oatk_hip_overlap_hist")
         return int(np_.value), int(ne.value)
 
+    def overlap_pairs(self):
+        k, d, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        self._check(self.L.oatk_hip_overlap_pairs(self.h, C.byref(k), C.byref(d), C.byref(n)), "oatk_hip_overlap_pairs")
+        return k.value, d.value, int(n.value)
+
+    def overlap_hist_from_pairs(self, d_keys, d_dist, n):
+        np_, ne = C.c_uint64(), C.c_uint64()
+        self._check(self.L.oatk_hip_overlap_hist_from_pairs(self.h, d_keys, d_dist, n, C.byref(np_), C.byref(ne)), "oatk_hip_overlap_hist_from_pairs")
+        return int(np_.value), int(ne.value)
+
     def consensus_ids(self, d_ids, n):
         """the same for a device array of ids; with sharded reads the results (CONS_TOT, CONS_MSEQ) are this shard's share"""
         self._check(self.L.oatk_hip_consensus_ids(self.h, d_ids, n), "oatk_hip_consensus_ids")

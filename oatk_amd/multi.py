@@ -251,6 +251,22 @@ class ShardedEc:
                                         int(min_k_cov), float(min_a_cov_f))
 
 
+    def overlap_hist(self):
+        """calc_syncmer_overlap's tables (include/oatk_hip_cons.h) for ALL reads after run(): the (key, distance) lists of the ranks' corrected
+        chains all-gathered in rank order -- the order one context holding all reads walks them in -- and the same tables built on every rank
+        (OVL_* buffers, global ids).  Returns (n_pairs, n_entries)."""
+        hip, dist, dev = self.hip, self.dist, self.device
+        kp, dp, n = hip.overlap_pairs()
+        if n:
+            keys = torch.as_tensor(_DevView(kp, n, "<i8"), device=dev)
+            dd = torch.as_tensor(_DevView(dp, n, "<i4"), device=dev)
+        else:
+            keys, dd = torch.zeros(0, dtype=torch.int64, device=dev), torch.zeros(0, dtype=torch.int32, device=dev)
+        keys_all = torch.cat(gather_var(keys, dist)).contiguous()
+        dist_all = torch.cat(gather_var(dd, dist)).contiguous()
+        self._ready()
+        return hip.overlap_hist_from_pairs(keys_all.data_ptr(), dist_all.data_ptr(), int(keys_all.numel()))
+
     def read_alignment(self, graph, old_ra=None):
         """scg_read_alignment (alignment.c:596) with sharded reads: no exchange at all -- the graph (dict shaped like oatk_ra_graph_t, global
         syncmer ids, e.g. built from asm_graph()'s result) is the same on every rank and a read aligns on its own; the alignments of all

@@ -44,6 +44,8 @@ def _worker(rank, world, port, reads, bounds, K, S, c, outdir):
     ag = hip.fetch_asm_graph()
     assert nv == len(ag["vtx_scm"]) and na == len(ag["arc_v"])
     np.savez(os.path.join(outdir, "ag%d.npz" % rank), **ag)
+    sh.overlap_hist()
+    np.savez(os.path.join(outdir, "ov%d.npz" % rank), **{k: hip.fetch("OVL_" + k) for k in OVL_NAMES})
     sh.read_alignment(vertex_graph(ag, nv, na))
     np.savez(os.path.join(outdir, "ra%d.npz" % rank), **{k: hip.fetch("RA_" + k) for k in RA_NAMES})
     np.savez(os.path.join(outdir, "r%d.npz" % rank), n_scm=hip.fetch("EC_N_SCM"), k_mer=hip.fetch("EC_KMER"), m_pos=hip.fetch("EC_MPOS"),
@@ -56,6 +58,7 @@ def _worker(rank, world, port, reads, bounds, K, S, c, outdir):
     dist.destroy_process_group()
 
 
+OVL_NAMES = ["KEY", "OFF", "DIST", "CNT", "TAIL"]
 RA_NAMES = ["ALN_SID", "ALN_OFF", "ALN_S", "FRG_UID", "FRG_UBEG", "FRG_UEND", "FRG_SBEG", "FRG_SEND"]
 
 
@@ -132,6 +135,13 @@ def test_sharded_ec_equals_single_context(hip, tmp_path, case):
                 assert np.array_equal(got_g[k][has], v[has]), k
             else:
                 assert np.array_equal(got_g[k], v), (r, k)
+    # pair-distance tables of all reads: every rank holds the tables the single context builds
+    hip.overlap_hist()
+    for r in range(world):
+        zo = np.load(os.path.join(str(tmp_path), "ov%d.npz" % r))
+        for k in OVL_NAMES:
+            assert np.array_equal(zo[k], hip.fetch("OVL_" + k)), (r, k)
+    assert len(hip.fetch("OVL_KEY")) > 10
     # read alignment: every shard aligns its own reads against the same graph; the results concatenate
     hip.read_alignment(vertex_graph(want_g, nv, na))
     want_ra = {k: hip.fetch("RA_" + k) for k in RA_NAMES}
