@@ -33,6 +33,13 @@ typedef struct {
  * correction (corrected chains; corrected entries carry no position and are left out of the distances, as in the reference). */
 int oatk_hip_stat(oatk_hip_ctx *ctx, oatk_stat_raw_t *out);
 
+/* The same in two steps, for reads sharded over GPUs (after oatk_hip_ec_correct; k-mer keys are then global ids): every shard lists the s-mer code
+ * and the k-mer key of each of its chain entries (DEVICE pointers, n_keys entries each) and its additive figures add4 = {reads, syncmers,
+ * sum of distances, number of distances}; the caller all-gathers the two lists (any order: they are sorted here) and sums add4; any shard
+ * then tabulates the whole. */
+int oatk_hip_stat_keys(oatk_hip_ctx *ctx, const void **d_smer, const void **d_kkey, uint64_t *n_keys, int64_t *add4);
+int oatk_hip_stat_from_keys(oatk_hip_ctx *ctx, const uint64_t *d_smer, const uint64_t *d_kkey, uint64_t n, const int64_t *add4, oatk_stat_raw_t *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,7 +43,7 @@ EXPORTS = [
     "oatk_hip_debug_hash_mask", "oatk_hip_debug_force_general", "oatk_hip_debug_list_cap",
     "oatk_hip_ec_graph", "oatk_hip_ec", "oatk_hip_ec_stats", "oatk_hip_debug_ec_tiers", "oatk_hip_ec_mark", "oatk_hip_ec_correct",
     "oatk_hip_ec_set_global", "oatk_hip_ec_pairs", "oatk_hip_ec_graph_from_pairs", "oatk_hip_ec_export_kmers", "oatk_hip_ec_import_kmers",
-    "oatk_hip_ec_reserve_import", "oatk_hip_consensus", "oatk_hip_consensus_ids", "oatk_hip_ingest", "oatk_hip_ingest_host", "oatk_hip_scan_ingested", "oatk_hip_stat",
+    "oatk_hip_ec_reserve_import", "oatk_hip_consensus", "oatk_hip_consensus_ids", "oatk_hip_ingest", "oatk_hip_ingest_host", "oatk_hip_scan_ingested", "oatk_hip_stat", "oatk_hip_stat_keys", "oatk_hip_stat_from_keys",
     "oatk_hip_asm_graph", "oatk_hip_asm_pairs", "oatk_hip_asm_graph_from_pairs", "oatk_hip_overlap_hist", "oatk_hip_overlap_pairs", "oatk_hip_overlap_hist_from_pairs", "oatk_hip_read_alignment", "oatk_hip_debug_align_two_pass",
 ]
 
@@ -130,6 +130,8 @@ def load():
     L.oatk_hip_ingest_host.argtypes = [vp, vp, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.oatk_hip_scan_ingested.argtypes = [vp, C.c_uint64, C.c_int, C.c_int]
     L.oatk_hip_stat.argtypes = [vp, C.POINTER(StatRaw)]
+    L.oatk_hip_stat_keys.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_uint64), vp]
+    L.oatk_hip_stat_from_keys.argtypes = [vp, vp, vp, C.c_uint64, vp, C.POINTER(StatRaw)]
     L.oatk_hip_debug_align_two_pass.argtypes = [vp, C.c_int]
     L.oatk_hip_read_alignment.argtypes = [vp, C.POINTER(RaGraph), vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), vp]
     L.oatk_hip_overlap_pairs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_uint64)]

@@ -163,12 +163,29 @@ class HipSyncasm:
         self._check(self.L.oatk_hip_scan_ingested(self.h, sid0, k, s), "oatk_hip_scan_ingested")
 
     # ---- scan statistics (include/oatk_hip_stat.h) ----
+    @staticmethod
+    def _stat_dict(r):
+        return {"n_reads": r.n_reads, "n_syncmers": r.n_syncmers, "sum_dist": r.sum_dist, "n_dist": r.n_dist, "smer_unique": r.smer_unique,
+                "kmer_unique": r.kmer_unique, "smer_cnt": np.array(r.smer_cnt, np.int64), "kmer_cnt": np.array(r.kmer_cnt, np.int64),
+                "smer_no_singleton": r.smer_no_singleton, "kmer_no_singleton": r.kmer_no_singleton}
+
     def stat_raw(self):
         """multiplicity histograms of s-mers / k-mers and the distance sum of sr_db_stat (syncmer.c:867), at the batch's current stage"""
         r = _lib.StatRaw()
         self._check(self.L.oatk_hip_stat(self.h, C.byref(r)), "oatk_hip_stat")
-        return {"n_reads": r.n_reads, "n_syncmers": r.n_syncmers, "sum_dist": r.sum_dist, "n_dist": r.n_dist, "smer_unique": r.smer_unique,
-                "kmer_unique": r.kmer_unique, "smer_cnt": np.array(r.smer_cnt, np.int64), "kmer_cnt": np.array(r.kmer_cnt, np.int64)}
+        return self._stat_dict(r)
+
+    def stat_keys(self):
+        s, k, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        add4 = np.zeros(4, np.int64)
+        self._check(self.L.oatk_hip_stat_keys(self.h, C.byref(s), C.byref(k), C.byref(n), add4.ctypes.data), "oatk_hip_stat_keys")
+        return s.value, k.value, int(n.value), add4
+
+    def stat_from_keys(self, d_smer, d_kkey, n, add4):
+        r = _lib.StatRaw()
+        a = np.ascontiguousarray(add4, dtype=np.int64)
+        self._check(self.L.oatk_hip_stat_from_keys(self.h, d_smer, d_kkey, n, a.ctypes.data, C.byref(r)), "oatk_hip_stat_from_keys")
+        return self._stat_dict(r)
 
     # ---- base-space consensus (include/oatk_hip_cons.h) ----
     def consensus(self, min_cov=1):

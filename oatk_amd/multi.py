@@ -267,6 +267,23 @@ class ShardedEc:
         self._ready()
         return hip.overlap_hist_from_pairs(keys_all.data_ptr(), dist_all.data_ptr(), int(keys_all.numel()))
 
+    def stat_raw(self):
+        """sr_db_stat's tabulation (include/oatk_hip_stat.h) over ALL reads after run(): the s-mer codes and k-mer keys (global ids) of every rank's
+        chain entries all-gathered (16 bytes per entry; the statistics run twice per assembly, not per batch), the additive figures all-reduced,
+        the same result on every rank."""
+        hip, dist, dev = self.hip, self.dist, self.device
+        sp, kp, n, add4 = hip.stat_keys()
+        if n:
+            sm = torch.as_tensor(_DevView(sp, n, "<i8"), device=dev)
+            kk = torch.as_tensor(_DevView(kp, n, "<i8"), device=dev)
+        else:
+            sm = kk = torch.zeros(0, dtype=torch.int64, device=dev)
+        sm_all = torch.cat(gather_var(sm, dist)).contiguous()
+        kk_all = torch.cat(gather_var(kk, dist)).contiguous()
+        tot = all_reduce(torch.from_numpy(add4).to(dev), dist).cpu().numpy()
+        self._ready()
+        return hip.stat_from_keys(sm_all.data_ptr(), kk_all.data_ptr(), int(sm_all.numel()), tot)
+
     def read_alignment(self, graph, old_ra=None):
         """scg_read_alignment (alignment.c:596) with sharded reads: no exchange at all -- the graph (dict shaped like oatk_ra_graph_t, global
         syncmer ids, e.g. built from asm_graph()'s result) is the same on every rank and a read aligns on its own; the alignments of all

@@ -44,6 +44,8 @@ def _worker(rank, world, port, reads, bounds, K, S, c, outdir):
     ag = hip.fetch_asm_graph()
     assert nv == len(ag["vtx_scm"]) and na == len(ag["arc_v"])
     np.savez(os.path.join(outdir, "ag%d.npz" % rank), **ag)
+    stt = sh.stat_raw()
+    np.savez(os.path.join(outdir, "st%d.npz" % rank), **{k: np.asarray(v) for k, v in stt.items()})
     sh.overlap_hist()
     np.savez(os.path.join(outdir, "ov%d.npz" % rank), **{k: hip.fetch("OVL_" + k) for k in OVL_NAMES})
     sh.read_alignment(vertex_graph(ag, nv, na))
@@ -135,6 +137,13 @@ def test_sharded_ec_equals_single_context(hip, tmp_path, case):
                 assert np.array_equal(got_g[k][has], v[has]), k
             else:
                 assert np.array_equal(got_g[k], v), (r, k)
+    # sr_db_stat's tabulation over all reads (run_syncasm.c:131)
+    want_st = hip.stat_raw()
+    for r in range(world):
+        zs = np.load(os.path.join(str(tmp_path), "st%d.npz" % r))
+        for k, v in want_st.items():
+            assert np.array_equal(zs[k], np.asarray(v)), (r, k)
+    assert want_st["kmer_unique"] > 10 and want_st["n_dist"] > 0
     # pair-distance tables of all reads: every rank holds the tables the single context builds
     hip.overlap_hist()
     for r in range(world):
