@@ -292,10 +292,17 @@ static int launch_scan_kernels(oatk_hip_ctx *ctx)
     else if (small) hipLaunchKernelGGL((syncmer_kernel<8, 4096, false>), dim3((unsigned) n), dim3(SYN_NT), 0, ctx->stream, s);
     else hipLaunchKernelGGL((syncmer_kernel<16, 8192, false>), dim3((unsigned) n), dim3(SYN_NT), 0, ctx->stream, s);
     t_end(ctx, OATK_T_SYNCMER);
+    // reads with ambiguous bases take the general kernel -- if there are any: kernel A has counted them, and the caller waits for these
+    // kernels anyway before it reads the record counts, so asking here costs nothing (a launch over 200 k reads that all return at once: 0.14 ms)
+    uint32_t n_amb = 0;
+    CK(hipMemcpyAsync(&n_amb, ctx->counters.as<uint32_t>(), 4, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
     s.want_n = 1;
     t_begin(ctx, OATK_T_SYNCMER_N);
-    if (small) hipLaunchKernelGGL((syncmer_kernel<8, 4096, true>), dim3((unsigned) n), dim3(SYN_NT), 0, ctx->stream, s);
-    else hipLaunchKernelGGL((syncmer_kernel<16, 8192, true>), dim3((unsigned) n), dim3(SYN_NT), 0, ctx->stream, s);
+    if (n_amb) {
+        if (small) hipLaunchKernelGGL((syncmer_kernel<8, 4096, true>), dim3((unsigned) n), dim3(SYN_NT), 0, ctx->stream, s);
+        else hipLaunchKernelGGL((syncmer_kernel<16, 8192, true>), dim3((unsigned) n), dim3(SYN_NT), 0, ctx->stream, s);
+    }
     t_end(ctx, OATK_T_SYNCMER_N);
     CK(hipGetLastError());
     return OATK_OK;
