@@ -413,6 +413,35 @@ void refx_ra_graph_flatten(scg_t *g, uint64_t *su_off, uint64_t *su_uid, uint32_
     memcpy(idx_p, u->idx_p, 8 * 2 * u->n_vtx); memcpy(idx_n, u->idx_n, 8 * 2 * u->n_vtx);
     for (i = 0; i < u->n_arc; ++i) arc_w[i] = u->arc[i].w, arc_ln[i] = u->arc[i].ln, arc_del[i] = u->arc[i].del;
 }
+/* an scg_t holding just what scg_read_alignment reads, from flat arrays (the inverse of refx_ra_graph_flatten): lets a test align against
+ * graphs no assembler would build.  Free with refx_scg_flat_destroy. */
+scg_t *refx_scg_from_flat(syncmer_db_t *scm_db, uint64_t n_utg, uint64_t n_arc, const uint64_t *su_off, const uint64_t *su_uid, const uint32_t *su_pos,
+        const uint32_t *utg_n, const uint64_t *idx_p, const uint64_t *idx_n, const uint64_t *arc_v, const uint64_t *arc_w, const uint64_t *arc_ln, const uint8_t *arc_del)
+{
+    scg_t *g = (scg_t *) calloc(1, sizeof(scg_t));
+    asmg_t *u = (asmg_t *) calloc(1, sizeof(asmg_t));
+    uint64_t i, s, ns = scm_db->n, nsu = su_off[ns];
+    g->scm_db = scm_db, g->utg_asmg = u;
+    u->n_vtx = u->m_vtx = n_utg, u->n_arc = u->m_arc = n_arc;
+    u->vtx = (asmg_vtx_t *) calloc(n_utg? n_utg : 1, sizeof(asmg_vtx_t));
+    u->arc = (asmg_arc_t *) calloc(n_arc? n_arc : 1, sizeof(asmg_arc_t));
+    u->idx_p = (uint64_t *) calloc(2 * n_utg + 1, 8), u->idx_n = (uint64_t *) calloc(2 * n_utg + 1, 8);
+    for (i = 0; i < n_utg; ++i) u->vtx[i].n = utg_n[i];
+    for (i = 0; i < n_arc; ++i) u->arc[i].v = arc_v[i], u->arc[i].w = arc_w[i], u->arc[i].ln = arc_ln[i], u->arc[i].del = arc_del[i];
+    memcpy(u->idx_p, idx_p, 8 * 2 * n_utg); memcpy(u->idx_n, idx_n, 8 * 2 * n_utg);
+    g->scm_u = (uint128_t *) calloc(nsu? nsu : 1, sizeof(uint128_t));
+    g->idx_u = (uint128_t **) calloc(ns + 1, sizeof(uint128_t *));
+    for (s = 0; s <= ns; ++s) g->idx_u[s] = g->scm_u + su_off[s];
+    for (s = 0; s < ns; ++s)
+        for (i = su_off[s]; i < su_off[s + 1]; ++i)       /* syncasm.c:142: scm << 78 | utg << 36 | pos, scm = id << 1 | rev */
+            g->scm_u[i] = ((uint128_t) (s << 1 | (su_uid[i] & 1)) << 78) | ((uint128_t) (su_uid[i] >> 1) << 36) | su_pos[i];
+    return g;
+}
+void refx_scg_flat_destroy(scg_t *g)
+{
+    free(g->utg_asmg->vtx); free(g->utg_asmg->arc); free(g->utg_asmg->idx_p); free(g->utg_asmg->idx_n); free(g->utg_asmg);
+    free(g->scm_u); free(g->idx_u); free(g);
+}
 /* graph surgery between alignment rounds, as run_syncasm.c:209-232 does it */
 void refx_update_utg_cov(scg_t *g) { scg_update_utg_cov(g); }
 int refx_multiplex(scg_t *g, scg_ra_v *v, uint32_t max_n_scm, double min_n_r, double min_d_f) { return scg_multiplex(g, v, max_n_scm, min_n_r, min_d_f); }

@@ -193,58 +193,6 @@ def test_read_alignment_matches_oracle_at_scale_and_reports_reads_over_the_limit
     assert np.array_equal(got2["sid"], want2["sid"][keep]) and np.array_equal(got2["s"], want2["s"][keep])
 
 
-def random_graph(rng, n_scm, chains, n_src, max_len, p_overlap, p_noise):
-    """unitigs cut out of the chains of n_src random reads (pieces of 1..max_len syncmers, consecutive pieces joined by an arc, with probability
-    p_overlap sharing one syncmer across an arc of ln = 1), so other reads of the same region hit several unitigs at once; plus random arcs
-    and a few deleted ones.  Nothing an assembler would build, but every path of the aligner gets walked: ties, many predecessors, several
-    best chains, chains that miss the 90 % mark"""
-    n_chain, k_mer, m_pos = chains
-    starts = np.cumsum(n_chain, dtype=np.int64) - n_chain
-    hits = [[] for _ in range(n_scm)]
-    utg_n, arcs = [], {}
-    for r in rng.choice(len(n_chain), size=min(n_src, len(n_chain)), replace=False).tolist():
-        n = int(n_chain[r])
-        ids = (k_mer[starts[r]:starts[r] + n] >> np.uint64(1)).astype(np.int64)
-        rev = (m_pos[starts[r]:starts[r] + n] & 1).astype(np.int64)
-        flip = int(rng.integers(0, 2))                   # lay the read down in either orientation
-        if flip:
-            ids, rev = ids[::-1], 1 - rev[::-1]
-        j, prev_u = 0, None
-        while j < n:
-            ln = int(rng.integers(1, max_len + 1))
-            ovl = 1 if (prev_u is not None and j > 0 and rng.random() < p_overlap) else 0
-            seg = list(range(j - ovl, min(j - ovl + ln + ovl, n)))
-            u = len(utg_n)
-            for q, t in enumerate(seg):
-                hits[int(ids[t])].append((u << 1 | int(rev[t]), q))
-            utg_n.append(len(seg))
-            if prev_u is not None:
-                arcs[(prev_u << 1, u << 1)] = ovl
-                arcs[(u << 1 | 1, prev_u << 1 | 1)] = ovl
-            prev_u, j = u, seg[-1] + 1
-    n_utg = len(utg_n)
-    for _ in range(int(p_noise * n_utg)):
-        v, w = int(rng.integers(0, 2 * n_utg)), int(rng.integers(0, 2 * n_utg))
-        if (v, w) not in arcs:
-            arcs[(v, w)] = arcs[(w ^ 1, v ^ 1)] = int(rng.integers(0, 3))
-    keys = sorted(arcs)
-    su_off = np.zeros(n_scm + 1, np.uint64)
-    su_uid, su_pos = [], []
-    for sid in range(n_scm):
-        hs = sorted(hits[sid], key=lambda t: (t[0] & 1, t[0] >> 1, t[1]))            # scg_scm_utg_index orders by (rev, utg, pos)
-        su_uid += [h[0] for h in hs]
-        su_pos += [h[1] for h in hs]
-        su_off[sid + 1] = len(su_uid)
-    idx_p, idx_n = np.zeros(2 * n_utg, np.uint64), np.zeros(2 * n_utg, np.uint64)
-    for i, (v, w) in enumerate(keys):
-        if idx_n[v] == 0:
-            idx_p[v] = i
-        idx_n[v] += 1
-    return {"n_scm": n_scm, "su_off": su_off, "su_uid": np.array(su_uid, np.uint64), "su_pos": np.array(su_pos, np.uint32), "utg_n": np.array(utg_n, np.uint32),
-            "idx_p": idx_p, "idx_n": idx_n, "arc_w": np.array([w for _, w in keys], np.uint64), "arc_ln": np.array([arcs[k] for k in keys], np.uint64),
-            "arc_del": (rng.random(len(keys)) < 0.03).astype(np.uint8)}
-
-
 @pytest.mark.parametrize("seed", range(6))
 def test_read_alignment_on_random_graphs_matches_oracle(hip, seed):
     import align_util as AU
@@ -259,7 +207,7 @@ def test_read_alignment_on_random_graphs_matches_oracle(hip, seed):
     rng = np.random.default_rng(seed)
     total = multi = 0
     for n_src, max_len, p_overlap, p_noise in ((25, 1, 0.0, 0.2), (25, 4, 0.3, 0.3), (60, 12, 0.5, 0.5), (150, 30, 0.2, 1.0), (12, 2, 0.5, 2.0)):
-        graph = random_graph(rng, n_scm, chains, n_src, max_len, p_overlap, p_noise)
+        graph = AU.random_graph(rng, n_scm, chains, n_src, max_len, p_overlap, p_noise)
         old = np.where(rng.random(len(chains[0])) < 0.8, 1, 0).astype(np.int64) | (rng.integers(0, 6, len(chains[0])).astype(np.int64) << 1)
         for o in (None, old):
             got = AU.device_align(hip, graph, o)

@@ -95,3 +95,54 @@ def test_oracle_alignment_side_by_side(K, S, c, seed, err):
         got = AU.oracle_align(*chains, graph, old)
         AU.assert_same(got, want, name)
     assert any(len(w["sid"]) > 20 for _, _, _, w in stages)
+
+
+@pytest.mark.skipif(not R.available(), reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("seed", range(4))
+def test_oracle_alignment_on_random_graphs_side_by_side(seed):
+    """graphs no assembler would build (tests/align_util.py: random_graph), handed to the compiled reference's scg_read_alignment through a
+    hand-made scg_t: ties, several best chains per read, noise arcs, random old_ra filters -- the oracle reproduces every alignment"""
+    import adversarial as A
+    import ec_util as E
+    L = R.lib()
+    L.refx_scg_from_flat.restype = C.c_void_p
+    L.refx_scg_from_flat.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64] + [C.c_void_p] * 10
+    L.refx_scg_flat_destroy.argtypes = [C.c_void_p]
+    L.refx_ra_new.restype = C.c_void_p
+    L.refx_ra_destroy.argtypes = [C.c_void_p]
+    L.refx_ra_build.restype = C.c_void_p
+    L.refx_ra_build.argtypes = [C.c_uint64] + [C.c_void_p] * 8
+    L.refx_read_alignment.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    K, S, c = 101, 11, 3
+    db = R.SrDb.from_reads(A.hifi_like(300, 12000, 2500, seed=70 + seed, err=0.002), K, S, threads=2)
+    scm = R.ScmDb(db)
+    g0, _ = E.ref_graph(db, scm)
+    E.reference_ec(db, scm, g0, 0.02, c, 0.35)
+    L.refx_scg_destroy(g0)
+    sr = db.flatten()
+    chains = (sr["n_scm"], sr["k_mer"], sr["m_pos"])
+    n_table = scm.flatten()["n_scm"]
+    rng = np.random.default_rng(seed)
+    total = multi = 0
+    for n_src, max_len, p_overlap, p_noise in ((25, 1, 0.0, 0.2), (25, 4, 0.3, 0.3), (60, 12, 0.5, 0.5), (12, 2, 0.5, 2.0)):
+        G = AU.random_graph(rng, n_table, chains, n_src, max_len, p_overlap, p_noise)
+        keep = [np.ascontiguousarray(G[k], dtype=dt) for k, dt in AU.GRAPH_FIELDS]
+        arc_v = np.ascontiguousarray(G["arc_v"], dtype=np.uint64)
+        order = [keep[0], keep[1], keep[2], keep[3], keep[4], keep[5], arc_v, keep[6], keep[7], keep[8]]
+        g = L.refx_scg_from_flat(scm.handle, len(G["utg_n"]), len(G["arc_w"]), *[a.ctypes.data for a in order])
+        # first call: every read; second: the for_unzip filter the reference derives from the first call's alignments
+        v = L.refx_ra_new()
+        L.refx_read_alignment(db.handle, v, g, 3, 0)
+        want = ref_flatten(L, v)
+        AU.assert_same(AU.oracle_align(*chains, G), want, (seed, n_src, "all"))
+        old = AU.old_ra_filter(want, len(chains[0]), 1)
+        L.refx_read_alignment(db.handle, v, g, 3, 1)
+        want1 = ref_flatten(L, v)
+        AU.assert_same(AU.oracle_align(*chains, G, old), want1, (seed, n_src, "unzip"))
+        total += len(want["sid"]) + len(want1["sid"])
+        multi += int((np.bincount(want["sid"].astype(np.int64)) > 1).sum()) if len(want["sid"]) else 0
+        L.refx_ra_destroy(v)
+        L.refx_scg_flat_destroy(g)
+    assert total > 100 and multi > 0
+    scm.close()
+    db.close()
