@@ -456,3 +456,38 @@ int64_t refx_syncmer_consensus(sr_db_t *db, syncmer_db_t *s, uint64_t id, int re
     free(ks.s);
     return l;
 }
+
+#ifdef REFX_HOOKED
+/* ---- the hooked build (make ref_hooked, oracle/ref_hooks.h): the glue a maintainer would write around the host library's adaptors ---- */
+#include "ref_hooks.h"
+int64_t (*refx_hook_cons)(void *, void *, int, int64_t, void *, int) = 0;
+int (*refx_hook_ovl)(void *, uint64_t, void *, uint64_t, const int32_t **, const uint32_t **, int *) = 0;
+
+typedef int64_t (*cons_fn_t)(const void *cs, const void *sr_db, uint64_t scm_id, int rev, int64_t beg, void *c_seq, int hoco_seq);   /* oatk_scg_syncmer_consensus */
+typedef int (*ovl_fn_t)(const void *ovl, uint64_t v, uint64_t w, const int32_t **dist, const uint32_t **cnt, int *tail);              /* oatk_overlap_lookup */
+static cons_fn_t g_cons_fn; static const void *g_cons; static ovl_fn_t g_ovl_fn; static const void *g_ovl; static syncmer_t *g_base;
+static uint64_t g_served[4];                         /* consensus served / declined, overlaps served / declined */
+
+static int64_t cons_trampoline(void *sr_db, void *scm, int rev, int64_t beg, void *c_seq, int hoco_seq)
+{
+    int64_t l = g_cons_fn(g_cons, sr_db, (uint64_t) ((syncmer_t *) scm - g_base), rev, beg, c_seq, hoco_seq);
+    ++g_served[l >= 0? 0 : 1];
+    return l;
+}
+static int ovl_trampoline(void *m1, uint64_t rc1, void *m2, uint64_t rc2, const int32_t **dist, const uint32_t **cnt, int *tail)
+{
+    int n = g_ovl_fn(g_ovl, (uint64_t) ((syncmer_t *) m1 - g_base) << 1 | rc1, (uint64_t) ((syncmer_t *) m2 - g_base) << 1 | rc2, dist, cnt, tail);
+    ++g_served[2];
+    return n;
+}
+/* scm_db: the table whose entries the hooks will be asked about; NULL function pointers take a hook out again */
+void refx_hooks_install(syncmer_db_t *scm_db, void *cons_fn, const void *cons, void *ovl_fn, const void *ovl)
+{
+    g_base = scm_db? scm_db->a : 0;
+    g_cons_fn = (cons_fn_t) cons_fn, g_cons = cons, g_ovl_fn = (ovl_fn_t) ovl_fn, g_ovl = ovl;
+    refx_hook_cons = cons_fn? cons_trampoline : 0;
+    refx_hook_ovl = ovl_fn? ovl_trampoline : 0;
+    memset(g_served, 0, sizeof(g_served));
+}
+void refx_hooks_served(uint64_t *out4) { memcpy(out4, g_served, sizeof(g_served)); }
+#endif
