@@ -77,6 +77,12 @@ oatk_sr_db_t *oatk_sr_db_new(int k, int s);
 int oatk_sr_read_packed(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, const uint8_t *seq, const uint64_t *off, const uint32_t *len,
                         uint64_t n_reads, uint64_t seq_bytes, char **names);
 
+/* the second half of the above for a scan that is already resident (off[i] = offset of read i in the packed stream that was scanned) */
+int oatk_sr_db_fill_resident(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, const uint64_t *off, uint64_t n_reads, char **names);
+/* sr_read (syncmer.c:487) for files (plain or gzip'ed FASTA / four-line FASTQ), without kseq: text to the device (oatk_ingest_files), record
+ * scan and syncmer scan there, sr_db filled from the resident results, snames cut out of the headers */
+int oatk_sr_read_files(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, char **files, int n_files);
+
 /* collect_syncmer_from_reads (syncmer.c:1397): count on the device, build syncmer_db_t, rewrite sr->k_mer to id << 1.
  * Returns NULL when there are no syncmers (syncmer.c:1414-1417) or on error (*rc set). */
 oatk_syncmer_db_t *oatk_collect_syncmer_from_reads(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, int *rc);

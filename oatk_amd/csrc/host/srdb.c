@@ -37,6 +37,13 @@ int oatk_sr_read_packed(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, const uint8_t *s
 {
     int rc = oatk_hip_scan_host(ctx, seq, off, len, n_reads, seq_bytes, 0, sr_db->k, sr_db->s);
     if (rc) return rc;
+    return oatk_sr_db_fill_resident(ctx, sr_db, off, n_reads, names);
+}
+
+/* sr_db->a[0 .. n_reads) from the scan resident in ctx; off[i] = offset of read i in the packed stream that was scanned */
+int oatk_sr_db_fill_resident(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, const uint64_t *off, uint64_t n_reads, char **names)
+{
+    int rc = 0;
     if (n_reads == 0) return OATK_OK;
 
     uint64_t b;

@@ -89,6 +89,7 @@ void refx_srdb_flatten(sr_db_t *db, uint8_t *hoco_s, uint8_t *ho_rl, uint32_t *h
 }
 
 /* sr_t does not store how many entries n_nucl holds (syncmer.c:321); the caller knows */
+const char *refx_srdb_name(sr_db_t *db, uint64_t i) { return db->a[i].sname; }
 void refx_srdb_nnucl(sr_db_t *db, uint64_t i, uint32_t cnt, uint32_t *out)
 {
     if (cnt) memcpy(out, db->a[i].n_nucl, sizeof(uint32_t) * cnt);

@@ -205,6 +205,46 @@ def test_structs_equal_reference_structs(hip):
     mine_scm.close(), mine_db.close(), ref_scm.close(), ref_db.close()
 
 
+@pytest.mark.parametrize("fmt,gz", [("fa", False), ("fq", False), ("fa", True)])
+def test_sr_read_files_fills_the_reference_structs(hip, tmp_path, fmt, gz):
+    """oatk_sr_read_files: files -> device reader -> device scan -> sr_db, member by member equal to the reference's sr_read of the same files
+    (two files, names with comments, a wrapped FASTA, optional gzip)"""
+    import gzip
+    L, H = R.lib(), host_lib()
+    H.oatk_sr_read_files.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_char_p), C.c_int]
+    L.refx_srdb_name.restype = C.c_char_p
+    L.refx_srdb_name.argtypes = [C.c_void_p, C.c_uint64]
+    K, S = 301, 21
+    reads = A.hifi_like(90, 30000, 4000, seed=5) + A.reads(K, S, seed=4, scale=0.2)[:20]
+    paths = []
+    for part, chunk in enumerate((reads[:60], reads[60:])):
+        p = str(tmp_path / ("part%d.%s%s" % (part, fmt, ".gz" if gz else "")))
+        op = gzip.open if gz else open
+        with op(p, "wb") as f:
+            for i, r in enumerate(chunk):
+                name = b"read_%d_%d some comment %d" % (part, i, i * 7)
+                if fmt == "fa":
+                    f.write(b">" + name + b"\n")
+                    for o in range(0, len(r), 70 if part else 10 ** 9):
+                        f.write(r[o:o + (70 if part else 10 ** 9)] + b"\n")
+                else:
+                    f.write(b"@" + name + b"\n" + r + b"\n+\n" + b"I" * len(r) + b"\n")
+        paths.append(p)
+    n_nn = np.array([sum(1 for c in r if c not in b"ACGTacgtUu\x00\x01\x02\x03") for r in reads], np.uint32)
+    db = H.oatk_sr_db_new(K, S)
+    files = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+    assert H.oatk_sr_read_files(hip.h, db, files, len(paths)) == 0, hip.L.oatk_hip_last_error(hip.h)
+    mine = object.__new__(R.SrDb)
+    mine._h, mine.K, mine.S = db, K, S
+    ref = R.SrDb(paths, K, S, 2)
+    got, want = mine.flatten(n_nn=n_nn), ref.flatten(n_nn=n_nn)
+    for f in want:
+        assert np.array_equal(got[f], want[f]), f
+    for i in (0, 1, 59, 60, len(reads) - 1):
+        assert L.refx_srdb_name(db, i) == L.refx_srdb_name(ref.handle, i) and L.refx_srdb_name(db, i).startswith(b"read_")
+    mine.close(), ref.close()
+
+
 class _KString(C.Structure):
     _fields_ = [("l", C.c_size_t), ("m", C.c_size_t), ("s", C.c_void_p)]
 
