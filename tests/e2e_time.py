@@ -2,7 +2,7 @@
 """Wall clock of a whole assembly, reads in a FASTA file -> both GFA files: the compiled reference alone, and the reference with every row of
 SURVEY 8 on the MI355X (scan, count, error correction, assembly graph, read alignments, consensus sums and distance tables through the hooked
 build) and only its graph surgery and printing on the host.  Needs oracle/_ref (built where /root/reference exists).  Development aid.
-usage: python tools/e2e_time.py [n_reads] [threads]"""
+usage: python tests/e2e_time.py [n_reads] [threads]"""
 import ctypes as C
 import filecmp
 import os
@@ -12,7 +12,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # tests/ may use the compiled reference; tools/ may not
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import ref_lib as R  # noqa: E402
