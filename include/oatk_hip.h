@@ -109,6 +109,9 @@ enum {
 };
 int oatk_hip_buffer(oatk_hip_ctx *ctx, int which, const void **d_ptr, uint64_t *bytes);
 int oatk_hip_d2h(oatk_hip_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes);
+/* Page-locked host memory owned by the context (one block, regrown on demand, freed with the context; NULL on failure): oatk_hip_d2h into it
+ * runs at PCIe speed, into pageable memory at a fraction of it -- callers that move gigabytes of results stage them through it in pieces. */
+void *oatk_hip_staging(oatk_hip_ctx *ctx, uint64_t bytes);
 
 /* ---- measurement: HIP-event timing of the phases, recorded on the handle's stream ---- */
 enum {

@@ -52,6 +52,8 @@ struct oatk_hip_ctx {
     float ms[OATK_T_COUNT_];
     uint64_t hash_mask = ~0ULL;
     bool force_general = false;   // test hook: run the general syncmer kernel even where the fast one applies
+    void *staging = nullptr;      // page-locked host memory lent to callers (oatk_hip_staging)
+    uint64_t staging_cap = 0;
     bool ra_two_pass = false;     // test hook: the read alignment counts, scans and runs again instead of writing into its pool
     int list_cap = 0;             // test hook: syncmers the fast kernel collects per read before writing records (0 = default)
     uint64_t import_reserve = 1u << 20;  // bytes kept free behind the hoco strings for k-mers imported from other shards (api_ec.inc)
@@ -193,6 +195,7 @@ void oatk_hip_destroy(oatk_hip_ctx *ctx)
         (void) hipEventDestroy(ctx->ev[i][0]);
         (void) hipEventDestroy(ctx->ev[i][1]);
     }
+    if (ctx->staging) (void) hipHostFree(ctx->staging);
     (void) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -607,6 +610,16 @@ int oatk_hip_buffer(oatk_hip_ctx *ctx, int which, const void **d_ptr, uint64_t *
     }
     *d_ptr = p, *bytes = b;
     return OATK_OK;
+}
+
+void *oatk_hip_staging(oatk_hip_ctx *ctx, uint64_t bytes)
+{
+    if (!ctx || hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+    if (bytes <= ctx->staging_cap) return ctx->staging;
+    if (ctx->staging) { (void) hipHostFree(ctx->staging); ctx->staging = nullptr; ctx->staging_cap = 0; }
+    if (hipHostMalloc(&ctx->staging, bytes, hipHostMallocDefault) != hipSuccess) { ctx->staging = nullptr; ctx->err = "hipHostMalloc failed (staging)"; return nullptr; }
+    ctx->staging_cap = bytes;
+    return ctx->staging;
 }
 
 int oatk_hip_d2h(oatk_hip_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes)

@@ -7,14 +7,41 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include "oatk_hip_ingest.h"
 #include "oatk_syncasm.h"
 
-static int ingest_files(oatk_hip_ctx *ctx, char **files, int n_files, uint64_t *n_reads, uint8_t **text, size_t *text_len)
+/* one plain file that ends in a newline needs no copy at all on the host: it is mapped and handed to the device reader as it lies in the page
+ * cache.  Returns 1 when it applied (*rc set), 0 when the general path must run. */
+static int ingest_one_mapped(oatk_hip_ctx *ctx, const char *path, uint64_t *n_reads, uint8_t **text, size_t *text_len, int *mapped, int *rc)
 {
+    struct stat sb;
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return 0;
+    if (fstat(fd, &sb) != 0 || sb.st_size < 3) { close(fd); return 0; }
+    uint8_t *m = (uint8_t *) mmap(0, (size_t) sb.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return 0;
+    if ((m[0] == 0x1f && m[1] == 0x8b) || m[sb.st_size - 1] != '\n') { munmap(m, (size_t) sb.st_size); return 0; }
+    uint64_t used = 0;
+    *rc = oatk_hip_ingest_host(ctx, m, (uint64_t) sb.st_size, OATK_FMT_AUTO, 1, n_reads, &used);
+    if (text && !*rc) *text = m, *text_len = (size_t) sb.st_size, *mapped = 1;
+    else munmap(m, (size_t) sb.st_size);
+    return 1;
+}
+
+static int ingest_files(oatk_hip_ctx *ctx, char **files, int n_files, uint64_t *n_reads, uint8_t **text, size_t *text_len, int *mapped)
+{
+    if (mapped) *mapped = 0;
+    if (n_files == 1) {
+        int rc = 0, dummy = 0;
+        if (ingest_one_mapped(ctx, files[0], n_reads, text, text_len, mapped? mapped : &dummy, &rc)) return rc;
+    }
     size_t cap = (size_t) 1 << 26, len = 0;
     {   /* size the buffer for the files as they lie (right for plain files, a start for gzip'ed ones): no regrowing copies of gigabytes */
         int j;
@@ -78,7 +105,7 @@ static int ingest_files(oatk_hip_ctx *ctx, char **files, int n_files, uint64_t *
 
 int oatk_ingest_files(oatk_hip_ctx *ctx, char **files, int n_files, uint64_t *n_reads)
 {
-    return ingest_files(ctx, files, n_files, n_reads, 0, 0);
+    return ingest_files(ctx, files, n_files, n_reads, 0, 0, 0);
 }
 
 /* sr_read (syncmer.c:487) for files, entirely through the device: text -> records -> scan, then sr_db filled from the resident results.
@@ -88,10 +115,11 @@ int oatk_sr_read_files(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, char **files, int
     uint8_t *text = 0;
     size_t text_len = 0;
     uint64_t n = 0, b = 0, i;
-    int rc = ingest_files(ctx, files, n_files, &n, &text, &text_len);
+    int mapped = 0;
+    int rc = ingest_files(ctx, files, n_files, &n, &text, &text_len, &mapped);
     if (rc) return rc;
     rc = oatk_hip_scan_ingested(ctx, 0, sr_db->k, sr_db->s);
-    if (rc) { free(text); return rc; }
+    if (rc) { if (mapped) munmap(text, text_len); else free(text); return rc; }
     uint64_t *off = 0, *hdr = 0;
     char **names = 0;
     if (n) {
@@ -112,6 +140,7 @@ int oatk_sr_read_files(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, char **files, int
             rc = oatk_sr_db_fill_resident(ctx, sr_db, off, n, names);
         }
     }
-    free(text); free(off); free(hdr); free(names);
+    if (mapped) munmap(text, text_len); else free(text);
+    free(off); free(hdr); free(names);
     return rc;
 }

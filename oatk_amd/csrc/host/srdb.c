@@ -51,8 +51,16 @@ int oatk_sr_db_fill_resident(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, const uint6
     uint32_t *n_scm = (uint32_t *) fetch(ctx, OATK_BUF_N_SCM, &b, &rc); if (rc) return rc;
     uint32_t *n_nn = (uint32_t *) fetch(ctx, OATK_BUF_N_NN, &b, &rc); if (rc) return rc;
     uint32_t *n_lrl = (uint32_t *) fetch(ctx, OATK_BUF_N_LRL, &b, &rc); if (rc) return rc;
-    uint8_t *ho_rl = (uint8_t *) fetch(ctx, OATK_BUF_HO_RL, &b, &rc); if (rc) return rc;
-    uint8_t *hoco_s = (uint8_t *) fetch(ctx, OATK_BUF_HOCO_S, &b, &rc); if (rc) return rc;
+    /* the two big per-base arrays (1 + 1/4 byte per raw base) come over in pieces through page-locked memory, straight into the reads' own
+     * blocks: no gigabyte-sized pageable landing buffer, PCIe at full speed */
+    const void *d_rl = 0, *d_hs = 0;
+    uint64_t b_rl = 0, b_hs = 0;
+    rc = oatk_hip_buffer(ctx, OATK_BUF_HO_RL, &d_rl, &b_rl); if (rc) return rc;
+    rc = oatk_hip_buffer(ctx, OATK_BUF_HOCO_S, &d_hs, &b_hs); if (rc) return rc;
+    (void) b_rl; (void) b_hs;
+    const uint64_t STAGE = 64ULL << 20;
+    uint8_t *stage = (uint8_t *) oatk_hip_staging(ctx, STAGE + STAGE / 4 + 4096);
+    if (!stage) return OATK_E_NOMEM;
     uint64_t *nn_key = (uint64_t *) fetch(ctx, OATK_BUF_NN_KEY, &b, &rc); if (rc) return rc;
     uint32_t *lrl_val = (uint32_t *) fetch(ctx, OATK_BUF_LRL_VAL, &b, &rc); if (rc) return rc;
     uint32_t *m_pos = (uint32_t *) fetch(ctx, OATK_BUF_POS_MPOS, &b, &rc); if (rc) return rc;
@@ -61,7 +69,8 @@ int oatk_sr_db_fill_resident(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, const uint6
 
     sr_db->a = (oatk_sr_t *) xmalloc(sizeof(oatk_sr_t) * n_reads);
     sr_db->n = sr_db->m = n_reads;
-    uint64_t i, o_scm = 0, o_nn = 0, o_lrl = 0;
+    uint64_t i, o_scm = 0, o_nn = 0, o_lrl = 0, stage_end = 0, stage_o0 = 0;
+    uint8_t *stage_hs = stage;
     for (i = 0; i < n_reads; ++i) {
         oatk_sr_t *r = &sr_db->a[i];
         const uint32_t hl = hoco_l[i], ns = n_scm[i];
@@ -70,8 +79,19 @@ int oatk_sr_db_fill_resident(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, const uint6
         r->sname = names? names[i] : 0;
         r->hoco_l = hl;
         /* empty arrays are NULL in the reference (kvec never allocated), syncmer.c:396-412 */
-        r->hoco_s = nb? (uint8_t *) memcpy(xmalloc(nb), hoco_s + off[i] / 4, nb) : 0;
-        r->ho_rl = hl? (uint8_t *) memcpy(xmalloc(hl), ho_rl + off[i], hl) : 0;
+        if (i == stage_end) {                              /* next piece: reads [i, j) whose packed range fits the staging block */
+            uint64_t j = i + 1;
+            const uint64_t o0 = off[i];
+            while (j < n_reads && off[j] + (((uint64_t) hoco_l[j] + 63) & ~63ULL) - o0 <= STAGE) ++j;
+            const uint64_t o1 = off[j - 1] + hoco_l[j - 1], bytes = o1 - o0;      /* one read longer than the block: the block grows */
+            if (bytes > STAGE) { stage = (uint8_t *) oatk_hip_staging(ctx, bytes + bytes / 4 + 4096); if (!stage) return OATK_E_NOMEM; }
+            stage_hs = stage + (((bytes > STAGE? bytes : STAGE) + 63) & ~63ULL);
+            rc = oatk_hip_d2h(ctx, stage, (const uint8_t *) d_rl + o0, bytes); if (rc) return rc;
+            rc = oatk_hip_d2h(ctx, stage_hs, (const uint8_t *) d_hs + o0 / 4, (bytes + 3) / 4 + 1); if (rc) return rc;
+            stage_o0 = o0, stage_end = j;
+        }
+        r->hoco_s = nb? (uint8_t *) memcpy(xmalloc(nb), stage_hs + (off[i] - stage_o0) / 4, nb) : 0;
+        r->ho_rl = hl? (uint8_t *) memcpy(xmalloc(hl), stage + (off[i] - stage_o0), hl) : 0;
         r->ho_l_rl = n_lrl[i]? (uint32_t *) memcpy(xmalloc(4 * (size_t) n_lrl[i]), lrl_val + o_lrl, 4 * (size_t) n_lrl[i]) : 0;
         r->n_nucl = 0;
         if (n_nn[i]) {
@@ -85,7 +105,7 @@ int oatk_sr_db_fill_resident(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, const uint6
         r->k_mer = ns? (uint64_t *) memcpy(xmalloc(8 * (size_t) ns), k_hash + o_scm, 8 * (size_t) ns) : 0;
         o_scm += ns, o_nn += n_nn[i], o_lrl += n_lrl[i];
     }
-    free(hoco_l); free(n_scm); free(n_nn); free(n_lrl); free(ho_rl); free(hoco_s); free(nn_key); free(lrl_val);
+    free(hoco_l); free(n_scm); free(n_nn); free(n_lrl); free(nn_key); free(lrl_val);
     free(m_pos); free(s_mer); free(k_hash);
     return OATK_OK;
 }
