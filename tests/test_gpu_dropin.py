@@ -205,8 +205,8 @@ def test_structs_equal_reference_structs(hip):
     mine_scm.close(), mine_db.close(), ref_scm.close(), ref_db.close()
 
 
-@pytest.mark.parametrize("fmt,gz", [("fa", False), ("fq", False), ("fa", True)])
-def test_sr_read_files_fills_the_reference_structs(hip, tmp_path, fmt, gz):
+@pytest.mark.parametrize("fmt,gz,one_file", [("fa", False, False), ("fq", False, False), ("fa", True, False), ("fa", False, True), ("fq", False, True)])
+def test_sr_read_files_fills_the_reference_structs(hip, tmp_path, fmt, gz, one_file):
     """oatk_sr_read_files: files -> device reader -> device scan -> sr_db, member by member equal to the reference's sr_read of the same files
     (two files, names with comments, a wrapped FASTA, optional gzip)"""
     import gzip
@@ -217,7 +217,8 @@ def test_sr_read_files_fills_the_reference_structs(hip, tmp_path, fmt, gz):
     K, S = 301, 21
     reads = A.hifi_like(90, 30000, 4000, seed=5) + A.reads(K, S, seed=4, scale=0.2)[:20]
     paths = []
-    for part, chunk in enumerate((reads[:60], reads[60:])):
+    # one file: mapped and handed over as it lies (it ends in a newline); the second variant of it does not and takes the copying path
+    for part, chunk in enumerate((reads,) if one_file else (reads[:60], reads[60:])):
         p = str(tmp_path / ("part%d.%s%s" % (part, fmt, ".gz" if gz else "")))
         op = gzip.open if gz else open
         with op(p, "wb") as f:
