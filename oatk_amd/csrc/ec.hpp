@@ -262,6 +262,9 @@ struct EcAssembleArgs {
     const uint64_t *new_off;      // [n_reads + 1] (pass 1)
     uint64_t *new_k_mer, *new_s_mer;
     uint32_t *new_m_pos;
+    uint32_t *key_id;             // pass 1: the (syncmer, occurrence) pairs update_syncmer_db sorts, written along with the chains
+    uint64_t *val_occ;
+    uint64_t sid0;
     const uint64_t *old_s_mer;
     unsigned long long *stats;    // [11]
     int pass;
@@ -279,9 +282,14 @@ __global__ void ec_assemble_kernel(EcAssembleArgs a)
     const uint32_t *mp = a.rd.m_pos + o;
     const EcBlockOut *bo = a.out + a.blk_off[r];
     uint64_t wpos = a.pass? a.new_off[r] : 0;
+    const uint64_t w0 = wpos;
     uint32_t cnt = 0;
     auto put = [&](uint64_t k, uint32_t m) {
-        if (a.pass) { a.new_k_mer[wpos] = k, a.new_m_pos[wpos] = m, a.new_s_mer[wpos] = a.scm_s[k >> 1]; ++wpos; }
+        if (a.pass) {
+            a.new_k_mer[wpos] = k, a.new_m_pos[wpos] = m, a.new_s_mer[wpos] = a.scm_s[k >> 1];
+            a.key_id[wpos] = (uint32_t) (k >> 1), a.val_occ[wpos] = (a.sid0 + r) << 32 | (wpos - w0) << 1 | (m & 1u);      // syncerr.c:796-805
+            ++wpos;
+        }
         ++cnt;
     };
     int nb = ec_blocks(a.scm_del, km, mp, n, a.rd.hoco_l[r], a.rd.K,
@@ -312,7 +320,10 @@ __global__ void ec_assemble_kernel(EcAssembleArgs a)
     if (nb < 0) {                                    // no good syncmer: the read keeps its arrays (syncerr.c:562-572)
         if (a.pass) {
             uint64_t q = a.new_off[r];
-            for (int32_t j = 0; j < n; ++j) a.new_k_mer[q + j] = km[j], a.new_m_pos[q + j] = mp[j], a.new_s_mer[q + j] = a.old_s_mer[o + j];
+            for (int32_t j = 0; j < n; ++j) {
+                a.new_k_mer[q + j] = km[j], a.new_m_pos[q + j] = mp[j], a.new_s_mer[q + j] = a.old_s_mer[o + j];
+                a.key_id[q + j] = (uint32_t) (km[j] >> 1), a.val_occ[q + j] = (a.sid0 + r) << 32 | (uint64_t) j << 1 | (mp[j] & 1u);
+            }
         }
         cnt = (uint32_t) n;
     }
