@@ -458,6 +458,29 @@ int64_t refx_syncmer_consensus(sr_db_t *db, syncmer_db_t *s, uint64_t id, int re
     return l;
 }
 
+/* ---- the reference's own hash table (khashl.h, instantiated exactly like syncasm.c:63 does) fed a raw sequence of add_ovl_count keys: what
+ * calc_syncmer_overlap's table looks like after a walk, and the distance it then picks (the selection loop of syncasm.c:558-571 in five
+ * lines).  `h` persists across calls like the table scg_unitig_consensus hands down (cleared, size kept); NULL = a fresh one. ---- */
+#include "khashl.h"
+KHASHL_MAP_INIT(KH_LOCAL, refx_kh_t, refx_kh, int, int, kh_hash_dummy, kh_eq_generic)
+void *refx_kh_new(void) { return refx_kh_init(); }
+void refx_kh_free(void *h) { refx_kh_destroy((refx_kh_t *) h); }
+int refx_kh_mode(void *hm, const int *seq, uint64_t n)
+{
+    refx_kh_t *h = hm? (refx_kh_t *) hm : refx_kh_init();
+    uint64_t i;
+    int absent, movl = 0, mcnt = 0;
+    khint_t k;
+    refx_kh_m_clear(h);
+    for (i = 0; i < n; ++i) {
+        k = refx_kh_put(h, seq[i], &absent);
+        if (absent) kh_val(h, k) = 1; else ++kh_val(h, k);
+    }
+    for (k = 0; k < kh_end(h); ++k) if (kh_exist(h, k) && kh_val(h, k) > mcnt) mcnt = kh_val(h, k), movl = kh_key(h, k);
+    if (!hm) refx_kh_destroy(h);
+    return movl;
+}
+
 #ifdef REFX_HOOKED
 /* ---- the hooked build (make ref_hooked, oracle/ref_hooks.h): the glue a maintainer would write around the host library's adaptors ---- */
 #include "ref_hooks.h"

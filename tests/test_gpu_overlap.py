@@ -147,3 +147,84 @@ def test_unitig_consensus_served_from_the_device(hip, K, S, c, mk):
     L.refx_scg_destroy(g)
     L.refx_scmdb_destroy(scm)
     L.refx_srdb_destroy(db)
+
+
+def test_tables_and_arc_overlaps_on_injected_walks(hip):
+    """Two syncmers adjacent on reads overlap, so real data gives a pair one distance (outside tandem repeats) and the multi-distance paths of
+    ovh_kernel and egr_mode_kernel would go untested.  The sharded entry points take (key, distance) lists from outside: random walks full of
+    ties and table growth, interleaved across pairs -- tables against the walks themselves, arc overlaps against the reference's own
+    khashl.h fed the same walks (oracle/ref_shim.c: refx_kh_mode)."""
+    from test_host_overlap import reduce_walk
+    K, S = 101, 11
+    hip.scan_host(*pack_reads(A.hifi_like(200, 8000, 2000, seed=9, err=0.001)), K, S)
+    hip.count()
+    n_scm = hip.info()["n_scm"]
+    rng = np.random.default_rng(3)
+    walks, keys = [], []
+    for i in range(min(n_scm // 2 - 1, 1500)):
+        nd = int(rng.integers(1, 30)) if i % 97 else int(rng.integers(1, 8))
+        vals = rng.integers(1, K - 1, nd)
+        seq = vals[rng.integers(0, nd, int(rng.integers(1, 5 * nd + 2)))]
+        if rng.random() < 0.5:
+            seq = np.concatenate([seq, seq])
+            rng.shuffle(seq)
+        if i % 97 == 0:
+            seq = np.concatenate([seq, rng.choice(np.arange(1, K - 1), 40, replace=False)[rng.integers(0, 40, 300)]])   # long runs: the wave-wide path of egr_mode_kernel; <= 40 + 30 > 48 distinct values would be refused
+        walks.append(seq.astype(np.uint32))
+        v, w = 2 * (2 * i) + int(rng.integers(0, 2)), 2 * (2 * i + 1) + int(rng.integers(0, 2))
+        keys.append(v << 32 | w)                                            # v < w: canonical as it stands
+    # interleave the pairs' entries the way reads would, keeping every pair's own order
+    owner = np.repeat(np.arange(len(walks)), [len(w) for w in walks])
+    rng.shuffle(owner)
+    cursor = np.zeros(len(walks), np.int64)
+    k_all, d_all = np.zeros(len(owner), np.uint64), np.zeros(len(owner), np.uint32)
+    for t, o in enumerate(owner.tolist()):
+        k_all[t], d_all[t] = keys[o], walks[o][cursor[o]]
+        cursor[o] += 1
+    # device copies through the HIP runtime the library itself runs on (torch's own copy of it does not initialise once that one is up)
+    rt = C.CDLL("libamdhip64.so")
+    rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    rt.hipFree.argtypes = [C.c_void_p]
+
+    class _Dev:
+        def __init__(self, a):
+            self.p = C.c_void_p()
+            assert rt.hipMalloc(C.byref(self.p), a.nbytes) == 0 and rt.hipMemcpy(self.p, a.ctypes.data, a.nbytes, 1) == 0
+
+        def data_ptr(self):
+            return self.p.value
+
+    dk, dd = _Dev(k_all), _Dev(d_all)
+    # --- tables
+    np_, ne = hip.overlap_hist_from_pairs(dk.data_ptr(), dd.data_ptr(), len(owner))
+    okey, ooff, odist, ocnt, otail = (hip.fetch("OVL_" + x) for x in ("KEY", "OFF", "DIST", "CNT", "TAIL"))
+    order = np.argsort(np.array(keys, np.uint64))
+    assert np_ == len(walks) and np.array_equal(okey, np.array(keys, np.uint64)[order])
+    many = 0
+    for j, i in enumerate(order.tolist()):
+        want = reduce_walk(walks[i].tolist())
+        lo, hi = int(ooff[j]), int(ooff[j + 1])
+        assert odist[lo:hi].tolist() == want[0] and ocnt[lo:hi].tolist() == want[1] and bool(otail[j]) == want[2], i
+        many += len(want[0]) > 1
+    assert many > 100 and ne == len(odist)
+    # --- arc overlaps of the EC graph built from the same lists
+    if not R.available():
+        rt.hipFree(dk.p), rt.hipFree(dd.p)
+        return
+    L = R.lib()
+    L.refx_kh_mode.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    hip.ec_graph_from_pairs(dk.data_ptr(), dd.data_ptr(), len(owner))
+    av, aw, als, comp = hip.fetch("EG_ARC_V"), hip.fetch("EG_ARC_W"), hip.fetch("EG_ARC_LS"), hip.fetch("EG_ARC_COMP")
+    by_key = {k: i for i, k in enumerate(keys)}
+    checked = tied = 0
+    for v, w, ls, cp in zip(av.tolist(), aw.tolist(), als.tolist(), comp.tolist()):
+        key = v << 32 | w if v <= w else (w ^ 1) << 32 | (v ^ 1)
+        seq = walks[by_key[key]].astype(np.int32)
+        movl = L.refx_kh_mode(None, seq.ctypes.data, len(seq))
+        assert ls == (K - movl if movl < K else 0), (v, w, movl, ls)
+        c = sorted(np.unique(seq, return_counts=True)[1].tolist(), reverse=True)
+        tied += len(c) > 1 and c[0] == c[1]
+        checked += 1
+    assert checked == 2 * len(walks) and tied > 20            # the bucket-order tie-break decided many of these
+    rt.hipFree(dk.p), rt.hipFree(dd.p)
