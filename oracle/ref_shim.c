@@ -458,6 +458,39 @@ int64_t refx_syncmer_consensus(sr_db_t *db, syncmer_db_t *s, uint64_t id, int re
     return l;
 }
 
+/* ---- databases made by hand: just the members make_syncmer_graph reads (sr_t.n / k_mer / m_pos, syncmer_t.cov / del), so that a test can put
+ * chains in front of the reference that no genome would produce.  Free with refx_fake_dbs_free. ---- */
+sr_db_t *refx_fake_srdb(uint64_t n_reads, const uint32_t *n_scm, const uint64_t *k_mer, const uint32_t *m_pos)
+{
+    sr_db_t *db = (sr_db_t *) calloc(1, sizeof(sr_db_t));
+    uint64_t i, o = 0;
+    db->n = db->m = n_reads;
+    db->a = (sr_t *) calloc(n_reads? n_reads : 1, sizeof(sr_t));
+    for (i = 0; i < n_reads; o += n_scm[i], ++i) {
+        sr_t *r = &db->a[i];
+        r->sid = i, r->n = n_scm[i];
+        r->k_mer = (uint64_t *) malloc(8 * (n_scm[i] + 1)); memcpy(r->k_mer, k_mer + o, 8 * n_scm[i]);
+        r->m_pos = (uint32_t *) malloc(4 * (n_scm[i] + 1)); memcpy(r->m_pos, m_pos + o, 4 * n_scm[i]);
+    }
+    return db;
+}
+syncmer_db_t *refx_fake_scmdb(uint64_t n, const uint32_t *cov, const uint8_t *del)
+{
+    syncmer_db_t *s = (syncmer_db_t *) calloc(1, sizeof(syncmer_db_t));
+    uint64_t i;
+    s->n = s->m = n;
+    s->a = (syncmer_t *) calloc(n? n : 1, sizeof(syncmer_t));
+    for (i = 0; i < n; ++i) s->a[i].cov = cov[i], s->a[i].del = del[i];
+    return s;
+}
+void refx_fake_scmdb_del(syncmer_db_t *s, uint8_t *del) { uint64_t i; for (i = 0; i < s->n; ++i) del[i] = s->a[i].del; }
+void refx_fake_dbs_free(sr_db_t *db, syncmer_db_t *s)
+{
+    uint64_t i;
+    if (db) { for (i = 0; i < db->n; ++i) { free(db->a[i].k_mer); free(db->a[i].m_pos); } free(db->a); free(db); }
+    if (s) { free(s->a); free(s); }
+}
+
 /* ---- the reference's own hash table (khashl.h, instantiated exactly like syncasm.c:63 does) fed a raw sequence of add_ovl_count keys: what
  * calc_syncmer_overlap's table looks like after a walk, and the distance it then picks (the selection loop of syncasm.c:558-571 in five
  * lines).  `h` persists across calls like the table scg_unitig_consensus hands down (cleared, size kept); NULL = a fresh one. ---- */

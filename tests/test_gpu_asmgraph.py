@@ -120,3 +120,59 @@ def test_device_asmgraph_matches_oracle_at_scale(hip):
     og = AU.oracle_asmgraph(hip.fetch("EC_N_SCM"), hip.fetch("EC_KMER"), hip.fetch("EC_MPOS"), hip.fetch("EC_SCM_COV"), hip.fetch("EC_SCM_DEL"), c, a)
     assert not og["multi_arc"] and nv > 300 and na > nv
     AU.assert_asm_equal(D, og)
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_device_asmgraph_on_injected_pairs_matches_oracle(hip, seed):
+    """corners that reads from a genome rarely produce: arcs that are their own complement (v -> v^1), pairs on both strands, random coverage
+    and deletion marks, filters from 0 to 2 -- two-syncmer "reads" for the oracle, their canonical keys through oatk_hip_asm_graph_from_pairs
+    for the device; and the duplicate-arc corner (a -> a on both strands) refused with OATK_E_SPLIT exactly when the oracle flags it"""
+    import ctypes as C
+    from oatk_amd import OatkHipError
+    scan_count(hip, A.hifi_like(20, 3000, 1000, seed=1), 101, 11)      # the result buffers are handed out on a context that holds a batch
+    rng = np.random.default_rng(100 + seed)
+    ns = 300
+    n_pairs = 6000
+    a, b = rng.integers(0, ns, n_pairs), rng.integers(0, ns, n_pairs)
+    near = rng.random(n_pairs) < 0.7                          # most pairs between neighbours, so that keys repeat and coverages add up
+    b[near] = (a[near] + rng.integers(1, 4, near.sum())) % ns
+    sa, sb = rng.integers(0, 2, n_pairs), rng.integers(0, 2, n_pairs)
+    selfc = rng.random(n_pairs) < 0.03                        # a+ -> a-: its own complement
+    b[selfc], sb[selfc] = a[selfc], 1 - sa[selfc]
+    if seed == 4:                                             # a+ -> a+ and a- -> a-: duplicate (v, w) after the complements are added
+        a[:4], b[:4], sa[:4], sb[:4] = [7, 7, 9, 9], [7, 7, 9, 9], [0, 1, 0, 1], [0, 1, 0, 1]
+    same = (a == b) & (sa == sb) & (np.arange(n_pairs) >= (4 if seed == 4 else 0))
+    b[same] = (b[same] + 1) % ns
+    k_mer = np.stack([a, b], 1).reshape(-1).astype(np.uint64) << np.uint64(1)
+    m_pos = (np.stack([sa, sb], 1).reshape(-1) | (np.arange(2 * n_pairs) << 1)).astype(np.uint32)
+    n_scm = np.full(n_pairs, 2, np.uint32)
+    cov = rng.integers(0, 60, ns).astype(np.uint32)
+    dele = (rng.random(ns) < 0.05).astype(np.uint8)
+    v0, v1 = (a << 1 | sa).astype(np.uint64), (b << 1 | sb).astype(np.uint64)
+    keys = np.where(v0 <= v1, v0 << np.uint64(32) | v1, (v1 ^ np.uint64(1)) << np.uint64(32) | (v0 ^ np.uint64(1)))
+    keys = np.concatenate([keys, np.full(50, 0xFFFFFFFFFFFFFFFF, np.uint64)])       # fillers, as slot 0 of every read produces them
+    rng.shuffle(keys)
+    rt = C.CDLL("libamdhip64.so")
+    rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    rt.hipFree.argtypes = [C.c_void_p]
+    dev = []
+    for arr in (keys, cov, dele):
+        p = C.c_void_p()
+        assert rt.hipMalloc(C.byref(p), arr.nbytes) == 0 and rt.hipMemcpy(p, arr.ctypes.data, arr.nbytes, 1) == 0
+        dev.append(p)
+    try:
+        for c, f in ((0, 0.0), (5, 0.35), (20, 0.9), (1, 2.0), (59, 0.0)):
+            og = AU.oracle_asmgraph(n_scm, k_mer, m_pos, cov, dele, c, f)
+            if og["multi_arc"]:
+                with pytest.raises(OatkHipError, match="duplicate arcs"):
+                    hip.asm_graph_from_pairs(dev[0].value, len(keys), ns, dev[1].value, dev[2].value, c, f)
+                continue
+            nv, na = hip.asm_graph_from_pairs(dev[0].value, len(keys), ns, dev[1].value, dev[2].value, c, f)
+            AU.assert_asm_equal(hip.fetch_asm_graph(), og)
+            assert nv == len(og["vtx_scm"]) and na == len(og["arc_v"])
+        if seed == 4:
+            assert AU.oracle_asmgraph(n_scm, k_mer, m_pos, cov, dele, 0, 0.0)["multi_arc"] or cov[7] == 0 or cov[9] == 0 or dele[7] or dele[9]
+    finally:
+        for p in dev:
+            rt.hipFree(p)
