@@ -15,6 +15,18 @@
 // coordinates; finished runs are staged in an LDS ring (one byte store per run, the 2-bit codes of a lane
 // OR-ed in as at most two words) and leave as full 16-byte stores.  Ambiguous bases and runs > 255 are
 // rare and handled off the fast path.
+//
+// The kernel is bound by VALU issue, not by HBM (PMC: 481 VALU wave-instructions per wave and tile = 30 per raw base, times
+// 4 cycles, over 1024 SIMDs IS its run time), so what counts is instructions per 16-byte lane:
+//  * a lane whose sixteen bytes (and the byte before them) are all ACGTU in either case -- every lane of a HiFi read -- never
+//    touches the table: the low three bits of such a byte are distinct (A 1, C 3, T 4, U 5, G 7), so one v_perm_b32 turns
+//    four bytes into four codes and a second one into the four bytes they SHOULD be; any difference sends the lane to the
+//    table path.  Codes are packed to sixteen 2-bit fields and run starts fall out of field XOR previous field.
+//  * the codes of the runs a lane finishes are squeezed together through a 4 KiB table (4 positions at a time: 4-bit
+//    keep mask x 4 codes -> the kept codes, first one on top) instead of a loop that drops one field per turn -- such a loop
+//    runs as long as the unluckiest lane of the wave (9 turns for a mean of 4).
+//  * runs longer than one base that begin and end inside the lane are at most 15 long: their loop carries no clamp and no
+//    overflow test; the one run that enters the lane from the left is handled before it.
 #pragma once
 #include "common.hpp"
 
@@ -24,6 +36,23 @@ constexpr int HPC_NT = 256;
 constexpr int HPC_BPT = 16;
 constexpr int HPC_TILE = HPC_NT * HPC_BPT;
 constexpr int HPC_RING = 8192;   // staged hoco positions; > one tile + one unflushed 64-group
+
+// squeeze table: index = keep << 8 | four 2-bit codes (position i in bits 2i+1:2i); value = the kept codes in position
+// order, the first in bits 7:6
+struct HpcSqueezeTab {
+    uint8_t v[4096];
+    constexpr HpcSqueezeTab() : v()
+    {
+        for (int m = 0; m < 16; ++m)
+            for (int c = 0; c < 256; ++c) {
+                int out = 0, k = 0;
+                for (int i = 0; i < 4; ++i)
+                    if (m >> i & 1) out |= ((c >> (2 * i)) & 3) << (6 - 2 * k), ++k;
+                v[m << 8 | c] = (uint8_t) out;
+            }
+    }
+};
+__device__ const HpcSqueezeTab hpc_squeeze_tab = HpcSqueezeTab();
 
 struct HpcArgs {
     const uint8_t *seq;       // packed read stream, read r at off[r] (64-byte aligned), len[r] bytes
@@ -77,6 +106,7 @@ __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
     __shared__ uint4 ring_rl4[HPC_RING / 16];      // run lengths, one byte per staged hoco position
     __shared__ uint4 ring_hs4[HPC_RING / 64];      // 2-bit codes, 16 per word, MSB-first words (byte-swapped on the way out)
     __shared__ uint8_t lut[256];
+    __shared__ uint4 sq4[HPC_NT];                   // the squeeze table, 4 KiB
     __shared__ uint32_t w_cnt[HPC_NT / OATK_WAVE];
     __shared__ int32_t w_max[HPC_NT / OATK_WAVE];
     __shared__ uint32_t s_nn, s_lrl;
@@ -94,6 +124,8 @@ __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
     uint32_t *out_nb = a.nbits + (o >> 5);
 
     lut[tid] = (uint8_t) nt4_code(tid);
+    sq4[tid] = ((const uint4 *) hpc_squeeze_tab.v)[tid];
+    const uint8_t *sq = (const uint8_t *) sq4;
     for (uint32_t i = tid; i < HPC_RING / 16; i += HPC_NT) ring_hs[i] = 0;
     for (uint32_t i = tid; i < HPC_RING / 16; i += HPC_NT) ring_rl4[i] = make_uint4(0, 0, 0, 0);      // runs of one base (most) never write their 0
     if (tid == 0) s_nn = 0, s_lrl = 0;
@@ -135,19 +167,59 @@ __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
     uint32_t flushed = 0;     // 64-groups already in HBM
 
     uint4 vnext = make_uint4(0, 0, 0, 0);
+    uint32_t upnext = 0;      // lane 0 of a wave: the byte before the wave's first (the other lanes get theirs from their neighbour)
     if (tid * HPC_BPT < L) vnext = *(const uint4 *) (in + tid * HPC_BPT);
+    if (lane == 0 && tid && tid * HPC_BPT <= L) upnext = in[tid * HPC_BPT - 1];
     __syncthreads();
 
     for (uint32_t t0 = 0; t0 < L; t0 += HPC_TILE) {
         const uint32_t b0 = t0 + tid * HPC_BPT;
         const uint4 v = vnext;
+        uint32_t upb = hpc_dpp<0x138>(0u, v.w >> 24);                             // wave_shr:1 -- the previous lane's last byte
+        if (lane == 0) upb = upnext;
         if (b0 + HPC_TILE < L) vnext = *(const uint4 *) (in + b0 + HPC_TILE);      // next tile's bytes, in flight while this one is processed
+        if (lane == 0 && b0 + HPC_TILE <= L) upnext = in[b0 + HPC_TILE - 1];
         const int nvalid = b0 < L? (int) (L - b0 < (uint32_t) HPC_BPT? L - b0 : (uint32_t) HPC_BPT) : 0;
 
-        // ---- classes as 16 nibbles (cx: bytes 0-7, cy: bytes 8-15); bytes past the read end get class 7 ----
-        uint32_t cx = 0x77777777u, cy = 0x77777777u, up = 7u;
-        if (nvalid) {
+        uint32_t smask = 0;       // run starts among the lane's sixteen positions
+        uint32_t pf = 0;          // sixteen 2-bit fields: the code of the byte BEFORE position b in field b
+        uint32_t cx = 0, cy = 0, up = 0;      // classes as nibbles, table path only (ambiguous bases need them further down)
+        bool slow = nvalid > 0 && nvalid < HPC_BPT;
+        if (nvalid == HPC_BPT) {
+            // ---- all ACGTU?  index = byte & 7 into two 8-byte tables: the code, and the case-folded byte that has this code ----
+            constexpr uint32_t TL = 0x01000000u, TH = 0x02000303u;               // idx 1 A 0, 3 C 1, 4 T 3, 5 U 3, 7 G 2
+            constexpr uint32_t EL = 0x43FF41FFu, EH = 0x47FF5554u;               // idx 1 'A', 3 'C', 4 'T', 5 'U', 7 'G'; 0xFF never matches
+            const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+            uint32_t diff = 0, f = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t sel = wds[q] & 0x07070707u;
+                uint32_t c = __builtin_amdgcn_perm(TH, TL, sel);
+                diff |= (wds[q] & 0xDFDFDFDFu) ^ __builtin_amdgcn_perm(EH, EL, sel);
+                c = (c | c >> 6) & 0x000F000Fu;                                   // four codes in four bytes -> four 2-bit fields
+                c = (c | c >> 12) & 0xFFu;
+                f |= c << (8 * q);
+            }
+            uint32_t cu = 0;
+            if (b0) {
+                const uint32_t sel = upb & 7u;
+                cu = __builtin_amdgcn_perm(TH, TL, sel) & 3u;
+                diff |= ((upb & 0xDFu) ^ __builtin_amdgcn_perm(EH, EL, sel)) & 0xFFu;
+            }
+            pf = f << 2 | cu;
+            uint32_t s = f ^ pf;                                                  // field b != 0: position b starts a run
+            s = (s | s >> 1) & 0x55555555u;
+            s = (s | s >> 1) & 0x33333333u;
+            s = (s | s >> 2) & 0x0F0F0F0Fu;
+            s = (s | s >> 4) & 0x00FF00FFu;
+            smask = (s | s >> 8) & 0xFFFFu;
+            if (b0 == 0) smask |= 1u;
+            slow = diff != 0;
+        }
+        if (slow) {
+            // ---- classes as 16 nibbles through the table (cx: bytes 0-7, cy: bytes 8-15); bytes past the read end get class 7 ----
             cx = cy = 0;
+            up = 7u;
             const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
@@ -155,17 +227,14 @@ __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
                 cy |= (uint32_t) lut[(wds[2 + (b >> 2)] >> (8 * (b & 3))) & 0xffu] << (4 * b);
             }
             if (nvalid < HPC_BPT) {     // tail lane: blank the nibbles beyond the read
-                const uint64_t keep = nvalid >= 16? ~0ULL : ((1ULL << (4 * nvalid)) - 1ULL);
+                const uint64_t keep = (1ULL << (4 * nvalid)) - 1ULL;
                 uint64_t cc = ((uint64_t) cy << 32 | cx);
                 cc = (cc & keep) | (0x7777777777777777ULL & ~keep);
                 cx = (uint32_t) cc, cy = (uint32_t) (cc >> 32);
             }
-            if (b0 > 0) up = lut[in[b0 - 1]];
-        }
-        // ---- run starts: class differs from the previous byte's, or the byte is ambiguous (class 4) ----
-        // nibble-parallel: d = c ^ prev; start <=> d != 0 or c == 4; positions past the end (class 7) never start
-        uint32_t smask;
-        {
+            if (b0 > 0) up = lut[upb & 0xffu];
+            // run starts: class differs from the previous byte's, or the byte is ambiguous (class 4); nibble-parallel:
+            // d = c ^ prev; start <=> d != 0 or c == 4; positions past the end (class 7) never start
             const uint32_t px = cx << 4 | up, py = cy << 4 | cx >> 28;
             const uint32_t dx = cx ^ px, dy = cy ^ py;
             const uint32_t LOW = 0x11111111u;
@@ -174,14 +243,19 @@ __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
             sy |= (cy >> 2) & ~(cy >> 1) & ~cy & LOW;
             sx &= ~((cx >> 2) & (cx >> 1) & cx) & LOW;          // class 7 = padding
             sy &= ~((cy >> 2) & (cy >> 1) & cy) & LOW;
-            // gather bits 0,4,...,28 into bits 0..7: multiply so that bit 4k lands on bit 28+k... use the classic 3-step fold
-            auto squeeze = [](uint32_t s) -> uint32_t {
-                s = (s | s >> 3) & 0x03030303u;     // pairs
-                s = (s | s >> 6) & 0x000f000fu;     // nibbles
-                s = (s | s >> 12) & 0x000000ffu;    // byte
+            auto squeeze = [](uint32_t s) -> uint32_t {        // bits 0, 4, ..., 28 -> bits 0..7
+                s = (s | s >> 3) & 0x03030303u;
+                s = (s | s >> 6) & 0x000f000fu;
+                s = (s | s >> 12) & 0x000000ffu;
                 return s;
             };
             smask = squeeze(sx) | squeeze(sy) << 8;
+            // the 2-bit code of the byte before every position (an ambiguous base is stored as A, syncmer.c:316-321)
+            uint64_t x = (((uint64_t) cy << 32 | cx) << 4 | up) & 0x3333333333333333ULL;
+            x = (x | x >> 2) & 0x0f0f0f0f0f0f0f0fULL;
+            x = (x | x >> 4) & 0x00ff00ff00ff00ffULL;
+            x = (x | x >> 8) & 0x0000ffff0000ffffULL;
+            pf = (uint32_t) (x | x >> 16);
         }
         const uint32_t cnt = __builtin_popcount(smask);
         const int32_t lpos = smask? (int32_t) (b0 + 31 - __builtin_clz(smask)) : -1;
@@ -211,17 +285,15 @@ __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
             // hoco index of the run finished by the k-th start of this lane: (n + k) - 1; the very first start of a
             // read (position 0) finishes nothing.  Three out of four positions are starts and most runs are one base long, so
             // nothing here walks the sixteen positions:
-            //   codes  : the 2-bit code of the byte BEFORE every position, folded to sixteen fields, then the fields of the few
-            //            positions that are NOT starts are squeezed out (a loop over ~4 clear bits)
+            //   codes  : the fields of pf at finishing starts, squeezed together four positions at a time through the table
             //   lengths: the ring is all zero (min(rl, 256) - 1 of a one-base run); only starts whose previous byte is not a
             //            start finish a longer run (a loop over ~3 set bits)
-            const uint64_t cls64 = (uint64_t) cy << 32 | cx;
-            const uint64_t prevc = cls64 << 4 | up;                        // class of the byte before position b, nibble b
+            const uint64_t cls64 = (uint64_t) cy << 32 | cx;               // zero unless the lane took the table path
             uint32_t fin = smask;                                          // starts that finish a run
             if (b0 == 0) fin &= ~1u;
-            const uint32_t kfin = (uint32_t) __builtin_popcount(fin);
             uint32_t special = 0;
-            {   // an ambiguous byte (class 4) before a finishing start?
+            if (slow) {     // an ambiguous byte (class 4) before a finishing start?
+                const uint64_t prevc = cls64 << 4 | up;                    // class of the byte before position b, nibble b
                 const uint64_t is4 = (prevc >> 2) & ~(prevc >> 1) & ~prevc & 0x1111111111111111ULL;
                 uint64_t spread = fin;                                     // bit b -> bit 4 b
                 spread = (spread | spread << 24) & 0x000000ff000000ffULL;
@@ -230,22 +302,15 @@ __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
                 spread = (spread | spread << 3) & 0x1111111111111111ULL;
                 special = (is4 & spread) != 0;
             }
-            if (kfin) {
-                uint64_t x = prevc & 0x3333333333333333ULL;                // low two bits of every nibble -> sixteen 2-bit fields
-                x = (x | x >> 2) & 0x0f0f0f0f0f0f0f0fULL;
-                x = (x | x >> 4) & 0x00ff00ff00ff00ffULL;
-                x = (x | x >> 8) & 0x0000ffff0000ffffULL;
-                uint32_t f2 = (uint32_t) (x | x >> 16);
-                uint32_t drop = ~fin & 0xffffu;                            // squeeze out the fields of non-finishing positions, top down
-                while (drop) {
-                    const int z = 31 - __builtin_clz(drop);
-                    drop &= ~(1u << z);
-                    const uint32_t lowm = (1u << (2 * z)) - 1u;
-                    f2 = (f2 & lowm) | ((f2 >> 2) & ~lowm);
-                }
-                // first finished run in the top field: reverse the order of the sixteen fields
-                uint32_t rv = __builtin_bitreverse32(f2);
-                rv = ((rv >> 1) & 0x55555555u) | ((rv & 0x55555555u) << 1);
+            if (fin) {
+                // kept codes of positions 4j .. 4j+3 on top of a byte; the bytes butt together, the first finished run on top
+                const uint32_t t0b = sq[(fin & 0xFu) << 8 | (pf & 0xFFu)];
+                const uint32_t t1b = sq[(fin & 0xF0u) << 4 | ((pf >> 8) & 0xFFu)];
+                const uint32_t t2b = sq[(fin & 0xF00u) | ((pf >> 16) & 0xFFu)];
+                const uint32_t t3b = sq[(fin & 0xF000u) >> 4 | pf >> 24];
+                const uint32_t c1 = (uint32_t) __builtin_popcount(fin & 0xFu), c2 = (uint32_t) __builtin_popcount(fin & 0xFFu),
+                               c3 = (uint32_t) __builtin_popcount(fin & 0xFFFu);
+                const uint32_t rv = t0b << 24 | t1b << (24u - 2u * c1) | t2b << (24u - 2u * c2) | t3b << (24u - 2u * c3);
                 const uint32_t hfirst = n - 1u + (b0 == 0? 1u : 0u);
                 const uint32_t off = (hfirst & 15u) * 2u;
                 const uint64_t sh = ((uint64_t) rv << 32) >> off;
@@ -253,17 +318,23 @@ __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
                 const uint32_t hiw = (uint32_t) (sh >> 32), low = (uint32_t) sh;
                 if (hiw) atomicOr(&ring_hs[w0], hiw);
                 if (low) atomicOr(&ring_hs[(w0 + 1) & (HPC_RING / 16 - 1)], low);
-                // runs longer than one base: finishing starts whose previous byte is not a start
-                uint32_t lng = fin & ~(smask << 1 | (uint32_t) (ls == (int32_t) b0 - 1));
+                // the run that enters the lane from the left ends at the lane's first start: the only one that can be long
+                const uint32_t bf = (uint32_t) __builtin_ctz(smask);
+                if ((fin >> bf) & 1u) {
+                    const uint32_t rl = (uint32_t) ((int32_t) (b0 + bf) - ls);
+                    if (rl > 1u) {
+                        ring_rl[(n - 1u) & (HPC_RING - 1)] = (uint8_t) ((rl > 256u? 256u : rl) - 1u);
+                        special |= rl > 255u;
+                    }
+                }
+                // runs longer than one base inside the lane (2 .. 15): finishing starts whose previous byte is not a start
+                uint32_t lng = fin & ~(smask << 1) & ~(1u << bf);
                 while (lng) {
-                    const int b = __builtin_ctz(lng);
+                    const uint32_t b = (uint32_t) __builtin_ctz(lng);
                     lng &= lng - 1;
-                    const uint32_t below = smask & ((1u << b) - 1u);
-                    const int32_t prev = below? (int32_t) (b0 + 31 - __builtin_clz(below)) : ls;
-                    const uint32_t rl = (uint32_t) ((int32_t) (b0 + b) - prev);
+                    const uint32_t below = smask & ((1u << b) - 1u);       // never empty: the lane's first start is below b
                     const uint32_t h = n + (uint32_t) __builtin_popcount(below) - 1u;
-                    ring_rl[h & (HPC_RING - 1)] = (uint8_t) ((rl > 256u? 256u : rl) - 1u);
-                    special |= rl > 255u;
+                    ring_rl[h & (HPC_RING - 1)] = (uint8_t) (b + (uint32_t) __builtin_clz(below) - 32u);     // b - top(below) - 1
                 }
             }
             if (special) {                                             // ambiguous bases / very long runs: walk again, slowly

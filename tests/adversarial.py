@@ -84,6 +84,28 @@ def reads(K, S, seed=7, scale=1.0):
     return out
 
 
+def byte_soup(K, seed=5):
+    """every byte value next to every other: bytes that share their low bits or their case-folded form with a base ('!' 0x21,
+    0xC1, 'I', 'Q', 'W', 'E', 0x01 .. 0x03 which ARE bases in the reference's table), at every offset inside a 16-byte vector and
+    across vector, wave (1 KiB) and tile (4 KiB) boundaries; long stretches of clean bases in between so that k-mers exist"""
+    rng = np.random.default_rng(seed)
+    out = [bytes(rng.integers(0, 256, 3 * K + 100).astype(np.uint8).tolist())]
+    alias = bytes([0x21, 0xC1, 0x49, 0x51, 0x57, 0x45, 0x01, 0x02, 0x03, 0x00, 0x63, 0x67, 0x74, 0x75, 0x55, 0x81, 0xE1, 0xD4, 0x14, 0x07])
+    for step in (1, 7, 16, 17, 63, 64, 255, 1023, 1024, 1025, 4095, 4096, 4097):
+        r = bytearray(rand_dna(rng, 9000 + 2 * K, b"ACGTacgtU"))
+        for j, p in enumerate(range(step, len(r), max(step, 13) * 3 + 1)):
+            r[p] = alias[j % len(alias)]
+        out.append(bytes(r))
+    for pos in (0, 15, 16, 1023, 1024, 4095, 4096, 4097, 8191, 8192):        # one odd byte, clean everywhere else
+        for c in (0x4E, 0x01, 0xC1, 0x21):
+            r = bytearray(rand_dna(rng, 8300 + K))
+            r[pos] = c
+            out.append(bytes(r))
+    out.append(rand_dna(rng, 4096) + b"A" * 5000 + rand_dna(rng, K + 77))      # a run across a whole tile of clean lanes
+    out.append(rand_dna(rng, 1000) + b"C" * 300 + b"N" + b"C" * 300 + rand_dna(rng, K + 5))
+    return out
+
+
 def hifi_like(n_reads, genome_len, mean_len, seed=11, err=0.0005):
     """small numpy model of HiFi sampling used by the CPU-side tests (the product generator is oatk_amd.synth)"""
     rng = np.random.default_rng(seed)

@@ -35,6 +35,15 @@ def test_scan_adversarial(hip, K, S):
     compare_scan(got, want)
 
 
+@pytest.mark.parametrize("K,S", [(1001, 31), (101, 11)])
+def test_scan_byte_soup(hip, K, S):
+    """kernel A classifies clean 16-byte vectors without its table; every byte that could be mistaken for a base sends its vector
+    (and the one after it) to the table path -- at vector, wave and tile boundaries"""
+    reads = A.byte_soup(K)
+    got, _ = run_hip(hip, reads, K, S)
+    compare_scan(got, O.scan(reads, K, S, mode=0))
+
+
 @pytest.mark.parametrize("K,S", [(1001, 31), (101, 11), (25, 5)])
 def test_count_adversarial(hip, K, S):
     reads = A.reads(K, S) + A.hifi_like(60, 6000 if K < 1001 else 30000, 1500 if K < 1001 else 8000)
