@@ -130,18 +130,19 @@ __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
     for (uint32_t i = tid; i < HPC_RING / 16; i += HPC_NT) ring_rl4[i] = make_uint4(0, 0, 0, 0);      // runs of one base (most) never write their 0
     if (tid == 0) s_nn = 0, s_lrl = 0;
 
-    // move finished 64-position groups [g0, g1) from the LDS ring to HBM as 16-byte stores
+    // move finished 64-position groups [g0, g1) from the LDS ring to HBM as 16-byte stores: four vectors of run lengths per group
+    // (consecutive in the ring and in HBM alike), then one vector of codes per group; what leaves is zeroed for its next use
     auto flush = [&](uint32_t g0, uint32_t g1) {
-        uint32_t n_item = (g1 - g0) * 5u;
+        const uint32_t n_rl = (g1 - g0) * 4u, n_item = n_rl + (g1 - g0);
         for (uint32_t it = tid; it < n_item; it += HPC_NT) {
-            uint32_t g = g0 + it / 5u, q = it % 5u;
-            uint32_t hr = (g * 64u) & (HPC_RING - 1);
-            if (q < 4u) {
-                ((uint4 *) out_rl)[g * 4u + q] = ring_rl4[hr / 16u + q];
-                ring_rl4[hr / 16u + q] = make_uint4(0, 0, 0, 0);
+            if (it < n_rl) {
+                const uint32_t idx = g0 * 4u + it;
+                ((uint4 *) out_rl)[idx] = ring_rl4[idx & (HPC_RING / 16 - 1)];
+                ring_rl4[idx & (HPC_RING / 16 - 1)] = make_uint4(0, 0, 0, 0);
             } else {
-                uint4 v = ring_hs4[hr / 64u];
-                ring_hs4[hr / 64u] = make_uint4(0, 0, 0, 0);
+                const uint32_t g = g0 + (it - n_rl);
+                uint4 v = ring_hs4[g & (HPC_RING / 64 - 1)];
+                ring_hs4[g & (HPC_RING / 64 - 1)] = make_uint4(0, 0, 0, 0);
                 v.x = __builtin_bswap32(v.x), v.y = __builtin_bswap32(v.y), v.z = __builtin_bswap32(v.z), v.w = __builtin_bswap32(v.w);
                 ((uint4 *) out_hs)[g] = v;
             }
@@ -266,20 +267,22 @@ __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
         const int32_t imax = __ballot(lpos < 0)? wave_incl_max_dpp(lpos, lane) : lpos;
         if (lane == 63) w_cnt[wid] = icnt, w_max[wid] = imax;
         __syncthreads();
-        uint32_t n = nstart + icnt - cnt;
         int32_t ls = (int32_t) hpc_dpp<0x138>((uint32_t) -1, (uint32_t) imax);   // wave_shr:1 -> the previous lane's inclusive max
         if (lane == 0) ls = -1;
-        if (last_start > ls) ls = last_start;
-        uint32_t tot = 0;
-        int32_t tmax = last_start;
+        // the other waves' totals are the same for every lane: scalar registers and scalar arithmetic
+        const uint32_t swid = (uint32_t) __builtin_amdgcn_readfirstlane((int) wid);
+        uint32_t before = 0, tot = 0;
+        int32_t mbefore = last_start, tmax = last_start;
 #pragma unroll
         for (uint32_t ww = 0; ww < HPC_NT / OATK_WAVE; ++ww) {
-            const uint32_t c = w_cnt[ww];
-            const int32_t m = w_max[ww];
-            if (ww < wid) { n += c; ls = m > ls? m : ls; }
+            const uint32_t c = (uint32_t) __builtin_amdgcn_readfirstlane((int) w_cnt[ww]);
+            const int32_t m = __builtin_amdgcn_readfirstlane(w_max[ww]);
+            if (ww < swid) { before += c; mbefore = m > mbefore? m : mbefore; }
             tot += c;
             tmax = m > tmax? m : tmax;
         }
+        const uint32_t n = nstart + before + icnt - cnt;
+        if (mbefore > ls) ls = mbefore;
         // ---- a run is finished when the next one starts: this lane finishes one run per start it holds ----
         if (smask) {
             // hoco index of the run finished by the k-th start of this lane: (n + k) - 1; the very first start of a
