@@ -60,15 +60,15 @@ __device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t src)
 // inclusive prefix-min and suffix-min over the 64 lanes of a wave (lanes without a source keep their value)
 __device__ __forceinline__ void wave_prefix_suffix_min_u32(uint32_t v, uint32_t lane, uint32_t &pre, uint32_t &suf)
 {
-    uint32_t p = v, s = v, t;
-    t = dpp_u32<OATK_DPP_ROW_SHR(1)>(p, p); p = t < p? t : p;
-    t = dpp_u32<OATK_DPP_ROW_SHR(2)>(p, p); p = t < p? t : p;
-    t = dpp_u32<OATK_DPP_ROW_SHR(4)>(p, p); p = t < p? t : p;
-    t = dpp_u32<OATK_DPP_ROW_SHR(8)>(p, p); p = t < p? t : p;
-    t = dpp_u32<OATK_DPP_ROW_SHL(1)>(s, s); s = t < s? t : s;
-    t = dpp_u32<OATK_DPP_ROW_SHL(2)>(s, s); s = t < s? t : s;
-    t = dpp_u32<OATK_DPP_ROW_SHL(4)>(s, s); s = t < s? t : s;
-    t = dpp_u32<OATK_DPP_ROW_SHL(8)>(s, s); s = t < s? t : s;
+    uint32_t p = v, s = v, t;         // (old = the identity of min: the compiler folds shift and minimum into one v_min_u32_dpp)
+    t = dpp_u32<OATK_DPP_ROW_SHR(1)>(0xFFFFFFFFu, p); p = t < p? t : p;
+    t = dpp_u32<OATK_DPP_ROW_SHR(2)>(0xFFFFFFFFu, p); p = t < p? t : p;
+    t = dpp_u32<OATK_DPP_ROW_SHR(4)>(0xFFFFFFFFu, p); p = t < p? t : p;
+    t = dpp_u32<OATK_DPP_ROW_SHR(8)>(0xFFFFFFFFu, p); p = t < p? t : p;
+    t = dpp_u32<OATK_DPP_ROW_SHL(1)>(0xFFFFFFFFu, s); s = t < s? t : s;
+    t = dpp_u32<OATK_DPP_ROW_SHL(2)>(0xFFFFFFFFu, s); s = t < s? t : s;
+    t = dpp_u32<OATK_DPP_ROW_SHL(4)>(0xFFFFFFFFu, s); s = t < s? t : s;
+    t = dpp_u32<OATK_DPP_ROW_SHL(8)>(0xFFFFFFFFu, s); s = t < s? t : s;
     // row totals: prefix totals sit in lanes 15/31/47, suffix totals in lanes 16/32/48
     const uint32_t r15 = __builtin_amdgcn_readlane(p, 15), r31 = __builtin_amdgcn_readlane(p, 31), r47 = __builtin_amdgcn_readlane(p, 47);
     const uint32_t p2 = r31 < r15? r31 : r15, p3 = r47 < p2? r47 : p2;
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
         const uint32_t w2 = __builtin_bswap32(ghs[wi + 2]);            // the slab has slack behind the last read
         return sh? (hi << sh) | ((uint64_t) w2 >> (32u - sh)) : hi;
     };
-    auto write_record = [&](int32_t E, uint32_t kind, uint32_t loc, uint32_t ordn) {
+    auto write_record = [&](int32_t E, uint32_t kind, uint32_t loc, uint32_t ordn) __attribute__((always_inline)) {
         const int32_t e = kind == 2u? E - w : E, j = E - K + 1;        // Open: first s-mer; Close: last s-mer
         const uint64_t X = get64g(e - S + 1) & (~0ULL << (64 - 2 * S));
         const uint64_t fw = X >> (64 - 2 * S), rv = revcomp32(X) & mask;
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
         }
     };
     // the list -> records, all threads; the entries must be visible (a barrier since the last append).  One slot atomic per call.
-    auto emit_list = [&]() {
+    auto emit_list = [&]() __attribute__((always_inline)) {
         if (sl_n) {
             if (tid == 0) s_gb = atomicAdd(&a.shard_cnt[blockIdx.x & (OATK_REC_SHARDS - 1)], sl_n);
             __syncthreads();
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
     // one per wave and tile, and the k-mer codes are computed by 256 lanes at once instead of by lone lanes between two barriers.
     uint32_t pend_kinds = 0, pend_rank = 0, pend_wtot = 0, pend_par = 0, pend_any = 0;
     int32_t pend_i0 = 0;
-    auto flush = [&]() {                        // call after a barrier that follows the tile
+    auto flush = [&]() __attribute__((always_inline)) {      // call after a barrier that follows the tile
         if (!pend_any) return;
         uint32_t before = 0, tot = 0;
 #pragma unroll
@@ -189,7 +189,8 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
         pend_any = 0;
         if (tot == 0) return;
         if (sl_n + tot > (uint32_t) a.list_cap) emit_list();               // uniform: sl_n and tot are the same in every thread
-        if (tot > (uint32_t) a.list_cap) {                                  // a tile with more syncmers than the list holds: straight to records
+        const bool direct = tot > (uint32_t) a.list_cap;                    // a tile with more syncmers than the list holds: straight to records
+        if (direct) {
             if (tid == 0) s_gb = atomicAdd(&a.shard_cnt[blockIdx.x & (OATK_REC_SHARDS - 1)], tot);
             __syncthreads();
             uint32_t rank = before + pend_rank, kk = pend_kinds;
@@ -201,10 +202,7 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
                 ++rank;
             }
             __syncthreads();
-            ord0 += tot;
-            return;
-        }
-        if (pend_wtot) {
+        } else if (pend_wtot) {
             uint32_t idx = sl_n + before + pend_rank, kk = pend_kinds;
             while (kk) {
                 const int o = __builtin_ctz(kk) >> 1;
@@ -213,7 +211,10 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
                 ++idx;
             }
         }
-        sl_n += tot;
+        // (both counters move in straight-line code: two "+= tot" in sibling branches are merged by the compiler into one store
+        //  through a selected address, which pins the counters in scratch memory -- a vector-memory round trip per tile)
+        ord0 += direct? tot : 0u;
+        sl_n += direct? 0u : tot;
     };
 
     for (uint32_t I0 = 0; I0 < hl; I0 += T) {
@@ -386,10 +387,10 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
                     const uint32_t u = m_hi[2u * mi(pos) + 1u];
                     const uint32_t yhi = (uint32_t) __builtin_amdgcn_readlane((int) u, 32), fhi = (uint32_t) __builtin_amdgcn_readlane((int) u, 33);
                     uint32_t v = valid? u : 0xFFFFFFFFu, x;
-                    x = dpp_u32<OATK_DPP_ROW_SHR(1)>(v, v); v = x < v? x : v;
-                    x = dpp_u32<OATK_DPP_ROW_SHR(2)>(v, v); v = x < v? x : v;
-                    x = dpp_u32<OATK_DPP_ROW_SHR(4)>(v, v); v = x < v? x : v;
-                    x = dpp_u32<OATK_DPP_ROW_SHR(8)>(v, v); v = x < v? x : v;
+                    x = dpp_u32<OATK_DPP_ROW_SHR(1)>(0xFFFFFFFFu, v); v = x < v? x : v;
+                    x = dpp_u32<OATK_DPP_ROW_SHR(2)>(0xFFFFFFFFu, v); v = x < v? x : v;
+                    x = dpp_u32<OATK_DPP_ROW_SHR(4)>(0xFFFFFFFFu, v); v = x < v? x : v;
+                    x = dpp_u32<OATK_DPP_ROW_SHR(8)>(0xFFFFFFFFu, v); v = x < v? x : v;
                     const uint32_t cmin = (uint32_t) __builtin_amdgcn_readlane((int) v, 15), omin = (uint32_t) __builtin_amdgcn_readlane((int) v, 31);
                     const uint32_t fb = o + sh < C? cf0 : cf1;
                     bool cl = false, op = false, tie = false;
