@@ -235,7 +235,7 @@ int oatk_hip_debug_align_two_pass(oatk_hip_ctx *ctx, int on)
 int oatk_hip_debug_list_cap(oatk_hip_ctx *ctx, int cap)
 {
     if (!ctx) return OATK_E_NODEV;
-    if (cap < 0 || cap > oatk::SYF_LIST) { ctx->err = "oatk_hip_debug_list_cap: 0 <= cap <= 512"; return OATK_E_ARG; }
+    if (cap < 0 || cap > oatk::SYF_LIST) { ctx->err = "oatk_hip_debug_list_cap: 0 <= cap <= 128"; return OATK_E_ARG; }
     ctx->list_cap = cap;
     return OATK_OK;
 }

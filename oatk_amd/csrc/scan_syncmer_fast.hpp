@@ -34,7 +34,7 @@ constexpr int SYF_C = 8;                 // positions per lane per tile (one chu
 constexpr int SYF_T = SYN_NT * SYF_C;    // 2048 positions per tile
 constexpr int SYF_BLK = 64;              // chunks per wave = block of the prefix/suffix minima
 constexpr int SYF_SEG = 64;              // candidate slots per wave per round
-constexpr int SYF_LIST = 512;            // syncmers a read collects in LDS before they become records
+constexpr int SYF_LIST = 128;            // syncmers a read collects in LDS before they become records (a 15 kb read has ~25)
 
 // ring size (positions) the fast kernel needs for this K, or 0 if it does not apply
 static inline int syncmer_fast_ring(int K, int S)
@@ -91,12 +91,13 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
                   "workgroups per CU but its modulo arithmetic cost more issue slots than the occupancy returned)");
 
     __shared__ uint64_t m_ring[R + R / 32];     // s-mer hashes by END position; one pad slot per 32 against bank conflicts
-    __shared__ uint64_t cm_ring[NCH];           // chunk minima (64-bit, for the exact window minimum)
     __shared__ uint32_t pre32[NCH], suf32[NCH]; // per-wave-block inclusive prefix / suffix minima of the chunk minima's top 32 bits
     __shared__ uint32_t pb[PBW];                // packed bases, 16 per word, MSB-first
     __shared__ uint32_t w_cnt[2][NWAVE];         // syncmers per wave of a tile, double-buffered (two barriers per tile)
-    __shared__ uint32_t sl_e[SYF_LIST];          // syncmers of the read so far, in position order: k-mer end ...
-    __shared__ uint8_t sl_k[SYF_LIST];           // ... and kind (1 Close, 2 Open); written out when the read is done (or the list is full)
+    __shared__ uint32_t sl_e[SYF_LIST];          // syncmers of the read so far, in position order: k-mer end | kind << 30 (1 Close, 2 Open);
+                                                 // written out when the read is done (or the list is full)
+    // (LDS is what limits residency: 40.5 KB leave room for FOUR workgroups per CU.  The 64-bit chunk minima the tie path wants are
+    //  recomputed from the ring when a tie happens, the list is short, the kind rides in the top bits of the position.)
     __shared__ uint32_t s_gb;                    // record slots of the list being written out
 
     const uint32_t r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
     };
 
     for (uint32_t i = tid; i < R + R / 32; i += NT) m_ring[i] = UINT64_MAX;
-    for (uint32_t i = tid; i < NCH; i += NT) cm_ring[i] = UINT64_MAX, pre32[i] = suf32[i] = 0xFFFFFFFFu;
+    for (uint32_t i = tid; i < NCH; i += NT) pre32[i] = suf32[i] = 0xFFFFFFFFu;
     for (uint32_t i = tid; i < PBW; i += NT) pb[i] = 0;
     __syncthreads();
     load_bases(0);
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
 
     uint32_t ord0 = 0, par = 0;                 // syncmers already turned into records; parity of the count buffer
     uint32_t sl_n = 0;                          // syncmers in the list (the same value in every thread)
+    const uint32_t lcap = hl < (1u << 30)? (uint32_t) a.list_cap : 0u;       // (list entries keep the kind above bit 29)
     const int HW = (w & (C - 1)) + C;           // window positions not covered by D whole chunks: w - C * D
 
     // s-mer code of a record from the read's packed bases in HBM (the LDS base ring only holds the last tiles)
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
             if (tid == 0) s_gb = atomicAdd(&a.shard_cnt[blockIdx.x & (OATK_REC_SHARDS - 1)], sl_n);
             __syncthreads();
             const uint32_t gb = s_gb;
-            for (uint32_t i = tid; i < sl_n; i += NT) write_record((int32_t) sl_e[i], sl_k[i], gb + i, ord0 + i);
+            for (uint32_t i = tid; i < sl_n; i += NT) write_record((int32_t) (sl_e[i] & 0x3FFFFFFFu), sl_e[i] >> 30, gb + i, ord0 + i);
             __syncthreads();                    // the list may be refilled, s_gb rewritten
         }
         ord0 += sl_n, sl_n = 0;
@@ -188,8 +190,8 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
         for (int ww = 0; ww < NWAVE; ++ww) { const uint32_t c = w_cnt[pend_par][ww]; tot += c; before += ww < (int) wid? c : 0u; }
         pend_any = 0;
         if (tot == 0) return;
-        if (sl_n + tot > (uint32_t) a.list_cap) emit_list();               // uniform: sl_n and tot are the same in every thread
-        const bool direct = tot > (uint32_t) a.list_cap;                    // a tile with more syncmers than the list holds: straight to records
+        if (sl_n + tot > lcap) emit_list();               // uniform: sl_n and tot are the same in every thread
+        const bool direct = tot > lcap;                    // a tile with more syncmers than the list holds: straight to records
         if (direct) {
             if (tid == 0) s_gb = atomicAdd(&a.shard_cnt[blockIdx.x & (OATK_REC_SHARDS - 1)], tot);
             __syncthreads();
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
             uint32_t idx = sl_n + before + pend_rank, kk = pend_kinds;
             while (kk) {
                 const int o = __builtin_ctz(kk) >> 1;
-                sl_e[idx] = (uint32_t) (pend_i0 + o), sl_k[idx] = (uint8_t) ((pend_kinds >> (2 * o)) & 3u);
+                sl_e[idx] = (uint32_t) (pend_i0 + o) | ((pend_kinds >> (2 * o)) & 3u) << 30;
                 kk &= ~(3u << (2 * o));
                 ++idx;
             }
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
             const uint64_t vb = (uint64_t) vbh << 32;
             uint64_t X = get64(i0 - S) & (~0ULL << (64 - 2 * S));
             uint64_t fw = X >> (64 - 2 * S), rv = revcomp32(X) & mask;
-            uint64_t cmin = UINT64_MAX;
+            uint32_t cmin = 0xFFFFFFFFu;                // top word of the chunk minimum: all the filter looks at
             const uint32_t mbase = mi(i0);              // 8 consecutive positions never straddle a pad slot
             if (i0 + 1 >= S && (uint32_t) (i0 + C) <= hl) {
 #pragma unroll
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
                     // (S31: an odd-length s-mer is never its own reverse complement, so no fw != rv test)
                     uint64_t mv = (S31 || fw != rv)? hash64(fw < rv? fw : rv, mask) : UINT64_MAX;
                     y[b] = mv;
-                    cmin = mv < cmin? mv : cmin;
+                    cmin = (uint32_t) (mv >> 32) < cmin? (uint32_t) (mv >> 32) : cmin;
                 }
             } else {                                    // first / last chunk of the read
 #pragma unroll
@@ -250,19 +252,19 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
                     uint64_t mv = UINT64_MAX;
                     if (i + 1 >= S && (uint32_t) i < hl && fw != rv) mv = hash64(fw < rv? fw : rv, mask);
                     y[b] = mv;
-                    cmin = mv < cmin? mv : cmin;
+                    cmin = (uint32_t) (mv >> 32) < cmin? (uint32_t) (mv >> 32) : cmin;
                 }
             }
             uint32_t pre, suf;
 #ifdef OATK_SCAN_SHFL
-            pre = suf = (uint32_t) (cmin >> 32);
+            pre = suf = cmin;
             for (int d = 1; d < OATK_WAVE; d <<= 1) {
                 uint32_t up = __shfl_up(pre, d), dn = __shfl_down(suf, d);
                 if ((int) lane >= d) pre = up < pre? up : pre;
                 if ((int) lane + d < OATK_WAVE) suf = dn < suf? dn : suf;
             }
 #else
-            wave_prefix_suffix_min_u32((uint32_t) (cmin >> 32), lane, pre, suf);
+            wave_prefix_suffix_min_u32(cmin, lane, pre, suf);
 #endif
             // everything above lives in registers: a wave that is done with the previous tile hashes ahead while the others
             // still read that tile's windows from the ring.  Ring slots are only overwritten behind this barrier.
@@ -270,7 +272,6 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
 #pragma unroll
             for (int b = 0; b < C; ++b) m_ring[mbase + b] = y[b];
             const uint32_t cs = rch(ch);
-            cm_ring[cs] = cmin;
             pre32[cs] = pre;
             suf32[cs] = suf;
         }
@@ -325,37 +326,6 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
         //      and Open.  Top words that TIE (~2^-28 per candidate on random sequence, common inside low-complexity repeats) send
         //      the position to the full 64-bit rule. ----
         uint32_t kinds = 0;                             // 2 bits per position of the chunk: 0 none, 1 Close, 2 Open
-        // the rule in full for one position (scan_syncmer.hpp states it; window = [E - w, E - 1]); rare
-        auto exact64 = [&](int o) -> uint32_t {
-                const int sh = SH >= 0? SH : ((-w) & (C - 1));
-                const uint32_t backF = backF_keep;
-                auto chunks_min = [&](int32_t c0, int32_t c1) -> uint64_t {
-                    uint64_t v = UINT64_MAX;
-                    for (int32_t cc = c0; cc <= c1; ++cc) { const uint64_t u = cm_ring[rch(cc)]; v = u < v? u : v; }
-                    return v;
-                };
-                const int32_t E = i0 + o, lo = E - w;
-                const uint64_t yy = m_ring[mi(E)], f = m_ring[mi(lo)], x = m_ring[mi(lo - 1)];
-                const uint32_t yhi = (uint32_t) (yy >> 32), fhi = (uint32_t) (f >> 32);
-                const uint32_t fb = o + sh < C? fwd0_keep : fwd1_keep;
-                bool cl = false, op = false;
-                if (yhi <= backF) {                     // Close: window = head [lo, lo + HW - o) + D chunks before `ch` + tail [i0, E)
-                    uint64_t b = UINT64_MAX;
-                    for (int t = 0; t < HW - o; ++t) { const uint64_t u = m_ring[mi(lo + t)]; b = u < b? u : b; }
-                    for (int t = 0; t < o; ++t) { const uint64_t u = m_ring[mi(i0 + t)]; b = u < b? u : b; }
-                    if (yhi == backF) { const uint64_t u = chunks_min(ch - D, ch - 1); b = u < b? u : b; }
-                    cl = yy != UINT64_MAX && (yy < b || (yy == b && (x >= b || f == b)));
-                }
-                if (fhi <= fb && fhi <= yhi) {          // Open: f must not exceed anything else in the window
-                    const int32_t ca = lo >> 3, tail0 = (ca + 1 + D) * C;
-                    uint64_t b = UINT64_MAX;
-                    for (int32_t q = lo + 1; q < (ca + 1) * C; ++q) { const uint64_t u = m_ring[mi(q)]; b = u < b? u : b; }
-                    for (int32_t q = tail0; q < E; ++q) { const uint64_t u = m_ring[mi(q)]; b = u < b? u : b; }
-                    if (fhi == fb) { const uint64_t u = chunks_min(ca + 1, ca + D); b = u < b? u : b; }
-                    op = f != UINT64_MAX && f <= b && f <= yy;
-                }
-                return cl && op? 0u : (cl? 1u : (op? 2u : 0u));
-        };
         // The wave decides its candidates TOGETHER, one after the other (there is about one per wave and tile): lanes 0-15 fetch the
         // ragged positions of the Close window, lanes 16-31 those of the Open window, lanes 32 / 33 the two hashes in question -- one
         // LDS read per lane, one row-wise DPP min, and the rest is scalar.  (A lone lane walking the same thirty positions cost the
@@ -408,12 +378,60 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
                 if ((int) lane == L) kinds = res, tiemask = ties;
             }
         }
-        if (tiemask) {                                  // top words tied: the full 64-bit rule, by the lane itself (rare)
+        // Top words tied: ~2^-28 per candidate on random sequence, but the rule rather than the exception inside tandem repeats
+        // (telomeres, microsatellites), where the window minimum comes back every period and every lane of the wave holds ties.
+        // Those are decided lane by lane on 64-bit hashes, and what makes that affordable is one 64-bit minimum per chunk: the wave
+        // computes them for the 192 chunks around its own when it meets its first tie (three per lane) and parks them in ring slots
+        // that nobody reads any more -- positions older than every window of this tile, which the next tile overwrites anyway.
+        // (Kept resident they would cost 4 KB of LDS and with it the fourth workgroup per CU.)
+        if (__ballot(tiemask != 0)) {
+            static_assert(R - T - 1040 >= NWAVE * 192, "room for the parked chunk minima behind the oldest window");
+            const int sh = SH >= 0? SH : ((-w) & (C - 1));
+            const int32_t cw0 = (int32_t) (I0 >> 3) + (int32_t) __builtin_amdgcn_readfirstlane((int) wid) * OATK_WAVE;   // the wave's first chunk
+            const int32_t sp = (int32_t) I0 + T - R + (int32_t) __builtin_amdgcn_readfirstlane((int) wid) * 192;       // parked: chunk cw0 - 128 + j at position sp + j
+            {
+                uint64_t ma = UINT64_MAX, mb = UINT64_MAX, mc = UINT64_MAX;
+                const int32_t pa = (cw0 - 128 + (int32_t) lane) * C, pbb = (cw0 - 64 + (int32_t) lane) * C;
+#pragma unroll
+                for (int t = 0; t < C; ++t) {
+                    const uint64_t ua = m_ring[mi(pa + t)], ub = m_ring[mi(pbb + t)];
+                    ma = ua < ma? ua : ma, mb = ub < mb? ub : mb, mc = y[t] < mc? y[t] : mc;
+                }
+                m_ring[mi(sp + (int32_t) lane)] = ma, m_ring[mi(sp + 64 + (int32_t) lane)] = mb, m_ring[mi(sp + 128 + (int32_t) lane)] = mc;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            auto chunks_min = [&](int32_t c0, int32_t c1) -> uint64_t {
+                uint64_t v = UINT64_MAX;
+                for (int32_t cc = c0; cc <= c1; ++cc) { const uint64_t u = m_ring[mi(sp + (cc - (cw0 - 128)))]; v = u < v? u : v; }
+                return v;
+            };
             uint32_t tm = tiemask;
-            while (tm) {
+            while (tm) {                                // the rule in full for one position (scan_syncmer.hpp states it; window = [E - w, E - 1])
                 const int o = __builtin_ctz(tm);
                 tm &= tm - 1;
-                kinds |= exact64(o) << (2 * o);
+                const int32_t E = i0 + o, lo = E - w;
+                const uint64_t yy = m_ring[mi(E)], f = m_ring[mi(lo)], x = m_ring[mi(lo - 1)];
+                const uint32_t yhi = (uint32_t) (yy >> 32), fhi = (uint32_t) (f >> 32);
+                const uint32_t fb = o + sh < C? fwd0_keep : fwd1_keep;
+                bool cl = false, op = false;
+                if (yhi <= backF_keep) {                // Close: window = head [lo, lo + HW - o) + D chunks before `ch` + tail [i0, E)
+                    uint64_t b = UINT64_MAX;
+                    for (int t = 0; t < HW - o; ++t) { const uint64_t u = m_ring[mi(lo + t)]; b = u < b? u : b; }
+                    for (int t = 0; t < o; ++t) { const uint64_t u = m_ring[mi(i0 + t)]; b = u < b? u : b; }
+                    if (yhi == backF_keep) { const uint64_t u = chunks_min(ch - D, ch - 1); b = u < b? u : b; }
+                    cl = yy != UINT64_MAX && (yy < b || (yy == b && (x >= b || f == b)));
+                }
+                if (fhi <= fb && fhi <= yhi) {          // Open: f must not exceed anything else in the window
+                    const int32_t ca = lo >> 3, tail0 = (ca + 1 + D) * C;
+                    uint64_t b = UINT64_MAX;
+                    for (int32_t q = lo + 1; q < (ca + 1) * C; ++q) { const uint64_t u = m_ring[mi(q)]; b = u < b? u : b; }
+                    for (int32_t q = tail0; q < E; ++q) { const uint64_t u = m_ring[mi(q)]; b = u < b? u : b; }
+                    if (fhi == fb) { const uint64_t u = chunks_min(ca + 1, ca + D); b = u < b? u : b; }
+                    op = f != UINT64_MAX && f <= b && f <= yy;
+                }
+                kinds |= (cl && op? 0u : (cl? 1u : (op? 2u : 0u))) << (2 * o);
             }
         }
         // ---- syncmers -> records, every wave its own.  Two things are only known a little later and neither is waited for:

@@ -152,7 +152,7 @@ def test_fast_kernel_record_list_overflows(hip, cap):
         hip.debug_list_cap(0)
     compare_scan(got, want)
     with pytest.raises(RuntimeError):
-        hip.debug_list_cap(513)
+        hip.debug_list_cap(129)
 
 
 @pytest.mark.parametrize("K,S", [(550, 31), (1500, 21), (1976, 31), (1977, 31)])
