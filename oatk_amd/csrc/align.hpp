@@ -102,26 +102,29 @@ template <bool WR>
 __device__ inline bool ra_backtrace(const RaArgs &a, uint16_t *st_mem, const RaFrgs &G, uint32_t nf, int64_t max_score, uint64_t n, uint64_t r,
                                     uint32_t tot_a, uint64_t wa, uint64_t wf, uint64_t f_base, uint32_t &n_a, uint32_t &n_fr)
 {
-    // the walk's stack lives in LDS (st_mem, 2 * RA_DEPTH * 256 entries per workgroup), one column per lane: an array in registers indexed by a per-lane depth turns every access into a
-    // loop over all its elements (measured: the walk took three times as long as everything before it)
+    // the walk's stack lives in LDS (st_mem, RA_DEPTH * 256 entries per workgroup), one column per lane: an array in registers indexed by a per-lane depth turns every access into a
+    // loop over all its elements (measured: the walk took three times as long as everything before it).  An entry is the fragment
+    // (< RA_MAXF = 128) in its low byte and the next predecessor to visit (<= RA_PREV) above it: 24 KB per workgroup, so that registers, not
+    // LDS, decide how many of the 782 workgroups of 200 k reads are resident at once (all of them at four waves per SIMD).
+    static_assert(RA_MAXF <= 256 && RA_PREV < 256, "stack entry: fragment in the low byte, child counter in the high byte");
     struct Col { uint16_t *p; __device__ uint16_t &operator[](int i) const { return p[i * 256]; } };
-    const Col st_node = {st_mem + threadIdx.x}, st_child = {st_mem + RA_DEPTH * 256 + threadIdx.x};
+    const Col st = {st_mem + threadIdx.x};
     n_a = 0, n_fr = 0;
     for (uint32_t j = 0; j < nf; ++j) {
         if (G.score[j] < max_score) continue;
         int d = 0;
-        st_node[0] = (uint16_t) j, st_child[0] = 0;
+        st[0] = (uint16_t) j;
         while (d >= 0) {
-            const uint32_t f = st_node[d];
+            const uint32_t e = st[d], f = e & 0xFFu, child = e >> 8;
             const uint32_t pn = G.prev_n[f];
-            if (pn == 0) {                                                         // a chain is complete: its fragments are st_node[d .. 0]
+            if (pn == 0) {                                                         // a chain is complete: its fragments are st[d .. 0]
                 uint64_t s = 0;
-                for (int t = d; t >= 0; --t) s += G.s_cnt[st_node[t]];
+                for (int t = d; t >= 0; --t) s += G.s_cnt[st[t] & 0xFFu];
                 if (!((double) s / (double) n < 0.9)) {                            // min_a_frac (:161, :547)
                     if (WR) {
                         a.o_sid[wa] = (uint32_t) r, a.o_off[wa] = wf - f_base, a.o_s[wa] = 1.0 / (double) tot_a + (double) max_score;
                         for (int t = d; t >= 0; --t, ++wf) {
-                            const uint32_t q = st_node[t];
+                            const uint32_t q = st[t] & 0xFFu;
                             a.o_uid[wf] = G.uid[q], a.o_ubeg[wf] = G.u_beg[q], a.o_uend[wf] = G.u_end[q], a.o_sbeg[wf] = G.s_beg[q], a.o_send[wf] = G.s_end[q];
                         }
                         ++wa;
@@ -129,11 +132,12 @@ __device__ inline bool ra_backtrace(const RaArgs &a, uint16_t *st_mem, const RaF
                     ++n_a, n_fr += (uint32_t) d + 1;
                 }
                 --d;
-            } else if (st_child[d] < pn) {
+            } else if (child < pn) {
                 if (d + 1 == RA_DEPTH) return true;
-                const uint16_t c = G.prev[f * RA_PREV + st_child[d]++];
+                const uint16_t c = G.prev[f * RA_PREV + child];
+                st[d] = (uint16_t) (e + 0x100u);
                 ++d;
-                st_node[d] = c, st_child[d] = 0;
+                st[d] = c;
             } else --d;
         }
     }
@@ -290,11 +294,11 @@ __device__ inline int ra_prepare(const RaArgs &a, uint64_t r, const RaWork &w, u
 //      handed out per WAVE -- the lanes' needs are summed with DPP and one lane asks -- because 200 k lanes asking one by one serialise
 //      on the two counters (measured: as long as the whole routine again).
 template <int MODE>
-__global__ __launch_bounds__(256) void ra_kernel(RaArgs a)
+__global__ __launch_bounds__(256, 4) void ra_kernel(RaArgs a)
 {
     const uint64_t tid = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x, nthr = (uint64_t) gridDim.x * blockDim.x;
     const uint32_t lane = threadIdx.x & 63u;
-    __shared__ uint16_t st_mem[2 * RA_DEPTH * 256];
+    __shared__ uint16_t st_mem[RA_DEPTH * 256];
     const RaWork w = ra_work(a.slab, tid, nthr);
     for (uint64_t base = tid - lane; base < a.n_reads; base += nthr) {                 // the same trip count in every lane of a wave
         const uint64_t r = base + lane;
