@@ -219,7 +219,29 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
         sl_n += direct? 0u : tot;
     };
 
-    for (uint32_t I0 = 0; I0 < hl; I0 += T) {
+    // Ring addresses.  A tile advances every lane by T positions = HALF the ring (and half the chunk ring), so each address a lane
+    // uses alternates between two values: a chunk-ring byte offset flips one bit, a hash-ring index is mirrored in the sum of its two
+    // values (the pad slots make it more than a bit flip).  Twelve registers updated by one instruction each per tile instead of
+    // ~40 instructions of shifts, masks and adds; which ranges hold a whole block in their middle does not change at all.
+    static_assert(2 * T == R, "the address toggling below needs tile = half the ring");
+    struct RangeAddr { uint32_t lo, hi, mid; bool whole; };
+    auto range_addr = [&](int32_t lo, int32_t hi) -> RangeAddr {
+        return RangeAddr{rch(lo) * 4u, rch(hi) * 4u, rch(((lo >> 6) + 1) * 64 + 63) * 4u, (hi >> 6) - (lo >> 6) == 2};
+    };
+    const int32_t ch_0 = (int32_t) tid, ca0_0 = ((int32_t) (tid * C) - w) >> 3;       // tile 0: the lane's chunk, the chunk of its first window start
+    RangeAddr rB = range_addr(ch_0 - D, ch_0 - 1), rF0 = range_addr(ca0_0 + 1, ca0_0 + D), rF1 = range_addr(ca0_0 + 2, ca0_0 + 1 + D);
+    uint32_t o_cs = rch(ch_0) * 4u;
+    uint32_t m_own = mi((int32_t) (tid * C)), m_fa = mi(ca0_0 * C), m_fb = mi((ca0_0 + 1) * C);
+    const uint32_t m_own_sum = m_own + mi((int32_t) (tid * C) + T), m_fa_sum = m_fa + mi(ca0_0 * C + T), m_fb_sum = m_fb + mi((ca0_0 + 1) * C + T);
+    auto next_tile_addr = [&]() __attribute__((always_inline)) {
+        constexpr uint32_t FLIP = (uint32_t) (NCH / 2) * 4u;
+        o_cs ^= FLIP;
+        rB.lo ^= FLIP, rB.hi ^= FLIP, rB.mid ^= FLIP, rF0.lo ^= FLIP, rF0.hi ^= FLIP, rF0.mid ^= FLIP, rF1.lo ^= FLIP, rF1.hi ^= FLIP, rF1.mid ^= FLIP;
+        m_own = m_own_sum - m_own, m_fa = m_fa_sum - m_fa, m_fb = m_fb_sum - m_fb;
+    };
+    auto ld32 = [](const uint32_t *base, uint32_t byte_off) -> uint32_t { return *(const uint32_t *) ((const char *) base + byte_off); };
+
+    for (uint32_t I0 = 0; I0 < hl; I0 += T, next_tile_addr()) {
         // ---- P1: s-mer hashes of this lane's chunk, chunk minimum, wave prefix/suffix minima ----
         const int32_t i0 = (int32_t) (I0 + tid * C);
         const int32_t ch = i0 / C;                      // chunk index; ch % 64 == lane
@@ -230,7 +252,7 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
             uint64_t X = get64(i0 - S) & (~0ULL << (64 - 2 * S));
             uint64_t fw = X >> (64 - 2 * S), rv = revcomp32(X) & mask;
             uint32_t cmin = 0xFFFFFFFFu;                // top word of the chunk minimum: all the filter looks at
-            const uint32_t mbase = mi(i0);              // 8 consecutive positions never straddle a pad slot
+            const uint32_t mbase = m_own;               // = mi(i0); 8 consecutive positions never straddle a pad slot
             if (i0 + 1 >= S && (uint32_t) (i0 + C) <= hl) {
 #pragma unroll
                 for (int b = 0; b < C; ++b) {
@@ -271,9 +293,8 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
             __syncthreads();
 #pragma unroll
             for (int b = 0; b < C; ++b) m_ring[mbase + b] = y[b];
-            const uint32_t cs = rch(ch);
-            pre32[cs] = pre;
-            suf32[cs] = suf;
+            *(uint32_t *) ((char *) pre32 + o_cs) = pre;
+            *(uint32_t *) ((char *) suf32 + o_cs) = suf;
         }
         if (I0 + T < hl) load_bases(I0 + T);            // next tile's bases ride on this barrier
         __syncthreads();
@@ -285,21 +306,21 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
             // minimum of the chunk minima over chunks [lo, hi], hi - lo = D - 1: suffix of lo's block, prefix of hi's block and,
             // when the two are not adjacent, the one whole block between them.  Chunks before the read map to ring slots that
             // still hold the initial MAX, which is exactly "no constraint".
-            auto range_min = [&](int32_t lo, int32_t hi) -> uint32_t {
-                const uint32_t a0 = suf32[rch(lo)], a1 = pre32[rch(hi)];
-                const uint32_t mid = pre32[rch(((lo >> 6) + 1) * 64 + 63)];
-                const uint32_t a2 = (hi >> 6) - (lo >> 6) == 2? mid : 0xFFFFFFFFu;
+            auto range_min = [&](const RangeAddr &ra) -> uint32_t {
+                const uint32_t a0 = ld32(suf32, ra.lo), a1 = ld32(pre32, ra.hi);
+                const uint32_t mid = ld32(pre32, ra.mid);
+                const uint32_t a2 = ra.whole? mid : 0xFFFFFFFFu;
                 const uint32_t v = a0 < a1? a0 : a1;
                 return a2 < v? a2 : v;
             };
             const int32_t a_first = i0 - w;             // first s-mer of the k-mer that ends at i0
             const int32_t ca0 = a_first >> 3;
             const int sh = SH >= 0? SH : ((-w) & (C - 1));   // = a_first & 7, the same for every lane
-            const uint32_t backF = range_min(ch - D, ch - 1);            // Close bound
-            const uint32_t fwd0 = range_min(ca0 + 1, ca0 + D);           // Open bound, first s-mers ending in chunk ca0
-            const uint32_t fwd1 = range_min(ca0 + 2, ca0 + 1 + D);       // ... and in chunk ca0 + 1
+            const uint32_t backF = range_min(rB);            // Close bound: chunks [ch - D, ch - 1]
+            const uint32_t fwd0 = range_min(rF0);            // Open bound, first s-mers ending in chunk ca0: chunks [ca0 + 1, ca0 + D]
+            const uint32_t fwd1 = range_min(rF1);            // ... and in chunk ca0 + 1: chunks [ca0 + 2, ca0 + 1 + D]
             // the eight first s-mers sit in chunks ca0 (from offset sh) and ca0 + 1: two base addresses, constant offsets
-            const uint32_t bA = 2u * mi(ca0 * C) + 1u, bB = 2u * mi((ca0 + 1) * C) + 1u;
+            const uint32_t bA = 2u * m_fa + 1u, bB = 2u * m_fb + 1u;
             backF_keep = backF, fwd0_keep = fwd0, fwd1_keep = fwd1;
             uint32_t hit = 0;
 #pragma unroll
