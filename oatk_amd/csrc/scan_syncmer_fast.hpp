@@ -356,6 +356,40 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
             const int sh = SH >= 0? SH : ((-w) & (C - 1));
             const uint32_t wbase = I0 + (uint32_t) __builtin_amdgcn_readfirstlane((int) wid) * (OATK_WAVE * C);
             uint64_t cand = __ballot(cmask != 0);
+            if (__builtin_popcountll(cand) > 4) {
+                // Many lanes with candidates: not random sequence (there it is one lane per wave and tile) but a tandem repeat, where the
+                // window minimum returns every period.  Taking turns would cost the wave ~60 issue slots per candidate; here every lane
+                // walks the ragged ends of its own windows -- the same arithmetic, all lanes at once.
+                cand = 0;
+                uint32_t mm = cmask, res = 0, ties = 0;
+                const int32_t ci0 = i0;
+                while (mm) {
+                    const int o = __builtin_ctz(mm);
+                    mm &= mm - 1;
+                    const int32_t E = ci0 + o, lo = E - w;
+                    const int32_t ca = lo >> 3, n1 = (ca + 1) * C - lo - 1, tail0 = (ca + 1 + D) * C, n2 = E - tail0;
+                    const uint32_t yhi = m_hi[2u * mi(E) + 1u], fhi = m_hi[2u * mi(lo) + 1u];
+                    const uint32_t fb = o + sh < C? fwd0_keep : fwd1_keep;
+                    bool cl = false, op = false, tie = false;
+                    if (yhi <= backF_keep) {                                             // Close: head [lo, lo + HW - o) + tail [i0, E)
+                        uint32_t cmin = 0xFFFFFFFFu;
+                        for (int32_t t = 0; t < HW - o; ++t) { const uint32_t u = m_hi[2u * mi(lo + t) + 1u]; cmin = u < cmin? u : cmin; }
+                        for (int32_t t = 0; t < o; ++t) { const uint32_t u = m_hi[2u * mi(ci0 + t) + 1u]; cmin = u < cmin? u : cmin; }
+                        const uint32_t bh = cmin < backF_keep? cmin : backF_keep;
+                        cl = yhi < bh, tie = yhi == bh;
+                    }
+                    if (fhi <= fb && fhi <= yhi) {                                       // Open: rest of f's chunk + [tail0, E)
+                        uint32_t omin = 0xFFFFFFFFu;
+                        for (int32_t t = 0; t < n1; ++t) { const uint32_t u = m_hi[2u * mi(lo + 1 + t) + 1u]; omin = u < omin? u : omin; }
+                        for (int32_t t = 0; t < n2; ++t) { const uint32_t u = m_hi[2u * mi(tail0 + t) + 1u]; omin = u < omin? u : omin; }
+                        const uint32_t rh = omin < fb? omin : fb;
+                        op = fhi < rh && fhi < yhi, tie |= fhi <= rh && !op;
+                    }
+                    ties |= (uint32_t) tie << o;
+                    res |= (tie? 0u : (cl && op? 0u : (cl? 1u : (op? 2u : 0u)))) << (2 * o);
+                }
+                kinds = res, tiemask = ties;
+            }
             while (cand) {
                 const int L = __builtin_ctzll(cand);
                 cand &= cand - 1;
@@ -423,11 +457,18 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
-            auto chunks_min = [&](int32_t c0, int32_t c1) -> uint64_t {
-                uint64_t v = UINT64_MAX;
-                for (int32_t cc = c0; cc <= c1; ++cc) { const uint64_t u = m_ring[mi(sp + (cc - (cw0 - 128)))]; v = u < v? u : v; }
-                return v;
-            };
+            // The whole chunks inside the windows of a lane's eight positions are only TWO ranges, [ca0 + 1, ca0 + D] and
+            // [ca0 + 2, ca0 + 1 + D] (ca0: the chunk the first window starts in), and the Close range [ch - D, ch - 1] is one of them:
+            // one walk over their common part serves every tie of the lane (in a repeat of period 2 that is four ties, eight ranges).
+            uint64_t r0 = UINT64_MAX, r1 = UINT64_MAX;
+            if (tiemask) {
+                const int32_t ca0 = (i0 - w) >> 3, pk = sp - (cw0 - 128);
+                uint64_t mid = UINT64_MAX;
+                for (int32_t cc = ca0 + 2; cc <= ca0 + D; ++cc) { const uint64_t u = m_ring[mi(pk + cc)]; mid = u < mid? u : mid; }
+                const uint64_t e0 = m_ring[mi(pk + ca0 + 1)], e1 = m_ring[mi(pk + ca0 + 1 + D)];
+                r0 = e0 < mid? e0 : mid, r1 = e1 < mid? e1 : mid;
+            }
+            const uint64_t r_close = (w & (C - 1))? r1 : r0;                // ch - D = ca0 + 2 unless w is a multiple of 8
             uint32_t tm = tiemask;
             while (tm) {                                // the rule in full for one position (scan_syncmer.hpp states it; window = [E - w, E - 1])
                 const int o = __builtin_ctz(tm);
@@ -441,7 +482,7 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
                     uint64_t b = UINT64_MAX;
                     for (int t = 0; t < HW - o; ++t) { const uint64_t u = m_ring[mi(lo + t)]; b = u < b? u : b; }
                     for (int t = 0; t < o; ++t) { const uint64_t u = m_ring[mi(i0 + t)]; b = u < b? u : b; }
-                    if (yhi == backF_keep) { const uint64_t u = chunks_min(ch - D, ch - 1); b = u < b? u : b; }
+                    if (yhi == backF_keep) b = r_close < b? r_close : b;
                     cl = yy != UINT64_MAX && (yy < b || (yy == b && (x >= b || f == b)));
                 }
                 if (fhi <= fb && fhi <= yhi) {          // Open: f must not exceed anything else in the window
@@ -449,7 +490,7 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
                     uint64_t b = UINT64_MAX;
                     for (int32_t q = lo + 1; q < (ca + 1) * C; ++q) { const uint64_t u = m_ring[mi(q)]; b = u < b? u : b; }
                     for (int32_t q = tail0; q < E; ++q) { const uint64_t u = m_ring[mi(q)]; b = u < b? u : b; }
-                    if (fhi == fb) { const uint64_t u = chunks_min(ca + 1, ca + D); b = u < b? u : b; }
+                    if (fhi == fb) { const uint64_t u = ca == ((i0 - w) >> 3)? r0 : r1; b = u < b? u : b; }
                     op = f != UINT64_MAX && f <= b && f <= yy;
                 }
                 kinds |= (cl && op? 0u : (cl? 1u : (op? 2u : 0u))) << (2 * o);
