@@ -186,7 +186,9 @@ __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
         uint32_t pf = 0;          // sixteen 2-bit fields: the code of the byte BEFORE position b in field b
         uint32_t cx = 0, cy = 0, up = 0;      // classes as nibbles, table path only (ambiguous bases need them further down)
         bool slow = nvalid > 0 && nvalid < HPC_BPT;
-        if (nvalid == HPC_BPT) {
+        const bool wave_slow = __ballot(slow) != 0;        // the wave with the read's last, partial vector takes the table path as a whole
+        if (nvalid == HPC_BPT && wave_slow) slow = true;   // (it would run both paths otherwise)
+        else if (nvalid == HPC_BPT) {
             // ---- all ACGTU?  index = byte & 7 into two 8-byte tables: the code, and the case-folded byte that has this code ----
             constexpr uint32_t TL = 0x01000000u, TH = 0x02000303u;               // idx 1 A 0, 3 C 1, 4 T 3, 5 U 3, 7 G 2
             constexpr uint32_t EL = 0x43FF41FFu, EH = 0x47FF5554u;               // idx 1 'A', 3 'C', 4 'T', 5 'U', 7 'G'; 0xFF never matches

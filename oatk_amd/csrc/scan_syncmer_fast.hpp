@@ -253,7 +253,9 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
             uint64_t fw = X >> (64 - 2 * S), rv = revcomp32(X) & mask;
             uint32_t cmin = 0xFFFFFFFFu;                // top word of the chunk minimum: all the filter looks at
             const uint32_t mbase = m_own;               // = mi(i0); 8 consecutive positions never straddle a pad slot
-            if (i0 + 1 >= S && (uint32_t) (i0 + C) <= hl) {
+            // (the test is made for the WAVE: a wave with one lane at either end of the read would otherwise run both branches, eight
+            //  hashes each -- two waves per read, 5 % of the kernel)
+            if (__ballot(!(i0 + 1 >= S && (uint32_t) (i0 + C) <= hl)) == 0) {
 #pragma unroll
                 for (int b = 0; b < C; ++b) {
                     const uint64_t c = (vbh >> (30 - 2 * b)) & 3u;
