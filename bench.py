@@ -359,11 +359,11 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 5),
                     "traffic": pmc_traffic({"hpc": "oatk::hpc_pack_kernel", "syncmer": "void oatk::syncmer_fast_kernel<4096, true"}[dom], args.workload, per_gpu),
                     "algorithmic_bytes_per_launch": alg_bytes[dom], "avg_launch_ms": round(phase_ms[dom], 4),
-                    "note": "kernel B is integer-VALU issue bound (PMC profiles/r01p_pmc_scan.csv: 80 VALU wave-instructions per 64 hoco positions, 41 of them roll + hash64, ~14 of those 64-bit forms that take two passes; 16 waves per CU), see DESIGN.md 5",
+                    "note": "kernel B is integer-VALU issue bound (PMC profiles/r01q_pmc_scan.csv: 78.7 VALU wave-instructions per 64 hoco positions, 41 of them roll + hash64, ~14 of those 64-bit forms that take two passes; 16 waves per CU), see DESIGN.md 5",
                     # the bound that actually binds kernel B: wave-instructions issued (PMC count per 64 positions, profiles/r01k_pmc_scan.csv)
                     # against 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction
-                    "valu": {"achieved": round(hoco / 64 * 80.0 / (phase_ms["syncmer"] / 1e3) / 1e9, 1), "peak": 614.4, "unit": "G wave-instr/s",
-                             "frac": round(hoco / 64 * 80.0 / (phase_ms["syncmer"] / 1e3) / 1e9 / 614.4, 3)},
+                    "valu": {"achieved": round(hoco / 64 * 78.7 / (phase_ms["syncmer"] / 1e3) / 1e9, 1), "peak": 614.4, "unit": "G wave-instr/s",
+                             "frac": round(hoco / 64 * 78.7 / (phase_ms["syncmer"] / 1e3) / 1e9 / 614.4, 3)},
                     "scan_bytes_per_base": round((alg_bytes["hpc"] + 28 * n_occ) / bases, 4),
                     "scan_achieved_GBs": round((alg_bytes["hpc"] + 28 * n_occ) / ((phase_ms["hpc"] + phase_ms["syncmer"]) / 1e3) / 1e9, 2)}
         cpu = None
