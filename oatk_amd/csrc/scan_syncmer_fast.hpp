@@ -3,7 +3,7 @@
 // Same contract and rule as scan_syncmer.hpp (the general kernel, kept for reads with N and unusual K/S); the
 // difference is HOW MUCH work and HOW MANY stalls are spent per position.  PMC on MI355X showed the general kernel
 // issuing ~1500 VALU wave-instructions per 2048-position tile per wave (486 of them in the unavoidable s-mer
-// hashing) and, once that was trimmed, waves sitting 72 % of their life in s_waitcnt / s_barrier.  Here:
+// hashing).  Here:
 //
 //  * the window decision sits behind a NECESSARY condition that costs two 32-bit compares per position:
 //      Close at k-mer end E needs  M[E]   <= every hash in [E-w, E-1]  -> in particular <= the D chunk minima before E's chunk
@@ -12,15 +12,20 @@
 //    one wave-level prefix-min and suffix-min over 32-bit keys done with DPP row shifts + v_readlane (VALU only, no
 //    LDS round trips).  About one position in 480 survives, and nearly every survivor IS a syncmer (closed syncmers have
 //    density 2/(w+1) = 1/486): the filter is almost the rule.
-//  * the exact rule is then finished by the very lane that found the candidate: the filter has already compared against
-//    the D whole chunks of the window, so only the w - 8 D = 8..15 ragged positions at the window's ends are left (a
-//    dozen LDS reads); the exact 64-bit chunk minima are consulted only when top words tie.  No candidate lists, no
-//    cooperative reduction; every wave writes its own records, one tile late, so that neither the other waves' counts
-//    nor the record-slot atomic is waited for.  A tile has two workgroup barriers, placed so that the s-mer hashing
-//    of the next tile (registers only) overlaps with the slower waves' decisions on this one.  (The previous
-//    version -- candidates listed per wave, one WAVE per exact decision, wave 0 writing all records, three barriers --
-//    spent as many VALU issue slots on ~4 candidates per tile as on hashing the tile's 2048 s-mers; PMC: 106 VALU
-//    instructions per position, 41 of them the hash, and the kernel is VALU-issue bound.)
+//  * the exact rule for a survivor only needs the w - 8 D = 8..15 ragged positions at either end of its window (the filter has
+//    compared against the D whole chunks), and on top words alone unless they tie.  On random sequence there is about one survivor
+//    per wave and tile and the whole wave decides it: lanes 0-15 fetch the ragged positions of the Close window, lanes 16-31 those
+//    of the Open window, one row-wise DPP minimum, scalar logic.  Inside a tandem repeat nearly every lane holds survivors (the
+//    window minimum returns every period); then every lane walks the ragged ends of its own windows, all lanes at once.
+//  * top words that tie send a position to the rule on full 64-bit hashes, lane by lane.  The 64-bit minima of whole chunks it needs
+//    are not kept resident (4 KB of LDS that cost the fourth workgroup per CU): the wave computes them for the 192 chunks around
+//    its own when it meets its first tie and parks them in ring slots older than every window of the tile.
+//  * syncmers are appended to a per-read list in LDS at positions that follow from the waves' counts alone (no atomics, position
+//    order, index = ordinal) and become records when the read is done: one record-slot atomic per read.  A tile has two workgroup
+//    barriers, placed so that the s-mer hashing of the next tile (registers only) overlaps with the slower waves' decisions on this one.
+//  * what bounds it: integer VALU issue at four workgroups per CU (40.5 KB of LDS each); ~79 VALU wave-instructions per position, 41 of
+//    them the rolling canonical s-mer and hash64.  Ring addresses alternate between two values per lane (a tile is half the ring) and
+//    are toggled, not recomputed; end-of-read special cases are decided per wave, not per lane.  DESIGN.md 5 has the measurements.
 //  * selected syncmers leave as (sid|ordinal|rev, s-mer code, pos) records; their 251-byte k-mers are hashed
 //    afterwards by kmer_hash_kernel (one lane per syncmer) instead of by a lone lane inside this kernel.
 #pragma once
