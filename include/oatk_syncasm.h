@@ -138,6 +138,9 @@ int oatk_ingest_files(oatk_hip_ctx *ctx, char **files, int n_files, uint64_t *n_
  * here; fills sr_db->stats (allocated if NULL) and prints the reference's nine lines to fo (may be NULL).  Works on the batch resident
  * in ctx at whatever stage it is -- after sr_read (run_syncasm.c:88) or after read_error_correction (:131). */
 int oatk_sr_db_stat(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, FILE *fo, int verbose);
+/* the peak finder of sr_db_stat alone (what ha_analyze_count, syncmer.c:768-864, returns for MAX_DEPTH + 1 = 1001 bins and LOWEST_CUT 5):
+ * cnt[c] = how many distinct s-mers / k-mers occur c times, c = 0 .. 1000 (the last bin collects everything deeper) */
+void oatk_stat_peaks(const int64_t *cnt, int *peak_hom, int *peak_het);
 
 /* ---- scg_syncmer_consensus (syncasm.c:888-1003) served from the device ----
  * oatk_consensus_fetch runs oatk_hip_consensus (include/oatk_hip_cons.h) on the resident batch -- after the count, or after the

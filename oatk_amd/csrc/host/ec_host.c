@@ -70,22 +70,25 @@ int oatk_read_error_correction(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, oatk_sync
     }
     if (stats12) oatk_hip_ec_stats(ctx, stats12);
 
-    uint32_t *new_n = (uint32_t *) fetch(ctx, OATK_BUF_EC_N_SCM, &b, &rc); if (rc) return rc;
-    uint64_t *new_k = (uint64_t *) fetch(ctx, OATK_BUF_EC_KMER, &b, &rc); if (rc) return rc;
-    uint32_t *new_m = (uint32_t *) fetch(ctx, OATK_BUF_EC_MPOS, &b, &rc); if (rc) return rc;
-    uint64_t *new_s = (uint64_t *) fetch(ctx, OATK_BUF_EC_SMER, &b, &rc); if (rc) return rc;
-    uint32_t *cov = (uint32_t *) fetch(ctx, OATK_BUF_EC_SCM_COV, &b, &rc); if (rc) return rc;
-    uint8_t *del = (uint8_t *) fetch(ctx, OATK_BUF_EC_SCM_DEL, &b, &rc); if (rc) return rc;
-    uint8_t *err_del = (uint8_t *) fetch(ctx, OATK_BUF_EC_ERR_DEL, &b, &rc); if (rc) return rc;
-    uint64_t *occ_off = (uint64_t *) fetch(ctx, OATK_BUF_EC_SCM_OCC_OFF, &b, &rc); if (rc) return rc;
-    uint64_t *occ = (uint64_t *) fetch(ctx, OATK_BUF_EC_SCM_OCC, &b, &rc); if (rc) return rc;
+    /* everything is fetched before anything is rewritten: a failure here leaves the reads and the table as they were */
+    uint32_t *new_n = 0, *new_m = 0, *cov = 0;
+    uint64_t *new_k = 0, *new_s = 0, *occ_off = 0, *occ = 0;
+    uint8_t *del = 0, *err_del = 0;
+    new_n = (uint32_t *) fetch(ctx, OATK_BUF_EC_N_SCM, &b, &rc); if (rc) goto done;
+    new_k = (uint64_t *) fetch(ctx, OATK_BUF_EC_KMER, &b, &rc); if (rc) goto done;
+    new_m = (uint32_t *) fetch(ctx, OATK_BUF_EC_MPOS, &b, &rc); if (rc) goto done;
+    new_s = (uint64_t *) fetch(ctx, OATK_BUF_EC_SMER, &b, &rc); if (rc) goto done;
+    cov = (uint32_t *) fetch(ctx, OATK_BUF_EC_SCM_COV, &b, &rc); if (rc) goto done;
+    del = (uint8_t *) fetch(ctx, OATK_BUF_EC_SCM_DEL, &b, &rc); if (rc) goto done;
+    err_del = (uint8_t *) fetch(ctx, OATK_BUF_EC_ERR_DEL, &b, &rc); if (rc) goto done;
+    occ_off = (uint64_t *) fetch(ctx, OATK_BUF_EC_SCM_OCC_OFF, &b, &rc); if (rc) goto done;
+    occ = (uint64_t *) fetch(ctx, OATK_BUF_EC_SCM_OCC, &b, &rc); if (rc) goto done;
 
     /* graph: what find_error_syncmers(..., del_err = 1) leaves behind -- every arc touching a marked syncmer */
     if (asmg) {
         for (i = 0; i < nv; ++i) if (err_del[i]) asmg->vtx[i].del = 1;
         for (i = 0; i < na; ++i) if (err_del[arc_v[i] >> 1] || err_del[arc_w[i] >> 1]) asmg->arc[i].del = 1;
     }
-    free(arc_v); free(arc_w);
 
     /* reads */
     uint64_t o = 0;
@@ -109,6 +112,8 @@ int oatk_read_error_correction(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, oatk_sync
         m->m_pos = (uint64_t *) xmalloc(8 * (size_t) cov[i]);
         for (j = 0; j < cov[i]; ++j) m->m_pos[j] = occ[occ_off[i] + j];
     }
+done:
+    free(arc_v); free(arc_w);
     free(new_n); free(new_k); free(new_m); free(new_s); free(cov); free(del); free(err_del); free(occ_off); free(occ);
-    return OATK_OK;
+    return rc;
 }

@@ -147,27 +147,26 @@ int oatk_calc_syncmer_overlap(const oatk_overlap_t *o, uint64_t v, uint64_t w, o
     return movl;
 }
 
-/* scg_unitig_consensus (syncasm.c:1004-1046): v[0..n) are the oriented syncmers of the unitig (vtx.a) */
+/* scg_unitig_consensus (syncasm.c:1004-1046): v[0..n) are the oriented syncmers of the unitig (vtx.a).  One pass: `here` is where syncmer i
+ * starts on the unitig (the running sum of the pair distances, each looked up once, in order, through ONE table whose size carries over),
+ * `done` where the sequence written so far ends.  A syncmer whose successor still starts inside the written part adds nothing; the others
+ * contribute their consensus from the first position not yet written. */
 int64_t oatk_scg_unitig_consensus(const oatk_consensus_t *cs, const oatk_overlap_t *o, const oatk_sr_db_t *sr_db, const uint64_t *v, uint64_t n,
                                   oatk_kstring_t *c_seq, int hoco_seq)
 {
-    if (n == 0) return 0;
-    uint64_t i;
-    int64_t beg_pos = 0, end_pos = 0, l = 0, r;
-    const int w = sr_db->k;
-    oatk_ovl_table_t *h = oatk_ovl_table_new();
-    int64_t *pos = (int64_t *) xmalloc(8 * n);
-    pos[0] = 0;
-    for (i = 1; i < n; ++i) pos[i] = pos[i - 1] + oatk_calc_syncmer_overlap(o, v[i - 1], v[i], h);
-    for (i = 0; i < n; ++i) {
-        while (i + 1 < n && pos[i + 1] <= end_pos) ++i;
-        beg_pos = pos[i];
-        r = oatk_scg_syncmer_consensus(cs, sr_db, v[i] >> 1, (int) (v[i] & 1), end_pos - beg_pos, c_seq, hoco_seq);
-        if (r < 0) { l = -1; break; }                                      /* a syncmer without prepared consensus: the caller's own routine */
-        l += r;
-        end_pos = beg_pos + w;
+    int64_t here = 0, done = 0, total = 0;
+    oatk_ovl_table_t *tab = n? oatk_ovl_table_new() : NULL;
+    for (uint64_t i = 0; i < n; ++i) {
+        const int last = i + 1 == n;
+        const int64_t next = last? 0 : here + oatk_calc_syncmer_overlap(o, v[i], v[i + 1], tab);
+        if (last || next > done) {
+            const int64_t got = oatk_scg_syncmer_consensus(cs, sr_db, v[i] >> 1, (int) (v[i] & 1), done - here, c_seq, hoco_seq);
+            if (got < 0) { total = -1; break; }                            /* a syncmer without prepared consensus: the caller's own routine */
+            total += got;
+            done = here + sr_db->k;
+        }
+        here = next;
     }
-    free(pos);
-    oatk_ovl_table_destroy(h);
-    return l;
+    if (tab) oatk_ovl_table_destroy(tab);
+    return total;
 }

@@ -47,28 +47,32 @@ int oatk_sr_db_fill_resident(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, const uint6
     if (n_reads == 0) return OATK_OK;
 
     uint64_t b;
-    uint32_t *hoco_l = (uint32_t *) fetch(ctx, OATK_BUF_HOCO_L, &b, &rc); if (rc) return rc;
-    uint32_t *n_scm = (uint32_t *) fetch(ctx, OATK_BUF_N_SCM, &b, &rc); if (rc) return rc;
-    uint32_t *n_nn = (uint32_t *) fetch(ctx, OATK_BUF_N_NN, &b, &rc); if (rc) return rc;
-    uint32_t *n_lrl = (uint32_t *) fetch(ctx, OATK_BUF_N_LRL, &b, &rc); if (rc) return rc;
+    uint32_t *hoco_l = 0, *n_scm = 0, *n_nn = 0, *n_lrl = 0, *lrl_val = 0, *m_pos = 0;
+    uint64_t *nn_key = 0, *s_mer = 0, *k_hash = 0;
+    hoco_l = (uint32_t *) fetch(ctx, OATK_BUF_HOCO_L, &b, &rc); if (rc) goto done;
+    n_scm = (uint32_t *) fetch(ctx, OATK_BUF_N_SCM, &b, &rc); if (rc) goto done;
+    n_nn = (uint32_t *) fetch(ctx, OATK_BUF_N_NN, &b, &rc); if (rc) goto done;
+    n_lrl = (uint32_t *) fetch(ctx, OATK_BUF_N_LRL, &b, &rc); if (rc) goto done;
     /* the two big per-base arrays (1 + 1/4 byte per raw base) come over in pieces through page-locked memory, straight into the reads' own
      * blocks: no gigabyte-sized pageable landing buffer, PCIe at full speed */
     const void *d_rl = 0, *d_hs = 0;
     uint64_t b_rl = 0, b_hs = 0;
-    rc = oatk_hip_buffer(ctx, OATK_BUF_HO_RL, &d_rl, &b_rl); if (rc) return rc;
-    rc = oatk_hip_buffer(ctx, OATK_BUF_HOCO_S, &d_hs, &b_hs); if (rc) return rc;
+    rc = oatk_hip_buffer(ctx, OATK_BUF_HO_RL, &d_rl, &b_rl); if (rc) goto done;
+    rc = oatk_hip_buffer(ctx, OATK_BUF_HOCO_S, &d_hs, &b_hs); if (rc) goto done;
     (void) b_rl; (void) b_hs;
     const uint64_t STAGE = 64ULL << 20;
     uint8_t *stage = (uint8_t *) oatk_hip_staging(ctx, STAGE + STAGE / 4 + 4096);
-    if (!stage) return OATK_E_NOMEM;
-    uint64_t *nn_key = (uint64_t *) fetch(ctx, OATK_BUF_NN_KEY, &b, &rc); if (rc) return rc;
-    uint32_t *lrl_val = (uint32_t *) fetch(ctx, OATK_BUF_LRL_VAL, &b, &rc); if (rc) return rc;
-    uint32_t *m_pos = (uint32_t *) fetch(ctx, OATK_BUF_POS_MPOS, &b, &rc); if (rc) return rc;
-    uint64_t *s_mer = (uint64_t *) fetch(ctx, OATK_BUF_POS_SMER, &b, &rc); if (rc) return rc;
-    uint64_t *k_hash = (uint64_t *) fetch(ctx, OATK_BUF_POS_HASH, &b, &rc); if (rc) return rc;
+    if (!stage) { rc = OATK_E_NOMEM; goto done; }
+    nn_key = (uint64_t *) fetch(ctx, OATK_BUF_NN_KEY, &b, &rc); if (rc) goto done;
+    lrl_val = (uint32_t *) fetch(ctx, OATK_BUF_LRL_VAL, &b, &rc); if (rc) goto done;
+    m_pos = (uint32_t *) fetch(ctx, OATK_BUF_POS_MPOS, &b, &rc); if (rc) goto done;
+    s_mer = (uint64_t *) fetch(ctx, OATK_BUF_POS_SMER, &b, &rc); if (rc) goto done;
+    k_hash = (uint64_t *) fetch(ctx, OATK_BUF_POS_HASH, &b, &rc); if (rc) goto done;
 
-    sr_db->a = (oatk_sr_t *) xmalloc(sizeof(oatk_sr_t) * n_reads);
-    sr_db->n = sr_db->m = n_reads;
+    /* zeroed, and counted only as far as it is filled: after a failure half way sr_db_destroy / oatk_sr_db_clean free what exists */
+    sr_db->a = (oatk_sr_t *) calloc(n_reads, sizeof(oatk_sr_t));
+    if (!sr_db->a) { rc = OATK_E_NOMEM; goto done; }
+    sr_db->n = 0, sr_db->m = n_reads;
     uint64_t i, o_scm = 0, o_nn = 0, o_lrl = 0, stage_end = 0, stage_o0 = 0;
     uint8_t *stage_hs = stage;
     for (i = 0; i < n_reads; ++i) {
@@ -84,10 +88,10 @@ int oatk_sr_db_fill_resident(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, const uint6
             const uint64_t o0 = off[i];
             while (j < n_reads && off[j] + (((uint64_t) hoco_l[j] + 63) & ~63ULL) - o0 <= STAGE) ++j;
             const uint64_t o1 = off[j - 1] + hoco_l[j - 1], bytes = o1 - o0;      /* one read longer than the block: the block grows */
-            if (bytes > STAGE) { stage = (uint8_t *) oatk_hip_staging(ctx, bytes + bytes / 4 + 4096); if (!stage) return OATK_E_NOMEM; }
+            if (bytes > STAGE) { stage = (uint8_t *) oatk_hip_staging(ctx, bytes + bytes / 4 + 4096); if (!stage) { rc = OATK_E_NOMEM; goto done; } }
             stage_hs = stage + (((bytes > STAGE? bytes : STAGE) + 63) & ~63ULL);
-            rc = oatk_hip_d2h(ctx, stage, (const uint8_t *) d_rl + o0, bytes); if (rc) return rc;
-            rc = oatk_hip_d2h(ctx, stage_hs, (const uint8_t *) d_hs + o0 / 4, (bytes + 3) / 4 + 1); if (rc) return rc;
+            rc = oatk_hip_d2h(ctx, stage, (const uint8_t *) d_rl + o0, bytes); if (rc) goto done;
+            rc = oatk_hip_d2h(ctx, stage_hs, (const uint8_t *) d_hs + o0 / 4, (bytes + 3) / 4 + 1); if (rc) goto done;
             stage_o0 = o0, stage_end = j;
         }
         r->hoco_s = nb? (uint8_t *) memcpy(xmalloc(nb), stage_hs + (off[i] - stage_o0) / 4, nb) : 0;
@@ -104,10 +108,12 @@ int oatk_sr_db_fill_resident(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, const uint6
         r->s_mer = ns? (uint64_t *) memcpy(xmalloc(8 * (size_t) ns), s_mer + o_scm, 8 * (size_t) ns) : 0;
         r->k_mer = ns? (uint64_t *) memcpy(xmalloc(8 * (size_t) ns), k_hash + o_scm, 8 * (size_t) ns) : 0;
         o_scm += ns, o_nn += n_nn[i], o_lrl += n_lrl[i];
+        sr_db->n = i + 1;
     }
+done:
     free(hoco_l); free(n_scm); free(n_nn); free(n_lrl); free(nn_key); free(lrl_val);
     free(m_pos); free(s_mer); free(k_hash);
-    return OATK_OK;
+    return rc;
 }
 
 oatk_syncmer_db_t *oatk_collect_syncmer_from_reads(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, int *rc_out)
@@ -124,12 +130,14 @@ oatk_syncmer_db_t *oatk_collect_syncmer_from_reads(oatk_hip_ctx *ctx, oatk_sr_db
     if (inf.n_occ == 0) return 0;                          /* syncmer.c:1414-1417 */
 
     uint64_t b;
-    uint64_t *h = (uint64_t *) fetch(ctx, OATK_BUF_SCM_H, &b, &rc); if (rc) goto fail;
-    uint64_t *s = (uint64_t *) fetch(ctx, OATK_BUF_SCM_S, &b, &rc); if (rc) goto fail;
-    uint32_t *cov = (uint32_t *) fetch(ctx, OATK_BUF_SCM_COV, &b, &rc); if (rc) goto fail;
-    uint64_t *occ_off = (uint64_t *) fetch(ctx, OATK_BUF_SCM_OCC_OFF, &b, &rc); if (rc) goto fail;
-    uint64_t *occ = (uint64_t *) fetch(ctx, OATK_BUF_SCM_OCC, &b, &rc); if (rc) goto fail;
-    uint64_t *kid = (uint64_t *) fetch(ctx, OATK_BUF_POS_KID, &b, &rc); if (rc) goto fail;
+    uint64_t *h = 0, *s = 0, *occ_off = 0, *occ = 0, *kid = 0;
+    uint32_t *cov = 0;
+    h = (uint64_t *) fetch(ctx, OATK_BUF_SCM_H, &b, &rc); if (rc) goto fail;
+    s = (uint64_t *) fetch(ctx, OATK_BUF_SCM_S, &b, &rc); if (rc) goto fail;
+    cov = (uint32_t *) fetch(ctx, OATK_BUF_SCM_COV, &b, &rc); if (rc) goto fail;
+    occ_off = (uint64_t *) fetch(ctx, OATK_BUF_SCM_OCC_OFF, &b, &rc); if (rc) goto fail;
+    occ = (uint64_t *) fetch(ctx, OATK_BUF_SCM_OCC, &b, &rc); if (rc) goto fail;
+    kid = (uint64_t *) fetch(ctx, OATK_BUF_POS_KID, &b, &rc); if (rc) goto fail;
 
     oatk_syncmer_db_t *db = (oatk_syncmer_db_t *) xmalloc(sizeof(oatk_syncmer_db_t));
     db->n = db->m = inf.n_scm;
@@ -152,6 +160,7 @@ oatk_syncmer_db_t *oatk_collect_syncmer_from_reads(oatk_hip_ctx *ctx, oatk_sr_db
     free(h); free(s); free(cov); free(occ_off); free(occ); free(kid);
     return db;
 fail:
+    free(h); free(s); free(cov); free(occ_off); free(occ); free(kid);
     if (rc_out) *rc_out = rc;
     return 0;
 }

@@ -15,46 +15,63 @@
 
 #define LOWEST_CUT 5                      /* syncmer.c:754 */
 
-/* ha_analyze_count (syncmer.c:768-864) without its verbose histogram */
+/*
+ * The peak finder behind "peak_hom / peak_het" (what ha_analyze_count, syncmer.c:768-864, decides; its verbose plots are not reproduced).
+ * In words: skip the error tail (counts fall from depth max(start, 5) on), take the tallest depth after the dip as the main peak, then look for
+ * one shoulder on each side: the tallest local maximum between dip and main peak (walking down from the peak) and the tallest one above it
+ * (walking up).  A shoulder counts when it reaches 5 % of the main peak and the valley between the two drops to 95 % of the shoulder or lower;
+ * one on the right must also sit below 2.5 x the main depth.  A right shoulder makes the main peak the heterozygous one.
+ */
+typedef struct { int at; int64_t height; } peak_t;
+
+/* tallest local maximum strictly between the depths `from` and `to`, met first when walking from `from` towards `to` */
+static peak_t tallest_between(const int64_t *cnt, int from, int to)
+{
+    peak_t best = {-1, -1};
+    const int step = to > from? 1 : -1;
+    for (int d = from + step; step > 0? d < to : d > to; d += step)
+        if (cnt[d] >= cnt[d - 1] && cnt[d] >= cnt[d + 1] && cnt[d] > best.height) best.at = d, best.height = cnt[d];
+    return best;
+}
+
+/* does the shoulder stand clear of the main peak?  (the comparisons are made in double, as the reference makes them) */
+static int stands_clear(const int64_t *cnt, peak_t shoulder, peak_t main_peak)
+{
+    const int lo = shoulder.at < main_peak.at? shoulder.at : main_peak.at, hi = shoulder.at < main_peak.at? main_peak.at : shoulder.at;
+    int64_t valley = main_peak.height;
+    for (int d = lo + 1; d < hi; ++d)
+        if (cnt[d] < valley) valley = cnt[d];
+    return !(shoulder.height < main_peak.height * 0.05 || valley > shoulder.height * 0.95);
+}
+
 static int analyze_count(int n_cnt, int start_cnt, const int64_t *cnt, int *peak_het)
 {
-    int i, start, low_i, max_i, max2_i, max3_i;
-    int64_t max, max2, max3, min;
     assert(n_cnt > start_cnt);
     *peak_het = -1;
-    start = cnt[1] > 0? 1 : 2;
-    low_i = start > start_cnt? start : start_cnt;                 /* the low point from the left */
-    for (i = low_i + 1; i < n_cnt; ++i)
-        if (cnt[i] > cnt[i - 1]) break;
-    low_i = i - 1;
-    if (low_i == n_cnt - 1) return -1;                             /* low coverage */
-    max_i = low_i + 1, max = cnt[max_i];                           /* the highest peak */
-    for (i = low_i + 1; i < n_cnt; ++i)
-        if (cnt[i] > max) max = cnt[i], max_i = i;
-    max2 = -1, max2_i = -1;                                        /* a smaller peak on the low end */
-    for (i = max_i - 1; i > low_i; --i)
-        if (cnt[i] >= cnt[i - 1] && cnt[i] >= cnt[i + 1])
-            if (cnt[i] > max2) max2 = cnt[i], max2_i = i;
-    if (max2_i > low_i && max2_i < max_i) {
-        for (i = max2_i + 1, min = max; i < max_i; ++i)
-            if (cnt[i] < min) min = cnt[i];
-        if (max2 < max * 0.05 || min > max2 * 0.95) max2 = -1, max2_i = -1;
+    int dip = cnt[1] > 0? 1 : 2;
+    if (dip < start_cnt) dip = start_cnt;
+    while (dip + 1 < n_cnt && cnt[dip + 1] <= cnt[dip]) ++dip;         /* the end of the falling error tail */
+    if (dip == n_cnt - 1) return -1;                                   /* it never rises again: low coverage */
+    peak_t top = {dip + 1, cnt[dip + 1]};
+    for (int d = dip + 2; d < n_cnt; ++d)
+        if (cnt[d] > top.height) top.at = d, top.height = cnt[d];
+    peak_t left = tallest_between(cnt, top.at, dip), right = tallest_between(cnt, top.at, n_cnt - 1);
+    if (left.at >= 0 && !stands_clear(cnt, left, top)) left.at = -1;
+    if (right.at >= 0 && (!stands_clear(cnt, right, top) || right.at > top.at * 2.5)) right.at = -1;
+    if (right.at > 0) {
+        *peak_het = top.at;
+        return right.at;
     }
-    max3 = -1, max3_i = -1;                                        /* ... and on the high end */
-    for (i = max_i + 1; i < n_cnt - 1; ++i)
-        if (cnt[i] >= cnt[i - 1] && cnt[i] >= cnt[i + 1])
-            if (cnt[i] > max3) max3 = cnt[i], max3_i = i;
-    if (max3_i > max_i) {
-        for (i = max_i + 1, min = max; i < max3_i; ++i)
-            if (cnt[i] < min) min = cnt[i];
-        if (max3 < max * 0.05 || min > max3 * 0.95 || max3_i > max_i * 2.5) max3 = -1, max3_i = -1;
-    }
-    if (max3_i > 0) {
-        *peak_het = max_i;
-        return max3_i;
-    }
-    if (max2_i > 0) *peak_het = max2_i;
-    return max_i;
+    if (left.at > 0) *peak_het = left.at;
+    return top.at;
+}
+
+/* the peak finder alone, for a histogram cnt[0 .. OATK_STAT_MAX_DEPTH] (include/oatk_syncasm.h) */
+void oatk_stat_peaks(const int64_t *cnt, int *peak_hom, int *peak_het)
+{
+    int het = 0;
+    *peak_hom = analyze_count(OATK_STAT_MAX_DEPTH + 1, LOWEST_CUT, cnt, &het);
+    *peak_het = het;
 }
 
 int oatk_sr_db_stat(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, FILE *fo, int verbose)

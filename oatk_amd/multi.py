@@ -25,6 +25,9 @@ def merge_syncmer_tables(h, s, cov, dist=None, group=None):
     cov: integer tensor.  Returns (G_h, G_s, G_cov, local_to_global) with G_* identical on every rank."""
     dev = h.device
     hk = _to_ordered_i64(h)
+    # a local table that split a 64-bit hash collision holds one hash twice: ranking by hash would fold two different k-mers into one row
+    if hk.numel() > 1 and bool((hk[1:] == hk[:-1]).any()):
+        raise RuntimeError("this shard's table holds one k-mer hash more than once (a split hash collision): sequence-level merge required")
     n_local = torch.tensor([h.numel()], dtype=torch.int64, device=dev)
     world = dist.get_world_size(group) if dist is not None else 1
     if world > 1:
@@ -82,7 +85,7 @@ class CountMerger:
         ptr, nbytes = self.hip.buffer(name)
         n = nbytes // itemsize
         if n == 0:
-            return torch.zeros(0, dtype={"<i8": torch.int64, "<i4": torch.int32}[typestr], device=self.device)
+            return torch.zeros(0, dtype={"<i8": torch.int64, "<i4": torch.int32, "|u1": torch.uint8}[typestr], device=self.device)
         return torch.as_tensor(_DevView(ptr, n, typestr), device=self.device)
 
     def merge(self):

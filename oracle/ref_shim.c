@@ -474,6 +474,15 @@ sr_db_t *refx_fake_srdb(uint64_t n_reads, const uint32_t *n_scm, const uint64_t 
     }
     return db;
 }
+/* the same with s-mers attached: what sr_db_stat (syncmer.c:867) reads */
+void refx_fake_srdb_smer(sr_db_t *db, const uint64_t *s_mer)
+{
+    uint64_t i, o = 0;
+    for (i = 0; i < db->n; o += db->a[i].n, ++i) {
+        sr_t *r = &db->a[i];
+        r->s_mer = (uint64_t *) malloc(8 * (r->n + 1)); memcpy(r->s_mer, s_mer + o, 8 * r->n);
+    }
+}
 syncmer_db_t *refx_fake_scmdb(uint64_t n, const uint32_t *cov, const uint8_t *del)
 {
     syncmer_db_t *s = (syncmer_db_t *) calloc(1, sizeof(syncmer_db_t));
@@ -487,7 +496,7 @@ void refx_fake_scmdb_del(syncmer_db_t *s, uint8_t *del) { uint64_t i; for (i = 0
 void refx_fake_dbs_free(sr_db_t *db, syncmer_db_t *s)
 {
     uint64_t i;
-    if (db) { for (i = 0; i < db->n; ++i) { free(db->a[i].k_mer); free(db->a[i].m_pos); } free(db->a); free(db); }
+    if (db) { for (i = 0; i < db->n; ++i) { free(db->a[i].k_mer); free(db->a[i].m_pos); free(db->a[i].s_mer); } free(db->stats); free(db->a); free(db); }
     if (s) { free(s->a); free(s); }
 }
 
