@@ -123,10 +123,14 @@ enum {
     OATK_T_COUNT_SORT,     /* radix sort by hash                                           */
     OATK_T_COUNT_GROUP,    /* heads + collision verification + ids + finish                */
     OATK_T_KMER_HASH,      /* MurmurHash64A of every syncmer's k-mer (kmer_hash.hpp)       */
+    OATK_T_EC_GRAPH,       /* oatk_hip_ec_graph: adjacent pairs, sort, arcs, overlaps      */
+    OATK_T_EC_MARK,        /* find_error_syncmers + live arcs + block lists                */
+    OATK_T_EC_SOLVE,       /* the path search of every error block, all tiers (ec_wave.hpp) */
+    OATK_T_EC_REFRESH,     /* corrected chains + update_syncmer_db                         */
     OATK_T_COUNT_
 };
 int oatk_hip_set_timing(oatk_hip_ctx *ctx, int enable);
-/* milliseconds of the most recent scan / count, one entry per OATK_T_* */
+/* milliseconds of the most recent scan / count / error-correction round, one entry per OATK_T_* */
 int oatk_hip_get_timing(oatk_hip_ctx *ctx, float *ms, int n);
 
 /* test hook: AND every k-mer hash with `mask` before grouping, to force "hash collisions" through the

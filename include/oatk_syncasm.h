@@ -193,7 +193,8 @@ int64_t oatk_scg_unitig_consensus(const oatk_consensus_t *cs, const oatk_overlap
  * new ones).  The reads aligned are the chains resident in ctx, which must be the whole of sr_db.  Layout-compatible mirrors of syncasm.h:51-80.
  * *n_skipped reads (indices in *skipped, malloc'ed, no particular order) exceeded the device routine's per-read limits (160 unitig hits,
  * 128 fragments, 6 equally good predecessors, 48 fragments in a chain) and got no alignment: the caller runs the original routine for
- * them (none on HiFi data so far). */
+ * them (none on HiFi data so far).  With skipped == NULL the call is all or nothing: if any read was skipped it returns OATK_E_SPLIT
+ * (*n_skipped set) and leaves ra_v as it was, so the caller can run the original routine on the untouched state. */
 typedef struct {
     oatk_syncmer_db_t *scm_db;
     oatk_asmg_t *utg_asmg;

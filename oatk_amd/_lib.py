@@ -34,7 +34,7 @@ BUF.update({name: 120 + i for i, name in enumerate([
 # include/oatk_hip_graph.h
 BUF.update({name: 180 + i for i, name in enumerate([
     "AG_SCM_DEL", "AG_VTX_SCM", "AG_VTX_COV", "AG_IDX_P", "AG_IDX_N", "AG_ARC_V", "AG_ARC_W", "AG_ARC_COV", "AG_ARC_COMP", "AG_ARC_LINK"])})
-TIMERS = ["hpc", "syncmer", "syncmer_n", "scan_post", "count_place", "count_sort", "count_group", "kmer_hash"]
+TIMERS = ["hpc", "syncmer", "syncmer_n", "scan_post", "count_place", "count_sort", "count_group", "kmer_hash", "ec_graph", "ec_mark", "ec_solve", "ec_refresh"]
 
 EXPORTS = [
     "oatk_hip_abi_version", "oatk_hip_device_count", "oatk_hip_create", "oatk_hip_destroy", "oatk_hip_last_error",

@@ -87,6 +87,10 @@ int oatk_scg_read_alignment(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, oatk_scg_ra_
     rc = oatk_hip_read_alignment(ctx, &fg, old_ra, &n_aln, &n_frg, st);
     free(su_off); free(su_uid); free(su_pos); free(utg_n); free(arc_w); free(arc_ln); free(arc_del); free(old_ra);
     if (rc) return rc;
+    if (st[2] && !skipped) {                                                       /* a caller that cannot finish the skipped reads itself gets */
+        if (n_skipped) *n_skipped = st[2];                                         /* all or nothing: ra_v is still the previous round's        */
+        return OATK_E_SPLIT;
+    }
 
     uint32_t *a_sid = (uint32_t *) fetch(ctx, OATK_BUF_RA_ALN_SID, &b, &rc); if (rc) return rc;
     uint64_t *a_off = (uint64_t *) fetch(ctx, OATK_BUF_RA_ALN_OFF, &b, &rc); if (rc) return rc;

@@ -123,6 +123,12 @@ __global__ void ing_fastq_record_kernel(IngLines l, uint64_t n_rec, uint32_t *le
     padded[r] = (n + 63) & ~63ULL;
     hdr_off[r] = s0;
 }
+// lines [first, l.n_lines) of the last chunk that do not make up a whole record: blank is fine, anything else is a truncated record
+__global__ void ing_fastq_leftover_kernel(IngLines l, uint64_t first, uint32_t *flags)
+{
+    const uint64_t i = first + threadIdx.x;
+    if (i < l.n_lines && ing_line_end(l, i) > ing_line_start(l, i)) flags[1] = 1u;
+}
 __global__ __launch_bounds__(256) void ing_copy_fastq_kernel(IngLines l, uint64_t n_rec, const uint64_t *off, uint8_t *seq)
 {
     const uint64_t r = (uint64_t) blockIdx.x * 4 + (threadIdx.x >> 6);

@@ -1,0 +1,92 @@
+"""GPU: the syncasm CLI itself (run_syncasm.c:342 main, untouched) over the device path.  oracle/_ref/syncasm_dropin is the reference's own
+translation units with six hot-path symbols bound to oatk_amd/lib/liboatk_dropin.a and the two consensus hooks (include/oatk_dropin.h;
+`make -C oracle ref_dropin`).  Same file, same options as the reference binary: both GFA files byte-identical, and the log must show the MI355X
+served every call -- or, for inputs the device path declines, that the ORIGINAL body did and the result is still identical."""
+import filecmp
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+import adversarial as A
+import cli_util as U
+import ref_lib as R
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not U.available(), reason="oracle/_ref CLI binaries not built")]
+
+SIX = ("sr_read", "sr_db_stat", "collect_syncmer_from_reads", "make_syncmer_graph", "read_error_correction", "scg_read_alignment")
+
+
+def both(tmp_path, files, k, s, c, extra=(), threads=4):
+    ref, dev = str(tmp_path / "ref"), str(tmp_path / "dev")
+    U.run_cli(U.CLI_REF, files, ref, k, c, threads, extra=["-s", str(s)] + list(extra))
+    _, err = U.run_cli(U.CLI_DROPIN, files, dev, k, c, threads, env={"OATK_DROPIN_LOG": "1"}, extra=["-s", str(s)] + list(extra))
+    for suffix in (".utg.gfa", ".utg.final.gfa"):
+        assert os.path.getsize(ref + suffix) > 100, suffix
+        assert filecmp.cmp(ref + suffix, dev + suffix, shallow=False), suffix
+    return U.served_table(err), err
+
+
+@pytest.mark.parametrize("K,S,cov,err", [(1001, 31, 8, 0.0008), (301, 21, 6, 0.001)])
+def test_cli_fasta_everything_from_the_device(tmp_path, K, S, cov, err):
+    reads = A.hifi_like(260, 50000, 9000 if K > 500 else 5000, seed=K + 77, err=err)
+    fa = str(tmp_path / "reads.fa")
+    R.write_fasta(reads, fa)
+    tab, log = both(tmp_path, fa, K, S, cov)
+    for f in SIX:
+        assert tab[f][0] >= 1 and tab[f][2] == 0, (f, tab[f], log[-2000:])
+    assert tab["make_syncmer_graph"][0] == 2 and tab["sr_db_stat"][0] == 2 and tab["scg_read_alignment"][0] >= 3
+    assert tab["scg_syncmer_consensus"][0] > 20 and tab["calc_syncmer_overlap"][0] > 20      # the consensus hooks were served from the device tables
+
+
+def test_cli_without_ec_and_unzip(tmp_path):
+    reads = A.hifi_like(260, 50000, 5000, seed=5)
+    fa = str(tmp_path / "reads.fa")
+    R.write_fasta(reads, fa)
+    tab, _ = both(tmp_path, fa, 301, 21, 6, extra=["--no-read-ec", "--unzip-round", "0"])
+    assert tab["read_error_correction"][0] == 0 and tab["read_error_correction"][2] == 0
+    assert tab["sr_read"][0] == 1 and tab["make_syncmer_graph"][0] == 1 and tab["scg_read_alignment"][0] >= 1
+
+
+def test_cli_two_files_fastq_gz_and_wrapped_fasta(tmp_path):
+    reads = A.hifi_like(300, 50000, 5000, seed=9, err=0.0008)
+    f1, f2 = str(tmp_path / "a.fq.gz"), str(tmp_path / "b.fa")
+    with gzip.open(f1, "wb") as f:
+        for i, r in enumerate(reads[:150]):
+            f.write(b"@q%d\n" % i + r + b"\n+\n" + b"I" * len(r) + b"\n")
+    with open(f2, "wb") as f:
+        for i, r in enumerate(reads[150:]):
+            f.write(b">w%d wrapped\n" % i + b"\n".join(r[j:j + 70] for j in range(0, len(r), 70)) + b"\n")
+    tab, _ = both(tmp_path, [f1, f2], 301, 21, 6)
+    for f in SIX:
+        assert tab[f][0] >= 1 and tab[f][2] == 0, (f, tab[f])
+
+
+def test_cli_auto_coverage(tmp_path):
+    """-c 0: min_k_cov comes from sr_db->stats->kmer_peak_* (run_syncasm.c:89-92), i.e. from the device's sr_db_stat"""
+    from oatk_amd.synth import ReadSet
+    reads = ReadSet(150_000, 1500, 12000).as_list(0, 1500)
+    fa = str(tmp_path / "reads.fa")
+    R.write_fasta(reads, fa)
+    tab, log = both(tmp_path, fa, 1001, 31, 0)
+    assert tab["sr_db_stat"][0] == 2 and tab["sr_read"][0] == 1
+
+
+def test_cli_declined_inputs_fall_back_to_the_original_bodies(tmp_path):
+    reads = A.hifi_like(260, 50000, 5000, seed=13, err=0.001)
+    fa = str(tmp_path / "reads.fa")
+    R.write_fasta(reads, fa)
+    # a data cap stops the reader mid-file: the original sr_read, and with it everything behind it
+    tab, log = both(tmp_path, fa, 301, 21, 6, extra=["-D", "600000"])
+    assert tab["sr_read"] [0] == 0 and tab["sr_read"][2] == 1 and "data cap" in log
+    for f in SIX:
+        assert tab[f][0] == 0, f
+    # wrapped FASTQ: the device reader refuses, kseq reads it
+    fq = str(tmp_path / "w.fq")
+    with open(fq, "wb") as f:
+        for i, r in enumerate(reads):
+            h = len(r) // 2
+            f.write(b"@q%d\n" % i + r[:h] + b"\n" + r[h:] + b"\n+\n" + b"I" * h + b"\n" + b"I" * (len(r) - h) + b"\n")
+    tab, log = both(tmp_path, fq, 301, 21, 6)
+    assert tab["sr_read"][0] == 0 and tab["sr_read"][2] == 1

@@ -86,6 +86,12 @@ def test_fastq_four_line(hip):
     with pytest.raises(OatkHipError):                   # wrapped FASTQ is refused, not misread
         bad = b"@r0\nACGTACGT\nACGT\n+\nIIIIIIII\nIIII\n@r1\nAC\n+\nII\n@r2\nAC\n+\nII\n"
         hip.ingest_host(bad, 2, True)
+    # behind the last whole record: blank lines are fine, a truncated record is refused, never dropped silently
+    t = fastq(READS[:5])
+    assert device_reads(hip, t + b"\n\r\n") == READS[:5]
+    for tail in (b"@r9\nACGT\n+\n", b"@r9\nACGT\n", b"junk"):
+        with pytest.raises(OatkHipError):
+            hip.ingest_host(t + tail, 2, True)
 
 
 @pytest.mark.parametrize("kind", ["fasta", "fastq"])
