@@ -42,6 +42,16 @@ int oatk_hip_ec_stats(oatk_hip_ctx *ctx, uint64_t *stats12);
  * next tier (the last one keeps its scratch in HBM and takes anything).  0 = defaults (2048, 16384).  Results never depend on it. */
 int oatk_hip_debug_ec_tiers(oatk_hip_ctx *ctx, int cap_t0, int cap_t1);
 
+/* The device edit distance on its own: wf_ed_core (levdist.c:265-312) in extension mode without traceback -- the routine every error block
+ * is solved with (ec_wave.hpp: ecw_step), one wavefront per job, no reads and no graph involved.  Job j aligns the target
+ * t_codes[t_off[j], t_off[j + 1]) against growing prefixes of the query q_codes[q_off[j], q_off[j + 1]): for every s in
+ * [step_off[j], step_off[j + 1]) the same wavefront is advanced with query length step_ql[s] (ascending; a step of a wf_config_t that is
+ * RESUMED, syncerr.c:165-195; one step with the whole query = wf_ed) and out3[3 s ..] receives (score, t_end, q_end) exactly as
+ * wf_config_t carries them after the call (ends are one past the last aligned base).  bw[j] < 0: no band.  Codes are one base per byte,
+ * values 0..3 -- the alphabet of sr_t.hoco_s, which is all the correction ever aligns.  All pointers are HOST memory. */
+int oatk_hip_debug_wf_ed(oatk_hip_ctx *ctx, uint64_t n_jobs, const uint8_t *t_codes, const uint64_t *t_off, const uint8_t *q_codes, const uint64_t *q_off,
+                         const int32_t *bw, const int32_t *step_ql, const uint64_t *step_off, int32_t *out3);
+
 /* Resident results of oatk_hip_ec (ids for oatk_hip_buffer):
  *   EC_N_SCM   u32[n_reads]      sr_t.n after correction
  *   EC_SCM_OFF u64[n_reads+1]    slots of the corrected chains

@@ -41,7 +41,7 @@ EXPORTS = [
     "oatk_hip_stream", "oatk_hip_sync", "oatk_hip_max_k", "oatk_hip_scan", "oatk_hip_scan_host", "oatk_hip_count",
     "oatk_hip_info", "oatk_hip_buffer", "oatk_hip_d2h", "oatk_hip_staging", "oatk_hip_set_timing", "oatk_hip_get_timing",
     "oatk_hip_debug_hash_mask", "oatk_hip_debug_force_general", "oatk_hip_debug_list_cap",
-    "oatk_hip_ec_graph", "oatk_hip_ec", "oatk_hip_ec_stats", "oatk_hip_debug_ec_tiers", "oatk_hip_ec_mark", "oatk_hip_ec_correct",
+    "oatk_hip_ec_graph", "oatk_hip_ec", "oatk_hip_ec_stats", "oatk_hip_debug_ec_tiers", "oatk_hip_debug_wf_ed", "oatk_hip_ec_mark", "oatk_hip_ec_correct",
     "oatk_hip_ec_set_global", "oatk_hip_ec_pairs", "oatk_hip_ec_graph_from_pairs", "oatk_hip_ec_export_kmers", "oatk_hip_ec_import_kmers",
     "oatk_hip_ec_reserve_import", "oatk_hip_consensus", "oatk_hip_consensus_ids", "oatk_hip_ingest", "oatk_hip_ingest_host", "oatk_hip_scan_ingested", "oatk_hip_stat", "oatk_hip_stat_keys", "oatk_hip_stat_from_keys",
     "oatk_hip_asm_graph", "oatk_hip_asm_pairs", "oatk_hip_asm_graph_from_pairs", "oatk_hip_overlap_hist", "oatk_hip_overlap_pairs", "oatk_hip_overlap_hist_from_pairs", "oatk_hip_read_alignment", "oatk_hip_debug_align_two_pass",
@@ -118,6 +118,7 @@ def load():
     L.oatk_hip_ec.argtypes = [vp, C.POINTER(EcGraph), C.c_double, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double]
     L.oatk_hip_ec_stats.argtypes = [vp, vp]
     L.oatk_hip_debug_ec_tiers.argtypes = [vp, C.c_int, C.c_int]
+    L.oatk_hip_debug_wf_ed.argtypes = [vp, C.c_uint64, vp, vp, vp, vp, vp, vp, vp, vp]
     L.oatk_hip_ec_mark.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double]
     L.oatk_hip_ec_correct.argtypes = [vp, C.c_double]
     L.oatk_hip_ec_set_global.argtypes = [vp, C.c_uint64, vp, vp, vp]

@@ -110,6 +110,17 @@ struct oatk_hip_ctx {
         }                                                                                          \
     } while (0)
 
+// Test hook (tests/test_gpu_cli.py): OATK_DEBUG_REFUSE=<bit mask> makes an entry point decline with OATK_E_SPLIT as if its input were one of the
+// rare shapes it refuses -- 1 the EC graph (duplicate arcs), 2 the assembly graph, 4 the count (oversized hash group), 8 the pair-distance tables --
+// so that a caller's fallback to the original routine can be exercised on inputs that do not produce those shapes.  Unset in production.
+static bool debug_refuse(oatk_hip_ctx *ctx, int bit, const char *what)
+{
+    const char *e = getenv("OATK_DEBUG_REFUSE");
+    if (!e || !(atoi(e) & bit)) return false;
+    ctx->err = std::string(what) + ": refused on request (OATK_DEBUG_REFUSE)";
+    return true;
+}
+
 static void t_begin(oatk_hip_ctx *ctx, int which)
 {
     if (!ctx->timing) return;
@@ -551,6 +562,7 @@ int oatk_hip_count(oatk_hip_ctx *ctx)
     CK(hipStreamSynchronize(ctx->stream));
     if (ctx->timing) t_collect(ctx, OATK_T_COUNT_SORT, OATK_T_COUNT_GROUP);
     if (fl[2]) { ctx->err = "hash group with too many distinct k-mers"; return OATK_E_SPLIT; }
+    if (debug_refuse(ctx, 4, "oatk_hip_count")) return OATK_E_SPLIT;
     if (fl[1]) { ctx->err = "identical kmers have different smers"; return OATK_E_SMER; }
     ctx->n_scm_total = n_scm;
     ctx->counted = true;

@@ -188,6 +188,32 @@ __device__ int ecw_step(const uint32_t *ts, int32_t tl, const uint32_t *qs, int3
     return 0;
 }
 
+// wf_ed_core on its own (levdist.c:265-312): one wave per job, every array in HBM; the wavefront survives from one query length to the next
+// exactly as the DFS keeps it from one appended k-mer to the next (include/oatk_hip_ec.h: oatk_hip_debug_wf_ed)
+__global__ __launch_bounds__(64) void ecw_wf_ed_kernel(const uint32_t *tw, const uint64_t *tw_off, const int32_t *tl, const uint32_t *qw, const uint64_t *qw_off,
+                                                       const int32_t *bw, const int32_t *step_ql, const uint64_t *step_off, int32_t *kbuf, const uint64_t *k_off,
+                                                       int32_t *out3)
+{
+    const uint64_t j = blockIdx.x;
+    const uint32_t *ts = tw + tw_off[j], *qs = qw + qw_off[j];
+    int32_t *ka = kbuf + k_off[j], *kb = ka + (k_off[j + 1] - k_off[j]) / 2;
+    const int32_t tlen = tl[j], band = bw[j];
+    EcwWave wv;
+    wv.k = ka, wv.spare = kb, wv.n = 1, wv.d0 = 0;              // the caller's initial state: diagonal 0, nothing matched, score 0 (syncerr.c:465-482)
+    if (threadIdx.x == 0) ka[0] = -1;
+    __syncthreads();
+    int32_t score = 0, t_end = -1, q_end = -1;
+    for (uint64_t s = step_off[j]; s < step_off[j + 1]; ++s) {
+        const int32_t ql = step_ql[s];
+        for (;;) {
+            if (ecw_step(ts, tlen, qs, ql, band, wv, ka, kb, t_end, q_end)) break;
+            ++score;
+            if (band >= 0 && score > band) break;
+        }
+        if (threadIdx.x == 0) out3[3 * s] = score, out3[3 * s + 1] = t_end + 1, out3[3 * s + 2] = q_end + 1;
+    }
+}
+
 // a live-arc record in flight: issued as two loads, made uniform only where it is used
 struct EcwArcRegs {
     uint4 a;                      // w, ls, hs16, mpos

@@ -113,6 +113,28 @@ class HipSyncasm:
         self._check(self.L.oatk_hip_ec_stats(self.h, st.ctypes.data), "oatk_hip_ec_stats")
         return st
 
+    def wf_ed(self, jobs):
+        """the device edit distance on its own (oatk_hip_debug_wf_ed): jobs = [(target, query, bw, [ql, ...]), ...] with target / query as
+        bytes over ACGT (any case); returns, per job, the list of (score, t_end, q_end) after each query length -- what wf_ed_core
+        (levdist.c:265-312, extension mode) leaves in a wf_config_t that is resumed with a longer and longer query"""
+        code = np.full(256, 255, np.uint8)
+        for i, ch in enumerate(b"ACGT"):
+            code[ch] = code[ch + 32] = i
+        t_off, q_off, s_off = np.zeros(len(jobs) + 1, np.uint64), np.zeros(len(jobs) + 1, np.uint64), np.zeros(len(jobs) + 1, np.uint64)
+        for j, (t, q, _, steps) in enumerate(jobs):
+            t_off[j + 1], q_off[j + 1], s_off[j + 1] = t_off[j] + len(t), q_off[j] + len(q), s_off[j] + len(steps)
+        tc = code[np.frombuffer(b"".join(j[0] for j in jobs), np.uint8)] if jobs else np.zeros(0, np.uint8)
+        qc = code[np.frombuffer(b"".join(j[1] for j in jobs), np.uint8)] if jobs else np.zeros(0, np.uint8)
+        if (tc == 255).any() or (qc == 255).any():
+            raise ValueError("wf_ed: the device alphabet is the 2-bit one of sr_t.hoco_s (ACGT)")
+        bw = np.array([j[2] for j in jobs], np.int32)
+        ql = np.array([x for j in jobs for x in j[3]], np.int32)
+        out = np.zeros((len(ql), 3), np.int32)
+        tc, qc = np.ascontiguousarray(tc), np.ascontiguousarray(qc)
+        self._check(self.L.oatk_hip_debug_wf_ed(self.h, len(jobs), tc.ctypes.data, t_off.ctypes.data, qc.ctypes.data, q_off.ctypes.data, bw.ctypes.data,
+                                                ql.ctypes.data, s_off.ctypes.data, out.ctypes.data), "oatk_hip_debug_wf_ed")
+        return [[tuple(int(v) for v in out[s]) for s in range(int(s_off[j]), int(s_off[j + 1]))] for j in range(len(jobs))]
+
     def ec_stats(self):
         st = np.zeros(12, np.uint64)
         self._check(self.L.oatk_hip_ec_stats(self.h, st.ctypes.data), "oatk_hip_ec_stats")

@@ -130,3 +130,28 @@ def hifi_like(n_reads, genome_len, mean_len, seed=11, err=0.0005):
             r = revcomp(r)
         out.append(r)
     return out
+
+
+def tandem_repeat_reads(K, n_reads=240, flank=20000, unit_len=47, mean_len=6000, seed=256, err=0.0):
+    """reads of both orientations over a genome that holds a PERFECT tandem repeat longer than K + period.  Inside it the same
+    k-mer recurs every period, so a syncmer is adjacent to itself -- on forward reads as (v+, v+), on reverse ones as (v-, v-); the reference's
+    arc counter keeps those as two keys (syncasm.c:256-257 canonicalises by v0 <= v1 only) and emits each with its complement: duplicate
+    (v, w) arcs whose order is that of its hash table (syncasm.c:264-282, graph.c:70-83)."""
+    rng = np.random.default_rng(seed)
+    unit = rand_nohp(rng, unit_len)
+    while unit[0] == unit[-1]:
+        unit = rand_nohp(rng, unit_len)
+    copies = (2 * K + 6 * unit_len) // unit_len + 4
+    genome = rand_dna(rng, flank) + unit * copies + rand_dna(rng, flank)
+    rep0, rep1 = flank, flank + unit_len * copies
+    out = []
+    for i in range(n_reads):
+        ln = int(np.clip(rng.normal(mean_len, 0.1 * mean_len), 2 * K, len(genome)))
+        # two thirds of the reads are laid across the repeat, the rest anywhere
+        st = int(rng.integers(max(0, rep0 - ln + K), min(len(genome) - ln, rep1 - K))) if i % 3 else int(rng.integers(0, len(genome) - ln))
+        r = bytearray(genome[st:st + ln])
+        for p in sorted(rng.integers(0, ln, size=rng.binomial(ln, err)).tolist(), reverse=True):
+            r[p] = b"ACGT"[(b"ACGT".index(bytes([r[p]])) + 1 + int(rng.integers(0, 3))) & 3]
+        r = bytes(r)
+        out.append(revcomp(r) if i % 2 else r)
+    return out

@@ -90,3 +90,32 @@ def test_cli_declined_inputs_fall_back_to_the_original_bodies(tmp_path):
             f.write(b"@q%d\n" % i + r[:h] + b"\n" + r[h:] + b"\n+\n" + b"I" * h + b"\n" + b"I" * (len(r) - h) + b"\n")
     tab, log = both(tmp_path, fq, 301, 21, 6)
     assert tab["sr_read"][0] == 0 and tab["sr_read"][2] == 1
+
+
+@pytest.mark.parametrize("refuse,originals", [(1, {"read_error_correction": 0, "make_syncmer_graph": 0}),      # EC graph refused: the original BUILDS it, the device still corrects
+                                              (2, {"make_syncmer_graph": 1}),                                    # assembly graph refused: original make_syncmer_graph(c, a)
+                                              (4, {"collect_syncmer_from_reads": 1, "make_syncmer_graph": 2, "read_error_correction": 1}),
+                                              (8, {})])                                                           # distance tables refused: calc_syncmer_overlap walks itself
+def test_cli_refusals_of_the_device_fall_back_and_stay_identical(tmp_path, refuse, originals):
+    """The shapes the device declines (OATK_E_SPLIT: duplicate (v, w) arcs, an arc with dozens of distances, an oversized hash group) cannot be
+    produced from sequence through the scan -- DESIGN.md 10 shows why two consecutive occurrences of one k-mer on one strand always have another
+    syncmer between them -- so the refusal itself is requested (OATK_DEBUG_REFUSE) and what is tested is everything behind it: the original
+    body runs on the structs the device filled, later calls go on where they still can, and both GFA files stay byte-identical."""
+    reads = A.hifi_like(260, 50000, 5000, seed=21 + refuse, err=0.001)
+    fa = str(tmp_path / "reads.fa")
+    R.write_fasta(reads, fa)
+    ref, dev = str(tmp_path / "ref"), str(tmp_path / "dev")
+    U.run_cli(U.CLI_REF, fa, ref, 301, 6, 4, extra=["-s", "21"])
+    _, err = U.run_cli(U.CLI_DROPIN, fa, dev, 301, 6, 4, env={"OATK_DROPIN_LOG": "1", "OATK_DEBUG_REFUSE": str(refuse)}, extra=["-s", "21"])
+    for suffix in (".utg.gfa", ".utg.final.gfa"):
+        assert filecmp.cmp(ref + suffix, dev + suffix, shallow=False), suffix
+    tab = U.served_table(err)
+    for f, n_orig in originals.items():
+        assert tab[f][2] == n_orig, (f, tab[f], err[-1500:])
+    assert tab["sr_read"][0] == 1 and tab["sr_read"][2] == 0
+    if refuse == 1:
+        assert "graph from the original make_syncmer_graph" in err and tab["read_error_correction"][0] == 1
+    if refuse == 8:
+        assert tab["calc_syncmer_overlap"][0] == 0 and tab["scg_syncmer_consensus"][0] > 20
+    if refuse in (1, 2, 8):
+        assert tab["scg_read_alignment"][0] >= 3 and tab["scg_read_alignment"][2] == 0

@@ -1,0 +1,117 @@
+"""GPU: the device edit distance ON ITS OWN (oatk_hip_debug_wf_ed over ec_wave.hpp's ecw_step -- the routine every error block is solved with)
+against the reference's wf_ed / wf_ed_core (levdist.c:265-345): all of tests/golden/levdist.npz -- 601 pairs incl. the reference's only built-in
+known answer (levdist.c:445-446: ED=8 t_EN=59 q_EN=56) and the band cut-offs, 120 resumable traces -- then fresh random jobs against the CPU
+oracle (oracle/levdist.c, itself pinned to the same goldens and to the compiled reference), long strings and many-diagonal wavefronts included.
+"north_star: edit distances match exactly"."""
+import numpy as np
+import pytest
+
+import adversarial as A
+import golden_util as G
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def two_bit(q, ts):
+    """the device alphabet is sr_t.hoco_s's 2-bit one (the correction never sees anything else: syncmer.c:268-283 stores N as A).  An N of the
+    known-answer query is replaced by a base for which the char-level routine -- pinned on the ORIGINAL pair -- still returns the same answer."""
+    want = O.wf_ed(ts, q, -1)
+    q = bytearray(q)
+    for i, ch in enumerate(q):
+        if ch in b"Nn":
+            for sub in b"ACGT":
+                q[i] = sub
+                if O.wf_ed(ts, bytes(q), -1) == want:
+                    break
+            else:
+                raise AssertionError("no substitution keeps the answer")
+    return bytes(q)
+
+
+def test_known_answer_of_the_reference(hip):
+    g = G.load("levdist")
+    ts, qs = g["pairs_t"][0], g["pairs_q"][0]
+    assert tuple(int(v) for v in g["pairs_out"][0]) == (8, 59, 56) == O.wf_ed(ts, qs, -1)
+    q2 = two_bit(qs, ts)
+    assert O.wf_ed(ts, q2, -1) == (8, 59, 56)
+    assert hip.wf_ed([(ts, q2, -1, [len(q2)])]) == [[(8, 59, 56)]]
+
+
+def test_golden_pairs(hip):
+    g = G.load("levdist")
+    jobs, want = [], []
+    for ts, qs, bw, out in list(zip(g["pairs_t"], g["pairs_q"], g["pairs_bw"], g["pairs_out"]))[1:]:
+        jobs.append((ts, qs, int(bw), [len(qs)]))
+        want.append([tuple(int(v) for v in out)])
+    assert len(jobs) == 600 and sum(1 for j, w in zip(jobs, want) if j[2] >= 0 and w[0][0] > j[2]) > 20      # band cut-offs are among them
+    got = hip.wf_ed(jobs)
+    for j, (a, b) in enumerate(zip(got, want)):
+        assert a == b, (j, jobs[j], a, b)
+
+
+def test_golden_resumable_traces(hip):
+    g = G.load("levdist")
+    jobs, want = [], []
+    for ts, qs, bw, steps in zip(g["tr_t"], g["tr_q"], g["tr_bw"], g["tr_steps"]):
+        jobs.append((ts, qs, int(bw), [int(s[0]) for s in steps]))
+        want.append([(int(s[1]), int(s[2]), int(s[3])) for s in steps])
+    assert len(jobs) == 120 and sum(len(w) for w in want) > 300
+    got = hip.wf_ed(jobs)
+    for j, (a, b) in enumerate(zip(got, want)):
+        assert a == b, (j, a, b)
+
+
+def mutate(rng, ts, n_edits, alpha=b"ACGT"):
+    q = bytearray(ts)
+    for _ in range(n_edits):
+        if not q:
+            break
+        p, kind = int(rng.integers(0, len(q))), int(rng.integers(0, 3))
+        if kind == 0:
+            q[p] = alpha[int(rng.integers(0, len(alpha)))]
+        elif kind == 1:
+            q.insert(p, alpha[int(rng.integers(0, len(alpha)))])
+        else:
+            del q[p]
+    return bytes(q) or b"A"
+
+
+def test_fresh_jobs_against_the_oracle(hip):
+    rng = np.random.default_rng(265)
+    jobs, want = [], []
+    for it in range(400):
+        alpha = [b"ACGT", b"AC", b"A", b"ACGT"][it % 4]
+        tl = int(rng.integers(1, 3000 if it % 10 == 0 else 300))
+        ts = A.rand_dna(rng, tl, alpha)
+        q = mutate(rng, ts, int(rng.integers(0, 1 + tl // 12)), alpha)
+        if it % 3 == 0:
+            q = q + A.rand_dna(rng, int(rng.integers(1, 80)), alpha)                       # the query runs past the target
+        if it % 7 == 0:
+            q = A.rand_dna(rng, int(rng.integers(1, 120)), alpha)                          # unrelated: every diagonal is alive, up to 200 of them
+        bw = [-1, 2, 6, 12, 40, 100][it % 6]
+        steps, ql = [], 0
+        w = O.Wavefront(ts, bw)
+        res = []
+        while ql < len(q):
+            ql = min(len(q), ql + int(rng.integers(1, max(2, len(q) // 2))))
+            r = w.step(q[:ql])
+            steps.append(ql), res.append(r)
+            if bw >= 0 and r[0] > bw:
+                break
+        w.close()
+        jobs.append((ts, q, bw, steps)), want.append(res)
+    got = hip.wf_ed(jobs)
+    n_wide = 0
+    for j, (a, b) in enumerate(zip(got, want)):
+        assert a == b, (j, jobs[j][2], jobs[j][3], a, b)
+        n_wide += b[-1][0] > 32
+    assert n_wide > 10                                                                      # wavefronts wider than one lane group per diagonal
+
+
+def test_bad_arguments_are_refused(hip):
+    from oatk_amd import OatkHipError
+    with pytest.raises(OatkHipError):
+        hip.wf_ed([(b"ACGT", b"ACGT", 2, [3, 2])])                                          # query lengths must ascend
+    with pytest.raises(ValueError):
+        hip.wf_ed([(b"ACGN", b"ACGT", 2, [4])])
