@@ -40,8 +40,8 @@ K, S = 1001, 31
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="config3")
     ap.add_argument("--reads-per-gpu", type=int, default=0, help="override the number of reads each GPU owns")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -245,20 +245,7 @@ def main():
             ec_summary["imported_kmers_rank0"] = sharded.n_imported
 
     extras = {}
-    if not args.no_extras:
-        hip.set_timing(False)
-        # ---- the same batch through scan + count only (BASELINE.json configs[1]'s shape at this size) ----
-        try:
-            dsc, _ = timed(scan_count, args.steps)
-            if dist is not None:
-                t = torch.tensor([dsc], dtype=torch.float64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                dsc = float(t.item())
-            extras["scan_count"] = {"value": round(total_bases / dsc / 1e9, 3), "unit": "Gbases/s", "ms_per_step": round(dsc * 1e3, 3),
-                                    "workload": "the same resident batch through scan + count only%s" % (" (no table merge)" if world > 1 else "")}
-        except Exception as ex:             # noqa: BLE001   (an extension must never take the headline down)
-            extras["scan_count"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
-
+    hip.set_timing(False)
     if rank == 0 and not args.no_extras:
         # ---- what follows the EC round in syncasm(), on the corrected batch of rank 0 (not part of `value`) ----
         if world == 1:
@@ -284,6 +271,20 @@ def main():
             except Exception as ex:         # noqa: BLE001
                 extras["after_syncerr"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
 
+    if not args.no_extras:
+        # ---- the same batch through scan + count only (BASELINE.json configs[1]'s shape at this size) ----
+        try:
+            dsc, _ = timed(scan_count, args.steps)
+            if dist is not None:
+                t = torch.tensor([dsc], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dsc = float(t.item())
+            extras["scan_count"] = {"value": round(total_bases / dsc / 1e9, 3), "unit": "Gbases/s", "ms_per_step": round(dsc * 1e3, 3),
+                                    "workload": "the same resident batch through scan + count only%s" % (" (no table merge)" if world > 1 else "")}
+        except Exception as ex:             # noqa: BLE001   (an extension must never take the headline down)
+            extras["scan_count"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+
+    if rank == 0 and not args.no_extras:
         # ---- BASELINE.json configs[1]: 200 k reads x 15 kb (its own 1 Mb genome), scan + count, and with the EC round ----
         if args.workload != "config2":
             try:

@@ -49,28 +49,44 @@ def test_cli_without_ec_and_unzip(tmp_path):
     assert tab["sr_read"][0] == 1 and tab["make_syncmer_graph"][0] == 1 and tab["scg_read_alignment"][0] >= 1
 
 
-def test_cli_two_files_fastq_gz_and_wrapped_fasta(tmp_path):
+def test_cli_two_files_fastq_gz_and_plain(tmp_path):
     reads = A.hifi_like(300, 50000, 5000, seed=9, err=0.0008)
-    f1, f2 = str(tmp_path / "a.fq.gz"), str(tmp_path / "b.fa")
+    f1, f2 = str(tmp_path / "a.fq.gz"), str(tmp_path / "b.fq")
     with gzip.open(f1, "wb") as f:
         for i, r in enumerate(reads[:150]):
             f.write(b"@q%d\n" % i + r + b"\n+\n" + b"I" * len(r) + b"\n")
     with open(f2, "wb") as f:
         for i, r in enumerate(reads[150:]):
-            f.write(b">w%d wrapped\n" % i + b"\n".join(r[j:j + 70] for j in range(0, len(r), 70)) + b"\n")
+            f.write(b"@w%d second file\r\n" % i + r + b"\r\n+\r\n" + b"5" * len(r) + b"\r\n")
     tab, _ = both(tmp_path, [f1, f2], 301, 21, 6)
     for f in SIX:
         assert tab[f][0] >= 1 and tab[f][2] == 0, (f, tab[f])
 
 
+def test_cli_wrapped_fasta_gz(tmp_path):
+    reads = A.hifi_like(300, 50000, 5000, seed=10, err=0.0008)
+    fa = str(tmp_path / "w.fa.gz")
+    with gzip.open(fa, "wb") as f:
+        for i, r in enumerate(reads):
+            f.write(b">w%d wrapped\n" % i + b"\n".join(r[j:j + 70] for j in range(0, len(r), 70)) + b"\n")
+    tab, _ = both(tmp_path, fa, 301, 21, 6)
+    for f in SIX:
+        assert tab[f][0] >= 1 and tab[f][2] == 0, (f, tab[f])
+
+
 def test_cli_auto_coverage(tmp_path):
-    """-c 0: min_k_cov comes from sr_db->stats->kmer_peak_* (run_syncasm.c:89-92), i.e. from the device's sr_db_stat"""
-    from oatk_amd.synth import ReadSet
-    reads = ReadSet(150_000, 1500, 12000).as_list(0, 1500)
+    """-c 0: min_k_cov = 10 x the k-mer peak of sr_db->stats (run_syncasm.c:89-92), i.e. it comes from the device's sr_db_stat.  The heuristic
+    is made for an organelle in total-DNA reads: a thin nuclear background (k-mer peak 8) under a 400x plastid-sized genome."""
+    nuc = A.hifi_like(700, 400000, 6000, seed=3, err=0.0005)
+    org = A.hifi_like(1300, 20000, 6000, seed=4, err=0.0005)
+    reads = nuc + org
+    reads = [reads[i] for i in np.random.default_rng(5).permutation(len(reads))]
     fa = str(tmp_path / "reads.fa")
     R.write_fasta(reads, fa)
-    tab, log = both(tmp_path, fa, 1001, 31, 0)
-    assert tab["sr_db_stat"][0] == 2 and tab["sr_read"][0] == 1
+    tab, log = both(tmp_path, fa, 301, 21, 0)
+    assert tab["sr_db_stat"][0] == 2 and tab["sr_read"][0] == 1 and "set minimum kmer coverage as 80" in log
+    for f in SIX:
+        assert tab[f][2] == 0, (f, tab[f])
 
 
 def test_cli_declined_inputs_fall_back_to_the_original_bodies(tmp_path):
@@ -89,6 +105,14 @@ def test_cli_declined_inputs_fall_back_to_the_original_bodies(tmp_path):
             h = len(r) // 2
             f.write(b"@q%d\n" % i + r[:h] + b"\n" + r[h:] + b"\n+\n" + b"I" * h + b"\n" + b"I" * (len(r) - h) + b"\n")
     tab, log = both(tmp_path, fq, 301, 21, 6)
+    assert tab["sr_read"][0] == 0 and tab["sr_read"][2] == 1
+    # a FASTQ file followed by a FASTA file: kseq decides per record, the device reader per input -- the original reads it
+    f1, f2 = str(tmp_path / "m.fq"), str(tmp_path / "m.fa")
+    with open(f1, "wb") as f:
+        for i, r in enumerate(reads[:130]):
+            f.write(b"@q%d\n" % i + r + b"\n+\n" + b"I" * len(r) + b"\n")
+    R.write_fasta(reads[130:], f2)
+    tab, log = both(tmp_path, [f1, f2], 301, 21, 6)
     assert tab["sr_read"][0] == 0 and tab["sr_read"][2] == 1
 
 

@@ -1,7 +1,8 @@
-"""GPU, BASELINE.json configs[1] at FULL size (200 k reads x ~15 kb, k = 1001, s = 31): properties that do not need an oracle
-run at that size -- conservation sums, orderings, run-to-run determinism of every resident result (the solver pulls blocks
-from a shared queue, so scheduling differs between runs), strand symmetry -- plus a bit-exact oracle check of reads sampled
-from the full batch."""
+"""GPU, BASELINE.json configs[1] (200 k reads x ~15 kb) and configs[2] (2 M reads x ~15 kb = 30 Gbases, the configuration the metric is quoted
+on) at FULL size, k = 1001, s = 31: properties that do not need an oracle run at that size -- conservation sums, orderings, run-to-run
+determinism of every resident result (the solver pulls blocks from a shared queue, so scheduling differs between runs), strand symmetry --
+plus a bit-exact oracle check of reads sampled from the full batch.  (tests/test_gpu_fullsize_ref.py compares config 2 with the compiled
+reference element for element.)"""
 import zlib
 
 import numpy as np
@@ -18,12 +19,13 @@ for a, b in zip(b"ACGTacgtNn", b"TGCAtgcaNn"):
     COMP[a] = b
 
 
-@pytest.fixture(scope="module")
-def batch():
-    cfg = dict(CONFIGS["config2"])
+@pytest.fixture(scope="module", params=["config2", "config3"])
+def batch(request):
+    cfg = dict(CONFIGS[request.param])
     rs = ReadSet(**cfg)
     seq, off, lens = rs.slice(0, cfg["n_reads"])
-    return cfg, seq, off, lens
+    yield cfg, seq, off, lens
+    del seq
 
 
 def crc(a):
@@ -70,10 +72,10 @@ def test_full_size_pipeline_properties(hip, batch):
     # EC graph: symmetric (every arc has its complement with equal coverage and overlap), CSR consistent
     av, aw, acov, als, idx_n = hip.fetch("EG_ARC_V"), hip.fetch("EG_ARC_W"), hip.fetch("EG_ARC_COV"), hip.fetch("EG_ARC_LS"), hip.fetch("EG_IDX_N")
     assert int(idx_n.sum()) == len(av) and np.all(np.diff((av << np.uint64(32) | aw).astype(np.uint64).view(np.int64)) > 0)
-    fwd = dict(zip((av << np.uint64(32) | aw).tolist(), zip(acov.tolist(), als.tolist())))
-    samp = np.random.default_rng(1).integers(0, len(av), 20000)
-    for i in samp.tolist():
-        assert fwd[int((aw[i] ^ np.uint64(1)) << np.uint64(32) | (av[i] ^ np.uint64(1)))] == (int(acov[i]), int(als[i]))
+    akey = av << np.uint64(32) | aw
+    ckey = (aw ^ np.uint64(1)) << np.uint64(32) | (av ^ np.uint64(1))
+    ci = np.searchsorted(akey, ckey)
+    assert np.array_equal(akey[ci], ckey) and np.array_equal(acov[ci], acov) and np.array_equal(als[ci], als)
     assert int(acov.sum()) + int(acov[(aw ^ np.uint64(1)) == av].sum()) == 2 * (info["n_occ"] - int((n_scm > 0).sum()))
     # error correction: conservation, the refreshed table is the histogram of the corrected chains, corrected entries point at live syncmers
     st = np.array(sums[0]["stats"])
@@ -102,6 +104,8 @@ def test_full_size_sample_against_oracle(hip, batch):
 def test_strand_symmetry(hip, batch):
     """a read and its reverse complement select the same k-mers: same hashes in reverse order, mirrored positions, flipped strands"""
     cfg, seq, off, lens = batch
+    if cfg["n_reads"] > 200000:
+        pytest.skip("per-read property: the 200 k-read batch covers it")
     m = 20000
     sub_end = int(off[m - 1]) + int((int(lens[m - 1]) + 63) // 64 * 64)
     fwd = seq[:sub_end]

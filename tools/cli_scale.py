@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""The syncasm CLI at scale (SURVEY.md 8d timing iii; the north-star comparison): N synthetic HiFi reads of BASELINE.json's config 3 genome as a
+FASTA file in shared memory, the drop-in binary with its per-function log, optionally the reference binary on the same file at -t T, GFA md5s.
+
+    python tools/cli_scale.py <n_reads> [--ref] [--threads T] [--workload config3] [--keep]
+"""
+import argparse
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oatk_amd.synth import CONFIGS, ReadSet  # noqa: E402
+
+BIN = os.path.join(ROOT, "oracle", "_ref")          # noqa: built artefacts of `make ref ref_dropin`
+
+ap = argparse.ArgumentParser()
+ap.add_argument("n_reads", type=int)
+ap.add_argument("--ref", action="store_true", help="also run the reference binary")
+ap.add_argument("--threads", type=int, default=8)
+ap.add_argument("--workload", default="config3")
+ap.add_argument("--dir", default="/dev/shm")
+ap.add_argument("--keep", action="store_true")
+args = ap.parse_args()
+
+cfg = dict(CONFIGS[args.workload])
+cfg["n_reads"] = args.n_reads
+c = cfg["min_k_cov"]
+rs = ReadSet(**cfg)
+fa = os.path.join(args.dir, "oatk_cli_%d.fa" % args.n_reads)
+t0 = time.perf_counter()
+bases = 0
+with open(fa, "wb") as f:
+    step = 100000
+    for first in range(0, args.n_reads, step):
+        n = min(step, args.n_reads - first)
+        seq, off, lens = rs.slice(first, n)
+        bases += int(lens.sum())
+        parts = []
+        for i in range(n):
+            parts.append(b">r%d\n" % (first + i))
+            parts.append(seq[int(off[i]):int(off[i]) + int(lens[i])].tobytes())
+            parts.append(b"\n")
+        f.write(b"".join(parts))
+print("wrote %s: %d reads, %.2f Gbases in %.1f s" % (fa, args.n_reads, bases / 1e9, time.perf_counter() - t0), flush=True)
+
+
+def md5(path):
+    h = hashlib.md5()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 22), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def run(binary, tag, env=None):
+    out = os.path.join(args.dir, "oatk_cli_%s" % tag)
+    e = dict(os.environ)
+    e.update(env or {})
+    t = time.perf_counter()
+    p = subprocess.run([os.path.join(BIN, binary), "-k", "1001", "-c", str(c), "-t", str(args.threads), "-o", out, fa], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
+    dt = time.perf_counter() - t
+    err = p.stderr.decode(errors="replace")
+    res = {"binary": binary, "rc": p.returncode, "wall_s": round(dt, 2), "gbases_per_s": round(bases / dt / 1e9, 3)}
+    for sfx in (".utg.gfa", ".utg.final.gfa"):
+        if os.path.exists(out + sfx):
+            res["md5" + sfx] = md5(out + sfx)
+            res["bytes" + sfx] = os.path.getsize(out + sfx)
+            if not args.keep:
+                os.unlink(out + sfx)
+    return res, err
+
+
+report = {"n_reads": args.n_reads, "gbases": round(bases / 1e9, 3), "threads": args.threads, "workload": args.workload}
+r, err = run("syncasm_dropin", "dev", {"OATK_DROPIN_LOG": "1"})
+report["dropin"] = r
+print("\n".join(l for l in err.splitlines() if "oatk_dropin" in l), flush=True)
+if args.ref:
+    r2, _ = run("syncasm", "ref")
+    report["reference"] = r2
+    report["speedup"] = round(r2["wall_s"] / r["wall_s"], 2)
+    report["gfa_identical"] = all(r.get(k) == r2.get(k) and r.get(k) for k in ("md5.utg.gfa", "md5.utg.final.gfa"))
+if not args.keep:
+    os.unlink(fa)
+print(json.dumps(report), flush=True)
