@@ -109,6 +109,10 @@ enum {
 };
 int oatk_hip_buffer(oatk_hip_ctx *ctx, int which, const void **d_ptr, uint64_t *bytes);
 int oatk_hip_d2h(oatk_hip_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes);
+/* the same without waiting: the copy is ordered on the handle's stream (oatk_hip_sync waits for it); the host side should be page-locked
+ * (oatk_hip_staging) or the runtime stages it and the call blocks anyway */
+int oatk_hip_d2h_async(oatk_hip_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes);
+int oatk_hip_h2d_async(oatk_hip_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes);
 /* Page-locked host memory owned by the context (one block, regrown on demand, freed with the context; NULL on failure): oatk_hip_d2h into it
  * runs at PCIe speed, into pageable memory at a fraction of it -- callers that move gigabytes of results stage them through it in pieces. */
 void *oatk_hip_staging(oatk_hip_ctx *ctx, uint64_t bytes);

@@ -34,6 +34,10 @@ extern "C" {
 int oatk_hip_ingest(oatk_hip_ctx *ctx, const uint8_t *d_text, uint64_t n_bytes, int format, int final, uint64_t *n_reads, uint64_t *consumed);
 /* the same from host memory (one hipMemcpy first) */
 int oatk_hip_ingest_host(oatk_hip_ctx *ctx, const uint8_t *h_text, uint64_t n_bytes, int format, int final, uint64_t *n_reads, uint64_t *consumed);
+/* device memory owned by the context for n_bytes of text (valid until the next call or the next oatk_hip_ingest_host): a caller that uploads the
+ * text itself -- in pieces, through page-locked memory, while it is still reading the file -- fills it with oatk_hip_h2d_async and then calls
+ * oatk_hip_ingest on it */
+int oatk_hip_ingest_text_buffer(oatk_hip_ctx *ctx, uint64_t n_bytes, uint8_t **d_text);
 /* oatk_hip_scan on the resident packed stream: reads are numbered sid0, sid0 + 1, ... in file order (syncmer.c:525) */
 int oatk_hip_scan_ingested(oatk_hip_ctx *ctx, uint64_t sid0, int k, int s);
 

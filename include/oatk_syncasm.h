@@ -68,6 +68,13 @@ typedef struct {
     uint64_t *h;
 } oatk_syncmer_db_t;
 
+/* Host threads the adaptors below use to fill the structs (default: up to 16 of the online cores): pass the caller's n_threads, as the
+ * reference's own functions take it (syncmer.c:487, syncerr.c:819).  oatk_par_run calls fn(arg, tid, n) on n threads and joins them. */
+void oatk_host_set_threads(int n);
+int oatk_host_threads(void);
+typedef void (*oatk_par_fn)(void *arg, int tid, int n_threads);
+void oatk_par_run(oatk_par_fn fn, void *arg);
+
 /* malloc'ed and initialised like sr_db_init (syncmer.c:1060-1067) */
 oatk_sr_db_t *oatk_sr_db_new(int k, int s);
 

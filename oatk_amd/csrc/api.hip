@@ -644,4 +644,22 @@ int oatk_hip_d2h(oatk_hip_ctx *ctx, void *h_dst, const void *d_src, uint64_t byt
     return OATK_OK;
 }
 
+int oatk_hip_d2h_async(oatk_hip_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes)
+{
+    if (!ctx) return OATK_E_NODEV;
+    if (bytes == 0) return OATK_OK;
+    CK(hipSetDevice(ctx->device));
+    CK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return OATK_OK;
+}
+
+int oatk_hip_h2d_async(oatk_hip_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes)
+{
+    if (!ctx) return OATK_E_NODEV;
+    if (bytes == 0) return OATK_OK;
+    CK(hipSetDevice(ctx->device));
+    CK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return OATK_OK;
+}
+
 }  // extern "C"

@@ -143,6 +143,7 @@ void sr_read(dropin_sstream_t *s_stream, oatk_sr_db_t *sr_db, size_t mD, int n_t
     else if (s_stream->n_seq != 0 || s_stream->n != 0) why = "the stream was already read from";
     else if (sr_db->k > oatk_hip_max_k()) why = "k beyond the device scan's window";
     if (!why) {
+        oatk_host_set_threads(n_threads);                                /* the struct filling uses as many host threads as the caller grants (-t) */
         oatk_sr_db_clean(sr_db);                                         /* syncmer.c:494-495: k and s stay */
         const int rc = oatk_sr_read_files(D.ctx, sr_db, s_stream->files, s_stream->n_files);
         if (rc == OATK_OK) {
@@ -326,6 +327,7 @@ void read_error_correction(oatk_sr_db_t *sr_db, oatk_scg_t *g, double max_edist,
     if (!D.resident || !D.counted || sr_db != D.sr_db || !g || g->scm_db != D.scm_db) why = "no resident batch";
     else if (fo) why = "the corrected reads are to be written out (debug build): the original does that";
     if (!why) {
+        oatk_host_set_threads(n_threads);
         int rc = oatk_read_error_correction(D.ctx, sr_db, g->scm_db, placeholder? 0 : g->utg_asmg, max_edist, err_mer_c, max_err_c, err_arc_c, max_arc_f, st);
         if (rc == OATK_E_SPLIT && placeholder) {
             /* the device refuses to ORDER this graph (duplicate arcs of a long tandem repeat, an arc with dozens of distances): the original

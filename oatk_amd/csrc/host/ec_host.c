@@ -35,10 +35,48 @@ static void *fetch(oatk_hip_ctx *ctx, int which, uint64_t *bytes, int *rc)
     return h;
 }
 
+typedef struct {
+    oatk_sr_db_t *sr_db;
+    oatk_syncmer_db_t *scm_db;
+    const uint32_t *new_n;
+    const uint64_t *new_k;
+    const uint32_t *new_m;
+    const uint64_t *new_s;
+    const uint32_t *cov;
+    const uint8_t *del;
+    const uint64_t *occ_off, *occ;
+    uint64_t *new_off;
+} ecw_job_t;
+
+/* what the reference's own threads leave per read (syncerr.c:600-612) and update_syncmer_db per syncmer (:769-814) */
+static void ecw_worker(void *arg, int tid, int n_threads)
+{
+    const ecw_job_t *j = (const ecw_job_t *) arg;
+    uint64_t i;
+    const uint64_t nr = j->sr_db->n, ra = nr * (uint64_t) tid / (uint64_t) n_threads, rb = nr * (uint64_t) (tid + 1) / (uint64_t) n_threads;
+    for (i = ra; i < rb; ++i) {
+        oatk_sr_t *r = &j->sr_db->a[i];
+        const uint32_t n = j->new_n[i];
+        const uint64_t o = j->new_off[i];
+        free(r->k_mer); free(r->m_pos); free(r->s_mer);
+        r->k_mer = (uint64_t *) memcpy(xmalloc(8 * (size_t) n), j->new_k + o, 8 * (size_t) n);
+        r->m_pos = (uint32_t *) memcpy(xmalloc(4 * (size_t) n), j->new_m + o, 4 * (size_t) n);
+        r->s_mer = (uint64_t *) memcpy(xmalloc(8 * (size_t) n), j->new_s + o, 8 * (size_t) n);
+        r->n = n;
+    }
+    const uint64_t ns = j->scm_db->n, sa = ns * (uint64_t) tid / (uint64_t) n_threads, sb = ns * (uint64_t) (tid + 1) / (uint64_t) n_threads;
+    for (i = sa; i < sb; ++i) {
+        oatk_syncmer_t *m = &j->scm_db->a[i];
+        free(m->m_pos);
+        m->cov = j->cov[i], m->del = j->del[i];
+        m->m_pos = (uint64_t *) memcpy(xmalloc(8 * (size_t) j->cov[i]), j->occ + j->occ_off[i], 8 * (size_t) j->cov[i]);
+    }
+}
+
 int oatk_read_error_correction(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, oatk_syncmer_db_t *scm_db, oatk_asmg_t *asmg, double max_edist,
                                uint32_t err_mer_c, uint32_t max_err_c, uint32_t err_arc_c, double max_arc_f, uint64_t *stats12)
 {
-    uint64_t i, j, b;
+    uint64_t i, b;
     int rc;
     uint64_t *arc_v = 0, *arc_w = 0;
     uint64_t nv = 0, na = 0;
@@ -90,27 +128,15 @@ int oatk_read_error_correction(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, oatk_sync
         for (i = 0; i < na; ++i) if (err_del[arc_v[i] >> 1] || err_del[arc_w[i] >> 1]) asmg->arc[i].del = 1;
     }
 
-    /* reads */
-    uint64_t o = 0;
-    for (i = 0; i < sr_db->n; ++i) {
-        oatk_sr_t *r = &sr_db->a[i];
-        const uint32_t n = new_n[i];
-        free(r->k_mer); free(r->m_pos); free(r->s_mer);
-        r->k_mer = (uint64_t *) memcpy(xmalloc(8 * (size_t) n), new_k + o, 8 * (size_t) n);
-        r->m_pos = (uint32_t *) memcpy(xmalloc(4 * (size_t) n), new_m + o, 4 * (size_t) n);
-        r->s_mer = (uint64_t *) memcpy(xmalloc(8 * (size_t) n), new_s + o, 8 * (size_t) n);
-        r->n = n;
-        o += n;
-    }
-    /* syncmer table */
-    free(scm_db->c); scm_db->c = 0;
-    free(scm_db->h); scm_db->h = 0;
-    for (i = 0; i < scm_db->n; ++i) {
-        oatk_syncmer_t *m = &scm_db->a[i];
-        free(m->m_pos);
-        m->cov = cov[i], m->del = del[i];
-        m->m_pos = (uint64_t *) xmalloc(8 * (size_t) cov[i]);
-        for (j = 0; j < cov[i]; ++j) m->m_pos[j] = occ[occ_off[i] + j];
+    /* reads and syncmer table, on the host threads */
+    {
+        ecw_job_t job = {sr_db, scm_db, new_n, new_k, new_m, new_s, cov, del, occ_off, occ, 0};
+        job.new_off = (uint64_t *) xmalloc(8 * (sr_db->n + 1));
+        for (i = 0, job.new_off[0] = 0; i < sr_db->n; ++i) job.new_off[i + 1] = job.new_off[i] + new_n[i];
+        free(scm_db->c); scm_db->c = 0;
+        free(scm_db->h); scm_db->h = 0;
+        oatk_par_run(ecw_worker, &job);
+        free(job.new_off);
     }
 done:
     free(arc_v); free(arc_w);

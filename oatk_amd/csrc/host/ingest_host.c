@@ -1,9 +1,11 @@
 /*
  * oatk_amd/csrc/host/ingest_host.c -- files to the device reader (include/oatk_hip_ingest.h), in place of sstream_open / sstream_read
- * (sstream.c:70-103): several files are read one after the other as one stream of records; plain or gzip'ed (zlib's gzread handles
- * both, exactly as the reference's gzdopen does, sstream.c:50).  The host only moves bytes: inflate (serial per stream on any
- * hardware) and one copy of the text to the device, where the records are found.
+ * (sstream.c:70-103): several files are read one after the other as one stream of records; plain or gzip'ed (zlib inflates, exactly as the
+ * reference's gzdopen does, sstream.c:50).  The host only moves bytes, and moves them once: a plain file goes from the page cache straight
+ * into page-locked memory (pread by the host threads, piece by piece) and from there over PCIe while the next piece is being read; a
+ * gzip'ed one is inflated first (serial per stream on any hardware) and then takes the same road.  The records are found on the device.
  */
+#define _GNU_SOURCE
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -16,131 +18,230 @@
 #include "oatk_hip_ingest.h"
 #include "oatk_syncasm.h"
 
-/* one plain file that ends in a newline needs no copy at all on the host: it is mapped and handed to the device reader as it lies in the page
- * cache.  Returns 1 when it applied (*rc set), 0 when the general path must run. */
-static int ingest_one_mapped(oatk_hip_ctx *ctx, const char *path, uint64_t *n_reads, uint8_t **text, size_t *text_len, int *mapped, int *rc)
+#define UP_CHUNK ((uint64_t) 96 << 20)                 /* bytes per upload piece */
+
+/* one input file as a segment of the text: either a descriptor to pread from or inflated bytes in memory */
+typedef struct {
+    int fd;                        /* >= 0: plain file */
+    uint8_t *mem;                  /* inflated content (gzip'ed file), malloc'ed */
+    uint64_t size;                 /* bytes of content */
+    uint64_t base;                 /* where the content starts in the text */
+    int add_nl;                    /* the file does not end in a newline: one is put behind it (a fresh kseq starts every file at a header
+                                    * line, sstream.c:91-97 -- its last line must not glue to the next file's first header) */
+    uint8_t *map;                  /* lazily mapped (no populate) for the header lines only */
+} seg_t;
+
+static void seg_close(seg_t *s, int n)
 {
-    struct stat sb;
-    int fd = open(path, O_RDONLY);
-    if (fd < 0) return 0;
-    if (fstat(fd, &sb) != 0 || sb.st_size < 3) { close(fd); return 0; }
-    uint8_t *m = (uint8_t *) mmap(0, (size_t) sb.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
-    close(fd);
-    if (m == MAP_FAILED) return 0;
-    if ((m[0] == 0x1f && m[1] == 0x8b) || m[sb.st_size - 1] != '\n') { munmap(m, (size_t) sb.st_size); return 0; }
-    uint64_t used = 0;
-    *rc = oatk_hip_ingest_host(ctx, m, (uint64_t) sb.st_size, OATK_FMT_AUTO, 1, n_reads, &used);
-    if (text && !*rc) *text = m, *text_len = (size_t) sb.st_size, *mapped = 1;
-    else munmap(m, (size_t) sb.st_size);
-    return 1;
+    int i;
+    for (i = 0; i < n; ++i) {
+        if (s[i].map) munmap(s[i].map, (size_t) s[i].size);
+        if (s[i].fd >= 0) close(s[i].fd);
+        free(s[i].mem);
+    }
+    free(s);
 }
 
-static int ingest_files(oatk_hip_ctx *ctx, char **files, int n_files, uint64_t *n_reads, uint8_t **text, size_t *text_len, int *mapped)
+static int inflate_file(const char *path, seg_t *s)
 {
-    if (mapped) *mapped = 0;
-    if (n_files == 1) {
-        int rc = 0, dummy = 0;
-        if (ingest_one_mapped(ctx, files[0], n_reads, text, text_len, mapped? mapped : &dummy, &rc)) return rc;
-    }
     size_t cap = (size_t) 1 << 26, len = 0;
-    {   /* size the buffer for the files as they lie (right for plain files, a start for gzip'ed ones): no regrowing copies of gigabytes */
-        int j;
-        for (j = 0; j < n_files; ++j) { struct stat sb; if (stat(files[j], &sb) == 0 && sb.st_size > 0) cap += (size_t) sb.st_size + 2; }
-    }
+    struct stat sb;
+    if (stat(path, &sb) == 0 && sb.st_size > 0) cap += (size_t) sb.st_size * 4;       /* HiFi FASTA compresses about fourfold */
     uint8_t *buf = (uint8_t *) malloc(cap);
-    int i, fmt = OATK_FMT_AUTO;
     if (!buf) return OATK_E_NOMEM;
-    for (i = 0; i < n_files; ++i) {
-        /* a plain file is read directly (gzread would copy it through zlib's buffers at a third of the speed); two magic bytes tell */
-        {
-            FILE *pf = fopen(files[i], "rb");
-            unsigned char mg[2] = {0, 0};
-            size_t nm = pf? fread(mg, 1, 2, pf) : 0;
-            if (pf && !(nm == 2 && mg[0] == 0x1f && mg[1] == 0x8b)) {
-                rewind(pf);
-                for (;;) {
-                    if (cap - len < ((size_t) 1 << 24)) {
-                        cap += cap / 2;
-                        uint8_t *nb = (uint8_t *) realloc(buf, cap);
-                        if (!nb) { fclose(pf); free(buf); return OATK_E_NOMEM; }
-                        buf = nb;
-                    }
-                    const size_t got = fread(buf + len, 1, cap - len - 1, pf);
-                    if (got == 0) break;
-                    len += got;
-                }
-                fclose(pf);
-                if (len && buf[len - 1] != '\n') buf[len++] = '\n';
-                continue;
-            }
-            if (pf) fclose(pf);
+    gzFile fp = gzopen(path, "r");
+    if (!fp) { free(buf); return OATK_E_ARG; }
+    (void) gzbuffer(fp, 1 << 20);
+    for (;;) {
+        if (cap - len < ((size_t) 1 << 24)) {
+            cap += cap / 2;
+            uint8_t *nb = (uint8_t *) realloc(buf, cap);
+            if (!nb) { gzclose(fp); free(buf); return OATK_E_NOMEM; }
+            buf = nb;
         }
-        gzFile fp = gzopen(files[i], "r");
-        if (!fp) { fprintf(stderr, "[E::%s] fail to open file \"%s\"\n", __func__, files[i]); free(buf); return OATK_E_ARG; }   /* sstream.c:46-49 */
-        (void) gzbuffer(fp, 1 << 20);
-        for (;;) {
-            if (cap - len < ((size_t) 1 << 24)) {
-                cap += cap / 2;
-                uint8_t *nb = (uint8_t *) realloc(buf, cap);
-                if (!nb) { gzclose(fp); free(buf); return OATK_E_NOMEM; }
-                buf = nb;
-            }
-            const size_t want = cap - len > ((size_t) 1 << 30)? (size_t) 1 << 30 : cap - len;
-            const int got = gzread(fp, buf + len, (unsigned) want);
-            if (got < 0) { gzclose(fp); free(buf); return OATK_E_ARG; }
-            if (got == 0) break;
-            len += (size_t) got;
-        }
-        gzclose(fp);
-        /* kseq starts every file at a header line (sstream.c:91-97 opens a fresh kseq): a file that does not end in a newline must not
-         * glue its last line to the next file's first header */
-        if (len && buf[len - 1] != '\n') buf[len++] = '\n';
+        const size_t want = cap - len > ((size_t) 1 << 30)? (size_t) 1 << 30 : cap - len;
+        const int got = gzread(fp, buf + len, (unsigned) want);
+        if (got < 0) { gzclose(fp); free(buf); return OATK_E_ARG; }
+        if (got == 0) break;
+        len += (size_t) got;
     }
-    uint64_t used = 0;
-    const int rc = oatk_hip_ingest_host(ctx, buf, len, fmt, 1, n_reads, &used);
-    if (text && !rc) *text = buf, *text_len = len;
-    else free(buf);
+    gzclose(fp);
+    s->fd = -1, s->mem = buf, s->size = len;
+    return OATK_OK;
+}
+
+static seg_t *open_segments(char **files, int n_files, uint64_t *total, int *rc)
+{
+    seg_t *s = (seg_t *) calloc((size_t) n_files, sizeof(seg_t));
+    uint64_t base = 0;
+    int i;
+    *rc = OATK_OK;
+    for (i = 0; i < n_files; ++i) s[i].fd = -1;
+    for (i = 0; i < n_files; ++i) {
+        unsigned char mg[2] = {0, 0};
+        struct stat sb;
+        const int fd = open(files[i], O_RDONLY);
+        if (fd < 0 || fstat(fd, &sb) != 0) {
+            fprintf(stderr, "[E::%s] fail to open file \"%s\"\n", __func__, files[i]);       /* sstream.c:46-49 */
+            if (fd >= 0) close(fd);
+            *rc = OATK_E_ARG;
+            break;
+        }
+        const ssize_t nm = pread(fd, mg, 2, 0);
+        if (nm == 2 && mg[0] == 0x1f && mg[1] == 0x8b) {          /* gzip magic: inflate; anything else is read as it lies (gzread would do the same) */
+            close(fd);
+            if ((*rc = inflate_file(files[i], &s[i])) != OATK_OK) break;
+        } else if (!S_ISREG(sb.st_mode)) {                         /* a pipe or device: no pread; let zlib's transparent mode stream it */
+            close(fd);
+            if ((*rc = inflate_file(files[i], &s[i])) != OATK_OK) break;
+        } else {
+            s[i].fd = fd, s[i].size = (uint64_t) sb.st_size;
+        }
+        uint8_t last = '\n';
+        if (s[i].size) {
+            if (s[i].fd >= 0) { if (pread(s[i].fd, &last, 1, (off_t) s[i].size - 1) != 1) last = '\n'; }
+            else last = s[i].mem[s[i].size - 1];
+        }
+        s[i].add_nl = s[i].size && last != '\n';
+        s[i].base = base;
+        base += s[i].size + (uint64_t) s[i].add_nl;
+    }
+    if (*rc) { seg_close(s, n_files); return 0; }
+    *total = base;
+    return s;
+}
+
+/* ---- upload: text range [g0, g1) into a page-locked buffer by the host threads, then one DMA ---- */
+typedef struct { const seg_t *seg; int n_seg; uint8_t *dst; uint64_t g0, g1; int failed; } up_job_t;
+
+static void up_worker(void *arg, int tid, int n_threads)
+{
+    up_job_t *j = (up_job_t *) arg;
+    const uint64_t n = j->g1 - j->g0;
+    uint64_t a = j->g0 + n * (uint64_t) tid / (uint64_t) n_threads, b = j->g0 + n * (uint64_t) (tid + 1) / (uint64_t) n_threads;
+    int i;
+    for (i = 0; i < j->n_seg && a < b; ++i) {
+        const seg_t *s = &j->seg[i];
+        const uint64_t end = s->base + s->size + (uint64_t) s->add_nl;
+        if (a >= end) continue;
+        uint64_t lo = a, hi = b < end? b : end;                    /* the part of [a, b) inside this segment */
+        uint8_t *d = j->dst + (lo - j->g0);
+        if (hi > s->base + s->size) { d[s->base + s->size - lo] = '\n'; hi = s->base + s->size; }       /* the added newline */
+        if (hi > lo) {
+            if (s->fd >= 0) {
+                uint64_t done = 0;
+                while (done < hi - lo) {
+                    const ssize_t got = pread(s->fd, d + done, (size_t) (hi - lo - done), (off_t) (lo - s->base + done));
+                    if (got <= 0) { j->failed = 1; return; }
+                    done += (uint64_t) got;
+                }
+            } else memcpy(d, s->mem + (lo - s->base), (size_t) (hi - lo));
+        }
+        a = b < end? b : end;
+    }
+}
+
+static int upload_text(oatk_hip_ctx *ctx, const seg_t *seg, int n_seg, uint64_t total, uint8_t **d_text_out)
+{
+    uint8_t *d_text = 0;
+    int rc = oatk_hip_ingest_text_buffer(ctx, total, &d_text);
+    if (rc) return rc;
+    *d_text_out = d_text;
+    if (total == 0) return OATK_OK;
+    const uint64_t chunk = total < UP_CHUNK? ((total + 63) & ~63ULL) : UP_CHUNK;
+    /* a large input asks at once for what filling the reads' structs will want afterwards (srdb.c), so the block is pinned only once */
+    uint8_t *stage = (uint8_t *) oatk_hip_staging(ctx, total > ((uint64_t) 1 << 30)? (uint64_t) 640 << 20 : 2 * chunk);
+    if (!stage) return OATK_E_NOMEM;
+    up_job_t job = {seg, n_seg, stage, 0, total < chunk? total : chunk, 0};
+    oatk_par_run(up_worker, &job);
+    uint64_t g0 = 0;
+    int which = 0;
+    while (g0 < total && !job.failed) {
+        const uint64_t g1 = g0 + chunk < total? g0 + chunk : total;
+        rc = oatk_hip_h2d_async(ctx, d_text + g0, stage + (uint64_t) which * chunk, g1 - g0);
+        if (rc) return rc;
+        if (g1 < total) {                                          /* read the next piece while this one is on the bus */
+            job.dst = stage + (uint64_t) (which ^ 1) * chunk, job.g0 = g1, job.g1 = g1 + chunk < total? g1 + chunk : total;
+            oatk_par_run(up_worker, &job);
+        }
+        rc = oatk_hip_sync(ctx);
+        if (rc) return rc;
+        g0 = g1, which ^= 1;
+    }
+    return job.failed? OATK_E_ARG : OATK_OK;
+}
+
+static int ingest_files(oatk_hip_ctx *ctx, char **files, int n_files, uint64_t *n_reads, seg_t **seg_out)
+{
+    uint64_t total = 0, used = 0;
+    int rc = OATK_OK;
+    seg_t *seg = open_segments(files, n_files, &total, &rc);
+    if (!seg) return rc;
+    uint8_t *d_text = 0;
+    rc = upload_text(ctx, seg, n_files, total, &d_text);
+    if (!rc) rc = oatk_hip_ingest(ctx, d_text, total, OATK_FMT_AUTO, 1, n_reads, &used);
+    if (rc || !seg_out) seg_close(seg, n_files);
+    else *seg_out = seg;
     return rc;
 }
 
 int oatk_ingest_files(oatk_hip_ctx *ctx, char **files, int n_files, uint64_t *n_reads)
 {
-    return ingest_files(ctx, files, n_files, n_reads, 0, 0, 0);
+    return ingest_files(ctx, files, n_files, n_reads, 0);
 }
 
-/* sr_read (syncmer.c:487) for files, entirely through the device: text -> records -> scan, then sr_db filled from the resident results.
- * Read names (kseq's name: the header up to the first white space) are cut out of the text here. */
+/* ---- read names (kseq's name: the header up to the first white space), cut out of the text on the host threads ---- */
+typedef struct { seg_t *seg; int n_seg; const uint64_t *hdr; uint64_t n; char **names; } name_job_t;
+
+static void name_worker(void *arg, int tid, int n_threads)
+{
+    name_job_t *j = (name_job_t *) arg;
+    const uint64_t a = j->n * (uint64_t) tid / (uint64_t) n_threads, b = j->n * (uint64_t) (tid + 1) / (uint64_t) n_threads;
+    uint64_t i;
+    int si = 0;
+    for (i = a; i < b; ++i) {
+        const uint64_t g = j->hdr[i] + 1;                          /* behind '>' / '@'; headers ascend, so the segment index only moves forward */
+        while (si + 1 < j->n_seg && g >= j->seg[si + 1].base) ++si;
+        const seg_t *s = &j->seg[si];
+        const uint8_t *t = s->fd >= 0? s->map : s->mem;
+        const uint64_t p = g - s->base;
+        uint64_t e = p;
+        while (e < s->size && t[e] != ' ' && t[e] != '\t' && t[e] != '\n' && t[e] != '\r') ++e;
+        char *nm = (char *) malloc(e - p + 1);
+        if (nm) { memcpy(nm, t + p, e - p); nm[e - p] = 0; }
+        j->names[i] = nm;
+    }
+}
+
+/* sr_read (syncmer.c:487) for files, entirely through the device: text -> records -> scan, then sr_db filled from the resident results */
 int oatk_sr_read_files(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, char **files, int n_files)
 {
-    uint8_t *text = 0;
-    size_t text_len = 0;
-    uint64_t n = 0, b = 0, i;
-    int mapped = 0;
-    int rc = ingest_files(ctx, files, n_files, &n, &text, &text_len, &mapped);
+    uint64_t n = 0, b = 0;
+    seg_t *seg = 0;
+    int i, rc = ingest_files(ctx, files, n_files, &n, &seg);
     if (rc) return rc;
     rc = oatk_hip_scan_ingested(ctx, 0, sr_db->k, sr_db->s);
-    if (rc) { if (mapped) munmap(text, text_len); else free(text); return rc; }
     uint64_t *off = 0, *hdr = 0;
     char **names = 0;
-    if (n) {
+    if (!rc && n) {
         const void *d = 0;
         rc = oatk_hip_buffer(ctx, OATK_BUF_INGEST_OFF, &d, &b);
         if (!rc) { off = (uint64_t *) malloc(b? b : 1); rc = oatk_hip_d2h(ctx, off, d, b); }
         if (!rc) rc = oatk_hip_buffer(ctx, OATK_BUF_INGEST_HDR, &d, &b);
         if (!rc) { hdr = (uint64_t *) malloc(b? b : 1); rc = oatk_hip_d2h(ctx, hdr, d, b); }
-        if (!rc) {
-            names = (char **) malloc(sizeof(char *) * n);
-            for (i = 0; i < n; ++i) {
-                size_t p = (size_t) hdr[i] + 1, e = p;                       /* behind '>' / '@' */
-                while (e < text_len && text[e] != ' ' && text[e] != '\t' && text[e] != '\n' && text[e] != '\r') ++e;
-                names[i] = (char *) malloc(e - p + 1);
-                memcpy(names[i], text + p, e - p);
-                names[i][e - p] = 0;
+        for (i = 0; !rc && i < n_files; ++i)
+            if (seg[i].fd >= 0 && seg[i].size) {
+                seg[i].map = (uint8_t *) mmap(0, (size_t) seg[i].size, PROT_READ, MAP_PRIVATE, seg[i].fd, 0);
+                if (seg[i].map == MAP_FAILED) { seg[i].map = 0; rc = OATK_E_NOMEM; }
             }
+        if (!rc) {
+            names = (char **) calloc(n, sizeof(char *));
+            name_job_t job = {seg, n_files, hdr, n, names};
+            oatk_par_run(name_worker, &job);
             rc = oatk_sr_db_fill_resident(ctx, sr_db, off, n, names);
         }
     }
-    if (mapped) munmap(text, text_len); else free(text);
+    seg_close(seg, n_files);
     free(off); free(hdr); free(names);
     return rc;
 }

@@ -40,80 +40,174 @@ int oatk_sr_read_packed(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, const uint8_t *s
     return oatk_sr_db_fill_resident(ctx, sr_db, off, n_reads, names);
 }
 
-/* sr_db->a[0 .. n_reads) from the scan resident in ctx; off[i] = offset of read i in the packed stream that was scanned */
+/* ---- sr_db->a[0 .. n_reads) from the scan resident in ctx ----
+ * The per-base arrays (ho_rl, hoco_s: 1 + 1/4 byte per hoco base) and the per-syncmer arrays (m_pos, s_mer, k_mer hash: 20 bytes each) come
+ * over in PIECES of consecutive reads through two page-locked buffers: while the host threads cut piece p into the reads' own malloc'ed
+ * blocks, piece p + 1 is already on its way (one stream, copies queue behind each other at PCIe speed). */
+#define FILL_RL_BYTES ((uint64_t) 192 << 20)          /* packed ho_rl bytes per piece */
+#define FILL_SCM ((uint64_t) 3 << 20)                 /* syncmers per piece */
+
+typedef struct {
+    uint8_t *rl, *hs;                                 /* page-locked: one piece */
+    uint32_t *m_pos;
+    uint64_t *s_mer, *k_hash;
+} fill_buf_t;
+
+typedef struct {
+    oatk_sr_db_t *sr_db;
+    const uint64_t *off, *scm_off;
+    const uint32_t *hoco_l, *n_nn, *n_lrl, *lrl_val;
+    const uint64_t *nn_key, *o_nn, *o_lrl;
+    char **names;
+    /* the piece being cut */
+    const fill_buf_t *buf;
+    uint64_t i0, i1, rl0, scm0;
+} fill_job_t;
+
+static void fill_worker(void *arg, int tid, int n_threads)
+{
+    const fill_job_t *j = (const fill_job_t *) arg;
+    const uint64_t n = j->i1 - j->i0, a = j->i0 + n * (uint64_t) tid / (uint64_t) n_threads, b = j->i0 + n * (uint64_t) (tid + 1) / (uint64_t) n_threads;
+    uint64_t i;
+    for (i = a; i < b; ++i) {
+        oatk_sr_t *r = &j->sr_db->a[i];
+        const uint32_t hl = j->hoco_l[i];
+        const uint64_t ns = j->scm_off[i + 1] - j->scm_off[i], os = j->scm_off[i] - j->scm0;
+        const size_t nb = ((size_t) hl + 3) / 4;
+        r->sid = i;                                        /* reads are numbered in input order, syncmer.c:525 */
+        r->sname = j->names? j->names[i] : 0;
+        r->hoco_l = hl;
+        /* empty arrays are NULL in the reference (kvec never allocated), syncmer.c:396-412 */
+        r->hoco_s = nb? (uint8_t *) memcpy(xmalloc(nb), j->buf->hs + (j->off[i] - j->rl0) / 4, nb) : 0;
+        r->ho_rl = hl? (uint8_t *) memcpy(xmalloc(hl), j->buf->rl + (j->off[i] - j->rl0), hl) : 0;
+        r->ho_l_rl = j->n_lrl[i]? (uint32_t *) memcpy(xmalloc(4 * (size_t) j->n_lrl[i]), j->lrl_val + j->o_lrl[i], 4 * (size_t) j->n_lrl[i]) : 0;
+        r->n_nucl = 0;
+        if (j->n_nn[i]) {
+            uint32_t t;
+            r->n_nucl = (uint32_t *) xmalloc(4 * (size_t) j->n_nn[i]);
+            for (t = 0; t < j->n_nn[i]; ++t) r->n_nucl[t] = (uint32_t) j->nn_key[j->o_nn[i] + t];     /* low word = raw coordinate */
+        }
+        r->n = (uint32_t) ns;
+        r->m_pos = ns? (uint32_t *) memcpy(xmalloc(4 * (size_t) ns), j->buf->m_pos + os, 4 * (size_t) ns) : 0;
+        r->s_mer = ns? (uint64_t *) memcpy(xmalloc(8 * (size_t) ns), j->buf->s_mer + os, 8 * (size_t) ns) : 0;
+        r->k_mer = ns? (uint64_t *) memcpy(xmalloc(8 * (size_t) ns), j->buf->k_hash + os, 8 * (size_t) ns) : 0;
+    }
+}
+
 int oatk_sr_db_fill_resident(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, const uint64_t *off, uint64_t n_reads, char **names)
 {
     int rc = 0;
     if (n_reads == 0) return OATK_OK;
 
-    uint64_t b;
-    uint32_t *hoco_l = 0, *n_scm = 0, *n_nn = 0, *n_lrl = 0, *lrl_val = 0, *m_pos = 0;
-    uint64_t *nn_key = 0, *s_mer = 0, *k_hash = 0;
+    uint64_t b, i;
+    uint32_t *hoco_l = 0, *n_nn = 0, *n_lrl = 0, *lrl_val = 0;
+    uint64_t *nn_key = 0, *scm_off = 0, *o_nn = 0, *o_lrl = 0;
     hoco_l = (uint32_t *) fetch(ctx, OATK_BUF_HOCO_L, &b, &rc); if (rc) goto done;
-    n_scm = (uint32_t *) fetch(ctx, OATK_BUF_N_SCM, &b, &rc); if (rc) goto done;
     n_nn = (uint32_t *) fetch(ctx, OATK_BUF_N_NN, &b, &rc); if (rc) goto done;
     n_lrl = (uint32_t *) fetch(ctx, OATK_BUF_N_LRL, &b, &rc); if (rc) goto done;
-    /* the two big per-base arrays (1 + 1/4 byte per raw base) come over in pieces through page-locked memory, straight into the reads' own
-     * blocks: no gigabyte-sized pageable landing buffer, PCIe at full speed */
-    const void *d_rl = 0, *d_hs = 0;
-    uint64_t b_rl = 0, b_hs = 0;
-    rc = oatk_hip_buffer(ctx, OATK_BUF_HO_RL, &d_rl, &b_rl); if (rc) goto done;
-    rc = oatk_hip_buffer(ctx, OATK_BUF_HOCO_S, &d_hs, &b_hs); if (rc) goto done;
-    (void) b_rl; (void) b_hs;
-    const uint64_t STAGE = 64ULL << 20;
-    uint8_t *stage = (uint8_t *) oatk_hip_staging(ctx, STAGE + STAGE / 4 + 4096);
-    if (!stage) { rc = OATK_E_NOMEM; goto done; }
+    scm_off = (uint64_t *) fetch(ctx, OATK_BUF_SCM_OFF, &b, &rc); if (rc) goto done;
     nn_key = (uint64_t *) fetch(ctx, OATK_BUF_NN_KEY, &b, &rc); if (rc) goto done;
     lrl_val = (uint32_t *) fetch(ctx, OATK_BUF_LRL_VAL, &b, &rc); if (rc) goto done;
-    m_pos = (uint32_t *) fetch(ctx, OATK_BUF_POS_MPOS, &b, &rc); if (rc) goto done;
-    s_mer = (uint64_t *) fetch(ctx, OATK_BUF_POS_SMER, &b, &rc); if (rc) goto done;
-    k_hash = (uint64_t *) fetch(ctx, OATK_BUF_POS_HASH, &b, &rc); if (rc) goto done;
+    o_nn = (uint64_t *) xmalloc(8 * (n_reads + 1)), o_lrl = (uint64_t *) xmalloc(8 * (n_reads + 1));
+    for (i = 0, o_nn[0] = o_lrl[0] = 0; i < n_reads; ++i) o_nn[i + 1] = o_nn[i] + n_nn[i], o_lrl[i + 1] = o_lrl[i] + n_lrl[i];
+
+    const void *d_rl = 0, *d_hs = 0, *d_mp = 0, *d_sm = 0, *d_kh = 0;
+    rc = oatk_hip_buffer(ctx, OATK_BUF_HO_RL, &d_rl, &b); if (rc) goto done;
+    rc = oatk_hip_buffer(ctx, OATK_BUF_HOCO_S, &d_hs, &b); if (rc) goto done;
+    rc = oatk_hip_buffer(ctx, OATK_BUF_POS_MPOS, &d_mp, &b); if (rc) goto done;
+    rc = oatk_hip_buffer(ctx, OATK_BUF_POS_SMER, &d_sm, &b); if (rc) goto done;
+    rc = oatk_hip_buffer(ctx, OATK_BUF_POS_HASH, &d_kh, &b); if (rc) goto done;
+
+    /* piece limits: a single read larger than the defaults makes its own (larger) piece */
+    uint64_t cap_rl = off[n_reads - 1] + (((uint64_t) hoco_l[n_reads - 1] + 63) & ~63ULL) + 64, cap_scm = scm_off[n_reads] + 1;      /* small inputs: one piece */
+    if (cap_rl > FILL_RL_BYTES) cap_rl = FILL_RL_BYTES;
+    if (cap_scm > FILL_SCM) cap_scm = FILL_SCM;
+    for (i = 0; i < n_reads; ++i) {
+        const uint64_t need = (((uint64_t) hoco_l[i] + 63) & ~63ULL) + 64, ns = scm_off[i + 1] - scm_off[i];
+        if (need > cap_rl) cap_rl = need;
+        if (ns > cap_scm) cap_scm = ns;
+    }
+    const uint64_t one = ((cap_rl + 63) & ~63ULL) + ((cap_rl / 4 + 128) & ~63ULL) + cap_scm * 20 + 256;
+    uint8_t *stage = (uint8_t *) oatk_hip_staging(ctx, 2 * one);
+    if (!stage) { rc = OATK_E_NOMEM; goto done; }
+    fill_buf_t buf[2];
+    for (i = 0; i < 2; ++i) {
+        uint8_t *p = stage + i * one;
+        buf[i].rl = p, p += (cap_rl + 63) & ~63ULL;
+        buf[i].hs = p, p += (cap_rl / 4 + 128) & ~63ULL;
+        buf[i].s_mer = (uint64_t *) p, p += cap_scm * 8;
+        buf[i].k_hash = (uint64_t *) p, p += cap_scm * 8;
+        buf[i].m_pos = (uint32_t *) p;
+    }
 
     /* zeroed, and counted only as far as it is filled: after a failure half way sr_db_destroy / oatk_sr_db_clean free what exists */
     sr_db->a = (oatk_sr_t *) calloc(n_reads, sizeof(oatk_sr_t));
     if (!sr_db->a) { rc = OATK_E_NOMEM; goto done; }
     sr_db->n = 0, sr_db->m = n_reads;
-    uint64_t i, o_scm = 0, o_nn = 0, o_lrl = 0, stage_end = 0, stage_o0 = 0;
-    uint8_t *stage_hs = stage;
-    for (i = 0; i < n_reads; ++i) {
-        oatk_sr_t *r = &sr_db->a[i];
-        const uint32_t hl = hoco_l[i], ns = n_scm[i];
-        const size_t nb = ((size_t) hl + 3) / 4;
-        r->sid = i;                                        /* reads are numbered in input order, syncmer.c:525 */
-        r->sname = names? names[i] : 0;
-        r->hoco_l = hl;
-        /* empty arrays are NULL in the reference (kvec never allocated), syncmer.c:396-412 */
-        if (i == stage_end) {                              /* next piece: reads [i, j) whose packed range fits the staging block */
-            uint64_t j = i + 1;
-            const uint64_t o0 = off[i];
-            while (j < n_reads && off[j] + (((uint64_t) hoco_l[j] + 63) & ~63ULL) - o0 <= STAGE) ++j;
-            const uint64_t o1 = off[j - 1] + hoco_l[j - 1], bytes = o1 - o0;      /* one read longer than the block: the block grows */
-            if (bytes > STAGE) { stage = (uint8_t *) oatk_hip_staging(ctx, bytes + bytes / 4 + 4096); if (!stage) { rc = OATK_E_NOMEM; goto done; } }
-            stage_hs = stage + (((bytes > STAGE? bytes : STAGE) + 63) & ~63ULL);
-            rc = oatk_hip_d2h(ctx, stage, (const uint8_t *) d_rl + o0, bytes); if (rc) goto done;
-            rc = oatk_hip_d2h(ctx, stage_hs, (const uint8_t *) d_hs + o0 / 4, (bytes + 3) / 4 + 1); if (rc) goto done;
-            stage_o0 = o0, stage_end = j;
+
+    fill_job_t job;
+    memset(&job, 0, sizeof(job));
+    job.sr_db = sr_db, job.off = off, job.scm_off = scm_off, job.hoco_l = hoco_l, job.n_nn = n_nn, job.n_lrl = n_lrl, job.lrl_val = lrl_val;
+    job.nn_key = nn_key, job.o_nn = o_nn, job.o_lrl = o_lrl, job.names = names;
+
+    uint64_t p0 = 0, p1 = 0, q0 = 0, q1 = 0;          /* piece in flight: reads [p0, p1); piece being cut: [q0, q1) */
+    int flight = -1, which = 0;
+    for (;;) {
+        /* queue the next piece */
+        p0 = p1;
+        if (p0 < n_reads) {
+            p1 = p0 + 1;
+            while (p1 < n_reads && off[p1] + (((uint64_t) hoco_l[p1] + 63) & ~63ULL) - off[p0] <= cap_rl && scm_off[p1 + 1] - scm_off[p0] <= cap_scm) ++p1;
+            const uint64_t rl_bytes = off[p1 - 1] + hoco_l[p1 - 1] - off[p0], ns = scm_off[p1] - scm_off[p0];
+            const fill_buf_t *B = &buf[which];
+            rc = oatk_hip_d2h_async(ctx, B->rl, (const uint8_t *) d_rl + off[p0], rl_bytes); if (rc) goto done;
+            rc = oatk_hip_d2h_async(ctx, B->hs, (const uint8_t *) d_hs + off[p0] / 4, (rl_bytes + 3) / 4 + 1); if (rc) goto done;
+            rc = oatk_hip_d2h_async(ctx, B->m_pos, (const uint32_t *) d_mp + scm_off[p0], ns * 4); if (rc) goto done;
+            rc = oatk_hip_d2h_async(ctx, B->s_mer, (const uint64_t *) d_sm + scm_off[p0], ns * 8); if (rc) goto done;
+            rc = oatk_hip_d2h_async(ctx, B->k_hash, (const uint64_t *) d_kh + scm_off[p0], ns * 8); if (rc) goto done;
         }
-        r->hoco_s = nb? (uint8_t *) memcpy(xmalloc(nb), stage_hs + (off[i] - stage_o0) / 4, nb) : 0;
-        r->ho_rl = hl? (uint8_t *) memcpy(xmalloc(hl), stage + (off[i] - stage_o0), hl) : 0;
-        r->ho_l_rl = n_lrl[i]? (uint32_t *) memcpy(xmalloc(4 * (size_t) n_lrl[i]), lrl_val + o_lrl, 4 * (size_t) n_lrl[i]) : 0;
-        r->n_nucl = 0;
-        if (n_nn[i]) {
-            uint32_t t;
-            r->n_nucl = (uint32_t *) xmalloc(4 * (size_t) n_nn[i]);
-            for (t = 0; t < n_nn[i]; ++t) r->n_nucl[t] = (uint32_t) nn_key[o_nn + t];   /* low word = raw coordinate */
+        /* cut the piece that arrived before it */
+        if (flight >= 0) {
+            job.buf = &buf[flight], job.i0 = q0, job.i1 = q1, job.rl0 = off[q0], job.scm0 = scm_off[q0];
+            oatk_par_run(fill_worker, &job);
+            sr_db->n = q1;
         }
-        r->n = ns;
-        r->m_pos = ns? (uint32_t *) memcpy(xmalloc(4 * (size_t) ns), m_pos + o_scm, 4 * (size_t) ns) : 0;
-        r->s_mer = ns? (uint64_t *) memcpy(xmalloc(8 * (size_t) ns), s_mer + o_scm, 8 * (size_t) ns) : 0;
-        r->k_mer = ns? (uint64_t *) memcpy(xmalloc(8 * (size_t) ns), k_hash + o_scm, 8 * (size_t) ns) : 0;
-        o_scm += ns, o_nn += n_nn[i], o_lrl += n_lrl[i];
-        sr_db->n = i + 1;
+        if (p0 >= n_reads) break;
+        rc = oatk_hip_sync(ctx); if (rc) goto done;   /* the queued piece has landed */
+        flight = which, which ^= 1, q0 = p0, q1 = p1;
     }
 done:
-    free(hoco_l); free(n_scm); free(n_nn); free(n_lrl); free(nn_key); free(lrl_val);
-    free(m_pos); free(s_mer); free(k_hash);
+    free(hoco_l); free(n_nn); free(n_lrl); free(nn_key); free(lrl_val); free(scm_off); free(o_nn); free(o_lrl);
     return rc;
+}
+
+typedef struct {
+    oatk_syncmer_db_t *db;
+    oatk_sr_db_t *sr_db;
+    const uint64_t *h, *s;
+    const uint32_t *cov;
+    const uint64_t *occ_off, *occ, *kid;
+    uint64_t *kid_off;
+} collect_job_t;
+
+static void collect_worker(void *arg, int tid, int n_threads)
+{
+    const collect_job_t *j = (const collect_job_t *) arg;
+    uint64_t i, t;
+    const uint64_t ns = j->db->n, a = ns * (uint64_t) tid / (uint64_t) n_threads, b = ns * (uint64_t) (tid + 1) / (uint64_t) n_threads;
+    for (i = a; i < b; ++i) {
+        oatk_syncmer_t *m = &j->db->a[i];
+        m->h = j->h[i], m->s = j->s[i], m->cov = j->cov[i], m->del = 0;
+        m->m_pos = (uint64_t *) memcpy(xmalloc(8 * (size_t) j->cov[i]), j->occ + j->occ_off[i], 8 * (size_t) j->cov[i]);
+        j->db->c[i] = 1;                                   /* syncmer.c:1443-1444 */
+    }
+    /* reads: k-mer hash -> syncmer id << 1 (syncmer.c:1378) */
+    const uint64_t nr = j->sr_db->n, ra = nr * (uint64_t) tid / (uint64_t) n_threads, rb = nr * (uint64_t) (tid + 1) / (uint64_t) n_threads;
+    for (i = ra; i < rb; ++i) {
+        oatk_sr_t *r = &j->sr_db->a[i];
+        const uint64_t *k = j->kid + j->kid_off[i];
+        for (t = 0; t < r->n; ++t) r->k_mer[t] = k[t];
+    }
 }
 
 oatk_syncmer_db_t *oatk_collect_syncmer_from_reads(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, int *rc_out)
@@ -144,19 +238,15 @@ oatk_syncmer_db_t *oatk_collect_syncmer_from_reads(oatk_hip_ctx *ctx, oatk_sr_db
     db->a = (oatk_syncmer_t *) xmalloc(sizeof(oatk_syncmer_t) * inf.n_scm);
     db->c = (uint16_t *) xmalloc(sizeof(uint16_t) * inf.n_scm);
     db->h = 0;
-    uint64_t i, j, o = 0;
-    for (i = 0; i < inf.n_scm; ++i) {
-        oatk_syncmer_t *m = &db->a[i];
-        m->h = h[i], m->s = s[i], m->cov = cov[i], m->del = 0;
-        m->m_pos = (uint64_t *) memcpy(xmalloc(8 * (size_t) cov[i]), occ + occ_off[i], 8 * (size_t) cov[i]);
-        db->c[i] = 1;                                      /* syncmer.c:1443-1444 */
+    collect_job_t job = {db, sr_db, h, s, cov, occ_off, occ, kid, 0};
+    /* where each read's ids start in POS_KID: the chain lengths have not changed since the scan */
+    job.kid_off = (uint64_t *) xmalloc(8 * (sr_db->n + 1));
+    {
+        uint64_t i;
+        for (i = 0, job.kid_off[0] = 0; i < sr_db->n; ++i) job.kid_off[i + 1] = job.kid_off[i] + sr_db->a[i].n;
     }
-    /* reads: k-mer hash -> syncmer id << 1 (syncmer.c:1378) */
-    for (i = 0; i < sr_db->n; ++i) {
-        oatk_sr_t *r = &sr_db->a[i];
-        for (j = 0; j < r->n; ++j) r->k_mer[j] = kid[o + j];
-        o += r->n;
-    }
+    oatk_par_run(collect_worker, &job);
+    free(job.kid_off);
     free(h); free(s); free(cov); free(occ_off); free(occ); free(kid);
     return db;
 fail:

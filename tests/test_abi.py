@@ -30,7 +30,8 @@ def test_hip_library_exports_every_declared_symbol():
 def test_host_library_exports_every_declared_symbol():
     assert os.path.exists(_lib.HOST_LIB_PATH)
     L = ctypes.CDLL(_lib.HOST_LIB_PATH)
-    for hdr in [h for h in os.listdir(os.path.join(ROOT, "include")) if h != "oatk_hip.h" and h.endswith(".h")]:
+    # (oatk_dropin.h belongs to the static archive that is linked into the CLI: tests/test_cli_fallback.py checks its symbols)
+    for hdr in [h for h in os.listdir(os.path.join(ROOT, "include")) if h not in ("oatk_hip.h", "oatk_dropin.h") and h.endswith(".h")]:
         for n in declared(hdr, "oatk_"):
             if n.startswith("oatk_hip_"):
                 continue
