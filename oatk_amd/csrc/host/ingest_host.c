@@ -12,6 +12,7 @@
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <time.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -218,9 +219,18 @@ int oatk_sr_read_files(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, char **files, int
 {
     uint64_t n = 0, b = 0;
     seg_t *seg = 0;
+    const char *lg = getenv("OATK_DROPIN_LOG");
+    const int log = lg && lg[0] && lg[0] != '0';
+    struct timespec t0, t1, t2;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
     int i, rc = ingest_files(ctx, files, n_files, &n, &seg);
     if (rc) return rc;
+    clock_gettime(CLOCK_MONOTONIC, &t1);
     rc = oatk_hip_scan_ingested(ctx, 0, sr_db->k, sr_db->s);
+    if (!rc) rc = oatk_hip_sync(ctx);
+    clock_gettime(CLOCK_MONOTONIC, &t2);
+    if (log) fprintf(stderr, "[M::%s] text to the device + record scan: %.3f s; syncmer scan: %.3f s\n", __func__,
+                     (double) (t1.tv_sec - t0.tv_sec) + 1e-9 * (double) (t1.tv_nsec - t0.tv_nsec), (double) (t2.tv_sec - t1.tv_sec) + 1e-9 * (double) (t2.tv_nsec - t1.tv_nsec));
     uint64_t *off = 0, *hdr = 0;
     char **names = 0;
     if (!rc && n) {

@@ -6,11 +6,25 @@
  * both computed on the MI355X through the C ABI of include/oatk_hip.h.  What remains on the host is what the struct
  * layout forces: one malloc + memcpy per member array per read (sr_destroy frees each of them, syncmer.c:1047-1058).
  */
+#include <malloc.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "oatk_syncasm.h"
+
+static double host_now(void)
+{
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double) t.tv_sec + 1e-9 * (double) t.tv_nsec;
+}
+static int host_log(void)
+{
+    const char *e = getenv("OATK_DROPIN_LOG");
+    return e && e[0] && e[0] != '0';
+}
 
 static void *xmalloc(size_t n)
 {
@@ -64,6 +78,31 @@ typedef struct {
     uint64_t i0, i1, rl0, scm0;
 } fill_job_t;
 
+/* the blocks of reads [i0, i1), allocated by ONE thread: glibc grows a thread arena a few pages at a time under the address-space lock, so
+ * many threads allocating gigabytes get in each other's way; the main heap grows in large steps (M_TOP_PAD below) and costs ~40 ns per block */
+static void fill_alloc(const fill_job_t *j)
+{
+    uint64_t i;
+    for (i = j->i0; i < j->i1; ++i) {
+        oatk_sr_t *r = &j->sr_db->a[i];
+        const uint32_t hl = j->hoco_l[i];
+        const uint64_t ns = j->scm_off[i + 1] - j->scm_off[i];
+        r->sid = i;                                        /* reads are numbered in input order, syncmer.c:525 */
+        r->sname = j->names? j->names[i] : 0;
+        r->hoco_l = hl;
+        /* empty arrays are NULL in the reference (kvec never allocated), syncmer.c:396-412 */
+        r->hoco_s = hl? (uint8_t *) xmalloc(((size_t) hl + 3) / 4) : 0;
+        r->ho_rl = hl? (uint8_t *) xmalloc(hl) : 0;
+        r->ho_l_rl = j->n_lrl[i]? (uint32_t *) xmalloc(4 * (size_t) j->n_lrl[i]) : 0;
+        r->n_nucl = j->n_nn[i]? (uint32_t *) xmalloc(4 * (size_t) j->n_nn[i]) : 0;
+        r->n = (uint32_t) ns;
+        r->m_pos = ns? (uint32_t *) xmalloc(4 * (size_t) ns) : 0;
+        r->s_mer = ns? (uint64_t *) xmalloc(8 * (size_t) ns) : 0;
+        r->k_mer = ns? (uint64_t *) xmalloc(8 * (size_t) ns) : 0;
+    }
+}
+
+/* ... and filled by all of them (the first touch of every page happens here, in parallel) */
 static void fill_worker(void *arg, int tid, int n_threads)
 {
     const fill_job_t *j = (const fill_job_t *) arg;
@@ -71,26 +110,22 @@ static void fill_worker(void *arg, int tid, int n_threads)
     uint64_t i;
     for (i = a; i < b; ++i) {
         oatk_sr_t *r = &j->sr_db->a[i];
-        const uint32_t hl = j->hoco_l[i];
-        const uint64_t ns = j->scm_off[i + 1] - j->scm_off[i], os = j->scm_off[i] - j->scm0;
-        const size_t nb = ((size_t) hl + 3) / 4;
-        r->sid = i;                                        /* reads are numbered in input order, syncmer.c:525 */
-        r->sname = j->names? j->names[i] : 0;
-        r->hoco_l = hl;
-        /* empty arrays are NULL in the reference (kvec never allocated), syncmer.c:396-412 */
-        r->hoco_s = nb? (uint8_t *) memcpy(xmalloc(nb), j->buf->hs + (j->off[i] - j->rl0) / 4, nb) : 0;
-        r->ho_rl = hl? (uint8_t *) memcpy(xmalloc(hl), j->buf->rl + (j->off[i] - j->rl0), hl) : 0;
-        r->ho_l_rl = j->n_lrl[i]? (uint32_t *) memcpy(xmalloc(4 * (size_t) j->n_lrl[i]), j->lrl_val + j->o_lrl[i], 4 * (size_t) j->n_lrl[i]) : 0;
-        r->n_nucl = 0;
+        const uint32_t hl = r->hoco_l;
+        const uint64_t ns = r->n, os = j->scm_off[i] - j->scm0;
+        if (hl) {
+            memcpy(r->hoco_s, j->buf->hs + (j->off[i] - j->rl0) / 4, ((size_t) hl + 3) / 4);
+            memcpy(r->ho_rl, j->buf->rl + (j->off[i] - j->rl0), hl);
+        }
+        if (j->n_lrl[i]) memcpy(r->ho_l_rl, j->lrl_val + j->o_lrl[i], 4 * (size_t) j->n_lrl[i]);
         if (j->n_nn[i]) {
             uint32_t t;
-            r->n_nucl = (uint32_t *) xmalloc(4 * (size_t) j->n_nn[i]);
             for (t = 0; t < j->n_nn[i]; ++t) r->n_nucl[t] = (uint32_t) j->nn_key[j->o_nn[i] + t];     /* low word = raw coordinate */
         }
-        r->n = (uint32_t) ns;
-        r->m_pos = ns? (uint32_t *) memcpy(xmalloc(4 * (size_t) ns), j->buf->m_pos + os, 4 * (size_t) ns) : 0;
-        r->s_mer = ns? (uint64_t *) memcpy(xmalloc(8 * (size_t) ns), j->buf->s_mer + os, 8 * (size_t) ns) : 0;
-        r->k_mer = ns? (uint64_t *) memcpy(xmalloc(8 * (size_t) ns), j->buf->k_hash + os, 8 * (size_t) ns) : 0;
+        if (ns) {
+            memcpy(r->m_pos, j->buf->m_pos + os, 4 * (size_t) ns);
+            memcpy(r->s_mer, j->buf->s_mer + os, 8 * (size_t) ns);
+            memcpy(r->k_mer, j->buf->k_hash + os, 8 * (size_t) ns);
+        }
     }
 }
 
@@ -98,6 +133,11 @@ int oatk_sr_db_fill_resident(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, const uint6
 {
     int rc = 0;
     if (n_reads == 0) return OATK_OK;
+    {   /* gigabytes of small blocks are about to be allocated: let the heap grow in large steps and never shrink in between */
+        static int tuned = 0;
+        if (!tuned) { (void) mallopt(M_TOP_PAD, 256 << 20); (void) mallopt(M_TRIM_THRESHOLD, 1 << 30); tuned = 1; }
+    }
+    const double t_begin = host_now();
 
     uint64_t b, i;
     uint32_t *hoco_l = 0, *n_nn = 0, *n_lrl = 0, *lrl_val = 0;
@@ -169,6 +209,7 @@ int oatk_sr_db_fill_resident(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, const uint6
         /* cut the piece that arrived before it */
         if (flight >= 0) {
             job.buf = &buf[flight], job.i0 = q0, job.i1 = q1, job.rl0 = off[q0], job.scm0 = scm_off[q0];
+            fill_alloc(&job);
             oatk_par_run(fill_worker, &job);
             sr_db->n = q1;
         }
@@ -178,6 +219,7 @@ int oatk_sr_db_fill_resident(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, const uint6
     }
 done:
     free(hoco_l); free(n_nn); free(n_lrl); free(nn_key); free(lrl_val); free(scm_off); free(o_nn); free(o_lrl);
+    if (host_log()) fprintf(stderr, "[M::%s] %lu reads into sr_db_t: %.3f s on %d host threads\n", __func__, (unsigned long) n_reads, host_now() - t_begin, oatk_host_threads());
     return rc;
 }
 
