@@ -62,6 +62,7 @@ static struct {
     oatk_overlap_t *ovl;
     uint64_t served[2 * F_COUNT_];
     double secs[2 * F_COUNT_];
+    double t_start, t_ready;       /* first call into this file; device context ready */
 } D;
 
 static double now(void)
@@ -76,7 +77,7 @@ static void note(int f, int original, double t0, const char *why)
     const double dt = now() - t0;
     D.served[2 * f + original] += 1, D.secs[2 * f + original] += dt;
     if (D.log && f < F_CONS)
-        fprintf(stderr, "[M::oatk_dropin] %s: %s, %.3f s%s%s\n", F_NAME[f], original? "original body" : "MI355X", dt, why? " -- " : "", why? why : "");
+        fprintf(stderr, "[M::oatk_dropin] +%.3f s %s: %s, %.3f s%s%s\n", t0 - D.t_start, F_NAME[f], original? "original body" : "MI355X", dt, why? " -- " : "", why? why : "");
 }
 
 static void hooks_off(void)
@@ -89,9 +90,11 @@ static void hooks_off(void)
 
 static void at_exit(void)
 {
+    const double t_exit = now();
     hooks_off();
     if (D.log) {
         int f;
+        fprintf(stderr, "[M::oatk_dropin] device context ready after %.3f s; exit handlers reached at +%.3f s\n", D.t_ready - D.t_start, t_exit - D.t_start);
         fprintf(stderr, "[M::oatk_dropin] %-28s %10s %10s %10s %10s\n", "function", "MI355X", "seconds", "original", "seconds");
         for (f = 0; f < F_COUNT_; ++f)
             fprintf(stderr, "[M::oatk_dropin] %-28s %10lu %10.3f %10lu %10.3f\n", F_NAME[f], (unsigned long) D.served[2 * f], D.secs[2 * f],
@@ -99,12 +102,14 @@ static void at_exit(void)
     }
     if (D.ctx) oatk_hip_destroy(D.ctx);
     D.ctx = 0;
+    if (D.log) fprintf(stderr, "[M::oatk_dropin] device context released in %.3f s\n", now() - t_exit);
 }
 
 static void init(void)
 {
     if (D.init) return;
     D.init = 1;
+    D.t_start = now();
     const char *e = getenv("OATK_DROPIN");
     D.enabled = !(e && (e[0] == '0' || e[0] == 'n' || e[0] == 'N'));
     e = getenv("OATK_DROPIN_LOG");
@@ -114,6 +119,7 @@ static void init(void)
         D.ctx = oatk_hip_create(e? atoi(e) : 0);
         if (!D.ctx) fprintf(stderr, "[W::oatk_dropin] no usable MI355X (gfx950) device: every call runs the original body\n");
     }
+    D.t_ready = now();
     atexit(at_exit);
 }
 

@@ -62,6 +62,7 @@ def run(binary, tag, env=None):
     e = dict(os.environ)
     e.update(env or {})
     t = time.perf_counter()
+    print("[cli_scale] start %s" % binary, flush=True)
     p = subprocess.run([os.path.join(BIN, binary), "-k", "1001", "-c", str(c), "-t", str(args.threads), "-o", out, fa], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
     dt = time.perf_counter() - t
     err = p.stderr.decode(errors="replace")
@@ -78,7 +79,7 @@ def run(binary, tag, env=None):
 report = {"n_reads": args.n_reads, "gbases": round(bases / 1e9, 3), "threads": args.threads, "workload": args.workload}
 r, err = run("syncasm_dropin", "dev", {"OATK_DROPIN_LOG": "1"})
 report["dropin"] = r
-print("\n".join(l for l in err.splitlines() if "oatk_dropin" in l), flush=True)
+print("\n".join(l for l in err.splitlines() if "oatk_" in l), flush=True)
 if args.ref:
     r2, _ = run("syncasm", "ref")
     report["reference"] = r2
