@@ -145,14 +145,24 @@ static void up_worker(void *arg, int tid, int n_threads)
 static int upload_text(oatk_hip_ctx *ctx, const seg_t *seg, int n_seg, uint64_t total, uint8_t **d_text_out)
 {
     uint8_t *d_text = 0;
+    struct timespec t_in;
+    clock_gettime(CLOCK_MONOTONIC, &t_in);
     int rc = oatk_hip_ingest_text_buffer(ctx, total, &d_text);
     if (rc) return rc;
     *d_text_out = d_text;
     if (total == 0) return OATK_OK;
     const uint64_t chunk = total < UP_CHUNK? ((total + 63) & ~63ULL) : UP_CHUNK;
     /* a large input asks at once for what filling the reads' structs will want afterwards (srdb.c), so the block is pinned only once */
+    struct timespec ta, tb;
+    ta = t_in;
     uint8_t *stage = (uint8_t *) oatk_hip_staging(ctx, total > ((uint64_t) 1 << 30)? (uint64_t) 640 << 20 : 2 * chunk);
     if (!stage) return OATK_E_NOMEM;
+    clock_gettime(CLOCK_MONOTONIC, &tb);
+    {
+        const char *lg = getenv("OATK_DROPIN_LOG");
+        if (lg && lg[0] && lg[0] != '0') fprintf(stderr, "[M::%s] device text buffer + page-locked staging: %.3f s\n", __func__,
+                                                 (double) (tb.tv_sec - ta.tv_sec) + 1e-9 * (double) (tb.tv_nsec - ta.tv_nsec));
+    }
     up_job_t job = {seg, n_seg, stage, 0, total < chunk? total : chunk, 0};
     oatk_par_run(up_worker, &job);
     uint64_t g0 = 0;
@@ -179,8 +189,18 @@ static int ingest_files(oatk_hip_ctx *ctx, char **files, int n_files, uint64_t *
     seg_t *seg = open_segments(files, n_files, &total, &rc);
     if (!seg) return rc;
     uint8_t *d_text = 0;
+    struct timespec t0, t1, t2;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
     rc = upload_text(ctx, seg, n_files, total, &d_text);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
     if (!rc) rc = oatk_hip_ingest(ctx, d_text, total, OATK_FMT_AUTO, 1, n_reads, &used);
+    clock_gettime(CLOCK_MONOTONIC, &t2);
+    {
+        const char *lg = getenv("OATK_DROPIN_LOG");
+        if (lg && lg[0] && lg[0] != '0') fprintf(stderr, "[M::%s] %.2f GB of text: upload %.3f s, record scan %.3f s\n", __func__, (double) total / 1e9,
+                                                 (double) (t1.tv_sec - t0.tv_sec) + 1e-9 * (double) (t1.tv_nsec - t0.tv_nsec),
+                                                 (double) (t2.tv_sec - t1.tv_sec) + 1e-9 * (double) (t2.tv_nsec - t1.tv_nsec));
+    }
     if (rc || !seg_out) seg_close(seg, n_files);
     else *seg_out = seg;
     return rc;

@@ -6,7 +6,9 @@
  * both computed on the MI355X through the C ABI of include/oatk_hip.h.  What remains on the host is what the struct
  * layout forces: one malloc + memcpy per member array per read (sr_destroy frees each of them, syncmer.c:1047-1058).
  */
+#define _GNU_SOURCE
 #include <malloc.h>
+#include <sys/mman.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -76,14 +78,19 @@ typedef struct {
     /* the piece being cut */
     const fill_buf_t *buf;
     uint64_t i0, i1, rl0, scm0;
+    /* the piece whose blocks are allocated meanwhile (thread 0) */
+    uint64_t a0, a1;
+    double t_alloc;
 } fill_job_t;
 
 /* the blocks of reads [i0, i1), allocated by ONE thread: glibc grows a thread arena a few pages at a time under the address-space lock, so
  * many threads allocating gigabytes get in each other's way; the main heap grows in large steps (M_TOP_PAD below) and costs ~40 ns per block */
-static void fill_alloc(const fill_job_t *j)
+static void fill_alloc(fill_job_t *j)
 {
     uint64_t i;
-    for (i = j->i0; i < j->i1; ++i) {
+    const double t0 = host_now();
+    uint8_t *first = 0, *last = 0;
+    for (i = j->a0; i < j->a1; ++i) {
         oatk_sr_t *r = &j->sr_db->a[i];
         const uint32_t hl = j->hoco_l[i];
         const uint64_t ns = j->scm_off[i + 1] - j->scm_off[i];
@@ -99,13 +106,27 @@ static void fill_alloc(const fill_job_t *j)
         r->m_pos = ns? (uint32_t *) xmalloc(4 * (size_t) ns) : 0;
         r->s_mer = ns? (uint64_t *) xmalloc(8 * (size_t) ns) : 0;
         r->k_mer = ns? (uint64_t *) xmalloc(8 * (size_t) ns) : 0;
+        if (!first) first = r->hoco_s;
+        if (r->ho_rl) last = r->ho_rl;
     }
+    /* the heap grew by this piece in one stretch: ask for huge pages there before the first touch (2 MiB faults instead of 4 KiB ones) */
+    if (first && last > first && (uint64_t) (last - first) < ((uint64_t) 2 << 30)) {
+        const uintptr_t lo = ((uintptr_t) first + ((uintptr_t) 2 << 20) - 1) & ~(((uintptr_t) 2 << 20) - 1), hi = (uintptr_t) last & ~(((uintptr_t) 2 << 20) - 1);
+        if (hi > lo) (void) madvise((void *) lo, hi - lo, MADV_HUGEPAGE);
+    }
+    j->t_alloc += host_now() - t0;
 }
 
 /* ... and filled by all of them (the first touch of every page happens here, in parallel) */
 static void fill_worker(void *arg, int tid, int n_threads)
 {
-    const fill_job_t *j = (const fill_job_t *) arg;
+    fill_job_t *j = (fill_job_t *) arg;
+    /* thread 0 allocates the NEXT piece's blocks while the others copy this one (alone, it does both) */
+    if (tid == 0 && j->a1 > j->a0) fill_alloc(j);
+    if (n_threads > 1) {
+        if (tid == 0) return;
+        --tid, --n_threads;
+    }
     const uint64_t n = j->i1 - j->i0, a = j->i0 + n * (uint64_t) tid / (uint64_t) n_threads, b = j->i0 + n * (uint64_t) (tid + 1) / (uint64_t) n_threads;
     uint64_t i;
     for (i = a; i < b; ++i) {
@@ -138,6 +159,9 @@ int oatk_sr_db_fill_resident(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, const uint6
         if (!tuned) { (void) mallopt(M_TOP_PAD, 256 << 20); (void) mallopt(M_TRIM_THRESHOLD, 1 << 30); tuned = 1; }
     }
     const double t_begin = host_now();
+    double t_copy = 0, t_wait = 0, t_setup = 0;
+    fill_job_t job;
+    memset(&job, 0, sizeof(job));
 
     uint64_t b, i;
     uint32_t *hoco_l = 0, *n_nn = 0, *n_lrl = 0, *lrl_val = 0;
@@ -185,11 +209,10 @@ int oatk_sr_db_fill_resident(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, const uint6
     if (!sr_db->a) { rc = OATK_E_NOMEM; goto done; }
     sr_db->n = 0, sr_db->m = n_reads;
 
-    fill_job_t job;
-    memset(&job, 0, sizeof(job));
     job.sr_db = sr_db, job.off = off, job.scm_off = scm_off, job.hoco_l = hoco_l, job.n_nn = n_nn, job.n_lrl = n_lrl, job.lrl_val = lrl_val;
     job.nn_key = nn_key, job.o_nn = o_nn, job.o_lrl = o_lrl, job.names = names;
 
+    t_setup = host_now() - t_begin;
     uint64_t p0 = 0, p1 = 0, q0 = 0, q1 = 0;          /* piece in flight: reads [p0, p1); piece being cut: [q0, q1) */
     int flight = -1, which = 0;
     for (;;) {
@@ -206,20 +229,27 @@ int oatk_sr_db_fill_resident(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, const uint6
             rc = oatk_hip_d2h_async(ctx, B->s_mer, (const uint64_t *) d_sm + scm_off[p0], ns * 8); if (rc) goto done;
             rc = oatk_hip_d2h_async(ctx, B->k_hash, (const uint64_t *) d_kh + scm_off[p0], ns * 8); if (rc) goto done;
         }
-        /* cut the piece that arrived before it */
+        /* cut the piece that arrived before it (its blocks exist already), allocating the queued one's meanwhile */
+        job.a0 = p0 < n_reads? p0 : 0, job.a1 = p0 < n_reads? p1 : 0;
         if (flight >= 0) {
+            const double tc = host_now();
             job.buf = &buf[flight], job.i0 = q0, job.i1 = q1, job.rl0 = off[q0], job.scm0 = scm_off[q0];
-            fill_alloc(&job);
             oatk_par_run(fill_worker, &job);
             sr_db->n = q1;
-        }
+            t_copy += host_now() - tc;
+        } else fill_alloc(&job);
         if (p0 >= n_reads) break;
-        rc = oatk_hip_sync(ctx); if (rc) goto done;   /* the queued piece has landed */
+        {
+            const double tw = host_now();
+            rc = oatk_hip_sync(ctx); if (rc) goto done;   /* the queued piece has landed */
+            t_wait += host_now() - tw;
+        }
         flight = which, which ^= 1, q0 = p0, q1 = p1;
     }
 done:
     free(hoco_l); free(n_nn); free(n_lrl); free(nn_key); free(lrl_val); free(scm_off); free(o_nn); free(o_lrl);
-    if (host_log()) fprintf(stderr, "[M::%s] %lu reads into sr_db_t: %.3f s on %d host threads\n", __func__, (unsigned long) n_reads, host_now() - t_begin, oatk_host_threads());
+    if (host_log()) fprintf(stderr, "[M::%s] %lu reads into sr_db_t: %.3f s on %d host threads (setup %.3f, block allocation %.3f beside copying %.3f, waiting for PCIe %.3f)\n",
+                            __func__, (unsigned long) n_reads, host_now() - t_begin, oatk_host_threads(), t_setup, job.t_alloc, t_copy, t_wait);
     return rc;
 }
 
