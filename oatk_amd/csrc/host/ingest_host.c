@@ -160,7 +160,7 @@ static int upload_text(oatk_hip_ctx *ctx, const seg_t *seg, int n_seg, uint64_t 
     clock_gettime(CLOCK_MONOTONIC, &tb);
     {
         const char *lg = getenv("OATK_DROPIN_LOG");
-        if (lg && lg[0] && lg[0] != '0') fprintf(stderr, "[M::%s] device text buffer + page-locked staging: %.3f s\n", __func__,
+        if (lg && lg[0] && lg[0] != '0') fprintf(stderr, "[M::oatk_%s] device text buffer + page-locked staging: %.3f s\n", __func__,
                                                  (double) (tb.tv_sec - ta.tv_sec) + 1e-9 * (double) (tb.tv_nsec - ta.tv_nsec));
     }
     up_job_t job = {seg, n_seg, stage, 0, total < chunk? total : chunk, 0};
@@ -197,7 +197,7 @@ static int ingest_files(oatk_hip_ctx *ctx, char **files, int n_files, uint64_t *
     clock_gettime(CLOCK_MONOTONIC, &t2);
     {
         const char *lg = getenv("OATK_DROPIN_LOG");
-        if (lg && lg[0] && lg[0] != '0') fprintf(stderr, "[M::%s] %.2f GB of text: upload %.3f s, record scan %.3f s\n", __func__, (double) total / 1e9,
+        if (lg && lg[0] && lg[0] != '0') fprintf(stderr, "[M::oatk_%s] %.2f GB of text: upload %.3f s, record scan %.3f s\n", __func__, (double) total / 1e9,
                                                  (double) (t1.tv_sec - t0.tv_sec) + 1e-9 * (double) (t1.tv_nsec - t0.tv_nsec),
                                                  (double) (t2.tv_sec - t1.tv_sec) + 1e-9 * (double) (t2.tv_nsec - t1.tv_nsec));
     }
