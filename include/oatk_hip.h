@@ -72,6 +72,20 @@ int oatk_hip_scan(oatk_hip_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off
 int oatk_hip_scan_host(oatk_hip_ctx *ctx, const uint8_t *h_seq, const uint64_t *h_off, const uint32_t *h_len,
                        uint64_t n_reads, uint64_t seq_bytes, uint64_t sid0, int k, int s);
 
+/* ---- a batch built from pieces: sr_read hands its reads to the analysis threads in batches too (10 000 per thread, syncmer.c:505-533) ----
+ * oatk_hip_scan_begin empties ctx and declares the geometry of the batch that is going to be assembled; oatk_hip_scan_append moves the scan
+ * that is resident in `piece` (another handle on the same device, scanned with sid0 = ctx's sid0 + the reads ctx already holds) behind the
+ * reads of ctx: hoco strings, run lengths, per-read arrays, syncmer slots and rare-event lists, with offsets rebased -- device-to-device, no
+ * recomputation.  Afterwards ctx is exactly what ONE scan of all the reads would have left (count, error correction, ... follow on ctx);
+ * `piece` can be scanned again.  oatk_hip_scan_reserve sizes ctx's buffers ahead (totals, may be rough: buffers grow when exceeded). */
+int oatk_hip_scan_begin(oatk_hip_ctx *ctx, uint64_t sid0, int k, int s);
+int oatk_hip_scan_reserve(oatk_hip_ctx *ctx, uint64_t seq_bytes, uint64_t n_reads, uint64_t n_occ);
+int oatk_hip_scan_append(oatk_hip_ctx *ctx, oatk_hip_ctx *piece);
+/* the device ordinal the handle was created on */
+int oatk_hip_device(oatk_hip_ctx *ctx);
+/* device-to-device copy on the handle's stream, completed on return */
+int oatk_hip_d2d(oatk_hip_ctx *ctx, void *d_dst, const void *d_src, uint64_t bytes);
+
 /* ---- count: replaces collect_syncmer_from_reads (syncmer.c:1397-1451) on the resident scan ---- */
 int oatk_hip_count(oatk_hip_ctx *ctx);
 

@@ -74,6 +74,7 @@ void oatk_host_set_threads(int n);
 int oatk_host_threads(void);
 typedef void (*oatk_par_fn)(void *arg, int tid, int n_threads);
 void oatk_par_run(oatk_par_fn fn, void *arg);
+void oatk_par_run_n(oatk_par_fn fn, void *arg, int n_threads);
 
 /* malloc'ed and initialised like sr_db_init (syncmer.c:1060-1067) */
 oatk_sr_db_t *oatk_sr_db_new(int k, int s);
@@ -84,11 +85,16 @@ oatk_sr_db_t *oatk_sr_db_new(int k, int s);
 int oatk_sr_read_packed(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, const uint8_t *seq, const uint64_t *off, const uint32_t *len,
                         uint64_t n_reads, uint64_t seq_bytes, char **names);
 
+/* sr_db->a[first .. first + n_reads) from the scan resident in ctx, whose read 0 is read `first` of the database (a piece of a batch that is
+ * assembled with oatk_hip_scan_append); sr_db->a must have room, sr_db->n is raised to first + n_reads */
+int oatk_sr_db_fill_range(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, uint64_t first, const uint64_t *off, uint64_t n_reads, char **names);
 /* the second half of the above for a scan that is already resident (off[i] = offset of read i in the packed stream that was scanned) */
 int oatk_sr_db_fill_resident(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, const uint64_t *off, uint64_t n_reads, char **names);
 /* sr_read (syncmer.c:487) for files (plain or gzip'ed FASTA / four-line FASTQ), without kseq: text to the device (oatk_ingest_files), record
  * scan and syncmer scan there, sr_db filled from the resident results, snames cut out of the headers */
 int oatk_sr_read_files(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, char **files, int n_files);
+/* Test hook: the text window (bytes) oatk_sr_read_files streams the input in; 0 = default (768 MiB).  Results never depend on it. */
+void oatk_host_debug_window(uint64_t bytes);
 
 /* collect_syncmer_from_reads (syncmer.c:1397): count on the device, build syncmer_db_t, rewrite sr->k_mer to id << 1.
  * Returns NULL when there are no syncmers (syncmer.c:1414-1417) or on error (*rc set). */

@@ -39,6 +39,7 @@ TIMERS = ["hpc", "syncmer", "syncmer_n", "scan_post", "count_place", "count_sort
 EXPORTS = [
     "oatk_hip_abi_version", "oatk_hip_device_count", "oatk_hip_create", "oatk_hip_destroy", "oatk_hip_last_error",
     "oatk_hip_stream", "oatk_hip_sync", "oatk_hip_max_k", "oatk_hip_scan", "oatk_hip_scan_host", "oatk_hip_count",
+    "oatk_hip_scan_begin", "oatk_hip_scan_reserve", "oatk_hip_scan_append", "oatk_hip_device", "oatk_hip_d2d",
     "oatk_hip_info", "oatk_hip_buffer", "oatk_hip_d2h", "oatk_hip_d2h_async", "oatk_hip_h2d_async", "oatk_hip_staging", "oatk_hip_ingest_text_buffer", "oatk_hip_set_timing", "oatk_hip_get_timing",
     "oatk_hip_debug_hash_mask", "oatk_hip_debug_force_general", "oatk_hip_debug_list_cap",
     "oatk_hip_ec_graph", "oatk_hip_ec", "oatk_hip_ec_stats", "oatk_hip_debug_ec_tiers", "oatk_hip_debug_wf_ed", "oatk_hip_ec_mark", "oatk_hip_ec_correct",
@@ -104,6 +105,11 @@ def load():
     L.oatk_hip_scan.argtypes = [vp, vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
     L.oatk_hip_scan_host.argtypes = [vp, vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
     L.oatk_hip_count.argtypes = [vp]
+    L.oatk_hip_scan_begin.argtypes = [vp, C.c_uint64, C.c_int, C.c_int]
+    L.oatk_hip_scan_reserve.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64]
+    L.oatk_hip_scan_append.argtypes = [vp, vp]
+    L.oatk_hip_device.argtypes = [vp]
+    L.oatk_hip_d2d.argtypes = [vp, vp, vp, C.c_uint64]
     L.oatk_hip_info.argtypes = [vp, C.POINTER(Info)]
     L.oatk_hip_buffer.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_uint64)]
     L.oatk_hip_d2h.argtypes = [vp, vp, vp, C.c_uint64]

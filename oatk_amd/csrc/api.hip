@@ -35,6 +35,19 @@ struct DevBuf {
         if (zero_new) (void) hipMemsetAsync(p, 0, want, st);
         return true;
     }
+    // grow without losing the first `used` bytes (appending to a resident batch)
+    bool grow_keep(size_t bytes, size_t used, hipStream_t st)
+    {
+        if (bytes <= cap) return true;
+        void *np = nullptr;
+        size_t want = bytes + bytes / 4 + 256;
+        if (hipMalloc(&np, want) != hipSuccess) return false;
+        if (p && used && hipMemcpyAsync(np, p, used, hipMemcpyDeviceToDevice, st) != hipSuccess) { (void) hipFree(np); return false; }
+        (void) hipStreamSynchronize(st);
+        if (p) (void) hipFree(p);
+        p = np, cap = want;
+        return true;
+    }
     void release() { if (p) (void) hipFree(p); p = nullptr; cap = 0; }
     template <class T> T *as() const { return (T *) p; }
 };
@@ -264,6 +277,8 @@ __global__ void widen_kernel(const uint32_t *in, uint64_t *out, uint64_t n)
     if (i == n) out[i] = 0;
 }
 
+static void scan_reset_downstream(oatk_hip_ctx *ctx);
+
 static int launch_scan_kernels(oatk_hip_ctx *ctx)
 {
     using namespace oatk;
@@ -331,12 +346,7 @@ int oatk_hip_scan(oatk_hip_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off
     if (seq_bytes % OATK_READ_ALIGN || n_reads >= 0xFFFFFFFFULL || sid0 + n_reads > 0xFFFFFFFFULL) { ctx->err = "bad batch geometry"; return OATK_E_ARG; }
     ctx->d_seq = d_seq, ctx->d_off = d_off, ctx->d_len = d_len;
     ctx->n_reads = n_reads, ctx->seq_bytes = seq_bytes, ctx->sid0 = sid0, ctx->K = k, ctx->S = s;
-    ctx->scanned = ctx->counted = false;
-    if (ctx->ec) ctx->ec->done = ctx->ec->marked = ctx->ec->graph_resident = ctx->ec->global = false;     // results of the previous batch
-    if (ctx->cons) ctx->cons->done = false;
-    if (ctx->ag) ctx->ag->done = false;
-    if (ctx->ovl) ctx->ovl->done = false;
-    if (ctx->ra) ctx->ra->done = false;
+    scan_reset_downstream(ctx);                                           // results of the previous batch
     ctx->retries = 0, ctx->collisions = 0;
     ctx->n_occ = ctx->tot_nn = ctx->tot_lrl = ctx->n_scm_total = 0;
     if (n_reads == 0) { ctx->scanned = true; return OATK_OK; }
@@ -462,6 +472,131 @@ int oatk_hip_scan(oatk_hip_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off
     CK(hipStreamSynchronize(ctx->stream));
     if (ctx->timing) { t_collect(ctx, OATK_T_SCAN_POST, OATK_T_COUNT_PLACE); t_collect(ctx, OATK_T_KMER_HASH, OATK_T_KMER_HASH); }
     ctx->scanned = true;
+    return OATK_OK;
+}
+
+// ---- a batch assembled from scanned pieces (include/oatk_hip.h) ----
+__global__ void append_rebase_kernel(const uint64_t *src, uint64_t *dst, uint64_t n, uint64_t add)
+{
+    uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i] + add;
+}
+__global__ void append_iota_kernel(uint32_t *iota, uint64_t first, uint64_t n)
+{
+    uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) iota[first + i] = (uint32_t) (first + i);
+}
+
+static void scan_reset_downstream(oatk_hip_ctx *ctx)
+{
+    ctx->scanned = ctx->counted = false;
+    if (ctx->ec) ctx->ec->done = ctx->ec->marked = ctx->ec->graph_resident = ctx->ec->global = false;
+    if (ctx->cons) ctx->cons->done = false;
+    if (ctx->ag) ctx->ag->done = false;
+    if (ctx->ovl) ctx->ovl->done = false;
+    if (ctx->ra) ctx->ra->done = false;
+}
+
+int oatk_hip_device(oatk_hip_ctx *ctx) { return ctx? ctx->device : -1; }
+
+int oatk_hip_d2d(oatk_hip_ctx *ctx, void *d_dst, const void *d_src, uint64_t bytes)
+{
+    if (!ctx) return OATK_E_NODEV;
+    if (bytes == 0) return OATK_OK;
+    CK(hipSetDevice(ctx->device));
+    CK(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    return OATK_OK;
+}
+
+int oatk_hip_scan_begin(oatk_hip_ctx *ctx, uint64_t sid0, int k, int s)
+{
+    if (!ctx) return OATK_E_NODEV;
+    CK(hipSetDevice(ctx->device));
+    if (!(s > 0 && s < 32 && k > s) || k > oatk_hip_max_k()) { ctx->err = "k/s out of range for the device scan"; return OATK_E_ARG; }
+    scan_reset_downstream(ctx);
+    ctx->d_seq = nullptr, ctx->d_off = nullptr, ctx->d_len = nullptr;
+    ctx->n_reads = 0, ctx->seq_bytes = 0, ctx->sid0 = sid0, ctx->K = k, ctx->S = s;
+    ctx->retries = 0, ctx->collisions = 0;
+    ctx->n_occ = ctx->tot_nn = ctx->tot_lrl = ctx->n_scm_total = 0;
+    ctx->nn_sorted_in_2 = ctx->lrl_sorted_in_2 = false;
+    ctx->scanned = true;                       // an empty batch is a valid batch
+    return OATK_OK;
+}
+
+#define KEEP(buf, bytes, used)                                                                     \
+    do {                                                                                           \
+        if (!ctx->buf.grow_keep((bytes), (used), ctx->stream)) {                                   \
+            ctx->err = "hipMalloc failed for " #buf " (append)";                                   \
+            return OATK_E_NOMEM;                                                                   \
+        }                                                                                          \
+    } while (0)
+
+static int append_ensure(oatk_hip_ctx *ctx, uint64_t nr, uint64_t sb, uint64_t occ, uint64_t nn, uint64_t lrl)
+{
+    const uint64_t n0 = ctx->n_reads, b0 = ctx->seq_bytes, o0 = ctx->n_occ;
+    KEEP(in_off, (nr + 1) * 8, n0 * 8);
+    KEEP(hoco_l, nr * 4 + 4, n0 * 4); KEEP(n_scm, nr * 4 + 4, n0 * 4); KEEP(n_nn, nr * 4 + 4, n0 * 4); KEEP(n_lrl, nr * 4 + 4, n0 * 4);
+    KEEP(ho_rl, sb + 64, b0);
+    KEEP(hoco_s, sb / 4 + 128 + 16 + ctx->import_reserve, b0 / 4 + 64);
+    KEEP(scm_off, (nr + 1) * 8, (n0 + 1) * 8);
+    KEEP(pos_hash, occ * 8 + 8, o0 * 8); KEEP(pos_lo, occ * 8 + 8, o0 * 8); KEEP(pos_smer, occ * 8 + 8, o0 * 8); KEEP(pos_mpos, occ * 4 + 4, o0 * 4);
+    KEEP(key_hash, occ * 8 + 8, o0 * 8); KEEP(iota, occ * 4 + 4, o0 * 4);
+    // the rare-event lists live in the "2" buffers of a finished scan when they were sorted; an assembled batch keeps them in the plain ones
+    KEEP(nn_key, nn * 8 + 8, ctx->tot_nn * 8); KEEP(lrl_key, lrl * 8 + 8, ctx->tot_lrl * 8); KEEP(lrl_val, lrl * 4 + 4, ctx->tot_lrl * 4);
+    return OATK_OK;
+}
+
+int oatk_hip_scan_reserve(oatk_hip_ctx *ctx, uint64_t seq_bytes, uint64_t n_reads, uint64_t n_occ)
+{
+    if (!ctx) return OATK_E_NODEV;
+    CK(hipSetDevice(ctx->device));
+    if (!ctx->scanned || ctx->d_seq) { ctx->err = "oatk_hip_scan_reserve: call oatk_hip_scan_begin first"; return OATK_E_STATE; }
+    seq_bytes = (seq_bytes + 63) & ~63ULL;
+    return append_ensure(ctx, ctx->n_reads + n_reads, ctx->seq_bytes + seq_bytes, ctx->n_occ + n_occ, ctx->tot_nn, ctx->tot_lrl);
+}
+
+int oatk_hip_scan_append(oatk_hip_ctx *ctx, oatk_hip_ctx *src)
+{
+    if (!ctx || !src) return OATK_E_NODEV;
+    CK(hipSetDevice(ctx->device));
+    if (ctx == src || ctx->device != src->device) { ctx->err = "oatk_hip_scan_append: the piece must be another handle on the same device"; return OATK_E_ARG; }
+    if (!ctx->scanned || ctx->d_seq) { ctx->err = "oatk_hip_scan_append: call oatk_hip_scan_begin first"; return OATK_E_STATE; }
+    if (!src->scanned) { ctx->err = "oatk_hip_scan_append: the piece holds no scan"; return OATK_E_STATE; }
+    const uint64_t n0 = ctx->n_reads, n1 = src->n_reads, b0 = ctx->seq_bytes, b1 = src->seq_bytes, o0 = ctx->n_occ, o1 = src->n_occ;
+    if (n1 == 0) return OATK_OK;
+    if (src->K != ctx->K || src->S != ctx->S) { ctx->err = "oatk_hip_scan_append: the piece was scanned with another k / s"; return OATK_E_ARG; }
+    if (src->sid0 != ctx->sid0 + n0) { ctx->err = "oatk_hip_scan_append: the piece's first read id must continue the batch"; return OATK_E_ARG; }
+    if (n0 + n1 >= 0xFFFFFFFFULL || o0 + o1 > 0xFFFFFFF0ULL) { ctx->err = "oatk_hip_scan_append: batch too large"; return OATK_E_ARG; }
+    scan_reset_downstream(ctx);
+    ctx->scanned = true;
+    { int rc = append_ensure(ctx, n0 + n1, b0 + b1, o0 + o1, ctx->tot_nn + src->tot_nn, ctx->tot_lrl + src->tot_lrl); if (rc) return rc; }
+    if (hipStreamSynchronize(src->stream) != hipSuccess) { ctx->err = "oatk_hip_scan_append: the piece's stream failed"; return OATK_E_NODEV; }
+    hipStream_t st = ctx->stream;
+    auto blocks = [](uint64_t n) { return dim3((unsigned) ((n + 255) / 256 > 0? (n + 255) / 256 : 1)); };
+    auto d2d = [&](void *dst, const void *from, size_t bytes) { return bytes? hipMemcpyAsync(dst, from, bytes, hipMemcpyDeviceToDevice, st) : hipSuccess; };
+    CK(d2d(ctx->ho_rl.as<uint8_t>() + b0, src->ho_rl.p, b1));
+    CK(d2d(ctx->hoco_s.as<uint8_t>() + b0 / 4, src->hoco_s.p, b1 / 4 + 64));
+    CK(d2d(ctx->hoco_l.as<uint32_t>() + n0, src->hoco_l.p, n1 * 4)); CK(d2d(ctx->n_scm.as<uint32_t>() + n0, src->n_scm.p, n1 * 4));
+    CK(d2d(ctx->n_nn.as<uint32_t>() + n0, src->n_nn.p, n1 * 4)); CK(d2d(ctx->n_lrl.as<uint32_t>() + n0, src->n_lrl.p, n1 * 4));
+    hipLaunchKernelGGL(append_rebase_kernel, blocks(n1), dim3(256), 0, st, src->d_off, ctx->in_off.as<uint64_t>() + n0, n1, b0);
+    hipLaunchKernelGGL(append_rebase_kernel, blocks(n1 + 1), dim3(256), 0, st, src->scm_off.as<uint64_t>(), ctx->scm_off.as<uint64_t>() + n0, n1 + 1, o0);
+    if (o1) {
+        CK(d2d(ctx->pos_hash.as<uint64_t>() + o0, src->pos_hash.p, o1 * 8)); CK(d2d(ctx->pos_lo.as<uint64_t>() + o0, src->pos_lo.p, o1 * 8));
+        CK(d2d(ctx->pos_smer.as<uint64_t>() + o0, src->pos_smer.p, o1 * 8)); CK(d2d(ctx->pos_mpos.as<uint32_t>() + o0, src->pos_mpos.p, o1 * 4));
+        CK(d2d(ctx->key_hash.as<uint64_t>() + o0, src->key_hash.p, o1 * 8));
+        hipLaunchKernelGGL(append_iota_kernel, blocks(o1), dim3(256), 0, st, ctx->iota.as<uint32_t>(), o0, o1);
+    }
+    // keys carry global read ids and the pieces come in read order: the concatenation is sorted
+    CK(d2d(ctx->nn_key.as<uint64_t>() + ctx->tot_nn, src->nn_sorted_in_2? src->nn_key2.p : src->nn_key.p, src->tot_nn * 8));
+    CK(d2d(ctx->lrl_key.as<uint64_t>() + ctx->tot_lrl, src->lrl_sorted_in_2? src->lrl_key2.p : src->lrl_key.p, src->tot_lrl * 8));
+    CK(d2d(ctx->lrl_val.as<uint32_t>() + ctx->tot_lrl, src->lrl_sorted_in_2? src->lrl_val2.p : src->lrl_val.p, src->tot_lrl * 4));
+    CK(hipGetLastError());
+    CK(hipStreamSynchronize(st));
+    ctx->d_off = ctx->in_off.as<uint64_t>();
+    ctx->n_reads = n0 + n1, ctx->seq_bytes = b0 + b1, ctx->n_occ = o0 + o1;
+    ctx->tot_nn += src->tot_nn, ctx->tot_lrl += src->tot_lrl;
+    ctx->retries += src->retries;
     return OATK_OK;
 }
 

@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <fcntl.h>
+#include <pthread.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <time.h>
@@ -212,7 +213,7 @@ int oatk_ingest_files(oatk_hip_ctx *ctx, char **files, int n_files, uint64_t *n_
 }
 
 /* ---- read names (kseq's name: the header up to the first white space), cut out of the text on the host threads ---- */
-typedef struct { seg_t *seg; int n_seg; const uint64_t *hdr; uint64_t n; char **names; } name_job_t;
+typedef struct { seg_t *seg; int n_seg; const uint64_t *hdr; uint64_t hdr_base, n; char **names; } name_job_t;
 
 static void name_worker(void *arg, int tid, int n_threads)
 {
@@ -221,7 +222,7 @@ static void name_worker(void *arg, int tid, int n_threads)
     uint64_t i;
     int si = 0;
     for (i = a; i < b; ++i) {
-        const uint64_t g = j->hdr[i] + 1;                          /* behind '>' / '@'; headers ascend, so the segment index only moves forward */
+        const uint64_t g = j->hdr_base + j->hdr[i] + 1;            /* behind '>' / '@'; headers ascend, so the segment index only moves forward */
         while (si + 1 < j->n_seg && g >= j->seg[si + 1].base) ++si;
         const seg_t *s = &j->seg[si];
         const uint8_t *t = s->fd >= 0? s->map : s->mem;
@@ -234,44 +235,246 @@ static void name_worker(void *arg, int tid, int n_threads)
     }
 }
 
-/* sr_read (syncmer.c:487) for files, entirely through the device: text -> records -> scan, then sr_db filled from the resident results */
-int oatk_sr_read_files(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, char **files, int n_files)
+/* ---- sr_read (syncmer.c:487) for files, streamed ----
+ * The text moves through the device in windows.  An uploader thread keeps reading the next window into page-locked memory and sending it
+ * (its own handle: stream + staging) while this thread takes the window before it through the record scan and the syncmer scan on a piece
+ * handle, fills the reads' structs from the piece (D2H behind the copying threads, srdb.c) and moves the piece behind the batch that is
+ * being assembled in the caller's handle (oatk_hip_scan_append).  A record cut by a window's end is carried over: the unconsumed tail is
+ * copied, on the device, in front of the next window.  Two slots alternate; nothing larger than a window (plus the assembled results) is
+ * ever allocated, and what the reference does one after the other -- read, analyse, store -- runs side by side. */
+#define WIN_DEFAULT ((uint64_t) 768 << 20)
+#define CARRY_CAP ((uint64_t) 32 << 20)
+
+static uint64_t g_window = 0;
+void oatk_host_debug_window(uint64_t bytes) { g_window = bytes; }
+
+typedef struct {
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    int state[2];                  /* 0 free, 1 window uploaded */
+    uint64_t g0[2], g1[2];         /* text range of the window in the slot */
+    int failed, stop;
+    oatk_hip_ctx *up;              /* the uploader's handle */
+    uint8_t *d_win[2];             /* where a slot's window goes on the device */
+    const seg_t *seg;
+    int n_seg, n_up;
+    uint64_t total, win;
+} stream_t;
+
+static void *uploader(void *arg)
 {
-    uint64_t n = 0, b = 0;
-    seg_t *seg = 0;
+    stream_t *st = (stream_t *) arg;
+    const uint64_t chunk = st->win < UP_CHUNK? ((st->win + 63) & ~63ULL) : UP_CHUNK;
+    uint8_t *stage = (uint8_t *) oatk_hip_staging(st->up, 2 * chunk);
+    uint64_t g0, w;
+    int rc = stage? OATK_OK : OATK_E_NOMEM;
+    for (w = 0, g0 = 0; !rc && g0 < st->total; ++w) {
+        const int s = (int) (w & 1);
+        const uint64_t g1 = g0 + st->win < st->total? g0 + st->win : st->total;
+        pthread_mutex_lock(&st->mu);
+        while (st->state[s] != 0 && !st->stop) pthread_cond_wait(&st->cv, &st->mu);
+        const int stop = st->stop;
+        pthread_mutex_unlock(&st->mu);
+        if (stop) break;
+        /* the window in pieces: read piece p + 1 while piece p is on the bus */
+        up_job_t job = {st->seg, st->n_seg, stage, g0, g0 + chunk < g1? g0 + chunk : g1, 0};
+        oatk_par_run_n(up_worker, &job, st->n_up);
+        uint64_t p0 = g0;
+        int which = 0;
+        while (!rc && p0 < g1 && !job.failed) {
+            const uint64_t p1 = p0 + chunk < g1? p0 + chunk : g1;
+            rc = oatk_hip_h2d_async(st->up, st->d_win[s] + (p0 - g0), stage + (uint64_t) which * chunk, p1 - p0);
+            if (!rc && p1 < g1) {
+                job.dst = stage + (uint64_t) (which ^ 1) * chunk, job.g0 = p1, job.g1 = p1 + chunk < g1? p1 + chunk : g1;
+                oatk_par_run_n(up_worker, &job, st->n_up);
+            }
+            if (!rc) rc = oatk_hip_sync(st->up);
+            p0 = p1, which ^= 1;
+        }
+        if (job.failed) rc = OATK_E_ARG;
+        pthread_mutex_lock(&st->mu);
+        if (rc) st->failed = rc;
+        else st->state[s] = 1, st->g0[s] = g0, st->g1[s] = g1;
+        pthread_cond_broadcast(&st->cv);
+        pthread_mutex_unlock(&st->mu);
+        g0 = g1;
+    }
+    if (rc) {
+        pthread_mutex_lock(&st->mu);
+        st->failed = rc;
+        pthread_cond_broadcast(&st->cv);
+        pthread_mutex_unlock(&st->mu);
+    }
+    return 0;
+}
+
+/* the first character of the text that is not white space decides the format, as kseq and oatk_hip_ingest(AUTO) decide it */
+static int sniff_format(const seg_t *seg, int n_seg, uint64_t total)
+{
+    uint8_t head[4096];
+    uint64_t n = total < sizeof(head)? total : sizeof(head), i;
+    up_job_t job = {seg, n_seg, head, 0, n, 0};
+    up_worker(&job, 0, 1);
+    for (i = 0; i < n && (head[i] == '\n' || head[i] == '\r' || head[i] == ' ' || head[i] == '\t'); ++i) {}
+    return i < n && head[i] == '@'? OATK_FMT_FASTQ : OATK_FMT_FASTA;
+}
+
+static double now_s(void)
+{
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double) t.tv_sec + 1e-9 * (double) t.tv_nsec;
+}
+
+static int sr_read_stream(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, seg_t *seg, int n_files, uint64_t total, uint64_t win)
+{
     const char *lg = getenv("OATK_DROPIN_LOG");
     const int log = lg && lg[0] && lg[0] != '0';
-    struct timespec t0, t1, t2;
-    clock_gettime(CLOCK_MONOTONIC, &t0);
-    int i, rc = ingest_files(ctx, files, n_files, &n, &seg);
-    if (rc) return rc;
-    clock_gettime(CLOCK_MONOTONIC, &t1);
-    rc = oatk_hip_scan_ingested(ctx, 0, sr_db->k, sr_db->s);
-    if (!rc) rc = oatk_hip_sync(ctx);
-    clock_gettime(CLOCK_MONOTONIC, &t2);
-    if (log) fprintf(stderr, "[M::%s] text to the device + record scan: %.3f s; syncmer scan: %.3f s\n", __func__,
-                     (double) (t1.tv_sec - t0.tv_sec) + 1e-9 * (double) (t1.tv_nsec - t0.tv_nsec), (double) (t2.tv_sec - t1.tv_sec) + 1e-9 * (double) (t2.tv_nsec - t1.tv_nsec));
+    const int dev = oatk_hip_device(ctx), threads = oatk_host_threads();
+    const double t_begin = now_s();
+    double t_wait = 0, t_dev = 0, t_fill = 0, t_app = 0;
+    oatk_hip_ctx *piece[2] = {0, 0};
+    stream_t st;
+    pthread_t th;
+    int rc = OATK_OK, started = 0, i;
+    uint64_t n_done = 0, carry = 0, w, text_done = 0;
     uint64_t *off = 0, *hdr = 0;
     char **names = 0;
-    if (!rc && n) {
+    memset(&st, 0, sizeof(st));
+    pthread_mutex_init(&st.mu, 0);
+    pthread_cond_init(&st.cv, 0);
+    st.seg = seg, st.n_seg = n_files, st.total = total, st.win = win;
+    st.n_up = threads > 1? threads - threads / 2 : 1;
+    const int fmt = sniff_format(seg, n_files, total);
+    rc = oatk_hip_scan_begin(ctx, 0, sr_db->k, sr_db->s);
+    st.up = rc? 0 : oatk_hip_create(dev);
+    for (i = 0; !rc && i < 2; ++i) {
+        uint8_t *d = 0;
+        piece[i] = oatk_hip_create(dev);
+        if (!piece[i] || !st.up) { rc = OATK_E_NODEV; break; }
+        if (i == 1 && total <= win) break;                        /* one window: one slot */
+        rc = oatk_hip_ingest_text_buffer(piece[i], CARRY_CAP + (win < total? win : total) + 64, &d);
+        st.d_win[i] = d + CARRY_CAP;
+    }
+    if (rc) goto done;
+    oatk_host_set_threads(threads > 1? threads / 2 : 1);           /* the other half reads the file */
+    if (pthread_create(&th, 0, uploader, &st) != 0) { rc = OATK_E_NOMEM; goto done; }
+    started = 1;
+
+    for (w = 0; text_done < total; ++w) {
+        const int s = (int) (w & 1);
+        double t0 = now_s();
+        pthread_mutex_lock(&st.mu);
+        while (st.state[s] != 1 && !st.failed) pthread_cond_wait(&st.cv, &st.mu);
+        rc = st.failed;
+        const uint64_t g0 = st.g0[s], g1 = st.g1[s];
+        pthread_mutex_unlock(&st.mu);
+        if (rc) break;
+        t_wait += now_s() - t0, t0 = now_s();
+        const int final = g1 == total;
+        uint8_t *d_text = st.d_win[s] - carry;
+        const uint64_t len = carry + (g1 - g0);
+        uint64_t n = 0, used = 0, b = 0;
+        rc = oatk_hip_ingest(piece[s], d_text, len, fmt, final, &n, &used);
+        if (rc) break;
+        const uint64_t next_carry = len - used;
+        if (!final) {
+            if (next_carry > CARRY_CAP || used == 0) { rc = OATK_E_NOMEM; break; }       /* a record longer than a window: the caller retries in one piece */
+            rc = oatk_hip_d2d(piece[s], st.d_win[s ^ 1] - next_carry, d_text + used, next_carry);
+            if (rc) break;
+        }
+        pthread_mutex_lock(&st.mu);                                 /* the window's text is spent: the uploader may have the slot back */
+        st.state[s] = 0;
+        pthread_cond_broadcast(&st.cv);
+        pthread_mutex_unlock(&st.mu);
+        const uint64_t text0 = g0 - carry;                          /* where this piece's text starts in the whole text */
+        carry = next_carry, text_done = g1;
+        if (n == 0) continue;
+        rc = oatk_hip_scan_ingested(piece[s], n_done, sr_db->k, sr_db->s);
+        if (rc) break;
+        t_dev += now_s() - t0, t0 = now_s();
+        /* room for the reads: from the first piece's density, generously; grown when a later piece needs more */
+        if (sr_db->m < n_done + n) {
+            uint64_t m = n_done + n;
+            if (!final && used) m = n_done + (uint64_t) ((double) n * ((double) (total - text0) / (double) used) * 1.05) + 1024;
+            oatk_sr_t *na = (oatk_sr_t *) realloc(sr_db->a, sizeof(oatk_sr_t) * m);
+            if (!na) { rc = OATK_E_NOMEM; break; }
+            memset(na + sr_db->m, 0, sizeof(oatk_sr_t) * (m - sr_db->m));
+            sr_db->a = na, sr_db->m = m;
+        }
+        if (n_done == 0 && !final && used) {                        /* ... and for the assembled batch on the device */
+            oatk_hip_info_t inf;
+            oatk_hip_info(piece[s], &inf);
+            const double scale = (double) total / (double) used * 1.03;
+            rc = oatk_hip_scan_reserve(ctx, (uint64_t) ((double) inf.seq_bytes * scale) + (1 << 20), (uint64_t) ((double) n * scale) + 1024,
+                                       (uint64_t) ((double) inf.n_occ * scale * 1.1) + 4096);
+            if (rc) break;
+        }
         const void *d = 0;
-        rc = oatk_hip_buffer(ctx, OATK_BUF_INGEST_OFF, &d, &b);
-        if (!rc) { off = (uint64_t *) malloc(b? b : 1); rc = oatk_hip_d2h(ctx, off, d, b); }
-        if (!rc) rc = oatk_hip_buffer(ctx, OATK_BUF_INGEST_HDR, &d, &b);
-        if (!rc) { hdr = (uint64_t *) malloc(b? b : 1); rc = oatk_hip_d2h(ctx, hdr, d, b); }
-        for (i = 0; !rc && i < n_files; ++i)
-            if (seg[i].fd >= 0 && seg[i].size) {
-                seg[i].map = (uint8_t *) mmap(0, (size_t) seg[i].size, PROT_READ, MAP_PRIVATE, seg[i].fd, 0);
-                if (seg[i].map == MAP_FAILED) { seg[i].map = 0; rc = OATK_E_NOMEM; }
-            }
-        if (!rc) {
-            names = (char **) calloc(n, sizeof(char *));
-            name_job_t job = {seg, n_files, hdr, n, names};
-            oatk_par_run(name_worker, &job);
-            rc = oatk_sr_db_fill_resident(ctx, sr_db, off, n, names);
+        off = (uint64_t *) malloc(8 * n), hdr = (uint64_t *) malloc(8 * n), names = (char **) calloc(n, sizeof(char *));
+        if (!off || !hdr || !names) { rc = OATK_E_NOMEM; break; }
+        rc = oatk_hip_buffer(piece[s], OATK_BUF_INGEST_OFF, &d, &b);
+        if (!rc) rc = oatk_hip_d2h(piece[s], off, d, 8 * n);
+        if (!rc) rc = oatk_hip_buffer(piece[s], OATK_BUF_INGEST_HDR, &d, &b);
+        if (!rc) rc = oatk_hip_d2h(piece[s], hdr, d, 8 * n);
+        if (rc) break;
+        name_job_t nj = {seg, n_files, hdr, text0, n, names};
+        oatk_par_run(name_worker, &nj);
+        rc = oatk_sr_db_fill_range(piece[s], sr_db, n_done, off, n, names);
+        free(off); free(hdr); free(names);
+        off = hdr = 0, names = 0;
+        if (rc) break;
+        t_fill += now_s() - t0, t0 = now_s();
+        rc = oatk_hip_scan_append(ctx, piece[s]);
+        if (rc) break;
+        t_app += now_s() - t0;
+        n_done += n;
+    }
+done:
+    if (started) {
+        pthread_mutex_lock(&st.mu);
+        st.stop = 1;
+        pthread_cond_broadcast(&st.cv);
+        pthread_mutex_unlock(&st.mu);
+        pthread_join(th, 0);
+    }
+    oatk_host_set_threads(threads);
+    free(off); free(hdr); free(names);
+    for (i = 0; i < 2; ++i) if (piece[i]) oatk_hip_destroy(piece[i]);
+    if (st.up) oatk_hip_destroy(st.up);
+    pthread_mutex_destroy(&st.mu);
+    pthread_cond_destroy(&st.cv);
+    if (!rc && sr_db->m > sr_db->n) {                               /* give back what the estimate left over */
+        oatk_sr_t *na = (oatk_sr_t *) realloc(sr_db->a, sizeof(oatk_sr_t) * (sr_db->n? sr_db->n : 1));
+        if (na) sr_db->a = na, sr_db->m = sr_db->n;
+    }
+    if (log) fprintf(stderr, "[M::oatk_sr_read_files] %.2f GB of text in %lu windows, %lu reads: %.3f s (waiting for the uploader %.3f, record + syncmer scan %.3f, "
+                             "structs %.3f, append %.3f)\n", (double) total / 1e9, (unsigned long) w, (unsigned long) n_done, now_s() - t_begin, t_wait, t_dev, t_fill, t_app);
+    return rc;
+}
+
+int oatk_sr_read_files(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, char **files, int n_files)
+{
+    uint64_t total = 0;
+    int i, rc = OATK_OK;
+    seg_t *seg = open_segments(files, n_files, &total, &rc);
+    if (!seg) return rc;
+    for (i = 0; !rc && i < n_files; ++i)                           /* the header lines are read where the file lies in the page cache */
+        if (seg[i].fd >= 0 && seg[i].size) {
+            seg[i].map = (uint8_t *) mmap(0, (size_t) seg[i].size, PROT_READ, MAP_PRIVATE, seg[i].fd, 0);
+            if (seg[i].map == MAP_FAILED) { seg[i].map = 0; rc = OATK_E_NOMEM; }
+        }
+    if (!rc && total == 0) rc = oatk_hip_scan_begin(ctx, 0, sr_db->k, sr_db->s);
+    else if (!rc) {
+        const char *ew = getenv("OATK_DEBUG_WINDOW");              /* test hook, like oatk_host_debug_window */
+        uint64_t win = g_window? g_window : (ew && atoll(ew) > 0? (uint64_t) atoll(ew) : WIN_DEFAULT);
+        if (win < 4096) win = 4096;
+        rc = sr_read_stream(ctx, sr_db, seg, n_files, total, win);
+        if (rc == OATK_E_NOMEM && win < total) {                    /* a record longer than a window: once more, in one piece */
+            oatk_sr_db_clean(sr_db);
+            rc = sr_read_stream(ctx, sr_db, seg, n_files, total, total);
         }
     }
     seg_close(seg, n_files);
-    free(off); free(hdr); free(names);
     return rc;
 }

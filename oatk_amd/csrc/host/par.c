@@ -31,10 +31,12 @@ static void *par_entry(void *p)
     return 0;
 }
 
-void oatk_par_run(oatk_par_fn fn, void *arg)
+void oatk_par_run(oatk_par_fn fn, void *arg) { oatk_par_run_n(fn, arg, oatk_host_threads()); }
+
+void oatk_par_run_n(oatk_par_fn fn, void *arg, int n)
 {
-    const int n = oatk_host_threads();
-    if (n == 1) { fn(arg, 0, 1); return; }
+    if (n > 256) n = 256;
+    if (n <= 1) { fn(arg, 0, 1); return; }
     pthread_t th[256];
     par_t job[256];
     int i, started = 1;

@@ -71,6 +71,7 @@ typedef struct {
 
 typedef struct {
     oatk_sr_db_t *sr_db;
+    uint64_t first;                                   /* read 0 of the resident scan is sr_db->a[first] */
     const uint64_t *off, *scm_off;
     const uint32_t *hoco_l, *n_nn, *n_lrl, *lrl_val;
     const uint64_t *nn_key, *o_nn, *o_lrl;
@@ -91,10 +92,10 @@ static void fill_alloc(fill_job_t *j)
     const double t0 = host_now();
     uint8_t *first = 0, *last = 0;
     for (i = j->a0; i < j->a1; ++i) {
-        oatk_sr_t *r = &j->sr_db->a[i];
+        oatk_sr_t *r = &j->sr_db->a[j->first + i];
         const uint32_t hl = j->hoco_l[i];
         const uint64_t ns = j->scm_off[i + 1] - j->scm_off[i];
-        r->sid = i;                                        /* reads are numbered in input order, syncmer.c:525 */
+        r->sid = j->first + i;                             /* reads are numbered in input order, syncmer.c:525 */
         r->sname = j->names? j->names[i] : 0;
         r->hoco_l = hl;
         /* empty arrays are NULL in the reference (kvec never allocated), syncmer.c:396-412 */
@@ -130,7 +131,7 @@ static void fill_worker(void *arg, int tid, int n_threads)
     const uint64_t n = j->i1 - j->i0, a = j->i0 + n * (uint64_t) tid / (uint64_t) n_threads, b = j->i0 + n * (uint64_t) (tid + 1) / (uint64_t) n_threads;
     uint64_t i;
     for (i = a; i < b; ++i) {
-        oatk_sr_t *r = &j->sr_db->a[i];
+        oatk_sr_t *r = &j->sr_db->a[j->first + i];
         const uint32_t hl = r->hoco_l;
         const uint64_t ns = r->n, os = j->scm_off[i] - j->scm0;
         if (hl) {
@@ -152,8 +153,19 @@ static void fill_worker(void *arg, int tid, int n_threads)
 
 int oatk_sr_db_fill_resident(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, const uint64_t *off, uint64_t n_reads, char **names)
 {
+    if (n_reads == 0) return OATK_OK;
+    /* zeroed, and counted only as far as it is filled: after a failure half way sr_db_destroy / oatk_sr_db_clean free what exists */
+    sr_db->a = (oatk_sr_t *) calloc(n_reads, sizeof(oatk_sr_t));
+    if (!sr_db->a) return OATK_E_NOMEM;
+    sr_db->n = 0, sr_db->m = n_reads;
+    return oatk_sr_db_fill_range(ctx, sr_db, 0, off, n_reads, names);
+}
+
+int oatk_sr_db_fill_range(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, uint64_t first, const uint64_t *off, uint64_t n_reads, char **names)
+{
     int rc = 0;
     if (n_reads == 0) return OATK_OK;
+    if (!sr_db->a || sr_db->m < first + n_reads) return OATK_E_ARG;
     {   /* gigabytes of small blocks are about to be allocated: let the heap grow in large steps and never shrink in between */
         static int tuned = 0;
         if (!tuned) { (void) mallopt(M_TOP_PAD, 256 << 20); (void) mallopt(M_TRIM_THRESHOLD, 1 << 30); tuned = 1; }
@@ -204,12 +216,7 @@ int oatk_sr_db_fill_resident(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, const uint6
         buf[i].m_pos = (uint32_t *) p;
     }
 
-    /* zeroed, and counted only as far as it is filled: after a failure half way sr_db_destroy / oatk_sr_db_clean free what exists */
-    sr_db->a = (oatk_sr_t *) calloc(n_reads, sizeof(oatk_sr_t));
-    if (!sr_db->a) { rc = OATK_E_NOMEM; goto done; }
-    sr_db->n = 0, sr_db->m = n_reads;
-
-    job.sr_db = sr_db, job.off = off, job.scm_off = scm_off, job.hoco_l = hoco_l, job.n_nn = n_nn, job.n_lrl = n_lrl, job.lrl_val = lrl_val;
+    job.sr_db = sr_db, job.first = first, job.off = off, job.scm_off = scm_off, job.hoco_l = hoco_l, job.n_nn = n_nn, job.n_lrl = n_lrl, job.lrl_val = lrl_val;
     job.nn_key = nn_key, job.o_nn = o_nn, job.o_lrl = o_lrl, job.names = names;
 
     t_setup = host_now() - t_begin;
@@ -235,7 +242,7 @@ int oatk_sr_db_fill_resident(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, const uint6
             const double tc = host_now();
             job.buf = &buf[flight], job.i0 = q0, job.i1 = q1, job.rl0 = off[q0], job.scm0 = scm_off[q0];
             oatk_par_run(fill_worker, &job);
-            sr_db->n = q1;
+            sr_db->n = first + q1;
             t_copy += host_now() - tc;
         } else fill_alloc(&job);
         if (p0 >= n_reads) break;

@@ -88,6 +88,17 @@ class HipSyncasm:
         rc = self.L.oatk_hip_scan(self.h, d_seq, d_off, d_len, n_reads, seq_bytes, sid0, k, s)
         self._check(rc, "oatk_hip_scan")
 
+    def scan_begin(self, k, s, sid0=0):
+        """start a batch that is assembled from scanned pieces (oatk_hip_scan_begin / _append)"""
+        self._check(self.L.oatk_hip_scan_begin(self.h, sid0, k, s), "oatk_hip_scan_begin")
+
+    def scan_reserve(self, seq_bytes, n_reads, n_occ):
+        self._check(self.L.oatk_hip_scan_reserve(self.h, seq_bytes, n_reads, n_occ), "oatk_hip_scan_reserve")
+
+    def scan_append(self, piece):
+        """move the scan resident in `piece` (another HipSyncasm on this device, scanned with sid0 = the reads held so far) behind this batch"""
+        self._check(self.L.oatk_hip_scan_append(self.h, piece.h), "oatk_hip_scan_append")
+
     def count(self):
         self._check(self.L.oatk_hip_count(self.h), "oatk_hip_count")
 

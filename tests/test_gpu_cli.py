@@ -18,10 +18,12 @@ pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not U.available(), reason="ora
 SIX = ("sr_read", "sr_db_stat", "collect_syncmer_from_reads", "make_syncmer_graph", "read_error_correction", "scg_read_alignment")
 
 
-def both(tmp_path, files, k, s, c, extra=(), threads=4):
+def both(tmp_path, files, k, s, c, extra=(), threads=4, env=None):
     ref, dev = str(tmp_path / "ref"), str(tmp_path / "dev")
     U.run_cli(U.CLI_REF, files, ref, k, c, threads, extra=["-s", str(s)] + list(extra))
-    _, err = U.run_cli(U.CLI_DROPIN, files, dev, k, c, threads, env={"OATK_DROPIN_LOG": "1"}, extra=["-s", str(s)] + list(extra))
+    e = {"OATK_DROPIN_LOG": "1"}
+    e.update(env or {})
+    _, err = U.run_cli(U.CLI_DROPIN, files, dev, k, c, threads, env=e, extra=["-s", str(s)] + list(extra))
     for suffix in (".utg.gfa", ".utg.final.gfa"):
         assert os.path.getsize(ref + suffix) > 100, suffix
         assert filecmp.cmp(ref + suffix, dev + suffix, shallow=False), suffix
@@ -61,6 +63,18 @@ def test_cli_two_files_fastq_gz_and_plain(tmp_path):
     tab, _ = both(tmp_path, [f1, f2], 301, 21, 6)
     for f in SIX:
         assert tab[f][0] >= 1 and tab[f][2] == 0, (f, tab[f])
+
+
+def test_cli_streamed_in_small_windows(tmp_path):
+    """the input goes through the device in windows (768 MiB by default); here they are 150 kB, so records straddle window ends all the time"""
+    reads = A.hifi_like(300, 50000, 5000, seed=12, err=0.0008)
+    fa = str(tmp_path / "reads.fa")
+    R.write_fasta(reads, fa)
+    tab, log = both(tmp_path, fa, 301, 21, 6, env={"OATK_DEBUG_WINDOW": "150000"})
+    for f in SIX:
+        assert tab[f][0] >= 1 and tab[f][2] == 0, (f, tab[f])
+    import re
+    assert int(re.search(r"of text in (\d+) windows", log).group(1)) >= 8
 
 
 def test_cli_wrapped_fasta_gz(tmp_path):

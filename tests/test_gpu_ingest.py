@@ -164,3 +164,59 @@ def test_files_plain_and_gzip_through_the_host_helper(hip, tmp_path):
     assert H.oatk_ingest_files(hip.h, files, 1, C.byref(n)) == 0 and n.value == len(READS)
     seq, off, lens = hip.fetch("INGEST_SEQ"), hip.fetch("INGEST_OFF"), hip.fetch("INGEST_LEN")
     assert [seq[int(o):int(o) + int(l)].tobytes() for o, l in zip(off, lens)] == READS
+
+
+@pytest.mark.skipif(not R.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("window", [0, 5000, 40000, 333333])
+def test_streamed_sr_read_files_equals_reference_sr_read(hip, tmp_path, window):
+    """oatk_sr_read_files (liboatk_host.so) streams the files through the device in windows -- upload, record scan, syncmer scan, struct filling and
+    the append to the assembled batch all overlap -- and must leave exactly the sr_db_t the reference's sr_read leaves for the same files, whatever
+    the window (here: records cut by window ends, windows inside one read's sequence line, several files, gzip, CRLF, a file without final
+    newline), AND a device batch on which the count continues as if it had been scanned in one go"""
+    import ctypes as C
+    import gzip
+    from test_gpu_dropin import host_lib
+    K, S = 301, 21
+    reads = A.hifi_like(90, 30000, 4000, seed=23) + [b"acgtnACGTN" * 60, b"A" * 900 + A.rand_dna(np.random.default_rng(1), 700), b"C"]
+    a, b, c = reads[:30], reads[30:60], reads[60:]
+    p1, p2, p3 = str(tmp_path / "a.fa"), str(tmp_path / "b.fa.gz"), str(tmp_path / "c.fa")
+    open(p1, "wb").write(fasta(a, 70, last_eol=False))
+    gzip.open(p2, "wb").write(fasta(b, 0))
+    open(p3, "wb").write(fasta(c, 61, b"\r\n"))
+    db = R.SrDb([p1, p2, p3], K, S, 2)
+    want = db.flatten()
+    H = host_lib()
+    H.oatk_sr_read_files.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_char_p), C.c_int]
+    H.oatk_host_debug_window.argtypes = [C.c_uint64]
+    H.oatk_host_set_threads.argtypes = [C.c_int]
+    L = R.lib()
+    L.refx_srdb_name.restype = C.c_char_p
+    L.refx_srdb_name.argtypes = [C.c_void_p, C.c_uint64]
+    mine = H.oatk_sr_db_new(K, S)
+    files = (C.c_char_p * 3)(p1.encode(), p2.encode(), p3.encode())
+    H.oatk_host_debug_window(window)
+    H.oatk_host_set_threads(5)
+    try:
+        rc = H.oatk_sr_read_files(hip.h, mine, files, 3)
+    finally:
+        H.oatk_host_debug_window(0)
+        H.oatk_host_set_threads(0)
+    assert rc == 0, hip.L.oatk_hip_last_error(hip.h)
+    got_db = R.SrDb.__new__(R.SrDb)
+    got_db.K, got_db.S, got_db._h = K, S, mine                      # the reference's own accessors read what liboatk_host.so built
+    got = got_db.flatten()
+    assert got_db.n() == db.n() == len(reads)
+    for f in ["hoco_l", "n_scm", "sid", "hoco_s", "ho_rl", "ho_l_rl", "m_pos", "s_mer", "k_mer"]:
+        assert np.array_equal(got[f], want[f]), f
+    for i in range(len(reads)):
+        assert L.refx_srdb_name(mine, i) == L.refx_srdb_name(db.handle, i)
+    # the assembled device batch: counting it gives the reference's table
+    hip.count()
+    scm = R.ScmDb(db)
+    rc_ = scm.flatten()
+    dc = hip.fetch_count()
+    for f in ("h", "s", "cov", "occ"):
+        assert np.array_equal(dc[f], rc_[f]), f
+    scm.close()
+    got_db.close()                                                   # sr_db_destroy of the reference frees every block
+    db.close()
