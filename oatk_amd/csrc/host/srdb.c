@@ -9,6 +9,7 @@
 #define _GNU_SOURCE
 #include <malloc.h>
 #include <sys/mman.h>
+#include <unistd.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -82,7 +83,11 @@ typedef struct {
     /* the piece whose blocks are allocated meanwhile (thread 0) */
     uint64_t a0, a1;
     double t_alloc;
+    /* the stretch of heap those blocks will come from: touched by the other threads first (see fill_prefault) */
+    uint8_t *pre0, *pre1;
 } fill_job_t;
+
+static uint8_t *g_heap_top = 0;                       /* where the last large block ended: survives from one call to the next */
 
 /* the blocks of reads [i0, i1), allocated by ONE thread: glibc grows a thread arena a few pages at a time under the address-space lock, so
  * many threads allocating gigabytes get in each other's way; the main heap grows in large steps (M_TOP_PAD below) and costs ~40 ns per block */
@@ -108,15 +113,45 @@ static void fill_alloc(fill_job_t *j)
         r->s_mer = ns? (uint64_t *) xmalloc(8 * (size_t) ns) : 0;
         r->k_mer = ns? (uint64_t *) xmalloc(8 * (size_t) ns) : 0;
         if (!first) first = r->hoco_s;
-        if (r->ho_rl) last = r->ho_rl;
+        if (r->ho_rl) last = r->ho_rl + hl;
     }
-    /* the heap grew by this piece in one stretch: ask for huge pages there before the first touch (2 MiB faults instead of 4 KiB ones) */
-    if (first && last > first && (uint64_t) (last - first) < ((uint64_t) 2 << 30)) {
-        const uintptr_t lo = ((uintptr_t) first + ((uintptr_t) 2 << 20) - 1) & ~(((uintptr_t) 2 << 20) - 1), hi = (uintptr_t) last & ~(((uintptr_t) 2 << 20) - 1);
-        if (hi > lo) (void) madvise((void *) lo, hi - lo, MADV_HUGEPAGE);
-    }
+    (void) first;
+    if (last) g_heap_top = last;                           /* large blocks are carved off the top of the heap one after the other */
     j->t_alloc += host_now() - t0;
 }
+
+/* Fresh heap costs a page fault per 4 KiB, and the thread that allocates would take one for nearly every block it heads (a read's arrays are
+ * larger than a page): 1.2 us per read, the whole pipeline's bottleneck.  So the stretch the NEXT blocks will be carved from -- from the top
+ * of the heap on, as far as the break already reaches (M_TOP_PAD keeps it far ahead) -- is declared huge-page territory and touched by the
+ * copying threads first, in parallel: an atomic OR of zero changes nothing (fresh heap must stay zero for calloc; a header the allocator has
+ * just written there survives) but brings the page in. */
+static void fill_prefault_plan(fill_job_t *j)
+{
+    j->pre0 = j->pre1 = 0;
+    if (!g_heap_top || j->a1 <= j->a0) return;
+    uint64_t need = 0, i;
+    for (i = j->a0; i < j->a1; ++i) need += (uint64_t) j->hoco_l[i] + ((uint64_t) j->hoco_l[i] + 3) / 4 + 20 * (j->scm_off[i + 1] - j->scm_off[i]) + 160;
+    uint8_t *brk_now = (uint8_t *) sbrk(0), *lo = g_heap_top + 4096, *hi = g_heap_top + need + (need >> 6);
+    if (brk_now == (uint8_t *) -1 || lo >= brk_now || g_heap_top + ((uint64_t) 8 << 30) < brk_now) return;       /* not the main heap */
+    if (hi > brk_now) hi = brk_now;
+    lo = (uint8_t *) (((uintptr_t) lo + 4095) & ~(uintptr_t) 4095), hi = (uint8_t *) ((uintptr_t) hi & ~(uintptr_t) 4095);
+    if (hi <= lo) return;
+    const uintptr_t h0 = ((uintptr_t) lo + (((uintptr_t) 2 << 20) - 1)) & ~(((uintptr_t) 2 << 20) - 1), h1 = (uintptr_t) hi & ~(((uintptr_t) 2 << 20) - 1);
+    if (h1 > h0) (void) madvise((void *) h0, h1 - h0, MADV_HUGEPAGE);
+    j->pre0 = lo, j->pre1 = hi;
+}
+
+static void fill_prefault_worker(void *arg, int tid, int n_threads);
+
+static void fill_prefault(const fill_job_t *j, int tid, int n_threads)
+{
+    if (j->pre1 <= j->pre0) return;
+    const uint64_t pages = (uint64_t) (j->pre1 - j->pre0) >> 12, a = pages * (uint64_t) tid / (uint64_t) n_threads, b = pages * (uint64_t) (tid + 1) / (uint64_t) n_threads;
+    uint64_t p;
+    for (p = a; p < b; ++p) (void) __atomic_fetch_or((uint64_t *) (j->pre0 + (p << 12)), 0, __ATOMIC_RELAXED);
+}
+
+static void fill_prefault_worker(void *arg, int tid, int n_threads) { fill_prefault((const fill_job_t *) arg, tid, n_threads); }
 
 /* ... and filled by all of them (the first touch of every page happens here, in parallel) */
 static void fill_worker(void *arg, int tid, int n_threads)
@@ -128,6 +163,7 @@ static void fill_worker(void *arg, int tid, int n_threads)
         if (tid == 0) return;
         --tid, --n_threads;
     }
+    fill_prefault(j, tid, n_threads);                      /* ahead of the allocating thread, before the copying */
     const uint64_t n = j->i1 - j->i0, a = j->i0 + n * (uint64_t) tid / (uint64_t) n_threads, b = j->i0 + n * (uint64_t) (tid + 1) / (uint64_t) n_threads;
     uint64_t i;
     for (i = a; i < b; ++i) {
@@ -168,7 +204,7 @@ int oatk_sr_db_fill_range(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, uint64_t first
     if (!sr_db->a || sr_db->m < first + n_reads) return OATK_E_ARG;
     {   /* gigabytes of small blocks are about to be allocated: let the heap grow in large steps and never shrink in between */
         static int tuned = 0;
-        if (!tuned) { (void) mallopt(M_TOP_PAD, 256 << 20); (void) mallopt(M_TRIM_THRESHOLD, 1 << 30); tuned = 1; }
+        if (!tuned) { (void) mallopt(M_TOP_PAD, 1 << 30); (void) mallopt(M_TRIM_THRESHOLD, 1 << 30); tuned = 1; }
     }
     const double t_begin = host_now();
     double t_copy = 0, t_wait = 0, t_setup = 0;
@@ -238,13 +274,17 @@ int oatk_sr_db_fill_range(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, uint64_t first
         }
         /* cut the piece that arrived before it (its blocks exist already), allocating the queued one's meanwhile */
         job.a0 = p0 < n_reads? p0 : 0, job.a1 = p0 < n_reads? p1 : 0;
+        fill_prefault_plan(&job);
         if (flight >= 0) {
             const double tc = host_now();
             job.buf = &buf[flight], job.i0 = q0, job.i1 = q1, job.rl0 = off[q0], job.scm0 = scm_off[q0];
             oatk_par_run(fill_worker, &job);
             sr_db->n = first + q1;
             t_copy += host_now() - tc;
-        } else fill_alloc(&job);
+        } else {
+            oatk_par_run(fill_prefault_worker, &job);
+            fill_alloc(&job);
+        }
         if (p0 >= n_reads) break;
         {
             const double tw = host_now();
