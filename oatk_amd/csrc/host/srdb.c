@@ -61,8 +61,8 @@ int oatk_sr_read_packed(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, const uint8_t *s
  * The per-base arrays (ho_rl, hoco_s: 1 + 1/4 byte per hoco base) and the per-syncmer arrays (m_pos, s_mer, k_mer hash: 20 bytes each) come
  * over in PIECES of consecutive reads through two page-locked buffers: while the host threads cut piece p into the reads' own malloc'ed
  * blocks, piece p + 1 is already on its way (one stream, copies queue behind each other at PCIe speed). */
-#define FILL_RL_BYTES ((uint64_t) 192 << 20)          /* packed ho_rl bytes per piece */
-#define FILL_SCM ((uint64_t) 3 << 20)                 /* syncmers per piece */
+#define FILL_RL_BYTES ((uint64_t) 64 << 20)          /* packed ho_rl bytes per piece */
+#define FILL_SCM ((uint64_t) 1 << 20)                 /* syncmers per piece */
 
 typedef struct {
     uint8_t *rl, *hs;                                 /* page-locked: one piece */

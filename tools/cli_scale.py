@@ -79,6 +79,7 @@ def run(binary, tag, env=None):
 report = {"n_reads": args.n_reads, "gbases": round(bases / 1e9, 3), "threads": args.threads, "workload": args.workload}
 r, err = run("syncasm_dropin", "dev", {"OATK_DROPIN_LOG": "1"})
 report["dropin"] = r
+report["dropin_log"] = [l for l in err.splitlines() if "oatk_dropin]" in l or "oatk_sr_read_files]" in l]
 print("\n".join(l for l in err.splitlines() if "oatk_" in l), flush=True)
 if args.ref:
     r2, _ = run("syncasm", "ref")
@@ -88,3 +89,7 @@ if args.ref:
 if not args.keep:
     os.unlink(fa)
 print(json.dumps(report), flush=True)
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+with open(os.path.join(ROOT, "gpurun_out", "cli_scale_%d.json" % args.n_reads), "w") as f:
+    json.dump(report, f, indent=1)
+    f.write("\n")
