@@ -91,13 +91,11 @@ template <int R, bool S31, int NT = SYN_NT, int SH = -1>
 __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
 {
     constexpr int C = SYF_C, T = NT * SYF_C, NCH = R / C, NWAVE = NT / OATK_WAVE;
-    constexpr int PBW = 512;                    // packed-base ring: 8192 positions, so the next tile's bases can be fetched early
     static_assert((R & (R - 1)) == 0, "power-of-two ring: index arithmetic is one AND (a 3200-slot ring raised occupancy from 3 to 4\n"
                   "workgroups per CU but its modulo arithmetic cost more issue slots than the occupancy returned)");
 
     __shared__ uint64_t m_ring[R + R / 32];     // s-mer hashes by END position; one pad slot per 32 against bank conflicts
     __shared__ uint32_t pre32[NCH], suf32[NCH]; // per-wave-block inclusive prefix / suffix minima of the chunk minima's top 32 bits
-    __shared__ uint32_t pb[PBW];                // packed bases, 16 per word, MSB-first
     __shared__ uint32_t w_cnt[2][NWAVE];         // syncmers per wave of a tile, double-buffered (two barriers per tile)
     __shared__ uint32_t sl_e[SYF_LIST];          // syncmers of the read so far, in position order: k-mer end | kind << 30 (1 Close, 2 Open);
                                                  // written out when the read is done (or the list is full)
@@ -119,29 +117,24 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
     auto rpos = [](int32_t i) -> uint32_t { return (uint32_t) i & (uint32_t) (R - 1); };
     auto mi = [&](int32_t i) -> uint32_t { uint32_t p = rpos(i); return p + (p >> 5); };
     auto rch = [](int32_t c) -> uint32_t { return (uint32_t) c & (uint32_t) (NCH - 1); };
-    auto load_bases = [&](uint32_t I0) {
-        if (tid < T / 16) {
-            uint32_t wi = I0 / 16 + tid;
-            uint32_t v = wi * 16 < hl? ghs[wi] : 0u;
-            pb[wi % (uint32_t) PBW] = __builtin_bswap32(v);     // hoco_s bytes are MSB-first; make the word MSB-first too
-        }
-    };
-
     for (uint32_t i = tid; i < R + R / 32; i += NT) m_ring[i] = UINT64_MAX;
     for (uint32_t i = tid; i < NCH; i += NT) pre32[i] = suf32[i] = 0xFFFFFFFFu;
-    for (uint32_t i = tid; i < PBW; i += NT) pb[i] = 0;
-    __syncthreads();
-    load_bases(0);
     __syncthreads();
 
-    auto get64 = [&](int32_t t) -> uint64_t {
-        int32_t wi = t >> 4;
-        uint32_t sh = ((uint32_t) t & 15u) * 2u;
-        uint32_t p0 = (uint32_t) (wi + PBW) % (uint32_t) PBW, p1 = p0 + 1 == PBW? 0 : p0 + 1, p2 = p1 + 1 == PBW? 0 : p1 + 1;
-        uint64_t hi = (uint64_t) pb[p0] << 32 | pb[p1];
-        uint32_t w2 = pb[p2];
-        return sh? (hi << sh) | ((uint64_t) w2 >> (32u - sh)) : hi;
-    };
+    // The bases a lane needs for a tile -- the 32 before its chunk (the s-mer that ends just in front of it) and the chunk's own 8 -- are
+    // 80 bits that start on a byte boundary: three consecutive 32-bit words of the read's packed string, at a bit offset of 0 (even lanes)
+    // or 16 (odd lanes) that never changes.  They come straight from HBM into registers, one tile AHEAD (the load is in flight during the
+    // hashing of the tile before), and one v_perm_b32 per output word undoes the byte order (the string is MSB-first, a dword load is
+    // little-endian) and the lane's offset at once.  (An LDS ring of bases fed by half the threads, two unaligned 64-bit extractions per lane
+    // and tile with their modulo arithmetic and variable shifts: 50 VALU per lane and tile more, and 2 KB of LDS.)
+    struct __attribute__((packed, aligned(4))) Words3 { uint32_t a, b, c; };
+    const uint32_t bsel = (tid & 1u)? 0x06070001u : 0x04050607u;    // {S0 = word k, S1 = word k + 1}: bytes of the MSB-first string from bit 16 / bit 0 on
+    const uint32_t last_w = (hl - 1u) >> 4;     // (two words of slack lie behind every read's string)
+    uint32_t rw0, rw1, rw2;                     // this tile's raw words: bases (i0 - 32) & ~15 ...
+    {
+        const int32_t wi0 = ((int32_t) (tid * C) - 32) >> 4;         // negative for the first four lanes: those bases lie before the read
+        rw0 = ghs[wi0 < 0? 0 : wi0], rw1 = ghs[wi0 + 1 < 0? 0 : wi0 + 1], rw2 = ghs[wi0 + 2];       // (and no k-mer can end there: any value does)
+    }
     const uint32_t *m_hi = (const uint32_t *) m_ring;    // top word of entry e is m_hi[2e + 1]
 
     uint32_t ord0 = 0, par = 0;                 // syncmers already turned into records; parity of the count buffer
@@ -252,9 +245,17 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
         const int32_t ch = i0 / C;                      // chunk index; ch % 64 == lane
         uint64_t y[C];
         {
-            const uint32_t vbh = (uint32_t) (get64(i0) >> 32);      // the chunk's 8 bases sit in the top word
+            const uint32_t a_hi = __builtin_amdgcn_perm(rw0, rw1, bsel), a_lo = __builtin_amdgcn_perm(rw1, rw2, bsel);   // bases i0 - 32 .. i0 - 1
+            const uint32_t vbh = __builtin_amdgcn_perm(rw2, 0u, bsel);  // the chunk's 8 bases sit in the top half
             const uint64_t vb = (uint64_t) vbh << 32;
-            uint64_t X = get64(i0 - S) & (~0ULL << (64 - 2 * S));
+            {   // the next tile's words, while this one is hashed (same lanes, 2048 positions on: 128 words).  Unconditional -- a load whose
+                // result is selected under a condition is waited for on the spot --, with the word index held inside the read: lanes (and a
+                // whole last tile) behind the read's end fetch its last words, which nobody looks at
+                const uint32_t wn = ((I0 + T + tid * C) - 32u) >> 4;
+                const Words3 nx = *(const Words3 *) (ghs + (wn < last_w? wn : last_w));
+                rw0 = nx.a, rw1 = nx.b, rw2 = nx.c;
+            }
+            const uint64_t X = ((uint64_t) a_hi << 32 | a_lo) << (2 * (32 - S));       // the S bases that end at i0 - 1, at the top
             uint64_t fw = X >> (64 - 2 * S), rv = revcomp32(X) & mask;
             uint32_t cmin = 0xFFFFFFFFu;                // top word of the chunk minimum: all the filter looks at
             const uint32_t mbase = m_own;               // = mi(i0); 8 consecutive positions never straddle a pad slot
@@ -303,7 +304,6 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
             *(uint32_t *) ((char *) pre32 + o_cs) = pre;
             *(uint32_t *) ((char *) suf32 + o_cs) = suf;
         }
-        if (I0 + T < hl) load_bases(I0 + T);            // next tile's bases ride on this barrier
         __syncthreads();
         flush();                                        // the previous tile's records
 
