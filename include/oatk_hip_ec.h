@@ -39,7 +39,7 @@ int oatk_hip_ec(oatk_hip_ctx *ctx, const oatk_ec_graph_t *g, double max_edist, u
 int oatk_hip_ec_stats(oatk_hip_ctx *ctx, uint64_t *stats12);
 
 /* Test hook: the longest block (hoco bases) the first and the second solver tier accept; longer blocks fall through to the
- * next tier (the last one keeps its scratch in HBM and takes anything).  0 = defaults (2048, 16384).  Results never depend on it. */
+ * next tier (the last one keeps its scratch in HBM and takes anything).  0 = defaults (3072, 16384).  Results never depend on it. */
 int oatk_hip_debug_ec_tiers(oatk_hip_ctx *ctx, int cap_t0, int cap_t1);
 
 /* The device edit distance on its own: wf_ed_core (levdist.c:265-312) in extension mode without traceback -- the routine every error block
