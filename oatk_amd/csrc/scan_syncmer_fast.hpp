@@ -244,7 +244,6 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
         const int32_t i0 = (int32_t) (I0 + tid * C);
         const int32_t ch = i0 / C;                      // chunk index; ch % 64 == lane
         uint64_t y[C];
-        uint32_t cmin_t;                                // top word of the chunk's minimum, for the filter's wave-level test
         {
             const uint32_t a_hi = __builtin_amdgcn_perm(rw0, rw1, bsel), a_lo = __builtin_amdgcn_perm(rw1, rw2, bsel);   // bases i0 - 32 .. i0 - 1
             const uint32_t vbh = __builtin_amdgcn_perm(rw2, 0u, bsel);  // the chunk's 8 bases sit in the top half
@@ -286,7 +285,6 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
                     cmin = (uint32_t) (mv >> 32) < cmin? (uint32_t) (mv >> 32) : cmin;
                 }
             }
-            cmin_t = cmin;
             uint32_t pre, suf;
 #ifdef OATK_SCAN_SHFL
             pre = suf = cmin;
@@ -332,31 +330,14 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
             const uint32_t bA = 2u * m_fa + 1u, bB = 2u * m_fb + 1u;
             backF_keep = backF, fwd0_keep = fwd0, fwd1_keep = fwd1;
             uint32_t hit = 0;
-            // Both halves of the filter sit behind a test on the CHUNK that costs one compare, made for the wave: a Close needs the chunk's
-            // own minimum at or below the bound (cmin is at hand), an Open the smallest of the eight first s-mers at or below the larger of
-            // its two bounds (three v_min3).  On random sequence six waves in ten skip each half -- eight positions x (compares, select, or).
-            if (__ballot(cmin_t <= backF)) {
-#pragma unroll
-                for (int o = 0; o < C; ++o) hit |= (uint32_t) ((uint32_t) (y[o] >> 32) <= backF) << o;
-            }
-            uint32_t fh[C];
 #pragma unroll
             for (int o = 0; o < C; ++o) {
                 const int q = o + sh;
-                fh[o] = q < C? m_hi[bA + 2u * (uint32_t) q] : m_hi[bB + 2u * (uint32_t) (q - C)];
-            }
-            {
-                uint32_t fm = fh[0] < fh[1]? fh[0] : fh[1];
-                auto min3 = [](uint32_t a_, uint32_t b_, uint32_t c_) { const uint32_t t_ = a_ < b_? a_ : b_; return t_ < c_? t_ : c_; };      // v_min3_u32
-                fm = min3(fm, fh[2], fh[3]), fm = min3(fm, fh[4], fh[5]), fm = min3(fm, fh[6], fh[7]);
-                if (__ballot(fm <= (fwd0 > fwd1? fwd0 : fwd1))) {
-#pragma unroll
-                    for (int o = 0; o < C; ++o) {
-                        const uint32_t fb = o + sh < C? fwd0 : fwd1;
-                        // (a MAX sentinel passes only when its whole window is MAX; the exact rule rejects it)
-                        hit |= (uint32_t) ((fh[o] <= fb) & (fh[o] <= (uint32_t) (y[o] >> 32))) << o;
-                    }
-                }
+                const uint32_t fhi = q < C? m_hi[bA + 2u * (uint32_t) q] : m_hi[bB + 2u * (uint32_t) (q - C)];
+                const uint32_t yhi = (uint32_t) (y[o] >> 32);
+                const uint32_t fb = o + sh < C? fwd0 : fwd1;
+                // (a MAX sentinel passes only when its whole window is MAX; the exact rule rejects it)
+                hit |= (uint32_t) ((yhi <= backF) | ((fhi <= fb) & (fhi <= yhi))) << o;
             }
             // k-mers that do not fit the read: E + 1 < K at the start, E >= hoco_l at the end
             if (hit) {
