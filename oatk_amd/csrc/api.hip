@@ -105,6 +105,7 @@ struct oatk_hip_ctx {
     struct AgState *ag = nullptr;       // assembly graph buffers (api_graph.inc)
     struct OvlState *ovl = nullptr;     // pair-distance tables (api_ovl.inc)
     struct RaState *ra = nullptr;       // read alignment buffers (api_align.inc)
+    struct MultiState *multi = nullptr; // merged table / sharded correction (api_multi.inc)
 };
 
 #define CK(call)                                                                                   \
@@ -163,6 +164,7 @@ static void t_collect(oatk_hip_ctx *ctx, int first, int last)
 #include "api_align.inc"
 #include "api_ingest.inc"
 #include "api_stat.inc"
+#include "api_multi.inc"
 
 extern "C" {
 
@@ -215,6 +217,7 @@ void oatk_hip_destroy(oatk_hip_ctx *ctx)
     ag_state_free(ctx);
     ovl_state_free(ctx);
     ra_state_free(ctx);
+    multi_state_free(ctx);
     for (int i = 0; i <= OATK_T_COUNT_; ++i) {
         (void) hipEventDestroy(ctx->ev[i][0]);
         (void) hipEventDestroy(ctx->ev[i][1]);
@@ -719,6 +722,7 @@ int oatk_hip_buffer(oatk_hip_ctx *ctx, int which, const void **d_ptr, uint64_t *
 {
     if (!ctx) return OATK_E_NODEV;
     if (which >= OATK_BUF_INGEST_SEQ && which <= OATK_BUF_INGEST_HDR) return ing_buffer(ctx, which, d_ptr, bytes);      // precedes any scan
+    if (which >= OATK_BUF_MG_H && which <= OATK_BUF_MG_EC_DEL) return multi_buffer(ctx, which, d_ptr, bytes);
     if (!ctx->scanned) { ctx->err = "no resident scan"; return OATK_E_STATE; }
     const uint64_t n = ctx->n_reads, occ = ctx->n_occ, ns = ctx->n_scm_total;
     const void *p = nullptr;

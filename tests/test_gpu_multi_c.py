@@ -1,0 +1,121 @@
+"""GPU: reads sharded by record through the C collectives (include/oatk_hip_multi.h: oatk_hip_merge_counts, oatk_hip_ec_sharded) equal one handle
+holding all the reads -- merged table, chains in global ids, refreshed coverage and deletion flags, block statistics, imported k-mers.
+
+The test box has one GPU and RCCL refuses two ranks on one device, so the N-rank cases run the ranks as threads of this process, each with its
+own handle, over the in-process communicator group (same code path above the three primitives; device-to-device copies instead of xGMI); the RCCL
+backend itself -- librccl loaded at run time, communicator from a unique id, ncclAllGather / grouped ncclBroadcast / ncclAllReduce on the handle's
+stream -- runs with a world of one."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+import adversarial as A
+import test_gpu_ec as E
+from oatk_amd import HipSyncasm, _lib, pack_reads
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    (301, 21, 6, lambda: A.hifi_like(300, 30000, 4000, seed=307, err=0.004), (0.0, 0.5, 1.0)),
+    (1001, 31, 6, lambda: E.sample_reads(E.genome_with_repeats(5, 50000), 260, 9000, 0.001, 6), (0.0, 0.35, 1.0)),
+    # a shard of a handful of reads sees few of the good syncmers: their k-mers must be imported
+    (101, 11, 5, lambda: E.sample_reads(E.genome_with_repeats(9, 9000, unit=600, copies=3), 300, 1500, 0.004, 10), (0.0, 0.02, 1.0)),
+    # three shards, one of them empty; four shards
+    (101, 11, 5, lambda: E.sample_reads(E.genome_with_repeats(9, 9000, unit=600, copies=3), 300, 1500, 0.004, 10), (0.0, 0.4, 0.4, 1.0)),
+    (301, 21, 6, lambda: A.hifi_like(300, 30000, 4000, seed=311, err=0.003), (0.0, 0.2, 0.5, 0.7, 1.0)),
+]
+
+
+def single(hip, reads, K, S, c):
+    seq, off, lens = pack_reads(reads)
+    hip.scan_host(seq, off, lens, K, S)
+    hip.count()
+    cnt = hip.fetch_count()
+    hip.ec_graph()
+    st = hip.ec(0.02, c, 0.35)
+    want = {k: hip.fetch(k) for k in ["EC_N_SCM", "EC_KMER", "EC_MPOS", "EC_SMER", "EC_SCM_COV", "EC_SCM_DEL"]}
+    return cnt, st, want
+
+
+def run_ranks(world, make_comm, reads, bounds, K, S, c):
+    out, errs = [None] * world, []
+
+    def work(rank):
+        try:
+            h = HipSyncasm(0)
+            comm = make_comm(rank)
+            lo, hi = bounds[rank], bounds[rank + 1]
+            seq, off, lens = pack_reads(reads[lo:hi])
+            h.scan_host(seq, off, lens, K, S, sid0=lo)
+            h.count()
+            ng = h.merge_counts(comm)
+            merged = {k: h.fetch(k) for k in ("MG_H", "MG_S", "MG_COV", "MG_L2G")}
+            local_h = h.fetch("SCM_H")
+            st, n_imp = h.ec_sharded(comm, 0.02, c, 0.35)
+            res = {k: h.fetch(k) for k in ("EC_N_SCM", "EC_KMER", "EC_MPOS", "EC_SMER", "MG_EC_COV", "MG_EC_DEL")}
+            out[rank] = (ng, merged, local_h, st, n_imp, res)
+            _lib.load().oatk_comm_destroy(comm)
+            h.close()
+        except Exception as ex:                          # noqa: BLE001
+            errs.append((rank, ex))
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in th), "a rank hangs in a collective"
+    assert not errs, errs
+    return out
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_sharded_through_the_c_collectives_equals_one_handle(hip, case):
+    K, S, c, mk, frac = CASES[case]
+    reads = mk()
+    bounds = [int(round(f * len(reads))) for f in frac]
+    world = len(bounds) - 1
+    L = _lib.load()
+    grp = L.oatk_comm_group_create(world)
+    assert grp
+    try:
+        out = run_ranks(world, lambda r: L.oatk_comm_group_rank(grp, r), reads, bounds, K, S, c)
+    finally:
+        L.oatk_comm_group_destroy(grp)
+    cnt, st, want = single(hip, reads, K, S, c)
+    order = np.argsort(cnt["h"], kind="stable")         # the merged table is in hash order; one handle numbers syncmers the same way
+    assert np.array_equal(order, np.arange(len(order)))
+    for rank, (ng, mg, local_h, st_r, n_imp, res) in enumerate(out):
+        assert ng == cnt["n_scm"]
+        assert np.array_equal(mg["MG_H"], cnt["h"]) and np.array_equal(mg["MG_S"], cnt["s"]) and np.array_equal(mg["MG_COV"], cnt["cov"])
+        assert np.array_equal(cnt["h"][mg["MG_L2G"].astype(np.int64)], local_h)
+        assert np.array_equal(res["MG_EC_COV"], want["EC_SCM_COV"]) and np.array_equal(res["MG_EC_DEL"], want["EC_SCM_DEL"])
+        assert st_r[:11].tolist() == st[:11].tolist()
+    assert np.array_equal(np.concatenate([o[5]["EC_N_SCM"] for o in out]), want["EC_N_SCM"])
+    for key in ("EC_KMER", "EC_MPOS", "EC_SMER"):
+        assert np.array_equal(np.concatenate([o[5][key] for o in out]), want[key]), key
+    assert int(st[0] + st[5] + st[10]) > 0
+    if case == 2:
+        assert sum(o[4] for o in out) > 0                 # k-mers did travel
+
+
+def test_rccl_backend_world_of_one(hip):
+    """the RCCL code path itself: unique id, ncclCommInitRank, all three primitives on the handle's stream"""
+    K, S, c = 301, 21, 6
+    reads = A.hifi_like(300, 30000, 4000, seed=313, err=0.004)
+    L = _lib.load()
+    uid = (C.c_uint8 * 128)()
+    assert L.oatk_comm_unique_id(uid) == 0, "librccl could not be loaded"
+    comm = L.oatk_comm_create(uid, 0, 1, 0)
+    assert comm and L.oatk_comm_backend(comm) == b"rccl" and L.oatk_comm_size(comm) == 1 and L.oatk_comm_rank(comm) == 0
+    out = run_ranks(1, lambda r: comm, reads, [0, len(reads)], K, S, c)       # (run_ranks destroys the communicator)
+    cnt, st, want = single(hip, reads, K, S, c)
+    ng, mg, local_h, st_r, n_imp, res = out[0]
+    assert ng == cnt["n_scm"] and np.array_equal(mg["MG_H"], cnt["h"]) and np.array_equal(mg["MG_COV"], cnt["cov"])
+    assert np.array_equal(mg["MG_L2G"], np.arange(ng, dtype=np.uint32)) and n_imp == 0
+    for key in ("EC_N_SCM", "EC_KMER", "EC_MPOS", "EC_SMER"):
+        assert np.array_equal(res[key], want[key]), key
+    assert np.array_equal(res["MG_EC_COV"], want["EC_SCM_COV"]) and np.array_equal(res["MG_EC_DEL"], want["EC_SCM_DEL"])
+    assert st_r[:11].tolist() == st[:11].tolist()
