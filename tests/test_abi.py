@@ -20,6 +20,7 @@ def test_hip_library_exports_every_declared_symbol():
     assert os.path.exists(_lib.LIB_PATH), "build with __graft_entry__.build()"
     L = ctypes.CDLL(_lib.LIB_PATH)
     names = sum((declared(h, "oatk_hip_") for h in sorted(os.listdir(os.path.join(ROOT, "include"))) if h.startswith("oatk_hip")), [])   # one library
+    names += declared("oatk_hip_multi.h", "oatk_comm_")
     assert len(names) >= 30
     for n in names:
         assert hasattr(L, n), n
@@ -33,7 +34,7 @@ def test_host_library_exports_every_declared_symbol():
     # (oatk_dropin.h belongs to the static archive that is linked into the CLI: tests/test_cli_fallback.py checks its symbols)
     for hdr in [h for h in os.listdir(os.path.join(ROOT, "include")) if h not in ("oatk_hip.h", "oatk_dropin.h") and h.endswith(".h")]:
         for n in declared(hdr, "oatk_"):
-            if n.startswith("oatk_hip_"):
+            if n.startswith("oatk_hip_") or n.startswith("oatk_comm_"):
                 continue
             assert hasattr(L, n), (hdr, n)
 
