@@ -47,6 +47,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; the contract) or gloo (development: several ranks on ONE GPU)")
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline only: no scan_count / config2 / results_back / ingest / cli legs")
+    ap.add_argument("--collectives", default="c", choices=["c", "torch"],
+                    help="at N > 1: 'c' = the C entry points over RCCL (include/oatk_hip_multi.h: oatk_hip_merge_counts / oatk_hip_ec_sharded; the communicator's "
+                         "128-byte id travels through torch.distributed once), 'torch' = the same exchange steps written over torch.distributed (oatk_amd/multi.py)")
     ap.add_argument("--no-sharded-syncerr", action="store_true",
                     help="at N > 1 stop after scan + count + table merge (the metric then says so); default is the whole step, sharded")
     ap.add_argument("--ingest-reads", type=int, default=50000)
@@ -135,7 +138,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    multi = world > 1 or bool(os.environ.get("OATK_BENCH_FORCE_DIST"))      # (the env switch: exercise the N > 1 code path with a world of one)
+    if multi:
         import datetime
         import torch.distributed as dist
         to = datetime.timedelta(seconds=args.dist_timeout_s)
@@ -170,24 +174,48 @@ def main():
 
     hip = HipSyncasm(local_rank)
     hip.set_timing(True)
-    merger = sharded = None
+    merger = sharded = comm = None
     with_ec = True
-    if world > 1:
-        from oatk_amd.multi import CountMerger, ShardedEc
+    collectives = None
+    if multi:
         with_ec = not args.no_sharded_syncerr
-        if with_ec:
-            sharded = ShardedEc(hip, dist, dev)
+        hip._check(hip.L.oatk_hip_ec_reserve_import(hip.h, 64 << 20), "oatk_hip_ec_reserve_import")     # k-mers a shard may have to be sent (before the scan)
+        if args.collectives == "c" and args.dist_backend == "nccl":
+            import ctypes as C
+            uid = (C.c_uint8 * 128)()
+            box = [None]
+            if rank == 0:
+                hip._check(hip.L.oatk_comm_unique_id(uid), "oatk_comm_unique_id")
+                box[0] = bytes(uid)
+            dist.broadcast_object_list(box, src=0)
+            uid = (C.c_uint8 * 128).from_buffer_copy(box[0])
+            comm = hip.L.oatk_comm_create(uid, rank, world, local_rank)
+        if comm:
+            collectives = "RCCL from C (oatk_hip_merge_counts / oatk_hip_ec_sharded)"
         else:
-            merger = CountMerger(hip, dist, dev)
+            from oatk_amd.multi import CountMerger, ShardedEc
+            collectives = "torch.distributed (%s), oatk_amd/multi.py" % args.dist_backend
+            if with_ec:
+                sharded = ShardedEc(hip, dist, dev)
+            else:
+                merger = CountMerger(hip, dist, dev)
 
     def scan_count(seq_t=d_seq, off_t=d_off, len_t=d_len, n=per_gpu, nbytes=seq_bytes, sid0=first):
         hip.scan_device(seq_t.data_ptr(), off_t.data_ptr(), len_t.data_ptr(), n, nbytes, K, S, sid0=sid0)
         hip.count()
 
+    n_imp = [0]
+
     def step():
         """run_syncasm.c:81-131 on the resident batch"""
         scan_count()
-        if sharded is not None:             # count-table merge, graph from everybody's pairs, correction in global ids (oatk_amd/multi.py)
+        if comm:                            # count-table merge, graph from everybody's pairs, correction in global ids: two C calls over RCCL
+            if not with_ec:
+                hip.merge_counts(comm)
+                return None
+            st_, n_imp[0] = hip.ec_sharded(comm, 0.02, c, 0.35)
+            return st_
+        if sharded is not None:             # the same over torch.distributed (oatk_amd/multi.py)
             return sharded.run(0.02, c, 0.35)["stats"]
         if merger is not None:
             merger.merge()
@@ -243,12 +271,14 @@ def main():
                       "ambiguous": int(st[3] + st[4] + st[8] + st[9]), "blocks_past_first_tier": int(st[11]) if len(st) > 11 else None}
         if sharded is not None:
             ec_summary["imported_kmers_rank0"] = sharded.n_imported
+        if comm:
+            ec_summary["imported_kmers_rank0"] = n_imp[0]
 
     extras = {}
     hip.set_timing(False)
     if rank == 0 and not args.no_extras:
         # ---- what follows the EC round in syncasm(), on the corrected batch of rank 0 (not part of `value`) ----
-        if world == 1:
+        if world == 1 and not multi:
             try:
                 after = {}
                 d, (nv, na) = timed(lambda: hip.asm_graph(c, 0.35), args.steps)
@@ -414,7 +444,7 @@ def main():
                                    "read_error_correction with its Levenshtein path search), reads resident in HBM" % (args.workload, per_gpu, cfg["mean_len"] // 1000, c)
                        if with_ec else "%s: %d reads x ~%d kb per GPU, scan + count + table merge" % (args.workload, per_gpu, cfg["mean_len"] // 1000),
                        "reads_per_gpu": per_gpu, "bases_per_gpu": bases, "genome_len": cfg["genome_len"],
-                       "parallelism": "reads sharded by record, %d rank(s)%s" % (world, "; table merge + pair all-gather + coverage all-reduce over RCCL" if world > 1 else ""),
+                       "parallelism": "reads sharded by record, %d rank(s)%s" % (world, "; table merge + pair all-gather + coverage all-reduce: %s" % collectives if multi else ""),
                        "setup_s_untimed": round(t_gen, 1)},
             "roofline": roofline, "cpu_baseline": cpu, "syncerr": ec_summary,
             "phases_ms": {k_: round(v, 4) for k_, v in phase_ms.items()},
@@ -422,6 +452,8 @@ def main():
         }
         out.update(extras)
         print(json.dumps(out), flush=True)
+    if comm:
+        hip.L.oatk_comm_destroy(comm)
     hip.close()
     if dist is not None:
         dist.barrier()
