@@ -93,6 +93,10 @@ int oatk_sr_db_fill_resident(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, const uint6
 /* sr_read (syncmer.c:487) for files (plain or gzip'ed FASTA / four-line FASTQ), without kseq: text to the device (oatk_ingest_files), record
  * scan and syncmer scan there, sr_db filled from the resident results, snames cut out of the headers */
 int oatk_sr_read_files(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, char **files, int n_files);
+/* the device half of the above for text that is already in host memory: streamed through the device in windows (upload of window i + 1 beside
+ * the record scan and syncmer scan of window i), the scanned pieces assembled in ctx; nothing is copied back.  pinned != 0: the text is
+ * page-locked and goes over PCIe as it lies.  window = 0: default. */
+int oatk_scan_text(oatk_hip_ctx *ctx, const uint8_t *text, uint64_t n_bytes, int pinned, int k, int s, uint64_t window, uint64_t *n_reads);
 /* Test hook: the text window (bytes) oatk_sr_read_files streams the input in; 0 = default (768 MiB).  Results never depend on it. */
 void oatk_host_debug_window(uint64_t bytes);
 

@@ -31,6 +31,8 @@ typedef struct {
     int add_nl;                    /* the file does not end in a newline: one is put behind it (a fresh kseq starts every file at a header
                                     * line, sstream.c:91-97 -- its last line must not glue to the next file's first header) */
     uint8_t *map;                  /* lazily mapped (no populate) for the header lines only */
+    int borrowed;                  /* mem belongs to the caller */
+    int pinned;                    /* ... and is page-locked: it goes over PCIe as it lies */
 } seg_t;
 
 static void seg_close(seg_t *s, int n)
@@ -39,7 +41,7 @@ static void seg_close(seg_t *s, int n)
     for (i = 0; i < n; ++i) {
         if (s[i].map) munmap(s[i].map, (size_t) s[i].size);
         if (s[i].fd >= 0) close(s[i].fd);
-        free(s[i].mem);
+        if (!s[i].borrowed) free(s[i].mem);
     }
     free(s);
 }
@@ -265,9 +267,10 @@ static void *uploader(void *arg)
 {
     stream_t *st = (stream_t *) arg;
     const uint64_t chunk = st->win < UP_CHUNK? ((st->win + 63) & ~63ULL) : UP_CHUNK;
-    uint8_t *stage = (uint8_t *) oatk_hip_staging(st->up, 2 * chunk);
+    const int direct = st->n_seg == 1 && st->seg[0].pinned;
+    uint8_t *stage = direct? 0 : (uint8_t *) oatk_hip_staging(st->up, 2 * chunk);
     uint64_t g0, w;
-    int rc = stage? OATK_OK : OATK_E_NOMEM;
+    int rc = stage || direct? OATK_OK : OATK_E_NOMEM;
     for (w = 0, g0 = 0; !rc && g0 < st->total; ++w) {
         const int s = (int) (w & 1);
         const uint64_t g1 = g0 + st->win < st->total? g0 + st->win : st->total;
@@ -276,6 +279,17 @@ static void *uploader(void *arg)
         const int stop = st->stop;
         pthread_mutex_unlock(&st->mu);
         if (stop) break;
+        if (st->n_seg == 1 && st->seg[0].pinned) {                   /* page-locked text: one copy, no staging */
+            rc = oatk_hip_h2d_async(st->up, st->d_win[s], st->seg[0].mem + g0, g1 - g0);
+            if (!rc) rc = oatk_hip_sync(st->up);
+            pthread_mutex_lock(&st->mu);
+            if (rc) st->failed = rc;
+            else st->state[s] = 1, st->g0[s] = g0, st->g1[s] = g1;
+            pthread_cond_broadcast(&st->cv);
+            pthread_mutex_unlock(&st->mu);
+            g0 = g1;
+            continue;
+        }
         /* the window in pieces: read piece p + 1 while piece p is on the bus */
         up_job_t job = {st->seg, st->n_seg, stage, g0, g0 + chunk < g1? g0 + chunk : g1, 0};
         oatk_par_run_n(up_worker, &job, st->n_up);
@@ -326,7 +340,7 @@ static double now_s(void)
     return (double) t.tv_sec + 1e-9 * (double) t.tv_nsec;
 }
 
-static int sr_read_stream(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, seg_t *seg, int n_files, uint64_t total, uint64_t win)
+static int sr_read_stream(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, int K, int S, seg_t *seg, int n_files, uint64_t total, uint64_t win)
 {
     const char *lg = getenv("OATK_DROPIN_LOG");
     const int log = lg && lg[0] && lg[0] != '0';
@@ -346,7 +360,7 @@ static int sr_read_stream(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, seg_t *seg, in
     st.seg = seg, st.n_seg = n_files, st.total = total, st.win = win;
     st.n_up = threads > 1? threads - threads / 2 : 1;
     const int fmt = sniff_format(seg, n_files, total);
-    rc = oatk_hip_scan_begin(ctx, 0, sr_db->k, sr_db->s);
+    rc = oatk_hip_scan_begin(ctx, 0, K, S);
     st.up = rc? 0 : oatk_hip_create(dev);
     for (i = 0; !rc && i < 2; ++i) {
         uint8_t *d = 0;
@@ -390,11 +404,11 @@ static int sr_read_stream(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, seg_t *seg, in
         const uint64_t text0 = g0 - carry;                          /* where this piece's text starts in the whole text */
         carry = next_carry, text_done = g1;
         if (n == 0) continue;
-        rc = oatk_hip_scan_ingested(piece[s], n_done, sr_db->k, sr_db->s);
+        rc = oatk_hip_scan_ingested(piece[s], n_done, K, S);
         if (rc) break;
         t_dev += now_s() - t0, t0 = now_s();
         /* room for the reads: from the first piece's density, generously; grown when a later piece needs more */
-        if (sr_db->m < n_done + n) {
+        if (sr_db && sr_db->m < n_done + n) {
             uint64_t m = n_done + n;
             if (!final && used) m = n_done + (uint64_t) ((double) n * ((double) (total - text0) / (double) used) * 1.05) + 1024;
             oatk_sr_t *na = (oatk_sr_t *) realloc(sr_db->a, sizeof(oatk_sr_t) * m);
@@ -409,6 +423,13 @@ static int sr_read_stream(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, seg_t *seg, in
             rc = oatk_hip_scan_reserve(ctx, (uint64_t) ((double) inf.seq_bytes * scale) + (1 << 20), (uint64_t) ((double) n * scale) + 1024,
                                        (uint64_t) ((double) inf.n_occ * scale * 1.1) + 4096);
             if (rc) break;
+        }
+        if (!sr_db) {                                               /* the scan only: no structs to fill */
+            rc = oatk_hip_scan_append(ctx, piece[s]);
+            if (rc) break;
+            t_app += now_s() - t0;
+            n_done += n;
+            continue;
         }
         const void *d = 0;
         off = (uint64_t *) malloc(8 * n), hdr = (uint64_t *) malloc(8 * n), names = (char **) calloc(n, sizeof(char *));
@@ -444,7 +465,7 @@ done:
     if (st.up) oatk_hip_destroy(st.up);
     pthread_mutex_destroy(&st.mu);
     pthread_cond_destroy(&st.cv);
-    if (!rc && sr_db->m > sr_db->n) {                               /* give back what the estimate left over */
+    if (!rc && sr_db && sr_db->m > sr_db->n) {                      /* give back what the estimate left over */
         oatk_sr_t *na = (oatk_sr_t *) realloc(sr_db->a, sizeof(oatk_sr_t) * (sr_db->n? sr_db->n : 1));
         if (na) sr_db->a = na, sr_db->m = sr_db->n;
     }
@@ -469,12 +490,35 @@ int oatk_sr_read_files(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, char **files, int
         const char *ew = getenv("OATK_DEBUG_WINDOW");              /* test hook, like oatk_host_debug_window */
         uint64_t win = g_window? g_window : (ew && atoll(ew) > 0? (uint64_t) atoll(ew) : WIN_DEFAULT);
         if (win < 4096) win = 4096;
-        rc = sr_read_stream(ctx, sr_db, seg, n_files, total, win);
+        rc = sr_read_stream(ctx, sr_db, sr_db->k, sr_db->s, seg, n_files, total, win);
         if (rc == OATK_E_NOMEM && win < total) {                    /* a record longer than a window: once more, in one piece */
             oatk_sr_db_clean(sr_db);
-            rc = sr_read_stream(ctx, sr_db, seg, n_files, total, total);
+            rc = sr_read_stream(ctx, sr_db, sr_db->k, sr_db->s, seg, n_files, total, total);
         }
     }
     seg_close(seg, n_files);
+    return rc;
+}
+
+/* The same stream for text that is already in memory (a caller with its own reader; bench.py's PCIe-inclusive leg): windows of the text go over
+ * PCIe while the window before is parsed and scanned on the device, the pieces are assembled in ctx; no structs are filled.  `pinned`: the
+ * text is page-locked (hipHostMalloc / hipHostRegister) and is copied as it lies; otherwise it is staged through page-locked pieces. */
+int oatk_scan_text(oatk_hip_ctx *ctx, const uint8_t *text, uint64_t n_bytes, int pinned, int k, int s, uint64_t window, uint64_t *n_reads)
+{
+    seg_t seg;
+    memset(&seg, 0, sizeof(seg));
+    seg.fd = -1, seg.mem = (uint8_t *) text, seg.size = n_bytes, seg.borrowed = 1, seg.pinned = pinned;
+    seg.add_nl = n_bytes && text[n_bytes - 1] != '\n';
+    const uint64_t total = n_bytes + (uint64_t) seg.add_nl;
+    if (seg.add_nl) seg.pinned = 0;                                  /* (the added newline is not in the caller's memory) */
+    int rc;
+    if (total == 0) rc = oatk_hip_scan_begin(ctx, 0, k, s);
+    else {
+        uint64_t win = window? window : WIN_DEFAULT;
+        if (win < 4096) win = 4096;
+        rc = sr_read_stream(ctx, 0, k, s, &seg, 1, total, win);
+        if (rc == OATK_E_NOMEM && win < total) rc = sr_read_stream(ctx, 0, k, s, &seg, 1, total, total);
+    }
+    if (!rc && n_reads) { oatk_hip_info_t inf; oatk_hip_info(ctx, &inf); *n_reads = inf.n_reads; }
     return rc;
 }
