@@ -53,7 +53,7 @@ def parse_args():
     ap.add_argument("--no-sharded-syncerr", action="store_true",
                     help="at N > 1 stop after scan + count + table merge (the metric then says so); default is the whole step, sharded")
     ap.add_argument("--ingest-reads", type=int, default=200000)
-    ap.add_argument("--ingest-window", type=int, default=192, help="MiB of text per window of the streamed ingest")
+    ap.add_argument("--ingest-window", type=int, default=64, help="MiB of text per window of the streamed ingest")
     ap.add_argument("--back-reads", type=int, default=100000)
     ap.add_argument("--cli-reads", type=int, default=40000)
     ap.add_argument("--cpu-sample-reads", type=int, default=80000)
