@@ -663,7 +663,7 @@ int oatk_hip_count(oatk_hip_ctx *ctx)
         CK(rocprim::inclusive_scan(ctx->tmp.p, tb, ctx->head_idx.as<uint32_t>(), ctx->head_idx.as<uint32_t>(), n, rocprim::maximum<uint32_t>(), ctx->stream));
     }
     CK(hipMemsetAsync(ctx->bad_head.p, 0, n * 4, ctx->stream));
-    hipLaunchKernelGGL(verify_group_kernel, dim3((unsigned) ((n + 15) / 16)), dim3(256), 0, ctx->stream, g, ctx->bad_head.as<uint32_t>());
+    hipLaunchKernelGGL(verify_group_kernel, dim3((unsigned) ((n + 8 * OATK_VG_STRIP - 1) / (8 * OATK_VG_STRIP))), dim3(256), 0, ctx->stream, g, ctx->bad_head.as<uint32_t>());
     uint32_t fl[4];
     CK(hipMemcpyAsync(fl, ctx->flags.p, sizeof(fl), hipMemcpyDeviceToHost, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));

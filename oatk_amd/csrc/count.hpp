@@ -117,32 +117,50 @@ __global__ void mark_heads_kernel(GroupArgs a)
     a.loc[i] = ((a.off[(a.pos_lo[p] >> 32) - a.sid0] >> 4) << 32) | a.pos_mpos[p];
 }
 
-// half a wave per sorted record that is not a group head: is its k-mer identical to the head's?  (32 lanes x 32 bases cover
-// k <= 1024 in one step; two records per wave keep all lanes busy)
+// Is the k-mer of every sorted record that is not a group head identical to its head's?  Half a wave (32 lanes x 32 bases cover k <= 1024
+// in one step) takes a STRIP of eight consecutive records.  The kernel is a chain of dependent gathers -- head flag and head index, the two
+// locators, the k-mer words -- and its rate is (bytes in flight) / (HBM latency): with two records per half wave and a wave that retires
+// after them it moved 1.5 TB/s at full occupancy (9.0 ms at config 3).  A strip pays the first two levels once for eight records (lane r of
+// the half wave fetches record r's, the values travel by shuffle) and has the sixteen k-mer word loads of the strip in flight together.
+#define OATK_VG_STRIP 8
 __global__ __launch_bounds__(256) void verify_group_kernel(GroupArgs a, uint32_t *bad_head)
 {
-    // two records per half wave, all their loads issued before the first comparison: the kernel is a chain of three dependent gathers
-    // (head index -> locators -> k-mer words) and waits on HBM latency; two chains in flight per lane: 0.87 -> 0.80 ms at config 2
-    const uint32_t hl = threadIdx.x & 31;
-    const uint32_t i0 = 2u * (blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5)), i1 = i0 + 1u;
-    const bool live0 = i0 < a.n_rec && !a.head[i0], live1 = i1 < a.n_rec && !a.head[i1];
-    const uint32_t h0 = live0? a.head_idx[i0] : 0u, h1 = live1? a.head_idx[i1] : 0u;
-    const uint64_t lp0 = live0? a.loc[i0] : 0, lq0 = live0? a.loc[h0] : 0, lp1 = live1? a.loc[i1] : 0, lq1 = live1? a.loc[h1] : 0;
+    const uint32_t hl = threadIdx.x & 31, half0 = threadIdx.x & 32;       // lane in the half wave; first lane of the half wave within the wave
+    const uint32_t i0 = (uint32_t) OATK_VG_STRIP * (blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5));
+    // level 1 + 2: lane r < 8 of the half wave owns record i0 + r
+    uint32_t my_h = 0;
+    uint64_t my_lp = 0, my_lq = 0;
+    bool my_live = false;
+    if (hl < OATK_VG_STRIP) {
+        const uint32_t i = i0 + hl;
+        my_live = i < a.n_rec && !a.head[i];
+        if (my_live) {
+            my_h = a.head_idx[i];
+            my_lp = a.loc[i];
+            my_lq = a.loc[my_h];
+        }
+    }
+    const uint64_t live_mask = (__ballot(my_live) >> half0) & 0xFFu;
+    if (live_mask == 0) return;                                           // (a strip of heads: singletons, most of the error k-mers)
     const uint32_t *hs32 = (const uint32_t *) a.hoco_s;
     const int nw = (a.K + 31) / 32;
-    bool d0 = false, d1 = false;
+    uint32_t diff = 0;                                                    // bit r: this lane saw record r differ from its head
     for (int wd = (int) hl; wd < nw; wd += 32) {
-        const uint64_t p0 = live0? kmer_word_global(hs32 + (lp0 >> 32), (uint32_t) lp0 >> 1, (uint32_t) lp0 & 1u, a.K, wd) : 0;
-        const uint64_t q0 = live0? kmer_word_global(hs32 + (lq0 >> 32), (uint32_t) lq0 >> 1, (uint32_t) lq0 & 1u, a.K, wd) : 0;
-        const uint64_t p1 = live1? kmer_word_global(hs32 + (lp1 >> 32), (uint32_t) lp1 >> 1, (uint32_t) lp1 & 1u, a.K, wd) : 0;
-        const uint64_t q1 = live1? kmer_word_global(hs32 + (lq1 >> 32), (uint32_t) lq1 >> 1, (uint32_t) lq1 & 1u, a.K, wd) : 0;
-        d0 |= p0 != q0, d1 |= p1 != q1;
+        uint64_t p[OATK_VG_STRIP], q[OATK_VG_STRIP];
+#pragma unroll
+        for (int r = 0; r < OATK_VG_STRIP; ++r) {                         // every load of the strip is issued before the first comparison
+            const uint64_t lp = (uint64_t) __shfl((long long) my_lp, (int) (half0 + r)), lq = (uint64_t) __shfl((long long) my_lq, (int) (half0 + r));
+            const bool live = (live_mask >> r) & 1u;
+            p[r] = live? kmer_word_global(hs32 + (lp >> 32), (uint32_t) lp >> 1, (uint32_t) lp & 1u, a.K, wd) : 0;
+            q[r] = live? kmer_word_global(hs32 + (lq >> 32), (uint32_t) lq >> 1, (uint32_t) lq & 1u, a.K, wd) : 0;
+        }
+#pragma unroll
+        for (int r = 0; r < OATK_VG_STRIP; ++r) diff |= (uint32_t) (p[r] != q[r]) << r;
     }
-    const uint64_t bad0 = __ballot(d0), bad1 = __ballot(d1);
-    const uint32_t m0 = (uint32_t) (threadIdx.x & 32? bad0 >> 32 : bad0), m1 = (uint32_t) (threadIdx.x & 32? bad1 >> 32 : bad1);
-    if (hl == 0) {
-        if (m0) a.flags[0] = 1u, bad_head[h0] = 1u;
-        if (m1) a.flags[0] = 1u, bad_head[h1] = 1u;
+#pragma unroll
+    for (int r = 0; r < OATK_VG_STRIP; ++r) {
+        const uint64_t bad = (__ballot((diff >> r) & 1u) >> half0) & 0xFFFFFFFFULL;
+        if (bad && hl == (uint32_t) r) a.flags[0] = 1u, bad_head[my_h] = 1u;   // lane r holds record r's head index
     }
 }
 
