@@ -145,14 +145,17 @@ __global__ __launch_bounds__(256) void verify_group_kernel(GroupArgs a, uint32_t
     const uint32_t *hs32 = (const uint32_t *) a.hoco_s;
     const int nw = (a.K + 31) / 32;
     uint32_t diff = 0;                                                    // bit r: this lane saw record r differ from its head
+    uint64_t lp[OATK_VG_STRIP], lq[OATK_VG_STRIP];                        // (handed round while every lane is still here: k < 225 leaves lanes 4 .. 7 out of the loop)
+#pragma unroll
+    for (int r = 0; r < OATK_VG_STRIP; ++r)
+        lp[r] = (uint64_t) __shfl((long long) my_lp, (int) (half0 + r)), lq[r] = (uint64_t) __shfl((long long) my_lq, (int) (half0 + r));
     for (int wd = (int) hl; wd < nw; wd += 32) {
         uint64_t p[OATK_VG_STRIP], q[OATK_VG_STRIP];
 #pragma unroll
         for (int r = 0; r < OATK_VG_STRIP; ++r) {                         // every load of the strip is issued before the first comparison
-            const uint64_t lp = (uint64_t) __shfl((long long) my_lp, (int) (half0 + r)), lq = (uint64_t) __shfl((long long) my_lq, (int) (half0 + r));
             const bool live = (live_mask >> r) & 1u;
-            p[r] = live? kmer_word_global(hs32 + (lp >> 32), (uint32_t) lp >> 1, (uint32_t) lp & 1u, a.K, wd) : 0;
-            q[r] = live? kmer_word_global(hs32 + (lq >> 32), (uint32_t) lq >> 1, (uint32_t) lq & 1u, a.K, wd) : 0;
+            p[r] = live? kmer_word_global(hs32 + (lp[r] >> 32), (uint32_t) lp[r] >> 1, (uint32_t) lp[r] & 1u, a.K, wd) : 0;
+            q[r] = live? kmer_word_global(hs32 + (lq[r] >> 32), (uint32_t) lq[r] >> 1, (uint32_t) lq[r] & 1u, a.K, wd) : 0;
         }
 #pragma unroll
         for (int r = 0; r < OATK_VG_STRIP; ++r) diff |= (uint32_t) (p[r] != q[r]) << r;
