@@ -145,17 +145,16 @@ __global__ __launch_bounds__(256) void verify_group_kernel(GroupArgs a, uint32_t
     const uint32_t *hs32 = (const uint32_t *) a.hoco_s;
     const int nw = (a.K + 31) / 32;
     uint32_t diff = 0;                                                    // bit r: this lane saw record r differ from its head
-    uint64_t lp[OATK_VG_STRIP], lq[OATK_VG_STRIP];                        // (handed round while every lane is still here: k < 225 leaves lanes 4 .. 7 out of the loop)
-#pragma unroll
-    for (int r = 0; r < OATK_VG_STRIP; ++r)
-        lp[r] = (uint64_t) __shfl((long long) my_lp, (int) (half0 + r)), lq[r] = (uint64_t) __shfl((long long) my_lq, (int) (half0 + r));
-    for (int wd = (int) hl; wd < nw; wd += 32) {
+    for (int w0 = 0; w0 < nw; w0 += 32) {                                 // (uniform trip count: every lane takes part in the shuffles, k < 225 idles lanes in the loads only)
+        const int wd = w0 + (int) hl;
+        const bool in = wd < nw;
         uint64_t p[OATK_VG_STRIP], q[OATK_VG_STRIP];
 #pragma unroll
         for (int r = 0; r < OATK_VG_STRIP; ++r) {                         // every load of the strip is issued before the first comparison
-            const bool live = (live_mask >> r) & 1u;
-            p[r] = live? kmer_word_global(hs32 + (lp[r] >> 32), (uint32_t) lp[r] >> 1, (uint32_t) lp[r] & 1u, a.K, wd) : 0;
-            q[r] = live? kmer_word_global(hs32 + (lq[r] >> 32), (uint32_t) lq[r] >> 1, (uint32_t) lq[r] & 1u, a.K, wd) : 0;
+            const uint64_t lp = (uint64_t) __shfl((long long) my_lp, (int) (half0 + r)), lq = (uint64_t) __shfl((long long) my_lq, (int) (half0 + r));
+            const bool live = in && ((live_mask >> r) & 1u);
+            p[r] = live? kmer_word_global(hs32 + (lp >> 32), (uint32_t) lp >> 1, (uint32_t) lp & 1u, a.K, wd) : 0;
+            q[r] = live? kmer_word_global(hs32 + (lq >> 32), (uint32_t) lq >> 1, (uint32_t) lq & 1u, a.K, wd) : 0;
         }
 #pragma unroll
         for (int r = 0; r < OATK_VG_STRIP; ++r) diff |= (uint32_t) (p[r] != q[r]) << r;
