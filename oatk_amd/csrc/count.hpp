@@ -122,7 +122,9 @@ __global__ void mark_heads_kernel(GroupArgs a)
 // locators, the k-mer words -- and its rate is (bytes in flight) / (HBM latency): with two records per half wave and a wave that retires
 // after them it moved 1.5 TB/s at full occupancy (9.0 ms at config 3).  A strip pays the first two levels once for eight records (lane r of
 // the half wave fetches record r's, the values travel by shuffle) and has the sixteen k-mer word loads of the strip in flight together.
+#ifndef OATK_VG_STRIP
 #define OATK_VG_STRIP 8
+#endif
 __global__ __launch_bounds__(256) void verify_group_kernel(GroupArgs a, uint32_t *bad_head)
 {
     const uint32_t hl = threadIdx.x & 31, half0 = threadIdx.x & 32;       // lane in the half wave; first lane of the half wave within the wave
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(256) void verify_group_kernel(GroupArgs a, uint32_t
             my_lq = a.loc[my_h];
         }
     }
-    const uint64_t live_mask = (__ballot(my_live) >> half0) & 0xFFu;
+    const uint64_t live_mask = (__ballot(my_live) >> half0) & ((1ULL << OATK_VG_STRIP) - 1ULL);
     if (live_mask == 0) return;                                           // (a strip of heads: singletons, most of the error k-mers)
     const uint32_t *hs32 = (const uint32_t *) a.hoco_s;
     const int nw = (a.K + 31) / 32;
