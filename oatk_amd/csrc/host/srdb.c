@@ -9,6 +9,8 @@
 #define _GNU_SOURCE
 #include <malloc.h>
 #include <sys/mman.h>
+#include <sys/syscall.h>
+#include <sys/types.h>
 #include <unistd.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -129,6 +131,7 @@ static void fill_prefault_plan(fill_job_t *j)
 {
     j->pre0 = j->pre1 = 0;
     if (!g_heap_top || j->a1 <= j->a0) return;
+    if ((pid_t) syscall(SYS_gettid) != getpid()) return;       /* the main heap is the main thread's arena: only there do the next blocks come from its top */
     uint64_t need = 0, i;
     for (i = j->a0; i < j->a1; ++i) need += (uint64_t) j->hoco_l[i] + ((uint64_t) j->hoco_l[i] + 3) / 4 + 20 * (j->scm_off[i + 1] - j->scm_off[i]) + 160;
     uint8_t *brk_now = (uint8_t *) sbrk(0), *lo = g_heap_top + 4096, *hi = g_heap_top + need + (need >> 6);
