@@ -113,10 +113,10 @@ def test_cli_declined_inputs_fall_back_to_the_original_bodies(tmp_path):
     for f in SIX:
         assert tab[f][0] == 0, f
     # k beyond the device scan's window (oatk_hip_max_k() = 4016): the original reads and analyses
-    long_reads = A.hifi_like(80, 60000, 12000, seed=17, err=0.0005)
+    long_reads = A.hifi_like(120, 60000, 20000, seed=17, err=0.0)
     fl = str(tmp_path / "long.fa")
     R.write_fasta(long_reads, fl)
-    tab, log = both(tmp_path, fl, 4101, 31, 4)
+    tab, log = both(tmp_path, fl, 4101, 31, 3)
     assert tab["sr_read"][0] == 0 and tab["sr_read"][2] == 1 and "beyond the device" in log
     # wrapped FASTQ: the device reader refuses, kseq reads it
     fq = str(tmp_path / "w.fq")
