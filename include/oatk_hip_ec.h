@@ -83,6 +83,13 @@ int oatk_hip_ec_correct(oatk_hip_ctx *ctx, double max_edist);
  *   EG_IDX_P u64[2 n_scm] (valid where EG_IDX_N > 0)   EG_IDX_N u32[2 n_scm]
  *   EG_ARC_V u64[n_arc]  EG_ARC_W u64[n_arc]  EG_ARC_LS u32[n_arc]  EG_ARC_COV u32[n_arc]  EG_ARC_COMP u8[n_arc] */
 int oatk_hip_ec_graph(oatk_hip_ctx *ctx);
+/* The LIGHT graph: all that read_error_correction (syncerr.c:819) asks of the graph when err_arc_c >= err_mer_c, as at its one call site
+ * (run_syncasm.c:124 passes min_k_cov for both).  find_error_syncmers (:679-757) deletes every syncmer seen fewer than err_mer_c times and
+ * every arc that touches one; before that it asks of such an arc only that it exists (:699-706) -- it cannot be "good", an arc being seen at
+ * most as often as its rarer end.  So only pairs between two syncmers with coverage >= err_mer_c are sorted into arcs, and the rest leave
+ * one flag per oriented vertex.  Marks, corrected reads and refreshed table are identical to those from the full graph; the arc arrays
+ * (OATK_BUF_EG_*) hold the kept arcs only.  oatk_hip_ec_mark / oatk_hip_ec refuse (OATK_E_ARG) thresholds a light graph cannot serve. */
+int oatk_hip_ec_graph_light(oatk_hip_ctx *ctx, uint32_t err_mer_c);
 
 /* ---- reads sharded by record over several GPUs (one context per GPU) --------------------------------------
  * The EC graph is a property of ALL reads, so every shard builds the same graph from the adjacent pairs of all shards and
@@ -105,6 +112,11 @@ int oatk_hip_ec_graph(oatk_hip_ctx *ctx);
 int oatk_hip_ec_set_global(oatk_hip_ctx *ctx, uint64_t n_global, const uint32_t *d_l2g, const uint32_t *d_cov, const uint64_t *d_s);
 int oatk_hip_ec_pairs(oatk_hip_ctx *ctx, const void **d_keys, const void **d_dist, uint64_t *n_pairs);
 int oatk_hip_ec_graph_from_pairs(oatk_hip_ctx *ctx, const uint64_t *d_keys, const uint32_t *d_dist, uint64_t n_pairs);
+/* the same from run-length compressed lists: entry i stands for (d_val[i] >> 32) consecutive pairs of key d_keys[i] at distance (uint32) d_val[i].
+ * What a shard sends instead of its pairs: sorted by key (stably) its list collapses to a few segments per arc, and the table that
+ * calc_syncmer_overlap (syncasm.c:477-582) fills -- khashl<int,int>, whose bucket order breaks the ties of the mode (:558-571) -- depends on
+ * the calls only through their order, which the segments of all shards in shard order preserve. */
+int oatk_hip_ec_graph_from_segments(oatk_hip_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_val, uint64_t n_seg);
 int oatk_hip_ec_export_kmers(oatk_hip_ctx *ctx, const uint32_t *d_ids, uint64_t n, uint8_t *d_out, uint32_t stride, uint8_t *d_rev);
 int oatk_hip_ec_import_kmers(oatk_hip_ctx *ctx, const uint32_t *d_ids, const uint8_t *d_rev, const uint8_t *d_kmers, uint64_t n, uint32_t stride);
 /* room kept behind the hoco strings for imported k-mers (default 1 MiB); call before the scan */

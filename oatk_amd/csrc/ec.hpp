@@ -41,6 +41,7 @@ struct EcGraph {
     // where the bases of a vertex live: byte offset of the read's hoco string, and pos << 1 | rev on it
     const uint64_t *vtx_hs_off;
     const uint32_t *vtx_mpos;
+    const uint8_t *other;         // light graph (ecgraph.hpp): [2 n_vtx] the oriented vertex has arcs that were never materialised; else null
 };
 
 struct EcReads {
@@ -68,7 +69,7 @@ __global__ void ec_mark_kernel(EcGraph g, uint32_t err_mer_c, uint32_t max_err_c
         const uint32_t na = g.idx_n[v];
         uint32_t live = 0;
         for (uint32_t j = 0; j < na; ++j) live += !g.arc_del[p + j];
-        if (!live) continue;
+        if (!live && !(g.other && g.other[v])) continue;
         b[k] = 0;
         for (uint32_t j = 0; j < na; ++j) {
             if (g.arc_del[p + j]) continue;

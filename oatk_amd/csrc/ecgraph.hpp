@@ -45,6 +45,42 @@ __global__ void egr_pair_keys_kernel(uint64_t n_reads, const uint64_t *scm_off, 
     }
 }
 
+// The LIGHT graph (api_ec.inc, oatk_hip_ec_graph_light): find_error_syncmers (syncerr.c:690-718) deletes every syncmer below err_mer_c, and with it
+// every arc that touches one (asmg_vtx_del :748-752); all it ever asks of such an arc is (a) that it EXISTS on its side of a kept candidate
+// (b[k] = 0 rather than -1, :699-706) and (b) whether it is "good" -- which it cannot be when err_arc_c >= err_mer_c, because an arc is seen at
+// most as often as its rarer end.  So pairs with an end below `c` do not go through the sorts at all: they leave one flag per oriented
+// candidate vertex (`other`), and only pairs between two candidates become arcs.  keep[i] = 1 for those.
+__global__ void egr_light_flag_kernel(uint64_t n, const uint64_t *keys, const uint32_t *cov, uint32_t c, uint8_t *keep, uint8_t *other)
+{
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = keys[i];
+    if (k == EGR_INVALID) { keep[i] = 0; return; }
+    const uint64_t v0 = k >> 32, v1 = k & 0xFFFFFFFFULL;           // the key stands for v0 -> v1 and (v1 ^ 1) -> (v0 ^ 1)
+    const bool c0 = cov[v0 >> 1] >= c, c1 = cov[v1 >> 1] >= c;
+    keep[i] = c0 && c1;
+    if (c0 && !c1) other[v0] = 1;
+    if (c1 && !c0) other[v1 ^ 1ULL] = 1;
+}
+// a run of equal (key, distance) in the key-sorted pair list becomes one weighted segment; head[i] = 1 where one starts
+__global__ void egr_seg_head_kernel(uint64_t n, const uint64_t *skeys, const uint32_t *sdist, uint8_t *head)
+{
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) head[i] = i == 0 || skeys[i] != skeys[i - 1] || sdist[i] != sdist[i - 1];
+}
+__global__ void egr_seg_emit_kernel(uint64_t n_seg, uint64_t n, const uint32_t *head_pos, const uint64_t *skeys, const uint32_t *sdist, uint64_t *okey, uint64_t *oval)
+{
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_seg) return;
+    const uint64_t p = head_pos[i], q = i + 1 < n_seg? head_pos[i + 1] : n;
+    okey[i] = skeys[p], oval[i] = (uint64_t) sdist[p] | (q - p) << 32;       // distance | weight << 32
+}
+__global__ void egr_seg_split_kernel(uint64_t n, const uint64_t *val, uint32_t *dist, uint32_t *wgt)
+{
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dist[i] = (uint32_t) val[i], wgt[i] = (uint32_t) (val[i] >> 32);
+}
+
 // arcs per distinct key: itself, plus its complement unless it is its own (syncasm.c:264-282)
 __global__ void egr_expand_count_kernel(uint64_t n_keys, const uint64_t *ukeys, uint32_t *n_out)
 {
@@ -58,7 +94,7 @@ __global__ void egr_expand_count_kernel(uint64_t n_keys, const uint64_t *ukeys, 
 
 // payload of an arc through the (v, w) sort: overlap << 44 | coverage << 1 | complement flag
 __global__ void egr_expand_kernel(uint64_t n_keys, const uint64_t *ukeys, const uint32_t *counts, const uint32_t *run_ls, const uint64_t *out_off,
-                                  uint64_t *akey, uint64_t *aval)
+                                  uint64_t *akey, uint64_t *aval)       // counts: calls per key (the run length, or the weighted sum of a run of segments)
 {
     uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_keys) return;
@@ -144,6 +180,17 @@ struct MiniKh {
         if (!((used >> i) & 1ULL)) keys[i] = key, vals[i] = 1, used |= 1ULL << i, ++count;
         else ++vals[i];
     }
+    __device__ void addw(int32_t key, uint32_t w)                          // w consecutive add_ovl_count calls for one distance
+    {
+        add1(key);
+        if (w < 2 || overflow) return;
+        add1(key);                                                         // the second call is the one that can find the table due to grow
+        if (w < 3 || overflow) return;
+        const uint32_t n = nb();
+        uint32_t i = h2b((uint32_t) key, bits);
+        while (keys[i] != key || !((used >> i) & 1ULL)) i = (i + 1U) & (n - 1);
+        vals[i] += (int32_t) (w - 2);
+    }
     __device__ int32_t mode() const                                        // syncasm.c:558-571: first bucket reaching the maximum
     {
         int32_t movl = 0, mcnt = 0;
@@ -227,8 +274,11 @@ struct WaveKh {
 // overlap of the arc a run of equal keys stands for: K minus the most frequent distance (calc_syncmer_overlap,
 // syncasm.c:477-582, and the arc.ls assignment :793-812).  One lane per short run; long runs are then taken by the
 // whole wave, sixty-four distances at a time.
+// With `swgt` the entries of a run are SEGMENTS -- swgt[t] consecutive calls for distance sdist[t] (the pair lists of several shards, each
+// compressed before it travelled) -- and run_cov[i] receives the number of calls, the arc's coverage.
 __global__ __launch_bounds__(64) void egr_mode_kernel(uint64_t n_runs, const uint64_t *ukeys, const uint32_t *counts, const uint64_t *run_off,
-                                                      const uint32_t *sdist, int K, uint32_t *run_ls, uint32_t *flags)
+                                                      const uint32_t *sdist, int K, uint32_t *run_ls, uint32_t *flags,
+                                                      const uint32_t *swgt = nullptr, uint32_t *run_cov = nullptr)
 {
     __shared__ int32_t tk[64], tv[64];
     const int lane = threadIdx.x;
@@ -244,7 +294,13 @@ __global__ __launch_bounds__(64) void egr_mode_kernel(uint64_t n_runs, const uin
     if (valid && c <= EGR_SMALL_RUN) {
         MiniKh h;
         h.init();
-        for (uint32_t t = 0; t < c; ++t) h.add1((int32_t) sdist[o + t]);
+        if (swgt) {
+            uint32_t tot = 0;
+            for (uint32_t t = 0; t < c; ++t) h.addw((int32_t) sdist[o + t], swgt[o + t]), tot += swgt[o + t];
+            run_cov[i] = tot;
+        } else {
+            for (uint32_t t = 0; t < c; ++t) h.add1((int32_t) sdist[o + t]);
+        }
         if (h.overflow) flags[1] = 1u;
         else run_ls[i] = to_ls(h.mode());
     }
@@ -258,19 +314,29 @@ __global__ __launch_bounds__(64) void egr_mode_kernel(uint64_t n_runs, const uin
         WaveKh h;
         h.init(tk, tv);
         bool tail_new = false;                         // was the very last add call an insert?
+        uint32_t tot = 0;
         for (uint32_t t0 = 0; t0 < cc && !h.overflow; t0 += 64) {
             const bool in = t0 + lane < cc;
             const int32_t d = in? (int32_t) sdist[oo + t0 + lane] : 0;
+            const uint32_t w = in? (swgt? swgt[oo + t0 + lane] : 1u) : 0u;
             uint64_t rest = __ballot(in);
             while (rest && !h.overflow) {
                 const int f = __builtin_ctzll(rest);
                 const int32_t x = __builtin_amdgcn_readfirstlane(__shfl(d, f));
                 const uint64_t eq = __ballot(in && d == x) & rest;
                 rest &= ~eq;
-                const bool fresh = h.add(x, (int32_t) __builtin_popcountll(eq));
-                tail_new = fresh && eq == (1ULL << f) && t0 + f == cc - 1;
+                uint32_t calls = (uint32_t) __builtin_popcountll(eq);
+                const uint32_t wf = (uint32_t) __builtin_amdgcn_readfirstlane((int32_t) __shfl(w, f));
+                if (swgt) {
+                    calls = 0;
+                    for (uint64_t q = eq; q; q &= q - 1) calls += (uint32_t) __builtin_amdgcn_readfirstlane((int32_t) __shfl(w, __builtin_ctzll(q)));
+                }
+                tot += calls;
+                const bool fresh = h.add(x, (int32_t) calls);
+                tail_new = fresh && eq == (1ULL << f) && t0 + f == cc - 1 && wf == 1u;
             }
         }
+        if (swgt && lane == src) run_cov[i] = tot;
         if (!h.overflow && h.due() && !tail_new) h.resize(h.nb() + 1U);       // khashl grows at the call AFTER the insert that filled it
         if (lane == src) {
             if (h.overflow) flags[1] = 1u;

@@ -116,9 +116,13 @@ class HipSyncasm:
         return st, int(ni.value)
 
     # ---- error correction (include/oatk_hip_ec.h) ----
-    def ec_graph(self):
-        """make_syncmer_graph(sr_db, scm_db, 0, 0.) + hoco arc overlaps on the device (run_syncasm.c:109-117)"""
-        self._check(self.L.oatk_hip_ec_graph(self.h), "oatk_hip_ec_graph")
+    def ec_graph(self, light_c=0):
+        """make_syncmer_graph(sr_db, scm_db, 0, 0.) + hoco arc overlaps on the device (run_syncasm.c:109-117); with light_c > 0 only what
+        read_error_correction(…, err_mer_c = light_c, …, err_arc_c >= err_mer_c, …) needs of it (include/oatk_hip_ec.h: the light graph)"""
+        if light_c:
+            self._check(self.L.oatk_hip_ec_graph_light(self.h, int(light_c)), "oatk_hip_ec_graph_light")
+        else:
+            self._check(self.L.oatk_hip_ec_graph(self.h), "oatk_hip_ec_graph")
 
     def ec(self, max_edist, c, a, graph=None):
         """read_error_correction(sr_db, g, max_edist, c, 10 c, c, a) (run_syncasm.c:124, syncerr.c:819); `graph` = dict of

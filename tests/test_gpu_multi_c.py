@@ -71,8 +71,13 @@ def run_ranks(world, make_comm, reads, bounds, K, S, c):
     return out
 
 
+@pytest.mark.parametrize("graph", ["light", "full"])
 @pytest.mark.parametrize("case", range(len(CASES)))
-def test_sharded_through_the_c_collectives_equals_one_handle(hip, case):
+def test_sharded_through_the_c_collectives_equals_one_handle(hip, case, graph, monkeypatch):
+    """graph = light: candidates' pairs travel as weighted segments plus one flag per oriented candidate (the default when err_arc_c >= err_mer_c);
+    full: every pair of every shard travels (any thresholds)"""
+    if graph == "full":
+        monkeypatch.setenv("OATK_DEBUG_FULL_GRAPH", "1")
     K, S, c, mk, frac = CASES[case]
     reads = mk()
     bounds = [int(round(f * len(reads))) for f in frac]
