@@ -52,6 +52,9 @@ def parse_args():
                          "128-byte id travels through torch.distributed once), 'torch' = the same exchange steps written over torch.distributed (oatk_amd/multi.py)")
     ap.add_argument("--no-sharded-syncerr", action="store_true",
                     help="at N > 1 stop after scan + count + table merge (the metric then says so); default is the whole step, sharded")
+    ap.add_argument("--ec-graph", default="light", choices=["light", "full"],
+                    help="light (default; what the drop-in uses): of make_syncmer_graph(0, 0.) only what read_error_correction can use at run_syncasm.c:124's "
+                         "thresholds -- arcs between syncmers seen >= c times, one flag for the rest (include/oatk_hip_ec.h); full: every arc.  Same corrected reads.")
     ap.add_argument("--ingest-reads", type=int, default=200000)
     ap.add_argument("--ingest-window", type=int, default=64, help="MiB of text per window of the streamed ingest")
     ap.add_argument("--back-reads", type=int, default=100000)
@@ -221,7 +224,7 @@ def main():
         if merger is not None:
             merger.merge()
             return None
-        hip.ec_graph()
+        hip.ec_graph(light_c=c if args.ec_graph == "light" else 0)
         return hip.ec(0.02, c, 0.35)
 
     def fence():
@@ -315,6 +318,23 @@ def main():
         except Exception as ex:             # noqa: BLE001   (an extension must never take the headline down)
             extras["scan_count"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
 
+    if world == 1 and not multi and not args.no_extras:
+        # ---- the same step with the other EC graph (light <-> full): what the restriction to usable arcs is worth ----
+        try:
+            other = "full" if args.ec_graph == "light" else "light"
+
+            def step_other():
+                scan_count()
+                hip.ec_graph(light_c=c if other == "light" else 0)
+                return hip.ec(0.02, c, 0.35)
+            step_other()
+            dso, st_o = timed(step_other, args.steps)
+            extras["ec_graph_" + other] = {"value": round(total_bases / dso / 1e9, 3), "unit": "Gbases/s", "ms_per_step": round(dso * 1e3, 3),
+                                           "same_statistics": bool(st is not None and st_o is not None and list(st_o[:11]) == list(st[:11])),
+                                           "workload": "the headline step with --ec-graph %s" % other}
+        except Exception as ex:             # noqa: BLE001
+            extras["ec_graph_other"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+
     if rank == 0 and not args.no_extras:
         # ---- BASELINE.json configs[1]: 200 k reads x 15 kb (its own 1 Mb genome), scan + count, and with the EC round ----
         if args.workload != "config2":
@@ -330,7 +350,7 @@ def main():
 
                 def full2():
                     sc2()
-                    hip.ec_graph()
+                    hip.ec_graph(light_c=int(c2["min_k_cov"]) if args.ec_graph == "light" else 0)
                     return hip.ec(0.02, int(c2["min_k_cov"]), 0.35)
                 full2()
                 d1, _ = timed(sc2, 5)
@@ -444,6 +464,8 @@ def main():
             "config": {"workload": "%s: %d reads x ~%d kb per GPU, k=1001 s=31 -c %d, full hot path of syncasm incl. syncerr (scan + count + EC graph + "
                                    "read_error_correction with its Levenshtein path search), reads resident in HBM" % (args.workload, per_gpu, cfg["mean_len"] // 1000, c)
                        if with_ec else "%s: %d reads x ~%d kb per GPU, scan + count + table merge" % (args.workload, per_gpu, cfg["mean_len"] // 1000),
+                       "ec_graph": ("light: arcs between syncmers seen >= %d times + one flag per oriented vertex for the rest (include/oatk_hip_ec.h); same corrected reads "
+                                    "as from the full graph (tests/test_gpu_light_graph.py)" % c) if args.ec_graph == "light" else "full: every arc of make_syncmer_graph(0, 0.)",
                        "reads_per_gpu": per_gpu, "bases_per_gpu": bases, "genome_len": cfg["genome_len"],
                        "parallelism": "reads sharded by record, %d rank(s)%s" % (world, "; table merge + pair all-gather + coverage all-reduce: %s" % collectives if multi else ""),
                        "setup_s_untimed": round(t_gen, 1)},

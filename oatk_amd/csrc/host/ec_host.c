@@ -81,8 +81,9 @@ int oatk_read_error_correction(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, oatk_sync
     uint64_t *arc_v = 0, *arc_w = 0;
     uint64_t nv = 0, na = 0;
     if (!asmg) {
-        /* no host graph at all: make_syncmer_graph(sr_db, scm_db, 0, 0.) + the hoco arc overlaps are built on the device too */
-        rc = oatk_hip_ec_graph(ctx);
+        /* no host graph at all: make_syncmer_graph(sr_db, scm_db, 0, 0.) + the hoco arc overlaps are built on the device too -- of them only
+         * what the correction can use when the thresholds allow it (include/oatk_hip_ec.h: the light graph; run_syncasm.c:124 always does) */
+        rc = err_mer_c > 0 && err_arc_c >= err_mer_c? oatk_hip_ec_graph_light(ctx, err_mer_c) : oatk_hip_ec_graph(ctx);
         if (rc) return rc;
         rc = oatk_hip_ec(ctx, 0, max_edist, err_mer_c, max_err_c, err_arc_c, max_arc_f);
         if (rc) return rc;
