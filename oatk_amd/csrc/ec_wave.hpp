@@ -410,6 +410,8 @@ struct EcwArgs {
     uint64_t pool_cap;
     unsigned long long *pool_cursor;
     unsigned long long *next;     // work counter
+    uint32_t *todo_out;           // blocks that did not fit this tier's carve-up: the next tier's list, appended by the waves themselves
+    unsigned long long *todo_cnt;
 #ifdef ECW_PROF
     unsigned long long *prof;
 #endif
@@ -476,6 +478,7 @@ __global__ __launch_bounds__(64) void ec_wave_kernel(EcwArgs a)
                 uint32_t st = 0, np = 0;
                 if (!ecw_solve_block(a.lv, a.rd, wk, s, a.max_edist, st, np)) {
                     o.flags = 1;
+                    if (lane == 0) a.todo_out[atomicAdd(a.todo_cnt, 1ULL)] = (uint32_t) wi;
                 } else {
                     o.status = st, o.np = np;
                     if (st == EC_SUCCESS && np) {

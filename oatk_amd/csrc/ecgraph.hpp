@@ -272,25 +272,26 @@ struct WaveKh {
 #define EGR_SMALL_RUN 48
 
 // overlap of the arc a run of equal keys stands for: K minus the most frequent distance (calc_syncmer_overlap,
-// syncasm.c:477-582, and the arc.ls assignment :793-812).  One lane per short run; long runs are then taken by the
-// whole wave, sixty-four distances at a time.
+// syncasm.c:477-582, and the arc.ls assignment :793-812).  One lane per short run; long runs go on a list and are then
+// taken one per wave, sixty-four distances at a time (egr_mode_big_kernel).
 // With `swgt` the entries of a run are SEGMENTS -- swgt[t] consecutive calls for distance sdist[t] (the pair lists of several shards, each
 // compressed before it travelled) -- and run_cov[i] receives the number of calls, the arc's coverage.
+__device__ __forceinline__ uint32_t egr_to_ls(int64_t l, int K)   // scg_syncmer_consensus(beg = l) then MIN with the vertex length K
+{
+    if (l < K) l = l < 0? K : K - l;
+    else l = 0;
+    return (uint32_t) l;
+}
+
 __global__ __launch_bounds__(64) void egr_mode_kernel(uint64_t n_runs, const uint64_t *ukeys, const uint32_t *counts, const uint64_t *run_off,
-                                                      const uint32_t *sdist, int K, uint32_t *run_ls, uint32_t *flags,
+                                                      const uint32_t *sdist, int K, uint32_t *run_ls, uint32_t *flags, uint32_t *big_list,
                                                       const uint32_t *swgt = nullptr, uint32_t *run_cov = nullptr)
 {
-    __shared__ int32_t tk[64], tv[64];
     const int lane = threadIdx.x;
     const uint64_t i = (uint64_t) blockIdx.x * 64 + lane;
     const bool valid = i < n_runs && ukeys[i] != EGR_INVALID;
     const uint32_t c = valid? counts[i] : 0u;
     const uint64_t o = valid? run_off[i] : 0;
-    auto to_ls = [&](int64_t l) -> uint32_t {          // scg_syncmer_consensus(beg = l) then MIN with the vertex length K
-        if (l < K) l = l < 0? K : K - l;
-        else l = 0;
-        return (uint32_t) l;
-    };
     if (valid && c <= EGR_SMALL_RUN) {
         MiniKh h;
         h.init();
@@ -302,15 +303,29 @@ __global__ __launch_bounds__(64) void egr_mode_kernel(uint64_t n_runs, const uin
             for (uint32_t t = 0; t < c; ++t) h.add1((int32_t) sdist[o + t]);
         }
         if (h.overflow) flags[1] = 1u;
-        else run_ls[i] = to_ls(h.mode());
+        else run_ls[i] = egr_to_ls(h.mode(), K);
     }
-    uint64_t big = __ballot(valid && c > EGR_SMALL_RUN);
-    while (big) {
-        const int src = __builtin_ctzll(big);
-        big &= big - 1;
-        const uint32_t cc = (uint32_t) __builtin_amdgcn_readfirstlane((int32_t) __shfl(c, src));
-        const uint64_t oo = (uint64_t) (uint32_t) __builtin_amdgcn_readfirstlane((int32_t) (__shfl(o, src) >> 32)) << 32
-                          | (uint32_t) __builtin_amdgcn_readfirstlane((int32_t) __shfl(o, src));
+    const bool is_big = valid && c > EGR_SMALL_RUN;
+    const uint64_t big = __ballot(is_big);
+    if (big) {
+        uint32_t base = 0;
+        if (lane == __builtin_ctzll(big)) base = atomicAdd(&flags[4], (uint32_t) __builtin_popcountll(big));
+        base = (uint32_t) __shfl((int32_t) base, __builtin_ctzll(big));
+        if (is_big) big_list[base + (uint32_t) __builtin_popcountll(big & ((1ULL << lane) - 1ULL))] = (uint32_t) i;
+    }
+}
+
+// the long runs, one per wave (flags[4] = how many; the grid is fixed and strides over the list)
+__global__ __launch_bounds__(64) void egr_mode_big_kernel(const uint32_t *counts, const uint64_t *run_off, const uint32_t *sdist, int K, uint32_t *run_ls,
+                                                          uint32_t *flags, const uint32_t *big_list, const uint32_t *swgt = nullptr, uint32_t *run_cov = nullptr)
+{
+    __shared__ int32_t tk[64], tv[64];
+    const int lane = threadIdx.x;
+    const uint32_t n_big = flags[4];
+    for (uint32_t b = blockIdx.x; b < n_big; b += gridDim.x) {
+        const uint32_t i = big_list[b];
+        const uint32_t cc = counts[i];
+        const uint64_t oo = run_off[i];
         WaveKh h;
         h.init(tk, tv);
         bool tail_new = false;                         // was the very last add call an insert?
@@ -336,12 +351,13 @@ __global__ __launch_bounds__(64) void egr_mode_kernel(uint64_t n_runs, const uin
                 tail_new = fresh && eq == (1ULL << f) && t0 + f == cc - 1 && wf == 1u;
             }
         }
-        if (swgt && lane == src) run_cov[i] = tot;
         if (!h.overflow && h.due() && !tail_new) h.resize(h.nb() + 1U);       // khashl grows at the call AFTER the insert that filled it
-        if (lane == src) {
+        if (lane == 0) {
+            if (swgt) run_cov[i] = tot;
             if (h.overflow) flags[1] = 1u;
-            else run_ls[i] = to_ls(h.mode());
+            else run_ls[i] = egr_to_ls(h.mode(), K);
         }
+        __syncthreads();                               // the table in LDS is reused
     }
 }
 
