@@ -339,6 +339,249 @@ __global__ void ec_assemble_kernel(EcAssembleArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same walk with ONE WAVE PER READ.  A HiFi read carries a few dozen syncmers, so its whole chain sits in the lanes of a wave: lane j
+// holds entry j, the two searches of the loop at syncerr.c:394-598 ("first good syncmer at or beyond a position", "first deleted syncmer
+// after it") are one ballot and a count-trailing-zeros each, and everything the callbacks write goes out with the lanes side by side
+// instead of one lane striding through its own read.  Four kernels use it -- block count, block list, and the two passes of the chain
+// assembly -- and the lane-per-read versions above remain for reads with more than 64 syncmers (lane 0 runs them).
+// ---------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t ecr_u32(uint32_t v, int lane) { return (uint32_t) __builtin_amdgcn_readfirstlane((int32_t) __shfl((int32_t) v, lane)); }
+__device__ __forceinline__ uint64_t ecr_u64(uint64_t v, int lane) { return (uint64_t) ecr_u32((uint32_t) (v >> 32), lane) << 32 | ecr_u32((uint32_t) v, lane); }
+__device__ __forceinline__ uint64_t ecr_above(int32_t j) { return j < 0? ~0ULL : (j >= 63? 0ULL : ~0ULL << (j + 1)); }      // lanes > j
+
+// km, mp, del: this lane's chain entry (lane < n <= 64); every argument of the callbacks is wave-uniform
+template <class FB, class FC>
+__device__ int ec_blocks_wave(int lane, int32_t n, uint64_t km, uint32_t mp, bool del, uint32_t hoco_l, int K, FB on_block, FC on_copy)
+{
+    const bool in = lane < n;
+    const uint64_t goodm = __ballot(in && !del && !(km & 1ULL)), delm = __ballot(in && del);
+    const uint32_t pos = mp >> 1;
+    int32_t beg = -1, end, nb = 0;
+    bool updated = true;
+    for (;;) {
+        uint32_t beg_pos = beg < 1? 0u : ecr_u32(pos, beg - 1) + (uint32_t) K;
+        beg_pos += EC_MIN_ERR_SEQ_LEN;
+        const uint64_t m = __ballot(pos >= beg_pos) & goodm & ecr_above(beg);
+        end = m? (int32_t) __builtin_ctzll(m) : (beg + 1 < n? n : beg + 1);
+        if (beg >= 0 || end < n) {
+            EcBlock b;
+            if (beg < 0) {
+                beg = end;
+                const uint64_t kb = ecr_u64(km, beg);
+                const uint32_t mb = ecr_u32(mp, beg);
+                b.beg_utg = (kb & ~1ULL) | (uint64_t) !(mb & 1u);
+                b.beg_pos = 0, b.end_utg = EC_NONE, b.l = (int32_t) (mb >> 1), b.r = 1;
+            } else {
+                --beg;
+                const uint64_t kb = ecr_u64(km, beg);
+                const uint32_t mb = ecr_u32(mp, beg);
+                b.beg_utg = (kb & ~1ULL) | (mb & 1u);
+                b.beg_pos = (mb >> 1) + (uint32_t) K;
+                if (end >= n) b.end_utg = EC_NONE, b.l = (int32_t) hoco_l - (int32_t) b.beg_pos;
+                else {
+                    const uint64_t ke = ecr_u64(km, end);
+                    const uint32_t me = ecr_u32(mp, end);
+                    b.end_utg = (ke & ~1ULL) | (me & 1u), b.l = (int32_t) (me >> 1) - (int32_t) b.beg_pos;
+                }
+                b.r = 0;
+            }
+            b.beg = beg, b.end = end;
+            on_block(nb, b);
+            ++nb;
+        } else {
+            updated = false;
+        }
+        if (end + 1 < n) {
+            if (ecr_u64(km, end) & 1ULL) beg = end + 1;                   // [end], as written in the reference (syncerr.c:579)
+            else { const uint64_t m2 = delm & ecr_above(end); beg = m2? (int32_t) __builtin_ctzll(m2) : n; }
+        } else {
+            beg = end + 1;
+        }
+        if (beg > n) break;
+        on_copy(end, beg);
+    }
+    return updated? nb : -1;
+}
+
+#define ECR_READS_PER_BLOCK 4
+
+__global__ __launch_bounds__(256) void ec_count_blocks_wave_kernel(EcReads rd, const uint8_t *scm_del, uint32_t *n_blocks)
+{
+    const uint64_t r = (uint64_t) blockIdx.x * ECR_READS_PER_BLOCK + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rd.n_reads) return;
+    const uint64_t o = rd.scm_off[r];
+    const int32_t n = (int32_t) (rd.scm_off[r + 1] - o);
+    int nb = 0;
+    if (n > 64) {
+        if (lane) return;
+        ec_blocks(scm_del, rd.k_mer + o, rd.m_pos + o, n, rd.hoco_l[r], rd.K, [&](int, const EcBlock &) { ++nb; }, [](int32_t, int32_t) {});
+        n_blocks[r] = (uint32_t) nb;
+        return;
+    }
+    const uint64_t km = lane < n? rd.k_mer[o + lane] : 0;
+    const uint32_t mp = lane < n? rd.m_pos[o + lane] : 0;
+    const bool del = lane < n && scm_del[km >> 1];
+    ec_blocks_wave(lane, n, km, mp, del, rd.hoco_l[r], rd.K, [&](int, const EcBlock &) { ++nb; }, [](int32_t, int32_t) {});
+    if (lane == 0) n_blocks[r] = (uint32_t) nb;
+}
+
+__global__ __launch_bounds__(256) void ec_list_blocks_wave_kernel(EcReads rd, EcLive lv, const uint8_t *scm_del, const uint64_t *blk_off, EcWork *work)
+{
+    const uint64_t r = (uint64_t) blockIdx.x * ECR_READS_PER_BLOCK + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rd.n_reads) return;
+    const uint64_t o = rd.scm_off[r];
+    const int32_t n = (int32_t) (rd.scm_off[r + 1] - o);
+    EcWork *w = work + blk_off[r];
+    const uint32_t hs16 = (uint32_t) (rd.off[r] >> 6);
+    auto put = [&](int k, const EcBlock &b) {
+        EcWork x;
+        x.beg_utg = b.beg_utg, x.end_utg = b.end_utg, x.read = (uint32_t) r, x.beg_pos = b.beg_pos, x.l = b.l, x.r = b.r;
+        x.hs16 = hs16, x.lp = lv.idx_p[b.beg_utg], x.ln = lv.idx_n[b.beg_utg], x.pad = 0;
+        w[k] = x;
+    };
+    if (n > 64) {
+        if (lane == 0) ec_blocks(scm_del, rd.k_mer + o, rd.m_pos + o, n, rd.hoco_l[r], rd.K, put, [](int32_t, int32_t) {});
+        return;
+    }
+    const uint64_t km = lane < n? rd.k_mer[o + lane] : 0;
+    const uint32_t mp = lane < n? rd.m_pos[o + lane] : 0;
+    const bool del = lane < n && scm_del[km >> 1];
+    ec_blocks_wave(lane, n, km, mp, del, rd.hoco_l[r], rd.K, [&](int k, const EcBlock &b) { if (lane == 0) put(k, b); }, [](int32_t, int32_t) {});
+}
+
+// stats[11] of read_error_correction (syncerr.c:502-504, :513-542) from the solved blocks; a fixed grid strides over them
+__global__ __launch_bounds__(256) void ec_block_stats_kernel(const EcWork *work, const EcBlockOut *out, uint64_t n_work, unsigned long long *stats)
+{
+    uint32_t loc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n_work; i += (uint64_t) gridDim.x * blockDim.x) {
+        const EcBlockOut x = out[i];
+        if (x.short_block) ++loc[10];
+        else if (work[i].end_utg == EC_NONE) ++loc[0], ++loc[1 + x.status];
+        else ++loc[5], ++loc[6 + x.status];
+    }
+    for (int i = 0; i < 11; ++i) {
+        uint32_t v = loc[i];
+        for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&stats[i], (unsigned long long) v);
+    }
+}
+
+// one read, lane-serial (the body of ec_assemble_kernel without the statistics): reads with more than 64 syncmers
+__device__ inline void ec_assemble_read_serial(const EcAssembleArgs &a, uint64_t r)
+{
+    const uint64_t o = a.rd.scm_off[r];
+    const int32_t n = (int32_t) (a.rd.scm_off[r + 1] - o);
+    const uint64_t *km = a.rd.k_mer + o;
+    const uint32_t *mp = a.rd.m_pos + o;
+    const EcBlockOut *bo = a.out + a.blk_off[r];
+    uint64_t wpos = a.pass? a.new_off[r] : 0;
+    const uint64_t w0 = wpos;
+    uint32_t cnt = 0;
+    auto put = [&](uint64_t k, uint32_t m) {
+        if (a.pass) {
+            a.new_k_mer[wpos] = k, a.new_m_pos[wpos] = m, a.new_s_mer[wpos] = a.scm_s[k >> 1];
+            a.key_id[wpos] = (uint32_t) (k >> 1), a.val_occ[wpos] = (a.sid0 + r) << 32 | (wpos - w0) << 1 | (m & 1u);
+            ++wpos;
+        }
+        ++cnt;
+    };
+    int nb = ec_blocks(a.scm_del, km, mp, n, a.rd.hoco_l[r], a.rd.K,
+        [&](int k, const EcBlock &b) {
+            const EcBlockOut &x = bo[k];
+            if (x.status == EC_SUCCESS) {
+                const uint64_t *path = a.path_pool + x.path_off;
+                const int32_t np = (int32_t) x.np;
+                if (b.r) {
+                    for (int32_t j = np - 1; j > 0; --j) put((path[j] & ~1ULL) | 1ULL, 0xFFFFFFFFu ^ (uint32_t) (path[j] & 1ULL));
+                } else {
+                    int32_t j;
+                    for (j = 1; j < np - 1; ++j) put((path[j] & ~1ULL) | 1ULL, 0xFFFFFFFEu | (uint32_t) (path[j] & 1ULL));
+                    if (b.end_utg == EC_NONE && np > 1) put((path[j] & ~1ULL) | 1ULL, 0xFFFFFFFEu | (uint32_t) (path[j] & 1ULL));
+                }
+            } else if (b.r) {
+                for (int32_t j = 0; j < b.beg; ++j) put(km[j], mp[j]);
+            } else if (b.beg + 1 < n) {
+                for (int32_t j = b.beg + 1; j < b.end; ++j) put(km[j], mp[j]);
+            }
+        },
+        [&](int32_t first, int32_t last) { for (int32_t j = first; j < last; ++j) put(km[j], mp[j]); });
+    if (nb < 0) {
+        if (a.pass) {
+            uint64_t q = a.new_off[r];
+            for (int32_t j = 0; j < n; ++j) {
+                a.new_k_mer[q + j] = km[j], a.new_m_pos[q + j] = mp[j], a.new_s_mer[q + j] = a.old_s_mer[o + j];
+                a.key_id[q + j] = (uint32_t) (km[j] >> 1), a.val_occ[q + j] = (a.sid0 + r) << 32 | (uint64_t) j << 1 | (mp[j] & 1u);
+            }
+        }
+        cnt = (uint32_t) n;
+    }
+    if (!a.pass) a.new_n[r] = cnt;
+}
+
+// the corrected chains (syncerr.c:513-542, :585-612), pass 0 counts and pass 1 writes, one wave per read
+template <int PASS>
+__global__ __launch_bounds__(256) void ec_assemble_wave_kernel(EcAssembleArgs a)
+{
+    const uint64_t r = (uint64_t) blockIdx.x * ECR_READS_PER_BLOCK + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= a.rd.n_reads) return;
+    const uint64_t o = a.rd.scm_off[r];
+    const int32_t n = (int32_t) (a.rd.scm_off[r + 1] - o);
+    if (n > 64) {
+        if (lane == 0) ec_assemble_read_serial(a, r);
+        return;
+    }
+    const uint64_t km = lane < n? a.rd.k_mer[o + lane] : 0;
+    const uint32_t mp = lane < n? a.rd.m_pos[o + lane] : 0;
+    const bool del = lane < n && a.scm_del[km >> 1];
+    const EcBlockOut *bo = a.out + a.blk_off[r];
+    const uint64_t w0 = PASS? a.new_off[r] : 0;
+    uint64_t wpos = w0;
+    const uint64_t sid = (a.sid0 + r) << 32;
+    auto write = [&](uint64_t at, uint64_t k, uint32_t m, uint64_t s) {
+        a.new_k_mer[at] = k, a.new_m_pos[at] = m, a.new_s_mer[at] = s;
+        a.key_id[at] = (uint32_t) (k >> 1), a.val_occ[at] = sid | (at - w0) << 1 | (m & 1u);                 // syncerr.c:796-805
+    };
+    auto copy = [&](int32_t first, int32_t last) {                     // original entries [first, last) stay
+        if (last <= first) return;
+        if (PASS && lane >= first && lane < last) write(wpos + (uint32_t) (lane - first), km, mp, a.scm_s[km >> 1]);
+        wpos += (uint32_t) (last - first);
+    };
+    const int nb = ec_blocks_wave(lane, n, km, mp, del, a.rd.hoco_l[r], a.rd.K,
+        [&](int k, const EcBlock &b) {
+            const uint32_t status = bo[k].status;
+            if (status == EC_SUCCESS) {
+                const int32_t np = (int32_t) bo[k].np;
+                const uint64_t *path = a.path_pool + bo[k].path_off;
+                int32_t c;
+                if (b.r) c = np >= 1? np - 1 : 0;
+                else c = (np >= 2? np - 2 : 0) + (b.end_utg == EC_NONE && np > 1? 1 : 0);
+                if (PASS) {
+                    for (int32_t t = lane; t < c; t += 64) {
+                        const uint64_t p = b.r? path[np - 1 - t] : path[1 + t];
+                        const uint64_t kk = (p & ~1ULL) | 1ULL;
+                        write(wpos + (uint32_t) t, kk, b.r? 0xFFFFFFFFu ^ (uint32_t) (p & 1ULL) : 0xFFFFFFFEu | (uint32_t) (p & 1ULL), a.scm_s[kk >> 1]);
+                    }
+                }
+                wpos += (uint32_t) c;
+            } else if (b.r) {
+                copy(0, b.beg);
+            } else if (b.beg + 1 < n) {
+                copy(b.beg + 1, b.end < n? b.end : n);
+            }
+        },
+        copy);
+    if (nb < 0) {                                    // no good syncmer: the read keeps its arrays (syncerr.c:562-572)
+        wpos = w0;
+        if (PASS && lane < n) write(w0 + (uint32_t) lane, km, mp, a.old_s_mer[o + lane]);
+        wpos += (uint32_t) n;
+    }
+    if (!PASS && lane == 0) a.new_n[r] = (uint32_t) (wpos - w0);
+}
+
 // ---- update_syncmer_db (syncerr.c:769-814): coverage, forward-strand presence; occurrence lists come from a stable sort ----
 __global__ void ec_cov_kernel(uint64_t tot, const uint64_t *new_k_mer, const uint32_t *new_m_pos, uint32_t *cov, uint32_t *fwd)
 {

@@ -139,6 +139,8 @@ CASES = [
     (1001, 31, 6, lambda: sample_reads(genome_with_repeats(5, 50000), 260, 9000, 0.001, 6)),
     (301, 21, 5, lambda: sample_reads(genome_with_repeats(7, 25000, unit=1500, copies=4), 320, 4000, 0.003, 8)),
     (101, 11, 5, lambda: sample_reads(genome_with_repeats(9, 9000, unit=600, copies=3), 300, 1500, 0.004, 10)),
+    # chains longer than a wave (about a hundred syncmers per read), mixed with short ones: the lane-serial walk beside the wave-per-read one
+    (101, 11, 5, lambda: A.hifi_like(150, 20000, 6000, seed=463, err=0.003) + A.hifi_like(150, 20000, 1500, seed=467, err=0.003)),
 ]
 
 
