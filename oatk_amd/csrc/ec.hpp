@@ -172,18 +172,6 @@ struct EcBlockOut {
     uint32_t short_block;         // 1 = l < EC_MIN_ERR_SEQ_LEN (stats[10])
 };
 
-// counts blocks per read (block slots are then laid out by a prefix sum)
-__global__ void ec_count_blocks_kernel(EcReads rd, const uint8_t *scm_del, uint32_t *n_blocks)
-{
-    uint64_t r = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rd.n_reads) return;
-    const uint64_t o = rd.scm_off[r];
-    const int32_t n = (int32_t) (rd.scm_off[r + 1] - o);
-    int nb = 0;
-    ec_blocks(scm_del, rd.k_mer + o, rd.m_pos + o, n, rd.hoco_l[r], rd.K, [&](int, const EcBlock &) { ++nb; }, [](int32_t, int32_t) {});
-    n_blocks[r] = (uint32_t) nb;
-}
-
 // The arcs the search may follow: the graph's arc array with the deleted arcs squeezed out (same order), each carrying
 // what the search needs to know about its target, so that one 32-byte load per arc is the only graph access.  At high
 // coverage a good syncmer has thousands of deleted arcs to one-off error syncmers; the search never sees them.
@@ -206,23 +194,6 @@ struct __attribute__((aligned(16))) EcWork {   // one block, self-contained for 
     uint32_t lp, ln;              // live arcs of beg_utg
     uint32_t pad;
 };
-
-__global__ void ec_list_blocks_kernel(EcReads rd, EcLive lv, const uint8_t *scm_del, const uint64_t *blk_off, EcWork *work)
-{
-    uint64_t r = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rd.n_reads) return;
-    const uint64_t o = rd.scm_off[r];
-    const int32_t n = (int32_t) (rd.scm_off[r + 1] - o);
-    EcWork *w = work + blk_off[r];
-    const uint32_t hs16 = (uint32_t) (rd.off[r] >> 6);
-    ec_blocks(scm_del, rd.k_mer + o, rd.m_pos + o, n, rd.hoco_l[r], rd.K,
-              [&](int k, const EcBlock &b) {
-                  EcWork x;
-                  x.beg_utg = b.beg_utg, x.end_utg = b.end_utg, x.read = (uint32_t) r, x.beg_pos = b.beg_pos, x.l = b.l, x.r = b.r;
-                  x.hs16 = hs16, x.lp = lv.idx_p[b.beg_utg], x.ln = lv.idx_n[b.beg_utg], x.pad = 0;
-                  w[k] = x;
-              }, [](int32_t, int32_t) {});
-}
 
 __global__ void ec_live_flag_kernel(uint64_t n_arc, const uint8_t *arc_del, uint32_t *live)
 {
@@ -270,74 +241,6 @@ struct EcAssembleArgs {
     unsigned long long *stats;    // [11]
     int pass;
 };
-
-__global__ void ec_assemble_kernel(EcAssembleArgs a)
-{
-    uint64_t r = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t loc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // this lane's share of stats[11]; one atomic per wave and counter
-    const bool live = r < a.rd.n_reads;
-    if (live) {
-    const uint64_t o = a.rd.scm_off[r];
-    const int32_t n = (int32_t) (a.rd.scm_off[r + 1] - o);
-    const uint64_t *km = a.rd.k_mer + o;
-    const uint32_t *mp = a.rd.m_pos + o;
-    const EcBlockOut *bo = a.out + a.blk_off[r];
-    uint64_t wpos = a.pass? a.new_off[r] : 0;
-    const uint64_t w0 = wpos;
-    uint32_t cnt = 0;
-    auto put = [&](uint64_t k, uint32_t m) {
-        if (a.pass) {
-            a.new_k_mer[wpos] = k, a.new_m_pos[wpos] = m, a.new_s_mer[wpos] = a.scm_s[k >> 1];
-            a.key_id[wpos] = (uint32_t) (k >> 1), a.val_occ[wpos] = (a.sid0 + r) << 32 | (wpos - w0) << 1 | (m & 1u);      // syncerr.c:796-805
-            ++wpos;
-        }
-        ++cnt;
-    };
-    int nb = ec_blocks(a.scm_del, km, mp, n, a.rd.hoco_l[r], a.rd.K,
-        [&](int k, const EcBlock &b) {
-            const EcBlockOut &x = bo[k];
-            if (a.pass == 0) {
-                if (x.short_block) ++loc[10];
-                else if (b.end_utg == EC_NONE) ++loc[0], ++loc[1 + x.status];
-                else ++loc[5], ++loc[6 + x.status];
-            }
-            if (x.status == EC_SUCCESS) {
-                const uint64_t *path = a.path_pool + x.path_off;
-                const int32_t np = (int32_t) x.np;
-                if (b.r) {
-                    for (int32_t j = np - 1; j > 0; --j) put((path[j] & ~1ULL) | 1ULL, 0xFFFFFFFFu ^ (uint32_t) (path[j] & 1ULL));
-                } else {
-                    int32_t j;
-                    for (j = 1; j < np - 1; ++j) put((path[j] & ~1ULL) | 1ULL, 0xFFFFFFFEu | (uint32_t) (path[j] & 1ULL));
-                    if (b.end_utg == EC_NONE && np > 1) put((path[j] & ~1ULL) | 1ULL, 0xFFFFFFFEu | (uint32_t) (path[j] & 1ULL));
-                }
-            } else if (b.r) {
-                for (int32_t j = 0; j < b.beg; ++j) put(km[j], mp[j]);
-            } else if (b.beg + 1 < n) {
-                for (int32_t j = b.beg + 1; j < b.end; ++j) put(km[j], mp[j]);
-            }
-        },
-        [&](int32_t first, int32_t last) { for (int32_t j = first; j < last; ++j) put(km[j], mp[j]); });
-    if (nb < 0) {                                    // no good syncmer: the read keeps its arrays (syncerr.c:562-572)
-        if (a.pass) {
-            uint64_t q = a.new_off[r];
-            for (int32_t j = 0; j < n; ++j) {
-                a.new_k_mer[q + j] = km[j], a.new_m_pos[q + j] = mp[j], a.new_s_mer[q + j] = a.old_s_mer[o + j];
-                a.key_id[q + j] = (uint32_t) (km[j] >> 1), a.val_occ[q + j] = (a.sid0 + r) << 32 | (uint64_t) j << 1 | (mp[j] & 1u);
-            }
-        }
-        cnt = (uint32_t) n;
-    }
-    if (!a.pass) a.new_n[r] = cnt;
-    }
-    if (!a.pass) {
-        for (int i = 0; i < 11; ++i) {
-            uint32_t v = loc[i];
-            for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d);
-            if ((threadIdx.x & 63) == 0 && v) atomicAdd(&a.stats[i], (unsigned long long) v);
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // The same walk with ONE WAVE PER READ.  A HiFi read carries a few dozen syncmers, so its whole chain sits in the lanes of a wave: lane j
