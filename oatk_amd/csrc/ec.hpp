@@ -352,7 +352,12 @@ __global__ __launch_bounds__(256) void ec_list_blocks_wave_kernel(EcReads rd, Ec
     const uint64_t km = lane < n? rd.k_mer[o + lane] : 0;
     const uint32_t mp = lane < n? rd.m_pos[o + lane] : 0;
     const bool del = lane < n && scm_del[km >> 1];
-    ec_blocks_wave(lane, n, km, mp, del, rd.hoco_l[r], rd.K, [&](int k, const EcBlock &b) { if (lane == 0) put(k, b); }, [](int32_t, int32_t) {});
+    // lane k keeps block k and writes it after the walk, so the gathers of a read's blocks are in flight together
+    EcBlock mine;
+    mine.beg_utg = 0, mine.end_utg = 0, mine.beg_pos = 0, mine.l = 0, mine.beg = 0, mine.end = 0, mine.r = 0;
+    const int nb = ec_blocks_wave(lane, n, km, mp, del, rd.hoco_l[r], rd.K,
+                                  [&](int k, const EcBlock &b) { if (k < 64) { if (lane == k) mine = b; } else if (lane == 0) put(k, b); }, [](int32_t, int32_t) {});
+    if (lane < nb) put(lane, mine);
 }
 
 // stats[11] of read_error_correction (syncerr.c:502-504, :513-542) from the solved blocks; a fixed grid strides over them
@@ -441,24 +446,30 @@ __global__ __launch_bounds__(256) void ec_assemble_wave_kernel(EcAssembleArgs a)
     const uint32_t mp = lane < n? a.rd.m_pos[o + lane] : 0;
     const bool del = lane < n && a.scm_del[km >> 1];
     const EcBlockOut *bo = a.out + a.blk_off[r];
+    const int32_t nbk = (int32_t) (a.blk_off[r + 1] - a.blk_off[r]);
+    // lane k holds the outcome of block k: one load for all of a read's blocks instead of one after the other inside the walk
+    uint32_t my_status = EC_FAILURE, my_np = 0;
+    uint64_t my_path = 0;
+    if (lane < nbk) my_status = bo[lane].status, my_np = bo[lane].np, my_path = bo[lane].path_off;
     const uint64_t w0 = PASS? a.new_off[r] : 0;
     uint64_t wpos = w0;
     const uint64_t sid = (a.sid0 + r) << 32;
+    const uint64_t my_s = PASS && lane < n? a.old_s_mer[o + lane] : 0;    // a syncmer's s-mer is the same at every occurrence (count.hpp: check_smer_kernel)
     auto write = [&](uint64_t at, uint64_t k, uint32_t m, uint64_t s) {
         a.new_k_mer[at] = k, a.new_m_pos[at] = m, a.new_s_mer[at] = s;
         a.key_id[at] = (uint32_t) (k >> 1), a.val_occ[at] = sid | (at - w0) << 1 | (m & 1u);                 // syncerr.c:796-805
     };
     auto copy = [&](int32_t first, int32_t last) {                     // original entries [first, last) stay
         if (last <= first) return;
-        if (PASS && lane >= first && lane < last) write(wpos + (uint32_t) (lane - first), km, mp, a.scm_s[km >> 1]);
+        if (PASS && lane >= first && lane < last) write(wpos + (uint32_t) (lane - first), km, mp, my_s);
         wpos += (uint32_t) (last - first);
     };
     const int nb = ec_blocks_wave(lane, n, km, mp, del, a.rd.hoco_l[r], a.rd.K,
         [&](int k, const EcBlock &b) {
-            const uint32_t status = bo[k].status;
+            const uint32_t status = k < 64? ecr_u32(my_status, k) : bo[k].status;
             if (status == EC_SUCCESS) {
-                const int32_t np = (int32_t) bo[k].np;
-                const uint64_t *path = a.path_pool + bo[k].path_off;
+                const int32_t np = (int32_t) (k < 64? ecr_u32(my_np, k) : bo[k].np);
+                const uint64_t *path = a.path_pool + (k < 64? ecr_u64(my_path, k) : bo[k].path_off);
                 int32_t c;
                 if (b.r) c = np >= 1? np - 1 : 0;
                 else c = (np >= 2? np - 2 : 0) + (b.end_utg == EC_NONE && np > 1? 1 : 0);
@@ -479,7 +490,7 @@ __global__ __launch_bounds__(256) void ec_assemble_wave_kernel(EcAssembleArgs a)
         copy);
     if (nb < 0) {                                    // no good syncmer: the read keeps its arrays (syncerr.c:562-572)
         wpos = w0;
-        if (PASS && lane < n) write(w0 + (uint32_t) lane, km, mp, a.old_s_mer[o + lane]);
+        if (PASS && lane < n) write(w0 + (uint32_t) lane, km, mp, my_s);
         wpos += (uint32_t) n;
     }
     if (!PASS && lane == 0) a.new_n[r] = (uint32_t) (wpos - w0);
