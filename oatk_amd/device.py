@@ -25,7 +25,7 @@ _DTYPES = {
     "RA_ALN_SID": np.uint32, "RA_ALN_OFF": np.uint64, "RA_ALN_S": np.float64, "RA_FRG_UID": np.uint64, "RA_FRG_UBEG": np.uint32,
     "RA_FRG_UEND": np.uint32, "RA_FRG_SBEG": np.uint32, "RA_FRG_SEND": np.uint32, "RA_SKIPPED": np.uint32,
     "OVL_KEY": np.uint64, "OVL_OFF": np.uint64, "OVL_DIST": np.int32, "OVL_CNT": np.uint32, "OVL_TAIL": np.uint8,
-    "MG_H": np.uint64, "MG_S": np.uint64, "MG_COV": np.uint32, "MG_L2G": np.uint32, "MG_EC_COV": np.uint32, "MG_EC_DEL": np.uint8,
+    "MG_H": np.uint64, "MG_S": np.uint64, "MG_COV": np.uint32, "MG_L2G": np.uint32, "MG_EC_COV": np.uint32, "MG_EC_DEL": np.uint8, "MG_LCOV": np.uint32,
     "AG_SCM_DEL": np.uint8, "AG_VTX_SCM": np.uint32, "AG_VTX_COV": np.uint32, "AG_IDX_P": np.uint64, "AG_IDX_N": np.uint32,
     "AG_ARC_V": np.uint64, "AG_ARC_W": np.uint64, "AG_ARC_COV": np.uint32, "AG_ARC_COMP": np.uint8, "AG_ARC_LINK": np.uint64,
 }
@@ -108,6 +108,12 @@ class HipSyncasm:
         n = C.c_uint64()
         self._check(self.L.oatk_hip_merge_counts(self.h, comm, C.byref(n)), "oatk_hip_merge_counts")
         return int(n.value)
+
+    def multi_range(self):
+        """(first global id, syncmers, size of the whole table) of the range of the merged table this handle owns (include/oatk_hip_multi.h)"""
+        a, b, g = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(self.L.oatk_hip_multi_range(self.h, C.byref(a), C.byref(b), C.byref(g)), "oatk_hip_multi_range")
+        return int(a.value), int(b.value), int(g.value)
 
     def ec_sharded(self, comm, max_edist, c, a):
         st = np.zeros(12, np.uint64)

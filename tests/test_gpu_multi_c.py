@@ -1,5 +1,6 @@
 """GPU: reads sharded by record through the C collectives (include/oatk_hip_multi.h: oatk_hip_merge_counts, oatk_hip_ec_sharded) equal one handle
-holding all the reads -- merged table, chains in global ids, refreshed coverage and deletion flags, block statistics, imported k-mers.
+holding all the reads -- merged table (partitioned by hash range: the ranks' ranges in rank order ARE the table of one handle), global ids and
+coverage of every shard's own syncmers, chains in global ids, refreshed coverage and deletion flags, block statistics, imported k-mers.
 
 The test box has one GPU and RCCL refuses two ranks on one device, so the N-rank cases run the ranks as threads of this process, each with its
 own handle, over the in-process communicator group (same code path above the three primitives; device-to-device copies instead of xGMI); the RCCL
@@ -51,7 +52,8 @@ def run_ranks(world, make_comm, reads, bounds, K, S, c):
             h.scan_host(seq, off, lens, K, S, sid0=lo)
             h.count()
             ng = h.merge_counts(comm)
-            merged = {k: h.fetch(k) for k in ("MG_H", "MG_S", "MG_COV", "MG_L2G")}
+            merged = {k: h.fetch(k) for k in ("MG_H", "MG_S", "MG_COV", "MG_L2G", "MG_LCOV")}
+            merged["range"] = h.multi_range()
             local_h = h.fetch("SCM_H")
             st, n_imp = h.ec_sharded(comm, 0.02, c, 0.35)
             res = {k: h.fetch(k) for k in ("EC_N_SCM", "EC_KMER", "EC_MPOS", "EC_SMER", "MG_EC_COV", "MG_EC_DEL")}
@@ -92,12 +94,22 @@ def test_sharded_through_the_c_collectives_equals_one_handle(hip, case, graph, m
     cnt, st, want = single(hip, reads, K, S, c)
     order = np.argsort(cnt["h"], kind="stable")         # the merged table is in hash order; one handle numbers syncmers the same way
     assert np.array_equal(order, np.arange(len(order)))
+    first = 0
     for rank, (ng, mg, local_h, st_r, n_imp, res) in enumerate(out):
         assert ng == cnt["n_scm"]
-        assert np.array_equal(mg["MG_H"], cnt["h"]) and np.array_equal(mg["MG_S"], cnt["s"]) and np.array_equal(mg["MG_COV"], cnt["cov"])
-        assert np.array_equal(cnt["h"][mg["MG_L2G"].astype(np.int64)], local_h)
-        assert np.array_equal(res["MG_EC_COV"], want["EC_SCM_COV"]) and np.array_equal(res["MG_EC_DEL"], want["EC_SCM_DEL"])
+        f, no, g = mg["range"]
+        assert f == first and g == ng and no == len(mg["MG_H"])           # the ranges tile the table in rank order
+        first += no
+        if no:                                                                # rank r owns the hashes with floor(h * world / 2^64) == r
+            assert int(mg["MG_H"][0]) * world >> 64 == rank and int(mg["MG_H"][-1]) * world >> 64 == rank
+        l2g = mg["MG_L2G"].astype(np.int64)
+        assert np.array_equal(cnt["h"][l2g], local_h) and np.array_equal(cnt["cov"][l2g], mg["MG_LCOV"])
         assert st_r[:11].tolist() == st[:11].tolist()
+    assert first == cnt["n_scm"]
+    for key, ref in (("MG_H", cnt["h"]), ("MG_S", cnt["s"]), ("MG_COV", cnt["cov"])):
+        assert np.array_equal(np.concatenate([o[1][key] for o in out]), ref), key
+    assert np.array_equal(np.concatenate([o[5]["MG_EC_COV"] for o in out]), want["EC_SCM_COV"])
+    assert np.array_equal(np.concatenate([o[5]["MG_EC_DEL"] for o in out]), want["EC_SCM_DEL"])
     assert np.array_equal(np.concatenate([o[5]["EC_N_SCM"] for o in out]), want["EC_N_SCM"])
     for key in ("EC_KMER", "EC_MPOS", "EC_SMER"):
         assert np.array_equal(np.concatenate([o[5][key] for o in out]), want[key]), key
@@ -118,7 +130,7 @@ def test_rccl_backend_world_of_one(hip):
     out = run_ranks(1, lambda r: comm, reads, [0, len(reads)], K, S, c)       # (run_ranks destroys the communicator)
     cnt, st, want = single(hip, reads, K, S, c)
     ng, mg, local_h, st_r, n_imp, res = out[0]
-    assert ng == cnt["n_scm"] and np.array_equal(mg["MG_H"], cnt["h"]) and np.array_equal(mg["MG_COV"], cnt["cov"])
+    assert ng == cnt["n_scm"] and np.array_equal(mg["MG_H"], cnt["h"]) and np.array_equal(mg["MG_COV"], cnt["cov"]) and mg["range"] == (0, ng, ng)
     assert np.array_equal(mg["MG_L2G"], np.arange(ng, dtype=np.uint32)) and n_imp == 0
     for key in ("EC_N_SCM", "EC_KMER", "EC_MPOS", "EC_SMER"):
         assert np.array_equal(res[key], want[key]), key
