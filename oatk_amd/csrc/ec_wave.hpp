@@ -412,10 +412,38 @@ struct EcwArgs {
     unsigned long long *next;     // work counter
     uint32_t *todo_out;           // blocks that did not fit this tier's carve-up: the next tier's list, appended by the waves themselves
     unsigned long long *todo_cnt;
+    int32_t skip_l;               // blocks longer than this were routed to a larger tier before the launch (ec_route_kernel): not this launch's business
 #ifdef ECW_PROF
     unsigned long long *prof;
 #endif
 };
+
+// Blocks too long for the first tier's carve-up are known before anything runs (the length is in the work item): they go straight onto the
+// list of the first tier that holds them, and those tiers run BESIDE the first one instead of after it.  cap[t] = longest block of tier t
+// (0 for a tier that is not in use); list[t] / cnt[t] for t = 1 .. 3.
+struct EcRoute {
+    int32_t cap[4];
+    uint32_t *list[4];
+    unsigned long long *cnt[4];
+};
+__global__ void ec_route_kernel(const EcWork *work, uint64_t n_work, EcRoute rt)
+{
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    int t = 0;
+    if (i < n_work) {
+        const int32_t l = work[i].l;
+        while (t < 3 && l > rt.cap[t]) ++t;
+    }
+    for (int k = 1; k <= 3; ++k) {
+        const uint64_t m = __ballot(t == k);
+        if (!m) continue;
+        const uint32_t lane = threadIdx.x & 63u;
+        unsigned long long base = 0;
+        if (lane == (uint32_t) __builtin_ctzll(m)) base = atomicAdd(rt.cnt[k], (unsigned long long) __builtin_popcountll(m));
+        base = (unsigned long long) __shfl((long long) base, __builtin_ctzll(m));
+        if (t == k) rt.list[k][base + (uint32_t) __builtin_popcountll(m & ((1ULL << lane) - 1ULL))] = (uint32_t) i;
+    }
+}
 
 __host__ __device__ inline uint32_t ecw_words(int32_t bases) { return (uint32_t) ((bases + 15) / 16 + 2); }
 // 32-bit words of one wave's carve-up: ts, cs, os, two wavefronts, two paths, frames
@@ -470,6 +498,7 @@ __global__ __launch_bounds__(64) void ec_wave_kernel(EcwArgs a)
             wk.read = ecw_uniu(__shfl(m1.x, i)), wk.beg_pos = ecw_uniu(__shfl(m1.y, i));
             wk.l = (int32_t) ecw_uniu(__shfl(m1.z, i)), wk.r = (int32_t) ecw_uniu(__shfl(m1.w, i));
             wk.hs16 = ecw_uniu(__shfl(m2.x, i)), wk.lp = ecw_uniu(__shfl(m2.y, i)), wk.ln = ecw_uniu(__shfl(m2.z, i)), wk.pad = 0;
+            if (wk.l > a.skip_l) continue;
             EcBlockOut o;
             o.status = EC_FAILURE, o.np = 0, o.path_off = 0, o.flags = 0, o.short_block = 0;
             if (wk.l < EC_MIN_ERR_SEQ_LEN) {
