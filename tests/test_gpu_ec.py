@@ -152,8 +152,7 @@ def test_device_ec_matches_reference(hip, case, graph, monkeypatch):
     # tiny first tiers: most blocks run in the large-LDS tier and in the HBM-slab tier -- routed there by length and run beside the first tier,
     # or (serial) found too long by each tier in turn
     t0, t1 = (48, 160) if graph.startswith("device-tiers") else (0, 0)
-    if graph == "device-tiers-serial":
-        monkeypatch.setenv("OATK_DEBUG_EC_SERIAL_TIERS", "1")
+    monkeypatch.setenv("OATK_DEBUG_EC_SERIAL_TIERS", "1" if graph == "device-tiers-serial" else "0")
     hip._check(hip.L.oatk_hip_debug_ec_tiers(hip.h, t0, t1), "oatk_hip_debug_ec_tiers")
     db, scm = device_dbs(hip, reads, K, S)                  # reference-layout structs built from the device scan + count
     L = R.lib()
