@@ -295,7 +295,12 @@ static int launch_scan_kernels(oatk_hip_ctx *ctx)
     h.nn_key = ctx->nn_key.as<uint64_t>(), h.lrl_key = ctx->lrl_key.as<uint64_t>(), h.lrl_val = ctx->lrl_val.as<uint32_t>();
     h.nn_cap = ctx->nn_cap, h.lrl_cap = ctx->lrl_cap, h.counters = ctx->counters.as<uint32_t>();
     t_begin(ctx, OATK_T_HPC);
-    hipLaunchKernelGGL(hpc_pack_kernel, dim3((unsigned) n), dim3(HPC_NT), 0, ctx->stream, h);
+    h.n_reads = (uint32_t) n;
+    uint64_t hpc_grid = (uint64_t) ctx->n_cu * 8 * 16;        // workgroups stride over the reads: eight resident per CU, sixteen rounds of them to even out read lengths
+                                                              // (config 3: 2048 workgroups 20.4 ms, 8192 17.0, 32768 16.5, one per read 17.4)
+    { const char *ev = getenv("OATK_DEBUG_HPC_GRID"); if (ev && atoi(ev) > 0) hpc_grid = (uint64_t) atoi(ev); }
+    if (hpc_grid > n) hpc_grid = n;
+    hipLaunchKernelGGL(hpc_pack_kernel, dim3((unsigned) (hpc_grid? hpc_grid : 1)), dim3(HPC_NT), 0, ctx->stream, h);
     t_end(ctx, OATK_T_HPC);
 
     SynArgs s;

@@ -68,6 +68,7 @@ struct HpcArgs {
     uint32_t *lrl_val;        // run length - 1
     uint32_t nn_cap, lrl_cap;
     uint32_t *counters;       // [0] appended to nn, [1] appended to lrl (may exceed the capacities)
+    uint32_t n_reads;         // workgroups stride over the reads (the tables and the zeroed rings are set up once per workgroup, not once per read)
 };
 
 template <int CTRL, int ROW_MASK = 0xf>
@@ -114,7 +115,15 @@ __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
     uint8_t *ring_rl = (uint8_t *) ring_rl4;
     uint32_t *ring_hs = (uint32_t *) ring_hs4;
 
-    const uint32_t r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    lut[tid] = (uint8_t) nt4_code(tid);
+    sq4[tid] = ((const uint4 *) hpc_squeeze_tab.v)[tid];
+    const uint8_t *sq = (const uint8_t *) sq4;
+    for (uint32_t i = tid; i < HPC_RING / 16; i += HPC_NT) ring_hs[i] = 0;
+    for (uint32_t i = tid; i < HPC_RING / 16; i += HPC_NT) ring_rl4[i] = make_uint4(0, 0, 0, 0);      // runs of one base (most) never write their 0
+    // (a read leaves the rings as it found them: what is flushed is zeroed, and everything staged is flushed at the read's end)
+
+    for (uint32_t r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
     const uint64_t o = a.off[r];
     const uint32_t L = a.len[r];
     const uint64_t sid = a.sid0 + r;
@@ -122,12 +131,6 @@ __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
     uint8_t *out_rl = a.ho_rl + o;
     uint8_t *out_hs = a.hoco_s + (o >> 2);
     uint32_t *out_nb = a.nbits + (o >> 5);
-
-    lut[tid] = (uint8_t) nt4_code(tid);
-    sq4[tid] = ((const uint4 *) hpc_squeeze_tab.v)[tid];
-    const uint8_t *sq = (const uint8_t *) sq4;
-    for (uint32_t i = tid; i < HPC_RING / 16; i += HPC_NT) ring_hs[i] = 0;
-    for (uint32_t i = tid; i < HPC_RING / 16; i += HPC_NT) ring_rl4[i] = make_uint4(0, 0, 0, 0);      // runs of one base (most) never write their 0
     if (tid == 0) s_nn = 0, s_lrl = 0;
 
     // move finished 64-position groups [g0, g1) from the LDS ring to HBM as 16-byte stores: four vectors of run lengths per group
@@ -379,6 +382,8 @@ __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
         a.hoco_l[r] = nstart;
         a.n_nn[r] = s_nn;
         a.n_lrl[r] = s_lrl;
+    }
+    __syncthreads();          // the rings are clean and the counters read before the next read touches them
     }
 }
 
