@@ -118,6 +118,26 @@ def test_sharded_through_the_c_collectives_equals_one_handle(hip, case, graph, m
         assert sum(o[4] for o in out) > 0                 # k-mers did travel
 
 
+def test_sharded_with_no_candidates_at_all(hip):
+    """a coverage threshold nothing reaches: no candidate is announced, no segment travels, every syncmer is deleted, no read changes"""
+    K, S, c = 301, 21, 5000
+    reads = A.hifi_like(200, 30000, 4000, seed=331, err=0.003)
+    bounds = [0, 70, 70, len(reads)]
+    L = _lib.load()
+    grp = L.oatk_comm_group_create(3)
+    try:
+        out = run_ranks(3, lambda r: L.oatk_comm_group_rank(grp, r), reads, bounds, K, S, c)
+    finally:
+        L.oatk_comm_group_destroy(grp)
+    cnt, st, want = single(hip, reads, K, S, c)
+    assert int(st[:11].sum()) == 0
+    for key in ("EC_N_SCM", "EC_KMER", "EC_MPOS", "EC_SMER"):
+        assert np.array_equal(np.concatenate([o[5][key] for o in out]), want[key]), key
+    assert np.array_equal(np.concatenate([o[5]["MG_EC_COV"] for o in out]), want["EC_SCM_COV"])
+    assert np.array_equal(np.concatenate([o[5]["MG_EC_DEL"] for o in out]), want["EC_SCM_DEL"])
+    assert all(o[3][:11].tolist() == st[:11].tolist() for o in out)
+
+
 def test_rccl_backend_world_of_one(hip):
     """the RCCL code path itself: unique id, ncclCommInitRank, all three primitives on the handle's stream"""
     K, S, c = 301, 21, 6
