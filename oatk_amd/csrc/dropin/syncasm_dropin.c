@@ -119,6 +119,8 @@ static void init(void)
         D.ctx = oatk_hip_create(e? atoi(e) : 0);
         if (!D.ctx) fprintf(stderr, "[W::oatk_dropin] no usable MI355X (gfx950) device: every call runs the original body\n");
     }
+    e = getenv("OATK_DROPIN_ARENA");
+    oatk_host_set_arena(!(e && e[0] == '0'));                            /* this build owns sr_destroy / sr_db_clean / sr_db_destroy (below) */
     D.t_ready = now();
     atexit(at_exit);
 }
@@ -133,6 +135,18 @@ static const char *why_not(int rc)
     static char buf[512];
     snprintf(buf, sizeof(buf), "device path declined (code %d: %s)", rc, D.ctx? oatk_hip_last_error(D.ctx) : "no device");
     return buf;
+}
+
+/* ------------------------------------------------- sr_destroy / sr_db_clean / sr_db_destroy ------------------------------------------------- */
+/* syncmer.c:1047-1084 with one difference: a member array that lives in an arena goes with its arena (include/oatk_syncasm.h) */
+
+void sr_destroy(oatk_sr_t *sr) { oatk_sr_destroy(sr); }
+void sr_db_clean(oatk_sr_db_t *sr_db) { oatk_sr_db_clean(sr_db); }
+void sr_db_destroy(oatk_sr_db_t *sr_db)
+{
+    if (!sr_db) return;
+    oatk_sr_db_clean(sr_db);
+    free(sr_db);
 }
 
 /* ---------------------------------------------------------------- sr_read ---------------------------------------------------------------- */
@@ -356,6 +370,7 @@ void read_error_correction(oatk_sr_db_t *sr_db, oatk_scg_t *g, double max_edist,
         real = orig_make_syncmer_graph(sr_db, g->scm_db, 0, 0.);
         scg_consensus(sr_db, real, 1, 1, 0);
     }
+    oatk_sr_db_own_chains(sr_db);                                       /* the original reallocs k_mer / m_pos / s_mer (syncerr.c:604-608) */
     orig_read_error_correction(sr_db, real? real : g, max_edist, err_mer_c, max_err_c, err_arc_c, max_arc_f, n_threads, fo, verbose);
     if (real) scg_destroy(real);
     note(F_EC, 1, t0, why);

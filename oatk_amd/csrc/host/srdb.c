@@ -15,6 +15,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
 #include <time.h>
 
 #include "oatk_syncasm.h"
@@ -91,6 +92,79 @@ typedef struct {
 
 static uint8_t *g_heap_top = 0;                       /* where the last large block ended: survives from one call to the next */
 
+/* ---- arenas (opt-in: oatk_host_set_arena) --------------------------------------------------------------------------------------------------
+ * The reference frees every member array of every read with free() (sr_destroy, syncmer.c:1047-1058) and reallocs the chains in
+ * read_error_correction (syncerr.c:604-608), so by default every array handed out is its own malloc'ed block: 7 per read, 14 M at 2 M reads,
+ * all from one thread (above), and as many free() calls at the end.  A program that also owns the destroy functions -- the drop-in binary
+ * does, include/oatk_dropin.h -- can ask for ARENAS instead: one block per piece of reads (tens of MB: an anonymous mapping, fresh zero pages
+ * that the copying threads touch first, in parallel), the member pointers carved from it; a registry of the blocks tells arena memory from
+ * malloc'ed memory wherever a member is freed or replaced. */
+typedef struct { uint8_t *base; size_t size; const void *owner; } host_arena_t;
+static host_arena_t *g_ar = 0;
+static size_t g_nar = 0, g_mar = 0;
+static int g_use_arena = 0;
+static pthread_mutex_t g_ar_mu = PTHREAD_MUTEX_INITIALIZER;
+
+void oatk_host_set_arena(int on) { g_use_arena = on != 0; }
+int oatk_host_arena(void) { return g_use_arena; }
+
+/* index of the arena that holds p, or -1; *hint (may be NULL) = where the previous lookup ended: members of consecutive reads are neighbours */
+static long arena_of(const void *p, long *hint)
+{
+    const uint8_t *q = (const uint8_t *) p;
+    if (!g_nar || !p) return -1;
+    if (hint && *hint >= 0 && (size_t) *hint < g_nar && q >= g_ar[*hint].base && q < g_ar[*hint].base + g_ar[*hint].size) return *hint;
+    size_t lo = 0, hi = g_nar;                       /* sorted by base */
+    while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (g_ar[mid].base + g_ar[mid].size <= q) lo = mid + 1; else hi = mid; }
+    if (lo < g_nar && q >= g_ar[lo].base) { if (hint) *hint = (long) lo; return (long) lo; }
+    return -1;
+}
+static uint8_t *arena_new(size_t size, const void *owner)
+{
+    uint8_t *b = (uint8_t *) xmalloc(size? size : 1);
+    pthread_mutex_lock(&g_ar_mu);
+    if (g_nar == g_mar) { g_mar = g_mar? 2 * g_mar : 256; g_ar = (host_arena_t *) realloc(g_ar, g_mar * sizeof(host_arena_t)); if (!g_ar) abort(); }
+    size_t at = g_nar;
+    while (at && g_ar[at - 1].base > b) { g_ar[at] = g_ar[at - 1]; --at; }
+    g_ar[at].base = b, g_ar[at].size = size? size : 1, g_ar[at].owner = owner;
+    ++g_nar;
+    pthread_mutex_unlock(&g_ar_mu);
+    if (size >= ((size_t) 4 << 20)) {               /* huge pages for the bulk of it: 512 times fewer first-touch faults */
+        const uintptr_t h0 = ((uintptr_t) b + (((uintptr_t) 2 << 20) - 1)) & ~(((uintptr_t) 2 << 20) - 1), h1 = ((uintptr_t) b + size) & ~(((uintptr_t) 2 << 20) - 1);
+        if (h1 > h0) (void) madvise((void *) h0, h1 - h0, MADV_HUGEPAGE);
+    }
+    return b;
+}
+static void arena_release(const void *owner)
+{
+    pthread_mutex_lock(&g_ar_mu);
+    size_t i, k = 0;
+    for (i = 0; i < g_nar; ++i) {
+        if (g_ar[i].owner == owner) free(g_ar[i].base);
+        else g_ar[k++] = g_ar[i];
+    }
+    g_nar = k;
+    pthread_mutex_unlock(&g_ar_mu);
+}
+/* free() for a member array that may live in an arena (then it goes with its arena) */
+void oatk_sr_member_free(void *p) { if (p && arena_of(p, 0) < 0) free(p); }
+void *oatk_host_arena_alloc(size_t bytes, const void *owner) { return arena_new(bytes, owner); }
+
+/* the chains of every read as blocks of their own again: what the reference's read_error_correction reallocs (syncerr.c:604-608) */
+void oatk_sr_db_own_chains(oatk_sr_db_t *sr_db)
+{
+    size_t i;
+    long hint = -1;
+    if (!sr_db || !g_nar) return;
+    for (i = 0; i < sr_db->n; ++i) {
+        oatk_sr_t *r = &sr_db->a[i];
+        const size_t n = r->n;
+        if (r->k_mer && arena_of(r->k_mer, &hint) >= 0) r->k_mer = (uint64_t *) memcpy(xmalloc(8 * n + 8), r->k_mer, 8 * n);
+        if (r->m_pos && arena_of(r->m_pos, &hint) >= 0) r->m_pos = (uint32_t *) memcpy(xmalloc(4 * n + 8), r->m_pos, 4 * n);
+        if (r->s_mer && arena_of(r->s_mer, &hint) >= 0) r->s_mer = (uint64_t *) memcpy(xmalloc(8 * n + 8), r->s_mer, 8 * n);
+    }
+}
+
 /* the blocks of reads [i0, i1), allocated by ONE thread: glibc grows a thread arena a few pages at a time under the address-space lock, so
  * many threads allocating gigabytes get in each other's way; the main heap grows in large steps (M_TOP_PAD below) and costs ~40 ns per block */
 static void fill_alloc(fill_job_t *j)
@@ -98,6 +172,34 @@ static void fill_alloc(fill_job_t *j)
     uint64_t i;
     const double t0 = host_now();
     uint8_t *first = 0, *last = 0;
+    if (g_use_arena) {
+        /* one block for the piece; every member 8-byte aligned inside it */
+#define A8(x) (((size_t) (x) + 7) & ~(size_t) 7)
+        size_t tot = 0;
+        for (i = j->a0; i < j->a1; ++i) {
+            const size_t hl = j->hoco_l[i], ns = j->scm_off[i + 1] - j->scm_off[i];
+            tot += A8((hl + 3) / 4) + A8(hl) + A8(4 * (size_t) j->n_lrl[i]) + A8(4 * (size_t) j->n_nn[i]) + A8(4 * ns) + 16 * ns;
+        }
+        uint8_t *p = arena_new(tot, j->sr_db);
+        for (i = j->a0; i < j->a1; ++i) {
+            oatk_sr_t *r = &j->sr_db->a[j->first + i];
+            const size_t hl = j->hoco_l[i], ns = j->scm_off[i + 1] - j->scm_off[i];
+            r->sid = j->first + i;
+            r->sname = j->names? j->names[i] : 0;
+            r->hoco_l = (uint32_t) hl;
+            r->hoco_s = hl? p : 0, p += A8((hl + 3) / 4);
+            r->ho_rl = hl? p : 0, p += A8(hl);
+            r->ho_l_rl = j->n_lrl[i]? (uint32_t *) p : 0, p += A8(4 * (size_t) j->n_lrl[i]);
+            r->n_nucl = j->n_nn[i]? (uint32_t *) p : 0, p += A8(4 * (size_t) j->n_nn[i]);
+            r->n = (uint32_t) ns;
+            r->m_pos = ns? (uint32_t *) p : 0, p += A8(4 * ns);
+            r->s_mer = ns? (uint64_t *) p : 0, p += 8 * ns;
+            r->k_mer = ns? (uint64_t *) p : 0, p += 8 * ns;
+        }
+#undef A8
+        j->t_alloc += host_now() - t0;
+        return;
+    }
     for (i = j->a0; i < j->a1; ++i) {
         oatk_sr_t *r = &j->sr_db->a[j->first + i];
         const uint32_t hl = j->hoco_l[i];
@@ -130,7 +232,7 @@ static void fill_alloc(fill_job_t *j)
 static void fill_prefault_plan(fill_job_t *j)
 {
     j->pre0 = j->pre1 = 0;
-    if (!g_heap_top || j->a1 <= j->a0) return;
+    if (g_use_arena || !g_heap_top || j->a1 <= j->a0) return;          /* (an arena is a fresh mapping: its pages are touched by the copies themselves) */
     if ((pid_t) syscall(SYS_gettid) != getpid()) return;       /* the main heap is the main thread's arena: only there do the next blocks come from its top */
     uint64_t need = 0, i;
     for (i = j->a0; i < j->a1; ++i) need += (uint64_t) j->hoco_l[i] + ((uint64_t) j->hoco_l[i] + 3) / 4 + 20 * (j->scm_off[i + 1] - j->scm_off[i]) + 160;
@@ -381,14 +483,33 @@ void oatk_sr_db_clean(oatk_sr_db_t *sr_db)
 {
     size_t i;
     if (!sr_db) return;
+    if (g_nar) {
+        long hint = -1;
+        for (i = 0; i < sr_db->n; ++i) {
+            oatk_sr_t *r = &sr_db->a[i];
+            void *m[8] = {r->sname, r->hoco_s, r->ho_rl, r->ho_l_rl, r->n_nucl, r->m_pos, r->s_mer, r->k_mer};
+            int k;
+            for (k = 0; k < 8; ++k) if (m[k] && arena_of(m[k], &hint) < 0) free(m[k]);
+        }
+        arena_release(sr_db);
+    } else {
     for (i = 0; i < sr_db->n; ++i) {
         oatk_sr_t *r = &sr_db->a[i];
         free(r->sname); free(r->hoco_s); free(r->ho_rl); free(r->ho_l_rl); free(r->n_nucl);
         free(r->m_pos); free(r->s_mer); free(r->k_mer);
     }
+    }
     free(sr_db->a);
     free(sr_db->stats);
     sr_db->a = 0, sr_db->n = sr_db->m = 0, sr_db->stats = 0;
+}
+
+void oatk_sr_destroy(oatk_sr_t *r)
+{
+    if (!r) return;
+    void *m[8] = {r->sname, r->hoco_s, r->ho_rl, r->ho_l_rl, r->n_nucl, r->m_pos, r->s_mer, r->k_mer};
+    int k;
+    for (k = 0; k < 8; ++k) oatk_sr_member_free(m[k]);
 }
 
 void oatk_syncmer_db_destroy(oatk_syncmer_db_t *db)
