@@ -9,12 +9,13 @@
  *     make_syncmer_graph           syncasm.c:203      -> oatk_hip_ec_graph (the (0, 0.) call) / oatk_make_syncmer_asmg
  *     read_error_correction        syncerr.c:819      -> oatk_read_error_correction
  *     scg_read_alignment           alignment.c:596    -> oatk_scg_read_alignment
- *     sr_destroy, sr_db_clean, sr_db_destroy   syncmer.c:1047-1084   -> oatk_sr_destroy / oatk_sr_db_clean: owning these three is what lets sr_read
+ *     sr_destroy, sr_db_clean, sr_db_destroy, syncmer_db_clean, syncmer_db_destroy   syncmer.c:1047-1110   -> oatk_sr_destroy / oatk_sr_db_clean /
+ *                                  oatk_syncmer_db_clean: owning these is what lets sr_read
  *                                  hand out the member arrays of a whole piece of reads as ONE block instead of seven malloc'ed blocks per read
  *                                  (include/oatk_syncasm.h: arenas; OATK_DROPIN_ARENA=0 keeps the reference's one-block-per-array layout)
  *
  * and the two hook pointers below, which scg_syncmer_consensus (syncasm.c:888) and calc_syncmer_overlap (:477) consult first
- * (INTEGRATION.md 3b / 3b').  A maintainer links it in front of the reference's objects after renaming the nine original
+ * (INTEGRATION.md 3b / 3b').  A maintainer links it in front of the reference's objects after renaming the eleven original
  * definitions to orig_<name> (objcopy --redefine-sym; every caller lives in another translation unit, so the calls bind to the
  * new definitions and the original bodies stay reachable):  run_syncasm.c, the CLI and everything downstream are untouched.
  *

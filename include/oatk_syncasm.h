@@ -231,13 +231,16 @@ void oatk_sr_db_clean(oatk_sr_db_t *sr_db);
  * By default every member array handed out is its own malloc'ed block, because the reference frees and reallocs them one by one (sr_destroy
  * syncmer.c:1047-1058; read_error_correction syncerr.c:604-608): 7 blocks per read.  With oatk_host_set_arena(1) the reads of a piece share ONE
  * block (and so do the chains read_error_correction rewrites); then ONLY these functions may free or replace members:
- *   oatk_sr_db_clean / oatk_sr_destroy   sr_db_clean / sr_destroy
+ *   oatk_sr_db_clean / oatk_sr_destroy   sr_db_clean / sr_destroy   (and oatk_syncmer_db_clean / _destroy for the occurrence lists of the syncmer table)
  *   oatk_sr_member_free(p)               free() for a member that may live in an arena
  *   oatk_sr_db_own_chains(sr_db)         k_mer / m_pos / s_mer of every read back into blocks of their own, before handing the database to code
  *                                        that reallocs them (the reference's own read_error_correction) */
 void oatk_host_set_arena(int on);
 int oatk_host_arena(void);
-void *oatk_host_arena_alloc(size_t bytes, const void *owner);      /* released with the owner's oatk_sr_db_clean */
+void *oatk_host_arena_alloc(size_t bytes, const void *owner);      /* released with the owner's oatk_sr_db_clean / oatk_syncmer_db_clean */
+void oatk_host_arena_adopt(void *block, size_t bytes, const void *owner);     /* a malloc'ed block becomes an arena of `owner` */
+void oatk_syncmer_db_clean(oatk_syncmer_db_t *scm_db);             /* syncmer_db_clean, arena-aware like oatk_syncmer_db_destroy */
+void oatk_syncmer_db_own_mpos(oatk_syncmer_db_t *scm_db);          /* every syncmer's m_pos back into a block of its own (before the reference's update_syncmer_db) */
 void oatk_sr_member_free(void *p);
 void oatk_sr_destroy(oatk_sr_t *sr);
 void oatk_sr_db_own_chains(oatk_sr_db_t *sr_db);

@@ -137,7 +137,7 @@ static const char *why_not(int rc)
     return buf;
 }
 
-/* ------------------------------------------------- sr_destroy / sr_db_clean / sr_db_destroy ------------------------------------------------- */
+/* ------------------------------- sr_destroy / sr_db_clean / sr_db_destroy / syncmer_db_clean / syncmer_db_destroy ------------------------------- */
 /* syncmer.c:1047-1084 with one difference: a member array that lives in an arena goes with its arena (include/oatk_syncasm.h) */
 
 void sr_destroy(oatk_sr_t *sr) { oatk_sr_destroy(sr); }
@@ -148,6 +148,8 @@ void sr_db_destroy(oatk_sr_db_t *sr_db)
     oatk_sr_db_clean(sr_db);
     free(sr_db);
 }
+void syncmer_db_clean(oatk_syncmer_db_t *scm_db) { oatk_syncmer_db_clean(scm_db); }          /* syncmer.c:1094-1110 */
+void syncmer_db_destroy(oatk_syncmer_db_t *scm_db) { oatk_syncmer_db_destroy(scm_db); }
 
 /* ---------------------------------------------------------------- sr_read ---------------------------------------------------------------- */
 
@@ -371,6 +373,7 @@ void read_error_correction(oatk_sr_db_t *sr_db, oatk_scg_t *g, double max_edist,
         scg_consensus(sr_db, real, 1, 1, 0);
     }
     oatk_sr_db_own_chains(sr_db);                                       /* the original reallocs k_mer / m_pos / s_mer (syncerr.c:604-608) */
+    oatk_syncmer_db_own_mpos(g->scm_db);                                /* ... and frees and mallocs every syncmer's occurrence list (:789-790) */
     orig_read_error_correction(sr_db, real? real : g, max_edist, err_mer_c, max_err_c, err_arc_c, max_arc_f, n_threads, fo, verbose);
     if (real) scg_destroy(real);
     note(F_EC, 1, t0, why);

@@ -46,7 +46,7 @@ typedef struct {
     const uint8_t *del;
     const uint64_t *occ_off, *occ;
     uint64_t *new_off;
-    uint8_t *chains;               /* arena for the new chains, or NULL: one malloc'ed block per array */
+    int adopt;                     /* arenas in use (include/oatk_syncasm.h): point into the fetched arrays instead of copying out of them */
 } ecw_job_t;
 
 /* what the reference's own threads leave per read (syncerr.c:600-612) and update_syncmer_db per syncmer (:769-814) */
@@ -60,12 +60,8 @@ static void ecw_worker(void *arg, int tid, int n_threads)
         const uint32_t n = j->new_n[i];
         const uint64_t o = j->new_off[i];
         oatk_sr_member_free(r->k_mer); oatk_sr_member_free(r->m_pos); oatk_sr_member_free(r->s_mer);
-        if (j->chains) {            /* arenas in use: the new chains of all reads share one block, entry o of the concatenation at 20 o bytes ... */
-            uint8_t *p = j->chains + 24 * o;       /* ... rounded up: 8 + 8 + 4 (+ 4 of padding) bytes per entry keep every array 8-byte aligned */
-            r->k_mer = (uint64_t *) memcpy(p, j->new_k + o, 8 * (size_t) n);
-            r->s_mer = (uint64_t *) memcpy(p + 8 * (size_t) n, j->new_s + o, 8 * (size_t) n);
-            r->m_pos = (uint32_t *) memcpy(p + 16 * (size_t) n, j->new_m + o, 4 * (size_t) n);
-            if (!n) r->k_mer = 0, r->s_mer = 0, r->m_pos = 0;
+        if (j->adopt) {             /* arenas in use: the arrays fetched from the device ARE the reads' storage from now on */
+            r->k_mer = n? (uint64_t *) j->new_k + o : 0, r->s_mer = n? (uint64_t *) j->new_s + o : 0, r->m_pos = n? (uint32_t *) j->new_m + o : 0;
         } else {
             r->k_mer = (uint64_t *) memcpy(xmalloc(8 * (size_t) n), j->new_k + o, 8 * (size_t) n);
             r->m_pos = (uint32_t *) memcpy(xmalloc(4 * (size_t) n), j->new_m + o, 4 * (size_t) n);
@@ -76,9 +72,10 @@ static void ecw_worker(void *arg, int tid, int n_threads)
     const uint64_t ns = j->scm_db->n, sa = ns * (uint64_t) tid / (uint64_t) n_threads, sb = ns * (uint64_t) (tid + 1) / (uint64_t) n_threads;
     for (i = sa; i < sb; ++i) {
         oatk_syncmer_t *m = &j->scm_db->a[i];
-        free(m->m_pos);
+        oatk_sr_member_free(m->m_pos);
         m->cov = j->cov[i], m->del = j->del[i];
-        m->m_pos = (uint64_t *) memcpy(xmalloc(8 * (size_t) j->cov[i]), j->occ + j->occ_off[i], 8 * (size_t) j->cov[i]);
+        m->m_pos = j->adopt? (uint64_t *) j->occ + j->occ_off[i]
+                           : (uint64_t *) memcpy(xmalloc(8 * (size_t) j->cov[i]), j->occ + j->occ_off[i], 8 * (size_t) j->cov[i]);
     }
 }
 
@@ -143,10 +140,19 @@ int oatk_read_error_correction(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, oatk_sync
         ecw_job_t job = {sr_db, scm_db, new_n, new_k, new_m, new_s, cov, del, occ_off, occ, 0, 0};
         job.new_off = (uint64_t *) xmalloc(8 * (sr_db->n + 1));
         for (i = 0, job.new_off[0] = 0; i < sr_db->n; ++i) job.new_off[i + 1] = job.new_off[i] + new_n[i];
-        job.chains = oatk_host_arena()? (uint8_t *) oatk_host_arena_alloc(24 * (size_t) job.new_off[sr_db->n] + 8, sr_db) : 0;
+        job.adopt = oatk_host_arena();
         free(scm_db->c); scm_db->c = 0;
         free(scm_db->h); scm_db->h = 0;
         oatk_par_run(ecw_worker, &job);
+        if (job.adopt) {
+            /* what the reads and the table pointed into before (their fill-time arenas, the arrays adopted by the count) stays until the
+             * databases are cleaned: a few arrays of the size of the chains, against a free() per read and per syncmer */
+            const size_t tot = (size_t) job.new_off[sr_db->n];
+            oatk_host_arena_adopt(new_k, 8 * tot, sr_db), new_k = 0;
+            oatk_host_arena_adopt(new_m, 4 * tot, sr_db), new_m = 0;
+            oatk_host_arena_adopt(new_s, 8 * tot, sr_db), new_s = 0;
+            oatk_host_arena_adopt(occ, 8 * tot, scm_db), occ = 0;
+        }
         free(job.new_off);
     }
 done:

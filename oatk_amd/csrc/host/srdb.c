@@ -119,9 +119,19 @@ static long arena_of(const void *p, long *hint)
     if (lo < g_nar && q >= g_ar[lo].base) { if (hint) *hint = (long) lo; return (long) lo; }
     return -1;
 }
+static void arena_register(uint8_t *b, size_t size, const void *owner);
 static uint8_t *arena_new(size_t size, const void *owner)
 {
     uint8_t *b = (uint8_t *) xmalloc(size? size : 1);
+    arena_register(b, size, owner);
+    if (size >= ((size_t) 4 << 20)) {               /* huge pages for the bulk of it: 512 times fewer first-touch faults */
+        const uintptr_t h0 = ((uintptr_t) b + (((uintptr_t) 2 << 20) - 1)) & ~(((uintptr_t) 2 << 20) - 1), h1 = ((uintptr_t) b + size) & ~(((uintptr_t) 2 << 20) - 1);
+        if (h1 > h0) (void) madvise((void *) h0, h1 - h0, MADV_HUGEPAGE);
+    }
+    return b;
+}
+static void arena_register(uint8_t *b, size_t size, const void *owner)
+{
     pthread_mutex_lock(&g_ar_mu);
     if (g_nar == g_mar) { g_mar = g_mar? 2 * g_mar : 256; g_ar = (host_arena_t *) realloc(g_ar, g_mar * sizeof(host_arena_t)); if (!g_ar) abort(); }
     size_t at = g_nar;
@@ -129,12 +139,9 @@ static uint8_t *arena_new(size_t size, const void *owner)
     g_ar[at].base = b, g_ar[at].size = size? size : 1, g_ar[at].owner = owner;
     ++g_nar;
     pthread_mutex_unlock(&g_ar_mu);
-    if (size >= ((size_t) 4 << 20)) {               /* huge pages for the bulk of it: 512 times fewer first-touch faults */
-        const uintptr_t h0 = ((uintptr_t) b + (((uintptr_t) 2 << 20) - 1)) & ~(((uintptr_t) 2 << 20) - 1), h1 = ((uintptr_t) b + size) & ~(((uintptr_t) 2 << 20) - 1);
-        if (h1 > h0) (void) madvise((void *) h0, h1 - h0, MADV_HUGEPAGE);
-    }
-    return b;
 }
+/* a malloc'ed block the caller already holds (an array fetched from the device) becomes an arena: its parts are handed out as they lie */
+void oatk_host_arena_adopt(void *block, size_t bytes, const void *owner) { if (block) arena_register((uint8_t *) block, bytes? bytes : 1, owner); }
 static void arena_release(const void *owner)
 {
     pthread_mutex_lock(&g_ar_mu);
@@ -149,6 +156,18 @@ static void arena_release(const void *owner)
 /* free() for a member array that may live in an arena (then it goes with its arena) */
 void oatk_sr_member_free(void *p) { if (p && arena_of(p, 0) < 0) free(p); }
 void *oatk_host_arena_alloc(size_t bytes, const void *owner) { return arena_new(bytes, owner); }
+
+/* the occurrence list of every syncmer as a block of its own again: what update_syncmer_db frees and mallocs (syncerr.c:789-790) */
+void oatk_syncmer_db_own_mpos(oatk_syncmer_db_t *db)
+{
+    size_t i;
+    long hint = -1;
+    if (!db || !g_nar) return;
+    for (i = 0; i < db->n; ++i) {
+        oatk_syncmer_t *m = &db->a[i];
+        if (m->m_pos && arena_of(m->m_pos, &hint) >= 0) m->m_pos = (uint64_t *) memcpy(xmalloc(8 * (size_t) m->cov + 8), m->m_pos, 8 * (size_t) m->cov);
+    }
+}
 
 /* the chains of every read as blocks of their own again: what the reference's read_error_correction reallocs (syncerr.c:604-608) */
 void oatk_sr_db_own_chains(oatk_sr_db_t *sr_db)
@@ -412,6 +431,7 @@ typedef struct {
     const uint32_t *cov;
     const uint64_t *occ_off, *occ, *kid;
     uint64_t *kid_off;
+    int adopt;
 } collect_job_t;
 
 static void collect_worker(void *arg, int tid, int n_threads)
@@ -422,7 +442,8 @@ static void collect_worker(void *arg, int tid, int n_threads)
     for (i = a; i < b; ++i) {
         oatk_syncmer_t *m = &j->db->a[i];
         m->h = j->h[i], m->s = j->s[i], m->cov = j->cov[i], m->del = 0;
-        m->m_pos = (uint64_t *) memcpy(xmalloc(8 * (size_t) j->cov[i]), j->occ + j->occ_off[i], 8 * (size_t) j->cov[i]);
+        m->m_pos = j->adopt? (uint64_t *) j->occ + j->occ_off[i]          /* arenas: the fetched array IS the table's storage */
+                           : (uint64_t *) memcpy(xmalloc(8 * (size_t) j->cov[i]), j->occ + j->occ_off[i], 8 * (size_t) j->cov[i]);
         j->db->c[i] = 1;                                   /* syncmer.c:1443-1444 */
     }
     /* reads: k-mer hash -> syncmer id << 1 (syncmer.c:1378) */
@@ -462,7 +483,7 @@ oatk_syncmer_db_t *oatk_collect_syncmer_from_reads(oatk_hip_ctx *ctx, oatk_sr_db
     db->a = (oatk_syncmer_t *) xmalloc(sizeof(oatk_syncmer_t) * inf.n_scm);
     db->c = (uint16_t *) xmalloc(sizeof(uint16_t) * inf.n_scm);
     db->h = 0;
-    collect_job_t job = {db, sr_db, h, s, cov, occ_off, occ, kid, 0};
+    collect_job_t job = {db, sr_db, h, s, cov, occ_off, occ, kid, 0, g_use_arena};
     /* where each read's ids start in POS_KID: the chain lengths have not changed since the scan */
     job.kid_off = (uint64_t *) xmalloc(8 * (sr_db->n + 1));
     {
@@ -471,6 +492,7 @@ oatk_syncmer_db_t *oatk_collect_syncmer_from_reads(oatk_hip_ctx *ctx, oatk_sr_db
     }
     oatk_par_run(collect_worker, &job);
     free(job.kid_off);
+    if (job.adopt) oatk_host_arena_adopt(occ, 8 * (size_t) inf.n_occ, db), occ = 0;
     free(h); free(s); free(cov); free(occ_off); free(occ); free(kid);
     return db;
 fail:
@@ -512,12 +534,26 @@ void oatk_sr_destroy(oatk_sr_t *r)
     for (k = 0; k < 8; ++k) oatk_sr_member_free(m[k]);
 }
 
-void oatk_syncmer_db_destroy(oatk_syncmer_db_t *db)
+void oatk_syncmer_db_clean(oatk_syncmer_db_t *db)      /* syncmer.c:1094-1103 */
 {
     size_t i;
     if (!db) return;
-    for (i = 0; i < db->n; ++i) free(db->a[i].m_pos);
-    free(db->a); free(db->c); free(db->h); free(db);
+    if (g_nar) {
+        long hint = -1;
+        for (i = 0; i < db->n; ++i) if (db->a[i].m_pos && arena_of(db->a[i].m_pos, &hint) < 0) free(db->a[i].m_pos);
+        arena_release(db);
+    } else {
+        for (i = 0; i < db->n; ++i) free(db->a[i].m_pos);
+    }
+    free(db->a); free(db->c); free(db->h);
+    db->a = 0, db->n = db->m = 0, db->c = 0, db->h = 0;
+}
+
+void oatk_syncmer_db_destroy(oatk_syncmer_db_t *db)
+{
+    if (!db) return;
+    oatk_syncmer_db_clean(db);
+    free(db);
 }
 
 /* malloc'ed, initialised like sr_db_init (syncmer.c:1060-1067); freed by the reference's sr_db_destroy or oatk_sr_db_clean + free */
