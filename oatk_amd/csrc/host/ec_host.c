@@ -74,7 +74,7 @@ static void ecw_worker(void *arg, int tid, int n_threads)
         oatk_syncmer_t *m = &j->scm_db->a[i];
         oatk_sr_member_free(m->m_pos);
         m->cov = j->cov[i], m->del = j->del[i];
-        m->m_pos = j->adopt? (uint64_t *) j->occ + j->occ_off[i]
+        m->m_pos = j->adopt? (j->cov[i]? (uint64_t *) j->occ + j->occ_off[i] : 0)         /* (an empty list: NULL, which free() and realloc() take) */
                            : (uint64_t *) memcpy(xmalloc(8 * (size_t) j->cov[i]), j->occ + j->occ_off[i], 8 * (size_t) j->cov[i]);
     }
 }

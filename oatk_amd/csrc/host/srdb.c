@@ -141,7 +141,7 @@ static void arena_register(uint8_t *b, size_t size, const void *owner)
     pthread_mutex_unlock(&g_ar_mu);
 }
 /* a malloc'ed block the caller already holds (an array fetched from the device) becomes an arena: its parts are handed out as they lie */
-void oatk_host_arena_adopt(void *block, size_t bytes, const void *owner) { if (block) arena_register((uint8_t *) block, bytes? bytes : 1, owner); }
+void oatk_host_arena_adopt(void *block, size_t bytes, const void *owner) { if (block) arena_register((uint8_t *) block, bytes + 1, owner); }      /* (+ 1: a pointer one past the end belongs to it too) */
 static void arena_release(const void *owner)
 {
     pthread_mutex_lock(&g_ar_mu);
@@ -442,7 +442,7 @@ static void collect_worker(void *arg, int tid, int n_threads)
     for (i = a; i < b; ++i) {
         oatk_syncmer_t *m = &j->db->a[i];
         m->h = j->h[i], m->s = j->s[i], m->cov = j->cov[i], m->del = 0;
-        m->m_pos = j->adopt? (uint64_t *) j->occ + j->occ_off[i]          /* arenas: the fetched array IS the table's storage */
+        m->m_pos = j->adopt? (j->cov[i]? (uint64_t *) j->occ + j->occ_off[i] : 0)          /* arenas: the fetched array IS the table's storage */
                            : (uint64_t *) memcpy(xmalloc(8 * (size_t) j->cov[i]), j->occ + j->occ_off[i], 8 * (size_t) j->cov[i]);
         j->db->c[i] = 1;                                   /* syncmer.c:1443-1444 */
     }
