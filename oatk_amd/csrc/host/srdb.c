@@ -124,7 +124,9 @@ static uint8_t *arena_new(size_t size, const void *owner)
 {
     uint8_t *b = (uint8_t *) xmalloc(size? size : 1);
     arena_register(b, size, owner);
-    if (size >= ((size_t) 4 << 20)) {               /* huge pages for the bulk of it: 512 times fewer first-touch faults */
+    static int thp = -1;
+    if (thp < 0) { const char *e = getenv("OATK_HOST_THP"); thp = !(e && e[0] == '0'); }
+    if (thp && size >= ((size_t) 4 << 20)) {        /* huge pages for the bulk of it: 512 times fewer first-touch faults */
         const uintptr_t h0 = ((uintptr_t) b + (((uintptr_t) 2 << 20) - 1)) & ~(((uintptr_t) 2 << 20) - 1), h1 = ((uintptr_t) b + size) & ~(((uintptr_t) 2 << 20) - 1);
         if (h1 > h0) (void) madvise((void *) h0, h1 - h0, MADV_HUGEPAGE);
     }
