@@ -358,7 +358,8 @@ static int sr_read_stream(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, int K, int S, 
     pthread_mutex_init(&st.mu, 0);
     pthread_cond_init(&st.cv, 0);
     st.seg = seg, st.n_seg = n_files, st.total = total, st.win = win;
-    st.n_up = threads > 1? threads - threads / 2 : 1;
+    st.n_up = threads > 1? threads : 1;            /* readers of the file beside the threads that fill the structs: with the reads in arenas the file is what sr_read waits for */
+    { const char *e = getenv("OATK_HOST_UP_THREADS"); if (e && atoi(e) > 0) st.n_up = atoi(e); }
     const int fmt = sniff_format(seg, n_files, total);
     rc = oatk_hip_scan_begin(ctx, 0, K, S);
     st.up = rc? 0 : oatk_hip_create(dev);
