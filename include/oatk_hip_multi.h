@@ -54,8 +54,10 @@ const char *oatk_comm_backend(const oatk_comm *c);          /* "rccl" or "local"
 /* after oatk_hip_count on every rank.  Resident afterwards (oatk_hip_buffer): this rank's RANGE of the global table -- MG_H u64[n_owned] hashes
  * ascending, MG_S u64[n_owned] s-mers, MG_COV u32[n_owned] coverage over all shards (global ids first_id .. first_id + n_owned, oatk_hip_multi_range;
  * the ranges of all ranks in rank order are the whole table) -- and for its own syncmers MG_L2G u32[n_local] global id, MG_LCOV u32[n_local]
- * coverage over all shards.  OATK_E_SPLIT when this shard's table holds one hash twice (a split collision: ranks by hash are ambiguous),
- * OATK_E_SMER when one hash carries different s-mers on two shards. */
+ * coverage over all shards.  Entries that share a hash -- one per shard for a true syncmer; or different k-mers, a 64-bit collision, within a
+ * shard or across shards -- are compared k-mer by k-mer on the owner (their shards send the k-mers) and clustered in first-seen order like
+ * process_kmer_cluster (syncmer.c:1293-1335) does for one database: the ids are the reference's, collisions included.  OATK_E_SMER when
+ * identical k-mers carry different s-mers (fatal in the reference, :1370). */
 int oatk_hip_merge_counts(oatk_hip_ctx *ctx, oatk_comm *comm, uint64_t *n_global);
 int oatk_hip_multi_range(oatk_hip_ctx *ctx, uint64_t *first_id, uint64_t *n_owned, uint64_t *n_global);      /* any pointer may be NULL */
 

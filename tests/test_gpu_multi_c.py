@@ -40,12 +40,14 @@ def single(hip, reads, K, S, c):
     return cnt, st, want
 
 
-def run_ranks(world, make_comm, reads, bounds, K, S, c):
+def run_ranks(world, make_comm, reads, bounds, K, S, c, mask=None):
     out, errs = [None] * world, []
 
     def work(rank):
         try:
             h = HipSyncasm(0)
+            if mask is not None:
+                h.debug_hash_mask(mask)
             comm = make_comm(rank)
             lo, hi = bounds[rank], bounds[rank + 1]
             seq, off, lens = pack_reads(reads[lo:hi])
@@ -116,6 +118,39 @@ def test_sharded_through_the_c_collectives_equals_one_handle(hip, case, graph, m
     assert int(st[0] + st[5] + st[10]) > 0
     if case == 2:
         assert sum(o[4] for o in out) > 0                 # k-mers did travel
+
+
+@pytest.mark.parametrize("mask", [0xFF, 0x3FF])
+def test_sharded_with_forced_hash_collisions(hip, mask):
+    """hashes ANDed down to a few bits (the hook of tests/test_gpu_scan.py::test_forced_hash_collisions): unrelated k-mers share a hash inside a
+    shard and across shards.  The owners compare the k-mers and cluster them in first-seen order, so ids, coverage and everything downstream
+    still equal one handle's -- which splits the same collisions on its own (process_kmer_cluster, syncmer.c:1293-1335)."""
+    K, S, c = 101, 11, 4
+    reads = A.hifi_like(120, 5000, 1500, seed=5, err=0.004)
+    bounds = [0, 35, 80, len(reads)]
+    L = _lib.load()
+    grp = L.oatk_comm_group_create(3)
+    try:
+        out = run_ranks(3, lambda r: L.oatk_comm_group_rank(grp, r), reads, bounds, K, S, c, mask=mask)
+    finally:
+        L.oatk_comm_group_destroy(grp)
+    hip.debug_hash_mask(mask)
+    try:
+        cnt, st, want = single(hip, reads, K, S, c)
+        assert hip.info()["collisions"] == 1
+    finally:
+        hip.debug_hash_mask(0xFFFFFFFFFFFFFFFF)
+    assert len(np.unique(cnt["h"])) < cnt["n_scm"]                       # several syncmers per "hash"
+    for key, ref in (("MG_H", cnt["h"]), ("MG_S", cnt["s"]), ("MG_COV", cnt["cov"])):
+        assert np.array_equal(np.concatenate([o[1][key] for o in out]), ref), key
+    for rank, (ng, mg, local_h, st_r, n_imp, res) in enumerate(out):
+        assert ng == cnt["n_scm"] and st_r[:11].tolist() == st[:11].tolist()
+        l2g = mg["MG_L2G"].astype(np.int64)
+        assert np.array_equal(cnt["h"][l2g], local_h) and np.array_equal(cnt["cov"][l2g], mg["MG_LCOV"]) and len(np.unique(l2g)) == len(l2g)
+    for key in ("EC_N_SCM", "EC_KMER", "EC_MPOS", "EC_SMER"):
+        assert np.array_equal(np.concatenate([o[5][key] for o in out]), want[key]), key
+    assert np.array_equal(np.concatenate([o[5]["MG_EC_COV"] for o in out]), want["EC_SCM_COV"])
+    assert np.array_equal(np.concatenate([o[5]["MG_EC_DEL"] for o in out]), want["EC_SCM_DEL"])
 
 
 def test_sharded_with_no_candidates_at_all(hip):
