@@ -307,57 +307,100 @@ __device__ int ec_blocks_wave(int lane, int32_t n, uint64_t km, uint32_t mp, boo
     return updated? nb : -1;
 }
 
-#define ECR_READS_PER_BLOCK 4
+// A wave takes ECR_RPW consecutive reads: everything the walks need of them is requested first (the loads of all of them are in flight
+// together), then the reads are walked one after the other.  Two million waves that each wait for three dependent loads are bound by the rate
+// at which waves can be launched; half as many that wait once for twice the data are not (count + list + both assembly passes at config 3:
+// 6.3 ms with one read per wave).
+#ifndef ECR_RPW
+#define ECR_RPW 2
+#endif
+#define ECR_READS_PER_BLOCK (4 * ECR_RPW)
+
+struct EcrRead {                  // one read of the wave's, as the lanes hold it
+    uint64_t r, o;
+    int32_t n;                    // -1: no such read
+    uint64_t km;
+    uint32_t mp, hoco_l;
+    bool del;
+};
+__device__ __forceinline__ void ecr_load(const EcReads &rd, const uint8_t *scm_del, uint64_t r0, int lane, EcrRead (&q)[ECR_RPW])
+{
+#pragma unroll
+    for (int k = 0; k < ECR_RPW; ++k) {
+        q[k].r = r0 + k;
+        const bool live = q[k].r < rd.n_reads;
+        q[k].o = live? rd.scm_off[q[k].r] : 0;
+        q[k].n = live? (int32_t) (rd.scm_off[q[k].r + 1] - q[k].o) : -1;
+        q[k].hoco_l = live? rd.hoco_l[q[k].r] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < ECR_RPW; ++k) {
+        const bool in = q[k].n >= 0 && q[k].n <= 64 && lane < q[k].n;
+        q[k].km = in? rd.k_mer[q[k].o + lane] : 0;
+        q[k].mp = in? rd.m_pos[q[k].o + lane] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < ECR_RPW; ++k) q[k].del = q[k].n >= 0 && q[k].n <= 64 && lane < q[k].n && scm_del[q[k].km >> 1];
+}
 
 __global__ __launch_bounds__(256) void ec_count_blocks_wave_kernel(EcReads rd, const uint8_t *scm_del, uint32_t *n_blocks)
 {
-    const uint64_t r = (uint64_t) blockIdx.x * ECR_READS_PER_BLOCK + (threadIdx.x >> 6);
+    const uint64_t r0 = ((uint64_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * ECR_RPW;
     const int lane = threadIdx.x & 63;
-    if (r >= rd.n_reads) return;
-    const uint64_t o = rd.scm_off[r];
-    const int32_t n = (int32_t) (rd.scm_off[r + 1] - o);
-    int nb = 0;
-    if (n > 64) {
-        if (lane) return;
-        ec_blocks(scm_del, rd.k_mer + o, rd.m_pos + o, n, rd.hoco_l[r], rd.K, [&](int, const EcBlock &) { ++nb; }, [](int32_t, int32_t) {});
-        n_blocks[r] = (uint32_t) nb;
-        return;
+    if (r0 >= rd.n_reads) return;
+    EcrRead q[ECR_RPW];
+    ecr_load(rd, scm_del, r0, lane, q);
+#pragma unroll
+    for (int k = 0; k < ECR_RPW; ++k) {
+        const EcrRead &x = q[k];
+        if (x.n < 0) continue;
+        int nb = 0;
+        if (x.n > 64) {
+            if (lane == 0) {
+                ec_blocks(scm_del, rd.k_mer + x.o, rd.m_pos + x.o, x.n, x.hoco_l, rd.K, [&](int, const EcBlock &) { ++nb; }, [](int32_t, int32_t) {});
+                n_blocks[x.r] = (uint32_t) nb;
+            }
+            continue;
+        }
+        ec_blocks_wave(lane, x.n, x.km, x.mp, x.del, x.hoco_l, rd.K, [&](int, const EcBlock &) { ++nb; }, [](int32_t, int32_t) {});
+        if (lane == 0) n_blocks[x.r] = (uint32_t) nb;
     }
-    const uint64_t km = lane < n? rd.k_mer[o + lane] : 0;
-    const uint32_t mp = lane < n? rd.m_pos[o + lane] : 0;
-    const bool del = lane < n && scm_del[km >> 1];
-    ec_blocks_wave(lane, n, km, mp, del, rd.hoco_l[r], rd.K, [&](int, const EcBlock &) { ++nb; }, [](int32_t, int32_t) {});
-    if (lane == 0) n_blocks[r] = (uint32_t) nb;
 }
 
 __global__ __launch_bounds__(256) void ec_list_blocks_wave_kernel(EcReads rd, EcLive lv, const uint8_t *scm_del, const uint64_t *blk_off, EcWork *work)
 {
-    const uint64_t r = (uint64_t) blockIdx.x * ECR_READS_PER_BLOCK + (threadIdx.x >> 6);
+    const uint64_t r0 = ((uint64_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * ECR_RPW;
     const int lane = threadIdx.x & 63;
-    if (r >= rd.n_reads) return;
-    const uint64_t o = rd.scm_off[r];
-    const int32_t n = (int32_t) (rd.scm_off[r + 1] - o);
-    EcWork *w = work + blk_off[r];
-    const uint32_t hs16 = (uint32_t) (rd.off[r] >> 6);
-    auto put = [&](int k, const EcBlock &b) {
-        EcWork x;
-        x.beg_utg = b.beg_utg, x.end_utg = b.end_utg, x.read = (uint32_t) r, x.beg_pos = b.beg_pos, x.l = b.l, x.r = b.r;
-        x.hs16 = hs16, x.lp = lv.idx_p[b.beg_utg], x.ln = lv.idx_n[b.beg_utg], x.pad = 0;
-        w[k] = x;
-    };
-    if (n > 64) {
-        if (lane == 0) ec_blocks(scm_del, rd.k_mer + o, rd.m_pos + o, n, rd.hoco_l[r], rd.K, put, [](int32_t, int32_t) {});
-        return;
+    if (r0 >= rd.n_reads) return;
+    EcrRead q[ECR_RPW];
+    ecr_load(rd, scm_del, r0, lane, q);
+    EcWork *wq[ECR_RPW];
+    uint32_t hq[ECR_RPW];
+#pragma unroll
+    for (int k = 0; k < ECR_RPW; ++k) wq[k] = q[k].n >= 0? work + blk_off[q[k].r] : nullptr, hq[k] = q[k].n >= 0? (uint32_t) (rd.off[q[k].r] >> 6) : 0u;
+#pragma unroll
+    for (int k = 0; k < ECR_RPW; ++k) {
+        const EcrRead &x = q[k];
+        if (x.n < 0) continue;
+        EcWork *w = wq[k];
+        const uint32_t hs16 = hq[k];
+        auto put = [&](int i, const EcBlock &b) {
+            EcWork y;
+            y.beg_utg = b.beg_utg, y.end_utg = b.end_utg, y.read = (uint32_t) x.r, y.beg_pos = b.beg_pos, y.l = b.l, y.r = b.r;
+            y.hs16 = hs16, y.lp = lv.idx_p[b.beg_utg], y.ln = lv.idx_n[b.beg_utg], y.pad = 0;
+            w[i] = y;
+        };
+        if (x.n > 64) {
+            if (lane == 0) ec_blocks(scm_del, rd.k_mer + x.o, rd.m_pos + x.o, x.n, x.hoco_l, rd.K, put, [](int32_t, int32_t) {});
+            continue;
+        }
+        // lane i keeps block i and writes it after the walk, so the gathers of a read's blocks are in flight together
+        EcBlock mine;
+        mine.beg_utg = 0, mine.end_utg = 0, mine.beg_pos = 0, mine.l = 0, mine.beg = 0, mine.end = 0, mine.r = 0;
+        const int nb = ec_blocks_wave(lane, x.n, x.km, x.mp, x.del, x.hoco_l, rd.K,
+                                      [&](int i, const EcBlock &b) { if (i < 64) { if (lane == i) mine = b; } else if (lane == 0) put(i, b); }, [](int32_t, int32_t) {});
+        if (lane < nb) put(lane, mine);
     }
-    const uint64_t km = lane < n? rd.k_mer[o + lane] : 0;
-    const uint32_t mp = lane < n? rd.m_pos[o + lane] : 0;
-    const bool del = lane < n && scm_del[km >> 1];
-    // lane k keeps block k and writes it after the walk, so the gathers of a read's blocks are in flight together
-    EcBlock mine;
-    mine.beg_utg = 0, mine.end_utg = 0, mine.beg_pos = 0, mine.l = 0, mine.beg = 0, mine.end = 0, mine.r = 0;
-    const int nb = ec_blocks_wave(lane, n, km, mp, del, rd.hoco_l[r], rd.K,
-                                  [&](int k, const EcBlock &b) { if (k < 64) { if (lane == k) mine = b; } else if (lane == 0) put(k, b); }, [](int32_t, int32_t) {});
-    if (lane < nb) put(lane, mine);
 }
 
 // stats[11] of read_error_correction (syncerr.c:502-504, :513-542) from the solved blocks; a small fixed grid strides over them and every
@@ -440,67 +483,80 @@ __device__ inline void ec_assemble_read_serial(const EcAssembleArgs &a, uint64_t
 template <int PASS>
 __global__ __launch_bounds__(256) void ec_assemble_wave_kernel(EcAssembleArgs a)
 {
-    const uint64_t r = (uint64_t) blockIdx.x * ECR_READS_PER_BLOCK + (threadIdx.x >> 6);
+    const uint64_t r0 = ((uint64_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * ECR_RPW;
     const int lane = threadIdx.x & 63;
-    if (r >= a.rd.n_reads) return;
-    const uint64_t o = a.rd.scm_off[r];
-    const int32_t n = (int32_t) (a.rd.scm_off[r + 1] - o);
-    if (n > 64) {
-        if (lane == 0) ec_assemble_read_serial(a, r);
-        return;
+    if (r0 >= a.rd.n_reads) return;
+    EcrRead q[ECR_RPW];
+    ecr_load(a.rd, a.scm_del, r0, lane, q);
+    // lane i holds the outcome of block i of each read: one load for all of a read's blocks instead of one after the other inside the walk
+    const EcBlockOut *boq[ECR_RPW];
+    uint32_t st_q[ECR_RPW], np_q[ECR_RPW];
+    uint64_t path_q[ECR_RPW], w0_q[ECR_RPW], s_q[ECR_RPW];
+#pragma unroll
+    for (int k = 0; k < ECR_RPW; ++k) {
+        const bool live = q[k].n >= 0;
+        const uint64_t b0 = live? a.blk_off[q[k].r] : 0;
+        const int32_t nbk = live? (int32_t) (a.blk_off[q[k].r + 1] - b0) : 0;
+        boq[k] = a.out + b0;
+        st_q[k] = EC_FAILURE, np_q[k] = 0, path_q[k] = 0;
+        if (lane < nbk) st_q[k] = boq[k][lane].status, np_q[k] = boq[k][lane].np, path_q[k] = boq[k][lane].path_off;
+        w0_q[k] = PASS && live? a.new_off[q[k].r] : 0;
+        s_q[k] = PASS && live && q[k].n <= 64 && lane < q[k].n? a.old_s_mer[q[k].o + lane] : 0;    // a syncmer's s-mer is the same at every occurrence (count.hpp: check_smer_kernel)
     }
-    const uint64_t km = lane < n? a.rd.k_mer[o + lane] : 0;
-    const uint32_t mp = lane < n? a.rd.m_pos[o + lane] : 0;
-    const bool del = lane < n && a.scm_del[km >> 1];
-    const EcBlockOut *bo = a.out + a.blk_off[r];
-    const int32_t nbk = (int32_t) (a.blk_off[r + 1] - a.blk_off[r]);
-    // lane k holds the outcome of block k: one load for all of a read's blocks instead of one after the other inside the walk
-    uint32_t my_status = EC_FAILURE, my_np = 0;
-    uint64_t my_path = 0;
-    if (lane < nbk) my_status = bo[lane].status, my_np = bo[lane].np, my_path = bo[lane].path_off;
-    const uint64_t w0 = PASS? a.new_off[r] : 0;
-    uint64_t wpos = w0;
-    const uint64_t sid = (a.sid0 + r) << 32;
-    const uint64_t my_s = PASS && lane < n? a.old_s_mer[o + lane] : 0;    // a syncmer's s-mer is the same at every occurrence (count.hpp: check_smer_kernel)
-    auto write = [&](uint64_t at, uint64_t k, uint32_t m, uint64_t s) {
-        a.new_k_mer[at] = k, a.new_m_pos[at] = m, a.new_s_mer[at] = s;
-        a.key_id[at] = (uint32_t) (k >> 1), a.val_occ[at] = sid | (at - w0) << 1 | (m & 1u);                 // syncerr.c:796-805
-    };
-    auto copy = [&](int32_t first, int32_t last) {                     // original entries [first, last) stay
-        if (last <= first) return;
-        if (PASS && lane >= first && lane < last) write(wpos + (uint32_t) (lane - first), km, mp, my_s);
-        wpos += (uint32_t) (last - first);
-    };
-    const int nb = ec_blocks_wave(lane, n, km, mp, del, a.rd.hoco_l[r], a.rd.K,
-        [&](int k, const EcBlock &b) {
-            const uint32_t status = k < 64? ecr_u32(my_status, k) : bo[k].status;
-            if (status == EC_SUCCESS) {
-                const int32_t np = (int32_t) (k < 64? ecr_u32(my_np, k) : bo[k].np);
-                const uint64_t *path = a.path_pool + (k < 64? ecr_u64(my_path, k) : bo[k].path_off);
-                int32_t c;
-                if (b.r) c = np >= 1? np - 1 : 0;
-                else c = (np >= 2? np - 2 : 0) + (b.end_utg == EC_NONE && np > 1? 1 : 0);
-                if (PASS) {
-                    for (int32_t t = lane; t < c; t += 64) {
-                        const uint64_t p = b.r? path[np - 1 - t] : path[1 + t];
-                        const uint64_t kk = (p & ~1ULL) | 1ULL;
-                        write(wpos + (uint32_t) t, kk, b.r? 0xFFFFFFFFu ^ (uint32_t) (p & 1ULL) : 0xFFFFFFFEu | (uint32_t) (p & 1ULL), a.scm_s[kk >> 1]);
+#pragma unroll
+    for (int k = 0; k < ECR_RPW; ++k) {
+        const EcrRead &x = q[k];
+        if (x.n < 0) continue;
+        if (x.n > 64) {
+            if (lane == 0) ec_assemble_read_serial(a, x.r);
+            continue;
+        }
+        const int32_t n = x.n;
+        const uint64_t km = x.km, my_s = s_q[k], w0 = w0_q[k], my_path = path_q[k];
+        const uint32_t mp = x.mp, my_status = st_q[k], my_np = np_q[k];
+        const EcBlockOut *bo = boq[k];
+        uint64_t wpos = w0;
+        const uint64_t sid = (a.sid0 + x.r) << 32;
+        auto write = [&](uint64_t at, uint64_t kk, uint32_t m, uint64_t sv) {
+            a.new_k_mer[at] = kk, a.new_m_pos[at] = m, a.new_s_mer[at] = sv;
+            a.key_id[at] = (uint32_t) (kk >> 1), a.val_occ[at] = sid | (at - w0) << 1 | (m & 1u);                 // syncerr.c:796-805
+        };
+        auto copy = [&](int32_t first, int32_t last) {                     // original entries [first, last) stay
+            if (last <= first) return;
+            if (PASS && lane >= first && lane < last) write(wpos + (uint32_t) (lane - first), km, mp, my_s);
+            wpos += (uint32_t) (last - first);
+        };
+        const int nb = ec_blocks_wave(lane, n, km, mp, x.del, x.hoco_l, a.rd.K,
+            [&](int i, const EcBlock &b) {
+                const uint32_t status = i < 64? ecr_u32(my_status, i) : bo[i].status;
+                if (status == EC_SUCCESS) {
+                    const int32_t np = (int32_t) (i < 64? ecr_u32(my_np, i) : bo[i].np);
+                    const uint64_t *path = a.path_pool + (i < 64? ecr_u64(my_path, i) : bo[i].path_off);
+                    int32_t c;
+                    if (b.r) c = np >= 1? np - 1 : 0;
+                    else c = (np >= 2? np - 2 : 0) + (b.end_utg == EC_NONE && np > 1? 1 : 0);
+                    if (PASS) {
+                        for (int32_t t = lane; t < c; t += 64) {
+                            const uint64_t p = b.r? path[np - 1 - t] : path[1 + t];
+                            const uint64_t kk = (p & ~1ULL) | 1ULL;
+                            write(wpos + (uint32_t) t, kk, b.r? 0xFFFFFFFFu ^ (uint32_t) (p & 1ULL) : 0xFFFFFFFEu | (uint32_t) (p & 1ULL), a.scm_s[kk >> 1]);
+                        }
                     }
+                    wpos += (uint32_t) c;
+                } else if (b.r) {
+                    copy(0, b.beg);
+                } else if (b.beg + 1 < n) {
+                    copy(b.beg + 1, b.end < n? b.end : n);
                 }
-                wpos += (uint32_t) c;
-            } else if (b.r) {
-                copy(0, b.beg);
-            } else if (b.beg + 1 < n) {
-                copy(b.beg + 1, b.end < n? b.end : n);
-            }
-        },
-        copy);
-    if (nb < 0) {                                    // no good syncmer: the read keeps its arrays (syncerr.c:562-572)
-        wpos = w0;
-        if (PASS && lane < n) write(w0 + (uint32_t) lane, km, mp, my_s);
-        wpos += (uint32_t) n;
+            },
+            copy);
+        if (nb < 0) {                                    // no good syncmer: the read keeps its arrays (syncerr.c:562-572)
+            wpos = w0;
+            if (PASS && lane < n) write(w0 + (uint32_t) lane, km, mp, my_s);
+            wpos += (uint32_t) n;
+        }
+        if (!PASS && lane == 0) a.new_n[x.r] = (uint32_t) (wpos - w0);
     }
-    if (!PASS && lane == 0) a.new_n[r] = (uint32_t) (wpos - w0);
 }
 
 // ---- update_syncmer_db (syncerr.c:769-814): coverage, forward-strand presence; occurrence lists come from a stable sort ----
