@@ -308,11 +308,11 @@ __device__ int ec_blocks_wave(int lane, int32_t n, uint64_t km, uint32_t mp, boo
 }
 
 // A wave takes ECR_RPW consecutive reads: everything the walks need of them is requested first (the loads of all of them are in flight
-// together), then the reads are walked one after the other.  Two million waves that each wait for three dependent loads are bound by the rate
-// at which waves can be launched; half as many that wait once for twice the data are not (count + list + both assembly passes at config 3:
-// 6.3 ms with one read per wave).
+// together), then the reads are walked one after the other.  Measured at config 3 (2 M reads): with two reads per wave the count + list
+// kernels take what they take with one (2.9 ms) and the assembly passes are slower (7.0 against 6.3 ms) -- the walks are not bound by the
+// rate at which waves launch but by what each does once its data is there -- so a wave takes ONE read.
 #ifndef ECR_RPW
-#define ECR_RPW 2
+#define ECR_RPW 1
 #endif
 #define ECR_READS_PER_BLOCK (4 * ECR_RPW)
 
