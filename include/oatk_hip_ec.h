@@ -94,11 +94,13 @@ int oatk_hip_ec_graph_light(oatk_hip_ctx *ctx, uint32_t err_mer_c);
 /* ---- reads sharded by record over several GPUs (one context per GPU) --------------------------------------
  * The EC graph is a property of ALL reads, so every shard builds the same graph from the adjacent pairs of all shards and
  * corrects its own reads against it, in GLOBAL syncmer ids (ranks in the merged, sorted hash table -- what the reference's ids
- * are, syncmer.c:1419-1438).  The exchange steps between the calls belong to the caller (oatk_amd/multi.py does them with
- * torch.distributed over RCCL):
+ * are, syncmer.c:1419-1438).  The exchange steps between the calls belong to the caller: include/oatk_hip_multi.h does them over RCCL from
+ * C (oatk_hip_ec_sharded: the light graph from weighted segments, the table partitioned by hash range), oatk_amd/multi.py over
+ * torch.distributed in the simplest form, which is the one listed here:
  *
  *   oatk_hip_ec_set_global(n_global, l2g, cov, s)   after the count tables were merged: local id -> global id, global coverage
- *                                                   and s-mer codes (DEVICE pointers; copied)
+ *                                                   and s-mer codes (DEVICE pointers; copied).  cov / s need only be right for the ids
+ *                                                   the shard looks at: its own syncmers and those seen >= err_mer_c times anywhere
  *   oatk_hip_ec_pairs(&keys, &dist, &n)             this shard's adjacent pairs: canonical key (global ids) and distance, in
  *                                                   (read, slot) order; entries with key ~0 (first slot of a read) are fillers
  *        -- all-gather keys and dist in shard order --
