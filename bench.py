@@ -334,6 +334,29 @@ def main():
                                            "workload": "the headline step with --ec-graph %s" % other}
         except Exception as ex:             # noqa: BLE001
             extras["ec_graph_other"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+        # ---- the same step through the code path of N > 1 with a world of ONE: librccl loaded, a communicator from a unique id, the table merge by
+        #      hash range (personalised exchange with itself), candidates, segments, refreshed counts to their owner -- what the sharded path costs
+        #      before any byte crosses xGMI ----
+        try:
+            import ctypes as C
+            uid = (C.c_uint8 * 128)()
+            hip._check(hip.L.oatk_comm_unique_id(uid), "oatk_comm_unique_id")
+            comm1 = hip.L.oatk_comm_create(uid, 0, 1, local_rank)
+            if not comm1:
+                raise RuntimeError("oatk_comm_create failed")
+
+            def step_sharded():
+                scan_count()
+                hip.merge_counts(comm1)
+                return hip.ec_sharded(comm1, 0.02, c, 0.35)[0]
+            step_sharded()
+            dss, st_s = timed(step_sharded, args.steps)
+            hip.L.oatk_comm_destroy(comm1)
+            extras["sharded_path_world_of_one"] = {"value": round(total_bases / dss / 1e9, 3), "unit": "Gbases/s", "ms_per_step": round(dss * 1e3, 3),
+                                                   "same_statistics": bool(st is not None and list(st_s[:11]) == list(st[:11])),
+                                                   "workload": "the headline step through oatk_hip_merge_counts + oatk_hip_ec_sharded over an RCCL communicator of one rank"}
+        except Exception as ex:             # noqa: BLE001
+            extras["sharded_path_world_of_one"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
 
     if rank == 0 and not args.no_extras:
         # ---- BASELINE.json configs[1]: 200 k reads x 15 kb (its own 1 Mb genome), scan + count, and with the EC round ----
