@@ -37,6 +37,12 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH
 K, S = 1001, 31
 
 
+# The contract is ONE JSON line on stdout.  Libraries write to file descriptor 1 as they please (RCCL prints a five-line version banner there
+# when its communicator goes away), so the real stdout is put aside for the result and descriptor 1 is pointed at stderr for everything else.
+_RESULT_OUT = os.fdopen(os.dup(1), "w")
+os.dup2(2, 1)
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -497,7 +503,7 @@ def main():
             "syncmers": {"occurrences": n_occ, "distinct": n_scm, "hoco_ratio": round(hoco / bases, 4)},
         }
         out.update(extras)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=_RESULT_OUT, flush=True)
     if comm:
         hip.L.oatk_comm_destroy(comm)
     hip.close()
