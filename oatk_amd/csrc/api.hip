@@ -503,6 +503,7 @@ static void scan_reset_downstream(oatk_hip_ctx *ctx)
     if (ctx->ag) ctx->ag->done = false;
     if (ctx->ovl) ctx->ovl->done = false;
     if (ctx->ra) ctx->ra->done = false;
+    if (ctx->multi) ctx->multi->merged = ctx->multi->ec_done = false;      // a merged table belongs to the batch it was merged for
 }
 
 int oatk_hip_device(oatk_hip_ctx *ctx) { return ctx? ctx->device : -1; }
@@ -630,6 +631,7 @@ int oatk_hip_count(oatk_hip_ctx *ctx)
     CK(hipSetDevice(ctx->device));
     ctx->counted = false;
     ctx->n_scm_total = 0;
+    if (ctx->multi) ctx->multi->merged = ctx->multi->ec_done = false;
     const uint64_t n = ctx->n_occ;
     if (n == 0) { ctx->counted = true; return OATK_OK; }
     const unsigned nb = (unsigned) ((n + 255) / 256);

@@ -248,3 +248,43 @@ def test_full_size_over_several_ranks(hip, which, world):
     for key, name in (("EC_N_SCM", "EC_N_SCM"), ("EC_KMER", "EC_KMER"), ("EC_MPOS", "EC_MPOS"), ("EC_SMER", "EC_SMER"), ("MG_EC_COV", "EC_SCM_COV"), ("MG_EC_DEL", "EC_SCM_DEL")):
         assert crc(np.concatenate([o[3][key] for o in out])) == crc(hip.fetch(name)), key
     assert int(st[0] + st[5] + st[10]) > 3.5 * n
+
+
+def test_a_new_batch_is_merged_again(hip):
+    """a merged table belongs to the batch it was merged for: after another scan + count on the same handles, oatk_hip_ec_sharded merges again"""
+    K, S, c = 301, 21, 6
+    first = A.hifi_like(200, 30000, 4000, seed=337, err=0.004)
+    second = A.hifi_like(260, 30000, 4000, seed=347, err=0.003)
+    world = 2
+    L = _lib.load()
+    grp = L.oatk_comm_group_create(world)
+    out, errs = [None] * world, []
+
+    def work(rank):
+        try:
+            h = HipSyncasm(0)
+            comm = L.oatk_comm_group_rank(grp, rank)
+            for reads in (first, second):
+                lo, hi = len(reads) * rank // world, len(reads) * (rank + 1) // world
+                seq, off, lens = pack_reads(reads[lo:hi])
+                h.scan_host(seq, off, lens, K, S, sid0=lo)
+                h.count()
+                st, _ = h.ec_sharded(comm, 0.02, c, 0.35)            # (no explicit merge_counts)
+                out[rank] = (h.multi_range(), st, {k: h.fetch(k) for k in ("MG_H", "EC_KMER", "MG_EC_COV")})
+            L.oatk_comm_destroy(comm)
+            h.close()
+        except Exception as ex:                          # noqa: BLE001
+            errs.append((rank, ex))
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    L.oatk_comm_group_destroy(grp)
+    assert not any(t.is_alive() for t in th) and not errs, errs
+    cnt, st, want = single(hip, second, K, S, c)
+    assert out[0][0][2] == cnt["n_scm"] and out[0][1][:11].tolist() == st[:11].tolist()
+    assert np.array_equal(np.concatenate([o[2]["MG_H"] for o in out]), cnt["h"])
+    assert np.array_equal(np.concatenate([o[2]["EC_KMER"] for o in out]), want["EC_KMER"])
+    assert np.array_equal(np.concatenate([o[2]["MG_EC_COV"] for o in out]), want["EC_SCM_COV"])
