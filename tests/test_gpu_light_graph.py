@@ -125,3 +125,20 @@ def test_segments_give_the_arcs_of_the_expanded_pairs(hip, seed):
     for k in want:
         assert np.array_equal(got[k], want[k]), k
     assert len(np.unique(want["arc_ls"])) > 20
+
+
+def test_light_graph_with_no_candidate_at_all(hip):
+    """a threshold nothing reaches: no pair is kept, no arc exists, every syncmer is deleted, no read changes -- as with the full graph"""
+    reads = A.hifi_like(150, 30000, 4000, seed=353, err=0.003)
+    seq, off, lens = pack_reads(reads)
+    hip.scan_host(seq, off, lens, 301, 21)
+    hip.count()
+    hip.ec_graph()
+    st_full = hip.ec(0.02, 5000, 0.35)
+    want = {k: E.fetch_ec(hip, k) for k in RES}
+    hip.ec_graph(light_c=5000)
+    assert len(graph_arrays(hip)["arc_v"]) == 0
+    st_light = hip.ec(0.02, 5000, 0.35)
+    for k in RES:
+        assert np.array_equal(E.fetch_ec(hip, k), want[k]), k
+    assert st_light.tolist() == st_full.tolist() and int(st_full[:11].sum()) == 0
