@@ -95,7 +95,7 @@ struct oatk_hip_ctx {
 
     // count outputs / scratch
     DevBuf n_scm64, scm_off, pos_hash, pos_lo, pos_smer, pos_mpos, pos_kid;
-    DevBuf key_hash, key_sorted, iota, perm, head, head_idx, newclus, clus_id, bad_head, tag, tmp_perm, flags, kloc, kloc_head;
+    DevBuf key_hash, key_sorted, iota, perm, head, head_idx, newclus, clus_id, bad_head, tag, tmp_perm, flags, kloc;
     DevBuf scm_h, scm_s, scm_cov, scm_occ_off, scm_occ;
     DevBuf tmp;           // rocprim temporary storage
     struct EcState *ec = nullptr;   // error-correction buffers (api_ec.inc)
@@ -206,7 +206,7 @@ void oatk_hip_destroy(oatk_hip_ctx *ctx)
                      &ctx->hoco_s, &ctx->nbits, &ctx->nn_key, &ctx->lrl_key, &ctx->lrl_val, &ctx->nn_key2, &ctx->lrl_key2,
                      &ctx->lrl_val2, &ctx->rec_hash, &ctx->rec_lo, &ctx->rec_smer, &ctx->rec_mpos, &ctx->raw_lo, &ctx->raw_smer, &ctx->raw_mpos, &ctx->shard_cnt, &ctx->shard_prefix, &ctx->counters, &ctx->n_scm64,
                      &ctx->scm_off, &ctx->pos_hash, &ctx->pos_lo, &ctx->pos_smer, &ctx->pos_mpos, &ctx->pos_kid, &ctx->key_hash,
-                     &ctx->key_sorted, &ctx->iota, &ctx->perm, &ctx->head, &ctx->head_idx, &ctx->newclus, &ctx->clus_id, &ctx->kloc, &ctx->kloc_head,
+                     &ctx->key_sorted, &ctx->iota, &ctx->perm, &ctx->head, &ctx->head_idx, &ctx->newclus, &ctx->clus_id, &ctx->kloc,
                      &ctx->bad_head, &ctx->tag, &ctx->tmp_perm, &ctx->flags, &ctx->scm_h, &ctx->scm_s, &ctx->scm_cov,
                      &ctx->scm_occ_off, &ctx->scm_occ, &ctx->tmp};
     for (DevBuf *b : all) b->release();
@@ -660,7 +660,7 @@ int oatk_hip_count(oatk_hip_ctx *ctx)
     g.pos_lo = ctx->pos_lo.as<uint64_t>(), g.pos_mpos = ctx->pos_mpos.as<uint32_t>(), g.hoco_s = ctx->hoco_s.as<uint8_t>();
     g.off = ctx->d_off, g.sid0 = ctx->sid0, g.K = ctx->K;
     g.head = ctx->head.as<uint32_t>(), g.head_idx = ctx->head_idx.as<uint32_t>(), g.newclus = ctx->newclus.as<uint32_t>();
-    g.loc = ctx->kloc.as<uint64_t>(), g.loc_head = nullptr;
+    g.loc = ctx->kloc.as<uint64_t>();
     g.flags = ctx->flags.as<uint32_t>();
     hipLaunchKernelGGL(mark_heads_kernel, dim3(nb), dim3(256), 0, ctx->stream, g);
     {   // head_idx := index of the latest head at or before i
@@ -669,9 +669,6 @@ int oatk_hip_count(oatk_hip_ctx *ctx)
         ENSURE(tmp, tb);
         CK(rocprim::inclusive_scan(ctx->tmp.p, tb, ctx->head_idx.as<uint32_t>(), ctx->head_idx.as<uint32_t>(), n, rocprim::maximum<uint32_t>(), ctx->stream));
     }
-    ENSURE(kloc_head, n * 8);
-    hipLaunchKernelGGL(head_loc_kernel, dim3(nb), dim3(256), 0, ctx->stream, ctx->head_idx.as<uint32_t>(), ctx->kloc.as<uint64_t>(), (uint32_t) n, ctx->kloc_head.as<uint64_t>());
-    g.loc_head = ctx->kloc_head.as<uint64_t>();
     CK(hipMemsetAsync(ctx->bad_head.p, 0, n * 4, ctx->stream));
     hipLaunchKernelGGL(verify_group_kernel, dim3((unsigned) ((n + 8 * OATK_VG_STRIP - 1) / (8 * OATK_VG_STRIP))), dim3(256), 0, ctx->stream, g, ctx->bad_head.as<uint32_t>());
     uint32_t fl[4];

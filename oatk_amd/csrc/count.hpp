@@ -95,7 +95,6 @@ struct GroupArgs {
     const uint32_t *pos_mpos;
     const uint8_t *hoco_s;
     const uint64_t *off;
-    const uint64_t *loc_head;     // loc of every record's group head (head_loc_kernel)
     uint64_t sid0;
     int K;
     uint32_t *head;               // 1 where a new equal-hash group starts
@@ -126,14 +125,6 @@ __global__ void mark_heads_kernel(GroupArgs a)
 #ifndef OATK_VG_STRIP
 #define OATK_VG_STRIP 8
 #endif
-// r02k: a wave's life was three round trips to HBM -- head flag and head index, the head's locator, the k-mers -- and only during the third is
-// there much in flight.  The head's locator of every record is gathered beforehand by a pass of its own (the heads are few: cache hits), so the
-// strip kernel starts with three coalesced loads and goes straight to the k-mers: two round trips.
-__global__ void head_loc_kernel(const uint32_t *head_idx, const uint64_t *loc, uint32_t n, uint64_t *loc_head)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) loc_head[i] = loc[head_idx[i]];
-}
 __global__ __launch_bounds__(256) void verify_group_kernel(GroupArgs a, uint32_t *bad_head)
 {
     const uint32_t hl = threadIdx.x & 31, half0 = threadIdx.x & 32;       // lane in the half wave; first lane of the half wave within the wave
@@ -142,10 +133,14 @@ __global__ __launch_bounds__(256) void verify_group_kernel(GroupArgs a, uint32_t
     uint32_t my_h = 0;
     uint64_t my_lp = 0, my_lq = 0;
     bool my_live = false;
-    if (hl < OATK_VG_STRIP && i0 + hl < a.n_rec) {
+    if (hl < OATK_VG_STRIP) {
         const uint32_t i = i0 + hl;
-        my_live = !a.head[i];
-        my_h = a.head_idx[i], my_lp = a.loc[i], my_lq = a.loc_head[i];      // (unconditional: the four loads leave together)
+        my_live = i < a.n_rec && !a.head[i];
+        if (my_live) {
+            my_h = a.head_idx[i];
+            my_lp = a.loc[i];
+            my_lq = a.loc[my_h];
+        }
     }
     const uint64_t live_mask = (__ballot(my_live) >> half0) & ((1ULL << OATK_VG_STRIP) - 1ULL);
     if (live_mask == 0) return;                                           // (a strip of heads: singletons, most of the error k-mers)
