@@ -512,7 +512,7 @@ def main():
         dist.destroy_process_group()
 
 
-# VALU wave-instructions kernel B issues per 64 hoco positions (profiles/r02c_pmc_scan.csv: SQ_INSTS_VALU 545.07 M over 450 M positions; updated with every PMC pass)
+# VALU wave-instructions kernel B issues per 64 hoco positions (profiles/r02l_pmc_scan.csv, the same in r02c: SQ_INSTS_VALU 545.07 M over 450 M positions; updated with every PMC pass)
 VALU_PER_64 = 77.5
 
 if __name__ == "__main__":
