@@ -102,9 +102,7 @@ struct EcwScratch {
 
 struct EcwFrame {                 // state at the entry of one DFS level (syncerr.c:158-171), followed by k[n]
     uint32_t arc_i, arc_end;
-    int32_t l0, score, t_end, q_end, n, d0, prev_off;
-    uint32_t sib_idx;             // the arc record parked in sib[] (0xFFFFFFFF: none): the next arc of this level, fetched while the current one was
-    uint32_t sib[6];              // being tried, so that coming back to the level does not wait for HBM (w, ls, hs16, mpos, lp, ln)
+    int32_t l0, score, t_end, q_end, n, d0, prev_off, pad;
 };
 
 struct EcwWave {                  // the working wavefront: diagonals d0 .. d0 + n - 1, furthest target index per diagonal in k[]
@@ -267,7 +265,6 @@ __device__ bool ecw_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
         if (lane == 0) {
             f->arc_i = lp, f->arc_end = lp + ln;
             f->l0 = c_len, f->score = score, f->t_end = t_end, f->q_end = q_end, f->n = wv.n, f->d0 = wv.d0, f->prev_off = top;
-            f->sib_idx = 0xFFFFFFFFu;
         }
         int32_t *sv = (int32_t *) (f + 1);
         for (int32_t j = lane; j < wv.n; j += 64) sv[j] = wv.k[j];
@@ -292,18 +289,7 @@ __device__ bool ecw_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
         }
         if (lane == 0) f->arc_i = a + 1;
         ECW_C(8, 1);                                   // 8: arcs tried
-        if (pre_idx != a) {
-            if (ecw_uniu(f->sib_idx) == a) {          // parked here when the level's previous arc was tried
-                pre.a = make_uint4(f->sib[0], f->sib[1], f->sib[2], f->sib[3]), pre.b = make_uint2(f->sib[4], f->sib[5]);
-            } else {
-                pre = ecw_arc_load(lv.arc, a);
-            }
-        }
-        // the level's NEXT arc: on its way while this one is appended and aligned, parked in the frame at the end of the iteration
-        EcwArcRegs sib;
-        sib.a = make_uint4(0, 0, 0, 0), sib.b = make_uint2(0, 0);
-        const bool has_sib = a + 1 < a_end;
-        if (has_sib) sib = ecw_arc_load(lv.arc, a + 1);
+        if (pre_idx != a) pre = ecw_arc_load(lv.arc, a);
         const uint64_t w = ecw_uniu(pre.a.x);
         const int32_t ls = (int32_t) ecw_uniu(pre.a.y), ext = K - ls;
         const uint32_t w_hs16 = ecw_uniu(pre.a.z), w_mpos = ecw_uniu(pre.a.w), w_lp = ecw_uniu(pre.b.x), w_ln = ecw_uniu(pre.b.y);
@@ -390,10 +376,6 @@ __device__ bool ecw_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
             } else if (sc < s_edist) {
                 s_edist = sc;
             }
-        }
-        if (has_sib && lane == 0) {
-            f->sib[0] = sib.a.x, f->sib[1] = sib.a.y, f->sib[2] = sib.a.z, f->sib[3] = sib.a.w, f->sib[4] = sib.b.x, f->sib[5] = sib.b.y;
-            f->sib_idx = a + 1;
         }
         if (score <= bw && ql - K <= tl + bw && ((wk.end_utg != EC_NONE && wk.end_utg != w) || t_end < tl)) {
             if (n_path < EC_MAX_DFS_PATH) {           // the callee would return at once otherwise (syncerr.c:146-148)
