@@ -1,5 +1,5 @@
-"""GPU, BASELINE.json configs[1] (200 k reads x ~15 kb) and configs[2] (2 M reads x ~15 kb = 30 Gbases, the configuration the metric is quoted
-on) at FULL size, k = 1001, s = 31: properties that do not need an oracle run at that size -- conservation sums, orderings, run-to-run
+"""GPU, BASELINE.json configs[1] (200 k reads x ~15 kb), configs[2] (2 M reads x ~15 kb = 30 Gbases, the configuration the metric is quoted
+on) and one GPU's eighth of configs[4] (1.25 M reads x ~20 kb, -c 150) at FULL size, k = 1001, s = 31: properties that do not need an oracle run at that size -- conservation sums, orderings, run-to-run
 determinism of every resident result (the solver pulls blocks from a shared queue, so scheduling differs between runs), strand symmetry --
 plus a bit-exact oracle check of reads sampled from the full batch.  (tests/test_gpu_fullsize_ref.py compares config 2 with the compiled
 reference element for element.)"""
@@ -19,9 +19,13 @@ for a, b in zip(b"ACGTacgtNn", b"TGCAtgcaNn"):
     COMP[a] = b
 
 
-@pytest.fixture(scope="module", params=["config2", "config3"])
+@pytest.fixture(scope="module", params=["config2", "config3", "config5/8"])
 def batch(request):
-    cfg = dict(CONFIGS[request.param])
+    """config5/8: what ONE of eight GPUs holds of BASELINE.json configs[4] (10 M reads x ~20 kb, -c 150): 1.25 M reads, 25 Gbases; reads of up to 40 kb
+    carry more syncmers than a wave has lanes, so the lane-serial block walk runs beside the wave-per-read one at scale"""
+    cfg = dict(CONFIGS[request.param.split("/")[0]])
+    if "/" in request.param:
+        cfg["n_reads"] //= int(request.param.split("/")[1])
     rs = ReadSet(**cfg)
     seq, off, lens = rs.slice(0, cfg["n_reads"])
     yield cfg, seq, off, lens

@@ -193,10 +193,11 @@ def test_rccl_backend_world_of_one(hip):
     assert st_r[:11].tolist() == st[:11].tolist()
 
 
-@pytest.mark.parametrize("which,world", [("config2", 4), ("config3", 2)])
+@pytest.mark.parametrize("which,world", [("config2", 4), ("config3", 2), ("config3", 8)])
 def test_full_size_over_several_ranks(hip, which, world):
-    """BASELINE.json configs[1] (200 k reads x ~15 kb, k = 1001) sharded over four ranks, and configs[2] (2 M reads, the headline workload) over two,
-    through the C collectives equal one handle: the ranks' ranges of the merged table, every corrected chain, the refreshed table, the statistics"""
+    """BASELINE.json configs[1] (200 k reads x ~15 kb, k = 1001) sharded over four ranks, configs[2] (2 M reads, the headline workload) over two, and
+    over EIGHT -- which is configs[3], "2 M reads read-sharded across 8 MI355X", with the eight ranks on the one GPU of the test box -- through the
+    C collectives equal one handle: the ranks' ranges of the merged table, every corrected chain, the refreshed table, the statistics"""
     import zlib
     from oatk_amd.synth import CONFIGS, ReadSet
     cfg = dict(CONFIGS[which])
