@@ -193,7 +193,8 @@ def test_full_size_graph_tables_and_alignment_properties(hip, batch):
     hip._check(hip.L.oatk_hip_debug_align_two_pass(hip.h, 0), "oatk_hip_debug_align_two_pass")
     assert res[0] == res[1]
     n_aln, n_frg, st = res[0][:3]
-    assert st[2] == 0 and st[0] > 0.99 * n and st[1] <= st[0]
+    # (reads beyond the aligner's working limits are handed back for the original routine: none at 15 kb, a handful of the longest at 20 kb)
+    assert st[2] <= (0 if cfg["mean_len"] <= 15000 else 1e-5 * n) and st[0] > 0.99 * n and st[1] <= st[0]
     sid, aoff, uid = hip.fetch("RA_ALN_SID"), hip.fetch("RA_ALN_OFF"), hip.fetch("RA_FRG_UID")
     sb, se = hip.fetch("RA_FRG_SBEG"), hip.fetch("RA_FRG_SEND")
     assert np.all(sid[1:] >= sid[:-1]) and int(aoff[-1]) == n_frg == len(uid)
