@@ -16,6 +16,7 @@ def _host():
     H.oatk_sr_db_new.argtypes = [C.c_int, C.c_int]
     H.oatk_sr_read_packed.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, C.c_uint64, vp]
     H.oatk_sr_db_clean.argtypes = [vp]
+    H.oatk_host_set_arena.argtypes = [C.c_int]
     return H
 
 
@@ -26,8 +27,11 @@ def time_sr_read_packed(hip, readset, first, n_reads, k, s):
     pinned = torch.empty(max(total, 64), dtype=torch.uint8).pin_memory()
     seq, off, lens = readset.slice(first, n_reads, out=pinned.numpy())
     bases = int(lens.sum())
-    best = None
-    for _ in range(2):
+    best = arena_best = None
+    for rep in range(4):
+        # runs 0, 1: every member array its own malloc'ed block, as the reference's sr_destroy needs them; runs 2, 3: ARENAS, for a caller that owns
+        # the destroy functions as the drop-in binary does (include/oatk_syncasm.h)
+        H.oatk_host_set_arena(1 if rep >= 2 else 0)
         db = H.oatk_sr_db_new(k, s)
         hip.sync()
         t0 = time.perf_counter()
@@ -39,8 +43,13 @@ def time_sr_read_packed(hip, readset, first, n_reads, k, s):
         H.oatk_sr_db_clean(db)
         C.CDLL(None).free(C.c_void_p(db))
         t_free = time.perf_counter() - t0
-        if best is None or dt < best[0]:
+        if rep < 2 and (best is None or dt < best[0]):
             best = (dt, t_free)
+        if rep >= 2 and (arena_best is None or dt < arena_best[0]):
+            arena_best = (dt, t_free)
+    H.oatk_host_set_arena(0)
     return {"value": round(bases / best[0] / 1e9, 3), "unit": "Gbases/s", "ms": round(best[0] * 1e3, 1), "ms_free": round(best[1] * 1e3, 1),
+            "with_arenas": {"value": round(bases / arena_best[0] / 1e9, 3), "unit": "Gbases/s", "ms": round(arena_best[0] * 1e3, 1), "ms_free": round(arena_best[1] * 1e3, 1),
+                            "note": "the reads of a piece share one block (oatk_host_set_arena): for callers that own sr_destroy / sr_db_clean, as the drop-in binary does"},
             "workload": "%d reads (%.2f Gbases) as a packed ASCII stream in pinned host memory -> oatk_sr_read_packed: H2D, scan, D2H of every per-read array, "
                         "sr_db_t filled with the reference's own malloc'ed members (sr_read's contract)" % (n_reads, bases / 1e9)}
