@@ -248,6 +248,26 @@ def main():
         fence()
         return (time.perf_counter() - t0) / max(steps, 1), r
 
+    # ---- N > 1 over the C entry points: one untimed probe step first.  If any rank's call returns an error (not a crash: those cannot be caught) every
+    #      rank switches to the torch.distributed form of the same exchange steps, and the result line says so ----
+    if comm and dist is not None:
+        ok, why = 1, ""
+        try:
+            step()
+        except Exception as ex:             # noqa: BLE001
+            ok, why = 0, "%s: %s" % (type(ex).__name__, ex)
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            from oatk_amd.multi import CountMerger, ShardedEc
+            hip.L.oatk_comm_destroy(comm)
+            comm = None
+            collectives = "torch.distributed (%s), oatk_amd/multi.py -- the C entry points failed on some rank%s" % (args.dist_backend, (": " + why[:200]) if why else "")
+            if with_ec:
+                sharded = ShardedEc(hip, dist, dev)
+            else:
+                merger = CountMerger(hip, dist, dev)
+
     # ---- the headline: EXACTLY --steps steps between two fences, max over ranks ----
     for _ in range(args.warmup):
         step()
