@@ -253,6 +253,8 @@ def main():
     if comm and dist is not None:
         ok, why = 1, ""
         try:
+            if os.environ.get("OATK_BENCH_FAIL_C_PROBE"):       # (test switch for the fallback below)
+                raise RuntimeError("OATK_BENCH_FAIL_C_PROBE")
             step()
         except Exception as ex:             # noqa: BLE001
             ok, why = 0, "%s: %s" % (type(ex).__name__, ex)
