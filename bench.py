@@ -518,7 +518,7 @@ def main():
                        "ec_graph": ("light: arcs between syncmers seen >= %d times + one flag per oriented vertex for the rest (include/oatk_hip_ec.h); same corrected reads "
                                     "as from the full graph (tests/test_gpu_light_graph.py)" % c) if args.ec_graph == "light" else "full: every arc of make_syncmer_graph(0, 0.)",
                        "reads_per_gpu": per_gpu, "bases_per_gpu": bases, "genome_len": cfg["genome_len"],
-                       "parallelism": "reads sharded by record, %d rank(s)%s" % (world, "; table merge by hash range (personalised exchange), candidates + pair segments all-gathered, refreshed counts to their owners: %s" % collectives if multi else ""),
+                       "parallelism": "reads sharded by record, %d rank(s)%s" % (world, ("; table merge by hash range (personalised exchange), candidates + pair segments all-gathered, refreshed counts to their owners: %s" if comm else "; table and pair lists all-gathered, coverage all-reduced (replicated): %s") % collectives if multi else ""),
                        "setup_s_untimed": round(t_gen, 1)},
             "roofline": roofline, "cpu_baseline": cpu, "syncerr": ec_summary,
             "phases_ms": {k_: round(v, 4) for k_, v in phase_ms.items()},
