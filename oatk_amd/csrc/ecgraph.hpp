@@ -62,6 +62,50 @@ __global__ void egr_light_flag_kernel(uint64_t n, const uint64_t *keys, const ui
     if (c0 && !c1) other[v0] = 1;
     if (c1 && !c0) other[v1 ^ 1ULL] = 1;
 }
+// pair keys + the light graph's split in one pass, a wave per read (lane j holds entry j of the chain and its left neighbour's comes by DPP;
+// reads with more than 64 syncmers are walked by lane 0): the lane-per-read key kernel strides through the chains (1.9 ms at 2 M reads) and the
+// flag kernel reads its output back (0.5 ms)
+__global__ __launch_bounds__(256) void egr_pair_light_wave_kernel(uint64_t n_reads, const uint64_t *scm_off, const uint64_t *k_mer, const uint32_t *m_pos, const uint32_t *cov,
+                                                                  uint32_t c, uint64_t *keys, uint32_t *dist, uint8_t *keep, uint8_t *other)
+{
+    const uint64_t r = (uint64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= n_reads) return;
+    const uint64_t o = scm_off[r];
+    const int64_t n = (int64_t) (scm_off[r + 1] - o);
+    auto emit = [&](uint64_t at, uint64_t v0, uint32_t p0, uint64_t v1, uint32_t p1) {
+        const bool c0 = cov[v0 >> 1] >= c, c1 = cov[v1 >> 1] >= c;
+        const uint64_t a = v0 <= v1? v0 : v1 ^ 1ULL, b = v0 <= v1? v1 : v0 ^ 1ULL;      // the key stands for a -> b and (b ^ 1) -> (a ^ 1)
+        keys[at] = a << 32 | b, dist[at] = p1 - p0, keep[at] = c0 && c1;
+        const bool ca = v0 <= v1? c0 : c1, cb = v0 <= v1? c1 : c0;
+        if (ca && !cb) other[a] = 1;
+        if (cb && !ca) other[b ^ 1ULL] = 1;
+    };
+    if (n > 64) {
+        if (lane == 0) {
+            keys[o] = EGR_INVALID, dist[o] = 0, keep[o] = 0;
+            uint64_t v0 = (k_mer[o] >> 1) << 1 | (m_pos[o] & 1u);
+            uint32_t p0 = m_pos[o] >> 1;
+            for (int64_t j = 1; j < n; ++j) {
+                const uint64_t v1 = (k_mer[o + j] >> 1) << 1 | (m_pos[o + j] & 1u);
+                const uint32_t p1 = m_pos[o + j] >> 1;
+                emit(o + j, v0, p0, v1, p1);
+                v0 = v1, p0 = p1;
+            }
+        }
+        return;
+    }
+    const bool in = lane < n;
+    const uint64_t km = in? k_mer[o + lane] : 0;
+    const uint32_t mp = in? m_pos[o + lane] : 0;
+    const uint64_t v1 = (km >> 1) << 1 | (mp & 1u);
+    const uint32_t p1 = mp >> 1;
+    const uint64_t v0 = (uint64_t) __shfl_up((long long) v1, 1);
+    const uint32_t p0 = (uint32_t) __shfl_up((int) p1, 1);
+    if (in && lane == 0) keys[o] = EGR_INVALID, dist[o] = 0, keep[o] = 0;
+    if (in && lane > 0) emit(o + lane, v0, p0, v1, p1);
+}
+
 // a run of equal (key, distance) in the key-sorted pair list becomes one weighted segment; head[i] = 1 where one starts
 __global__ void egr_seg_head_kernel(uint64_t n, const uint64_t *skeys, const uint32_t *sdist, uint8_t *head)
 {
