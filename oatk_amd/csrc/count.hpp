@@ -102,6 +102,10 @@ struct GroupArgs {
     uint32_t *newclus;            // 1 where a new syncmer (cluster) starts; starts as a copy of head
     uint32_t *flags;              // [0] some group holds different k-mers, [1] s-mer mismatch, [2] too many clusters
     uint64_t *loc;                // where the k-mer of sorted record i lives: (32-bit word index of its read's hoco string) << 32 | pos << 1 | rev
+    // what else the sort permutation is followed for, fetched while it is followed the first time: the occurrence word (sid | index | strand)
+    // and the s-mer of every sorted record -- finish_heads and check_smer then read them in order instead of gathering them again
+    const uint64_t *pos_smer;
+    uint64_t *occ_sorted, *smer_sorted;
 };
 
 __global__ void mark_heads_kernel(GroupArgs a)
@@ -114,7 +118,17 @@ __global__ void mark_heads_kernel(GroupArgs a)
     a.head_idx[i] = h? i : 0u;
     // the gathers verify_group would otherwise chain in front of every k-mer read, done here once, a lane per record
     const uint32_t p = a.perm[i];
-    a.loc[i] = ((a.off[(a.pos_lo[p] >> 32) - a.sid0] >> 4) << 32) | a.pos_mpos[p];
+    const uint64_t lo = a.pos_lo[p];
+    a.loc[i] = ((a.off[(lo >> 32) - a.sid0] >> 4) << 32) | a.pos_mpos[p];
+    a.occ_sorted[i] = lo, a.smer_sorted[i] = a.pos_smer[p];
+}
+// after a split of colliding groups the permutation has changed inside them: fetch again
+__global__ void regather_kernel(GroupArgs a)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_rec) return;
+    const uint32_t p = a.perm[i];
+    a.occ_sorted[i] = a.pos_lo[p], a.smer_sorted[i] = a.pos_smer[p];
 }
 
 // Is the k-mer of every sorted record that is not a group head identical to its head's?  Half a wave (32 lanes x 32 bases cover k <= 1024
@@ -219,10 +233,10 @@ struct FinishArgs {
     const uint32_t *newclus;
     const uint32_t *clus_id;      // inclusive scan of newclus, minus one
     uint32_t n_rec;
-    const uint64_t *sorted_key, *pos_lo, *pos_smer;
+    const uint64_t *sorted_key, *smer_sorted;     // smer_sorted: the s-mer of every sorted record (mark_heads_kernel)
     uint64_t *scm_h, *scm_s;
     uint64_t *scm_occ_off;        // [n_scm + 1]
-    uint64_t *scm_occ;            // [n_rec]
+    uint64_t *scm_occ;            // [n_rec]: written by mark_heads_kernel (GroupArgs::occ_sorted)
     uint64_t *pos_kid;            // id << 1 per slot
     uint32_t *flags;
 };
@@ -232,11 +246,10 @@ __global__ void finish_heads_kernel(FinishArgs a, uint32_t n_scm)
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n_rec) return;
     uint32_t p = a.perm[i], id = a.clus_id[i];
-    a.scm_occ[i] = a.pos_lo[p];
     a.pos_kid[p] = (uint64_t) id << 1;
     if (a.newclus[i]) {
         a.scm_h[id] = a.sorted_key[i];
-        a.scm_s[id] = a.pos_smer[p];
+        a.scm_s[id] = a.smer_sorted[i];
         a.scm_occ_off[id] = i;
     }
     if (i == a.n_rec - 1) a.scm_occ_off[n_scm] = a.n_rec;
@@ -248,7 +261,7 @@ __global__ void check_smer_kernel(FinishArgs a)
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n_rec) return;
     uint32_t id = a.clus_id[i];
-    if (a.pos_smer[a.perm[i]] != a.scm_s[id]) a.flags[1] = 1u;
+    if (a.smer_sorted[i] != a.scm_s[id]) a.flags[1] = 1u;
 }
 
 __global__ void cov_kernel(const uint64_t *occ_off, uint32_t *cov, uint32_t n_scm)
