@@ -95,7 +95,7 @@ struct oatk_hip_ctx {
 
     // count outputs / scratch
     DevBuf n_scm64, scm_off, pos_hash, pos_lo, pos_smer, pos_mpos, pos_kid;
-    DevBuf key_hash, key_sorted, iota, perm, head, head_idx, newclus, clus_id, bad_head, tag, tmp_perm, flags, kloc, smer_sorted;
+    DevBuf key_hash, key_sorted, iota, perm, head, head_idx, newclus, clus_id, bad_head, tag, tmp_perm, flags, kloc, smer_sorted, slot_rec;
     DevBuf scm_h, scm_s, scm_cov, scm_occ_off, scm_occ;
     DevBuf tmp;           // rocprim temporary storage
     struct EcState *ec = nullptr;   // error-correction buffers (api_ec.inc)
@@ -206,7 +206,7 @@ void oatk_hip_destroy(oatk_hip_ctx *ctx)
                      &ctx->hoco_s, &ctx->nbits, &ctx->nn_key, &ctx->lrl_key, &ctx->lrl_val, &ctx->nn_key2, &ctx->lrl_key2,
                      &ctx->lrl_val2, &ctx->rec_hash, &ctx->rec_lo, &ctx->rec_smer, &ctx->rec_mpos, &ctx->raw_lo, &ctx->raw_smer, &ctx->raw_mpos, &ctx->shard_cnt, &ctx->shard_prefix, &ctx->counters, &ctx->n_scm64,
                      &ctx->scm_off, &ctx->pos_hash, &ctx->pos_lo, &ctx->pos_smer, &ctx->pos_mpos, &ctx->pos_kid, &ctx->key_hash,
-                     &ctx->key_sorted, &ctx->iota, &ctx->perm, &ctx->head, &ctx->head_idx, &ctx->newclus, &ctx->clus_id, &ctx->kloc, &ctx->smer_sorted,
+                     &ctx->key_sorted, &ctx->iota, &ctx->perm, &ctx->head, &ctx->head_idx, &ctx->newclus, &ctx->clus_id, &ctx->kloc, &ctx->smer_sorted, &ctx->slot_rec,
                      &ctx->bad_head, &ctx->tag, &ctx->tmp_perm, &ctx->flags, &ctx->scm_h, &ctx->scm_s, &ctx->scm_cov,
                      &ctx->scm_occ_off, &ctx->scm_occ, &ctx->tmp};
     for (DevBuf *b : all) b->release();
@@ -664,6 +664,9 @@ int oatk_hip_count(oatk_hip_ctx *ctx)
     ENSURE(smer_sorted, n * 8);
     g.pos_smer = ctx->pos_smer.as<uint64_t>(), g.occ_sorted = ctx->scm_occ.as<uint64_t>(), g.smer_sorted = ctx->smer_sorted.as<uint64_t>();
     g.flags = ctx->flags.as<uint32_t>();
+    ENSURE(slot_rec, n * 32);
+    g.slot_rec = ctx->slot_rec.as<uint4>();
+    hipLaunchKernelGGL(pack_slots_kernel, dim3(nb), dim3(256), 0, ctx->stream, g);
     hipLaunchKernelGGL(mark_heads_kernel, dim3(nb), dim3(256), 0, ctx->stream, g);
     {   // head_idx := index of the latest head at or before i
         size_t tb = 0;

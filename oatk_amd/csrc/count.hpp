@@ -106,7 +106,21 @@ struct GroupArgs {
     // and the s-mer of every sorted record -- finish_heads and check_smer then read them in order instead of gathering them again
     const uint64_t *pos_smer;
     uint64_t *occ_sorted, *smer_sorted;
+    // ... and fetched as ONE 32-byte record per slot (pack_slots_kernel): occurrence word, s-mer, k-mer locator.  Three arrays indexed by the same
+    // random slot cost three 64-byte fetches and the locator a fourth, dependent one (the read's offset); packed side by side in slot order -- a
+    // streaming pass -- they cost one
+    uint4 *slot_rec;
 };
+
+__global__ void pack_slots_kernel(GroupArgs a)
+{
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.n_rec) return;
+    const uint64_t lo = a.pos_lo[p], sm = a.pos_smer[p];
+    const uint64_t loc = ((a.off[(lo >> 32) - a.sid0] >> 4) << 32) | a.pos_mpos[p];      // (slots are in read order: the offsets stream too)
+    a.slot_rec[2 * (size_t) p] = make_uint4((uint32_t) lo, (uint32_t) (lo >> 32), (uint32_t) sm, (uint32_t) (sm >> 32));
+    a.slot_rec[2 * (size_t) p + 1] = make_uint4((uint32_t) loc, (uint32_t) (loc >> 32), 0u, 0u);
+}
 
 __global__ void mark_heads_kernel(GroupArgs a)
 {
@@ -118,9 +132,9 @@ __global__ void mark_heads_kernel(GroupArgs a)
     a.head_idx[i] = h? i : 0u;
     // the gathers verify_group would otherwise chain in front of every k-mer read, done here once, a lane per record
     const uint32_t p = a.perm[i];
-    const uint64_t lo = a.pos_lo[p];
-    a.loc[i] = ((a.off[(lo >> 32) - a.sid0] >> 4) << 32) | a.pos_mpos[p];
-    a.occ_sorted[i] = lo, a.smer_sorted[i] = a.pos_smer[p];
+    const uint4 r0 = a.slot_rec[2 * (size_t) p], r1 = a.slot_rec[2 * (size_t) p + 1];
+    a.loc[i] = (uint64_t) r1.y << 32 | r1.x;
+    a.occ_sorted[i] = (uint64_t) r0.y << 32 | r0.x, a.smer_sorted[i] = (uint64_t) r0.w << 32 | r0.z;
 }
 // after a split of colliding groups the permutation has changed inside them: fetch again
 __global__ void regather_kernel(GroupArgs a)
