@@ -95,7 +95,7 @@ struct oatk_hip_ctx {
 
     // count outputs / scratch
     DevBuf n_scm64, scm_off, pos_hash, pos_lo, pos_smer, pos_mpos, pos_kid;
-    DevBuf key_hash, key_sorted, iota, perm, head, head_idx, newclus, clus_id, bad_head, tag, tmp_perm, flags, kloc, smer_sorted, slot_rec;
+    DevBuf key_hash, key_sorted, iota, perm, head, head_idx, newclus, clus_id, bad_head, tag, tmp_perm, flags, kloc, smer_sorted, slot_rec, scm_loc;
     DevBuf scm_h, scm_s, scm_cov, scm_occ_off, scm_occ;
     DevBuf tmp;           // rocprim temporary storage
     struct EcState *ec = nullptr;   // error-correction buffers (api_ec.inc)
@@ -206,7 +206,7 @@ void oatk_hip_destroy(oatk_hip_ctx *ctx)
                      &ctx->hoco_s, &ctx->nbits, &ctx->nn_key, &ctx->lrl_key, &ctx->lrl_val, &ctx->nn_key2, &ctx->lrl_key2,
                      &ctx->lrl_val2, &ctx->rec_hash, &ctx->rec_lo, &ctx->rec_smer, &ctx->rec_mpos, &ctx->raw_lo, &ctx->raw_smer, &ctx->raw_mpos, &ctx->shard_cnt, &ctx->shard_prefix, &ctx->counters, &ctx->n_scm64,
                      &ctx->scm_off, &ctx->pos_hash, &ctx->pos_lo, &ctx->pos_smer, &ctx->pos_mpos, &ctx->pos_kid, &ctx->key_hash,
-                     &ctx->key_sorted, &ctx->iota, &ctx->perm, &ctx->head, &ctx->head_idx, &ctx->newclus, &ctx->clus_id, &ctx->kloc, &ctx->smer_sorted, &ctx->slot_rec,
+                     &ctx->key_sorted, &ctx->iota, &ctx->perm, &ctx->head, &ctx->head_idx, &ctx->newclus, &ctx->clus_id, &ctx->kloc, &ctx->smer_sorted, &ctx->slot_rec, &ctx->scm_loc,
                      &ctx->bad_head, &ctx->tag, &ctx->tmp_perm, &ctx->flags, &ctx->scm_h, &ctx->scm_s, &ctx->scm_cov,
                      &ctx->scm_occ_off, &ctx->scm_occ, &ctx->tmp};
     for (DevBuf *b : all) b->release();
@@ -695,13 +695,14 @@ int oatk_hip_count(oatk_hip_ctx *ctx)
     CK(hipMemcpyAsync(&last_id, ctx->clus_id.as<uint32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
     const uint32_t n_scm = last_id;       // inclusive scan: last value = number of clusters
-    ENSURE(scm_h, (size_t) n_scm * 8); ENSURE(scm_s, (size_t) n_scm * 8); ENSURE(scm_cov, (size_t) n_scm * 4);
+    ENSURE(scm_h, (size_t) n_scm * 8); ENSURE(scm_s, (size_t) n_scm * 8); ENSURE(scm_cov, (size_t) n_scm * 4); ENSURE(scm_loc, (size_t) n_scm * 8);
     ENSURE(scm_occ_off, ((size_t) n_scm + 1) * 8);
     // clus_id currently holds id+1; shift in place with a tiny transform
     CK(rocprim::transform(ctx->clus_id.as<uint32_t>(), ctx->clus_id.as<uint32_t>(), n, [] __device__(uint32_t v) { return v - 1u; }, ctx->stream));
     FinishArgs f;
     f.perm = ctx->perm.as<uint32_t>(), f.newclus = ctx->newclus.as<uint32_t>(), f.clus_id = ctx->clus_id.as<uint32_t>(), f.n_rec = (uint32_t) n;
     f.sorted_key = ctx->key_sorted.as<uint64_t>(), f.smer_sorted = ctx->smer_sorted.as<uint64_t>();
+    f.loc = ctx->kloc.as<uint64_t>(), f.scm_loc = ctx->scm_loc.as<uint64_t>();
     f.scm_h = ctx->scm_h.as<uint64_t>(), f.scm_s = ctx->scm_s.as<uint64_t>(), f.scm_occ_off = ctx->scm_occ_off.as<uint64_t>();
     f.scm_occ = ctx->scm_occ.as<uint64_t>(), f.pos_kid = ctx->pos_kid.as<uint64_t>(), f.flags = ctx->flags.as<uint32_t>();
     hipLaunchKernelGGL(finish_heads_kernel, dim3(nb), dim3(256), 0, ctx->stream, f, n_scm);

@@ -251,6 +251,8 @@ struct FinishArgs {
     uint64_t *scm_h, *scm_s;
     uint64_t *scm_occ_off;        // [n_scm + 1]
     uint64_t *scm_occ;            // [n_rec]: written by mark_heads_kernel (GroupArgs::occ_sorted)
+    const uint64_t *loc;          // k-mer locator of every sorted record (mark_heads_kernel)
+    uint64_t *scm_loc;            // [n_scm] where a syncmer's k-mer can be read: the locator of its first occurrence (what the EC graph's vertices need)
     uint64_t *pos_kid;            // id << 1 per slot
     uint32_t *flags;
 };
@@ -265,6 +267,7 @@ __global__ void finish_heads_kernel(FinishArgs a, uint32_t n_scm)
         a.scm_h[id] = a.sorted_key[i];
         a.scm_s[id] = a.smer_sorted[i];
         a.scm_occ_off[id] = i;
+        a.scm_loc[id] = a.loc[i];
     }
     if (i == a.n_rec - 1) a.scm_occ_off[n_scm] = a.n_rec;
 }

@@ -93,14 +93,14 @@ __global__ void ec_arc_del_kernel(EcGraph g)
 // (sharded reads: `l2g` maps the shard's syncmer ids to the global ids the graph is built on; vertices this shard never saw
 // keep EC_NO_SRC until their k-mer is imported)
 #define EC_NO_SRC 0xFFFFFFFFFFFFFFFFULL
-__global__ void ec_vtx_src_kernel(uint64_t n_local, const uint64_t *occ_off, const uint64_t *occ, uint64_t sid0, const uint64_t *off,
-                                  const uint64_t *scm_off, const uint32_t *m_pos, const uint32_t *l2g, uint64_t *vtx_hs_off, uint32_t *vtx_mpos)
+__global__ void ec_vtx_src_kernel(uint64_t n_local, const uint64_t *scm_loc, const uint32_t *l2g, uint64_t *vtx_hs_off, uint32_t *vtx_mpos)
 {
+    // scm_loc (count.hpp: the locator of a syncmer's first occurrence) = (32-bit word index of the read's hoco string) << 32 | pos << 1 | rev
     uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_local) return;
-    const uint64_t o = occ[occ_off[i]], rd = (o >> 32) - sid0, idx = (uint32_t) o >> 1, v = l2g? l2g[i] : i;
-    vtx_hs_off[v] = off[rd] >> 2;
-    vtx_mpos[v] = m_pos[scm_off[rd] + idx];
+    const uint64_t loc = scm_loc[i], v = l2g? l2g[i] : i;
+    vtx_hs_off[v] = (loc >> 32) << 2;
+    vtx_mpos[v] = (uint32_t) loc;
 }
 __global__ void ec_remap_kernel(uint64_t n, const uint64_t *k_mer, const uint32_t *l2g, uint64_t *out)
 {
