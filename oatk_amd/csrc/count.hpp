@@ -142,7 +142,9 @@ __global__ void regather_kernel(GroupArgs a)
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n_rec) return;
     const uint32_t p = a.perm[i];
-    a.occ_sorted[i] = a.pos_lo[p], a.smer_sorted[i] = a.pos_smer[p];
+    const uint4 r0 = a.slot_rec[2 * (size_t) p], r1 = a.slot_rec[2 * (size_t) p + 1];
+    a.loc[i] = (uint64_t) r1.y << 32 | r1.x;
+    a.occ_sorted[i] = (uint64_t) r0.y << 32 | r0.x, a.smer_sorted[i] = (uint64_t) r0.w << 32 | r0.z;
 }
 
 // Is the k-mer of every sorted record that is not a group head identical to its head's?  Half a wave (32 lanes x 32 bases cover k <= 1024
