@@ -53,7 +53,6 @@ struct EcReads {
     const uint64_t *scm_off;      // [n_reads + 1] slots of the per-read chains
     const uint64_t *k_mer;        // id << 1 (| corrected)
     const uint32_t *m_pos;
-    const uint8_t *occ_del;       // the syncmer of chain entry j is marked deleted (ec_occ_del_kernel), or null: look scm_del[k_mer >> 1] up
 };
 
 // ---- find_error_syncmers, first loop (syncerr.c:690-718) ----
@@ -308,13 +307,6 @@ __device__ int ec_blocks_wave(int lane, int32_t n, uint64_t km, uint32_t mp, boo
     return updated? nb : -1;
 }
 
-// the marks of the syncmers, once per chain entry: the four walks below read them with the chains instead of gathering them four times
-__global__ void ec_occ_del_kernel(uint64_t n, const uint64_t *k_mer, const uint8_t *scm_del, uint8_t *occ_del)
-{
-    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) occ_del[i] = scm_del[k_mer[i] >> 1];
-}
-
 // A wave takes ECR_RPW consecutive reads: everything the walks need of them is requested first (the loads of all of them are in flight
 // together), then the reads are walked one after the other.  Measured at config 3 (2 M reads): with two reads per wave the count + list
 // kernels take what they take with one (2.9 ms) and the assembly passes are slower (7.0 against 6.3 ms) -- the walks are not bound by the
@@ -348,10 +340,7 @@ __device__ __forceinline__ void ecr_load(const EcReads &rd, const uint8_t *scm_d
         q[k].mp = in? rd.m_pos[q[k].o + lane] : 0;
     }
 #pragma unroll
-    for (int k = 0; k < ECR_RPW; ++k) {
-        const bool in = q[k].n >= 0 && q[k].n <= 64 && lane < q[k].n;
-        q[k].del = in && (rd.occ_del? rd.occ_del[q[k].o + lane] != 0 : scm_del[q[k].km >> 1] != 0);      // (occ_del: no dependent gather behind the chain's own load)
-    }
+    for (int k = 0; k < ECR_RPW; ++k) q[k].del = q[k].n >= 0 && q[k].n <= 64 && lane < q[k].n && scm_del[q[k].km >> 1];
 }
 
 __global__ __launch_bounds__(256) void ec_count_blocks_wave_kernel(EcReads rd, const uint8_t *scm_del, uint32_t *n_blocks)
