@@ -95,7 +95,7 @@ struct oatk_hip_ctx {
 
     // count outputs / scratch
     DevBuf n_scm64, scm_off, pos_hash, pos_lo, pos_smer, pos_mpos, pos_kid;
-    DevBuf key_hash, key_sorted, iota, perm, head, head_idx, newclus, clus_id, bad_head, tag, tmp_perm, flags, kloc, smer_sorted, slot_rec, scm_loc, slot_head;
+    DevBuf key_hash, key_sorted, iota, perm, head, head_idx, newclus, clus_id, bad_head, tag, tmp_perm, flags, kloc, smer_sorted, slot_rec, scm_loc;
     DevBuf scm_h, scm_s, scm_cov, scm_occ_off, scm_occ;
     DevBuf tmp;           // rocprim temporary storage
     struct EcState *ec = nullptr;   // error-correction buffers (api_ec.inc)
@@ -206,7 +206,7 @@ void oatk_hip_destroy(oatk_hip_ctx *ctx)
                      &ctx->hoco_s, &ctx->nbits, &ctx->nn_key, &ctx->lrl_key, &ctx->lrl_val, &ctx->nn_key2, &ctx->lrl_key2,
                      &ctx->lrl_val2, &ctx->rec_hash, &ctx->rec_lo, &ctx->rec_smer, &ctx->rec_mpos, &ctx->raw_lo, &ctx->raw_smer, &ctx->raw_mpos, &ctx->shard_cnt, &ctx->shard_prefix, &ctx->counters, &ctx->n_scm64,
                      &ctx->scm_off, &ctx->pos_hash, &ctx->pos_lo, &ctx->pos_smer, &ctx->pos_mpos, &ctx->pos_kid, &ctx->key_hash,
-                     &ctx->key_sorted, &ctx->iota, &ctx->perm, &ctx->head, &ctx->head_idx, &ctx->newclus, &ctx->clus_id, &ctx->kloc, &ctx->smer_sorted, &ctx->slot_rec, &ctx->scm_loc, &ctx->slot_head,
+                     &ctx->key_sorted, &ctx->iota, &ctx->perm, &ctx->head, &ctx->head_idx, &ctx->newclus, &ctx->clus_id, &ctx->kloc, &ctx->smer_sorted, &ctx->slot_rec, &ctx->scm_loc,
                      &ctx->bad_head, &ctx->tag, &ctx->tmp_perm, &ctx->flags, &ctx->scm_h, &ctx->scm_s, &ctx->scm_cov,
                      &ctx->scm_occ_off, &ctx->scm_occ, &ctx->tmp};
     for (DevBuf *b : all) b->release();
@@ -675,14 +675,7 @@ int oatk_hip_count(oatk_hip_ctx *ctx)
         CK(rocprim::inclusive_scan(ctx->tmp.p, tb, ctx->head_idx.as<uint32_t>(), ctx->head_idx.as<uint32_t>(), n, rocprim::maximum<uint32_t>(), ctx->stream));
     }
     CK(hipMemsetAsync(ctx->bad_head.p, 0, n * 4, ctx->stream));
-    if (getenv("OATK_DEBUG_VERIFY_SORTED")) {
-        hipLaunchKernelGGL(verify_group_kernel, dim3((unsigned) ((n + 8 * OATK_VG_STRIP - 1) / (8 * OATK_VG_STRIP))), dim3(256), 0, ctx->stream, g, ctx->bad_head.as<uint32_t>());
-    } else {        // in slot order: the records' own k-mers stream, their heads' stay in cache (count.hpp)
-        ENSURE(slot_head, n * 16);
-        hipLaunchKernelGGL(head_to_slots_kernel, dim3(nb), dim3(256), 0, ctx->stream, g, ctx->slot_head.as<uint4>());
-        hipLaunchKernelGGL(verify_slots_kernel, dim3((unsigned) ((n + 8 * OATK_VG_STRIP - 1) / (8 * OATK_VG_STRIP))), dim3(256), 0, ctx->stream, g, ctx->slot_head.as<uint4>(),
-                           ctx->bad_head.as<uint32_t>());
-    }
+    hipLaunchKernelGGL(verify_group_kernel, dim3((unsigned) ((n + 8 * OATK_VG_STRIP - 1) / (8 * OATK_VG_STRIP))), dim3(256), 0, ctx->stream, g, ctx->bad_head.as<uint32_t>());
     uint32_t fl[4];
     CK(hipMemcpyAsync(fl, ctx->flags.p, sizeof(fl), hipMemcpyDeviceToHost, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));

@@ -198,60 +198,6 @@ __global__ __launch_bounds__(256) void verify_group_kernel(GroupArgs a, uint32_t
     }
 }
 
-// The same check in SLOT order (r02o).  In hash order the members of a group lie all over the reads: 251 bytes at a random place per record,
-// 6.3 GB fetched at ~1 TB/s.  In slot order -- the order of the reads -- consecutive records are neighbouring syncmers of one read, whose k-mers
-// overlap by half and stream; what is random then is the HEAD of a record's group, and the heads that matter are few (a true syncmer heads
-// thousands of records; a sequencing error is its own head and is skipped), so they stay in cache.  head_to_slots_kernel takes every record's
-// head (its k-mer locator and its sorted index) to the record's slot, one 16-byte scatter per record.
-__global__ void head_to_slots_kernel(GroupArgs a, uint4 *slot_head)
-{
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n_rec) return;
-    const uint32_t p = a.perm[i];
-    if (a.head[i]) { slot_head[p] = make_uint4(0u, 0u, 0xFFFFFFFFu, 0u); return; }
-    const uint32_t h = a.head_idx[i];
-    const uint64_t lq = a.loc[h];
-    slot_head[p] = make_uint4((uint32_t) lq, (uint32_t) (lq >> 32), h, 0u);
-}
-__global__ __launch_bounds__(256) void verify_slots_kernel(GroupArgs a, const uint4 *slot_head, uint32_t *bad_head)
-{
-    const uint32_t hl = threadIdx.x & 31, half0 = threadIdx.x & 32;
-    const uint32_t p0 = (uint32_t) OATK_VG_STRIP * (blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5));
-    uint32_t my_h = 0;
-    uint64_t my_lp = 0, my_lq = 0;
-    bool my_live = false;
-    if (hl < OATK_VG_STRIP && p0 + hl < a.n_rec) {
-        const uint32_t p = p0 + hl;
-        const uint4 sh = slot_head[p], r1 = a.slot_rec[2 * (size_t) p + 1];
-        my_live = sh.z != 0xFFFFFFFFu;
-        my_h = sh.z, my_lq = (uint64_t) sh.y << 32 | sh.x, my_lp = (uint64_t) r1.y << 32 | r1.x;
-    }
-    const uint64_t live_mask = (__ballot(my_live) >> half0) & ((1ULL << OATK_VG_STRIP) - 1ULL);
-    if (live_mask == 0) return;
-    const uint32_t *hs32 = (const uint32_t *) a.hoco_s;
-    const int nw = (a.K + 31) / 32;
-    uint32_t diff = 0;
-    for (int w0 = 0; w0 < nw; w0 += 32) {
-        const int wd = w0 + (int) hl;
-        const bool in = wd < nw;
-        uint64_t p[OATK_VG_STRIP], q[OATK_VG_STRIP];
-#pragma unroll
-        for (int r = 0; r < OATK_VG_STRIP; ++r) {
-            const uint64_t lp = (uint64_t) __shfl((long long) my_lp, (int) (half0 + r)), lq = (uint64_t) __shfl((long long) my_lq, (int) (half0 + r));
-            const bool live = in && ((live_mask >> r) & 1u);
-            p[r] = live? kmer_word_global(hs32 + (lp >> 32), (uint32_t) lp >> 1, (uint32_t) lp & 1u, a.K, wd) : 0;
-            q[r] = live? kmer_word_global(hs32 + (lq >> 32), (uint32_t) lq >> 1, (uint32_t) lq & 1u, a.K, wd) : 0;
-        }
-#pragma unroll
-        for (int r = 0; r < OATK_VG_STRIP; ++r) diff |= (uint32_t) (p[r] != q[r]) << r;
-    }
-#pragma unroll
-    for (int r = 0; r < OATK_VG_STRIP; ++r) {
-        const uint64_t bad = (__ballot((diff >> r) & 1u) >> half0) & 0xFFFFFFFFULL;
-        if (bad && hl == (uint32_t) r) a.flags[0] = 1u, bad_head[my_h] = 1u;
-    }
-}
-
 // one lane per colliding group: first-seen clustering, then a stable partition of the group's slice of perm
 #define OATK_MAX_SPLIT 16
 __global__ void split_collisions_kernel(GroupArgs a, const uint32_t *bad_head, uint32_t *perm_rw, uint32_t *tag, uint32_t *tmp_perm)
