@@ -4,7 +4,7 @@
 //   find_error_syncmers            syncerr.c:679-757   -> ec_mark_kernel, ec_arc_del_kernel
 //   error blocks of a read         syncerr.c:339-612   -> ec_blocks (device function, shared by three kernels)
 //   dfs_search + wf_ed_core        syncerr.c:144-286, levdist.c:75-310 -> ec_wave_kernel (ec_wave.hpp)
-//   update_syncmer_db              syncerr.c:769-814   -> ec_cov_kernel (+ a stable radix sort in api.hip)
+//   update_syncmer_db              syncerr.c:769-814   -> a stable radix sort of (syncmer, occurrence) pairs + ec_fwd_flag / ec_cov_sorted kernels (api_ec.inc)
 //
 // The graph is the reference's asmg_t in arc-array order (sorted (v,w), graph.c:70-83) as CSR over oriented vertices.
 // Every vertex is one syncmer (utg id == syncmer id, syncerr.c:421-423) and its hoco consensus is the oriented k-mer of
@@ -560,17 +560,6 @@ __global__ __launch_bounds__(256) void ec_assemble_wave_kernel(EcAssembleArgs a)
 }
 
 // ---- update_syncmer_db (syncerr.c:769-814): coverage, forward-strand presence; occurrence lists come from a stable sort ----
-__global__ void ec_cov_kernel(uint64_t tot, const uint64_t *new_k_mer, const uint32_t *new_m_pos, uint32_t *cov, uint32_t *fwd)
-{
-    uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= tot) return;
-    const uint64_t k = new_k_mer[i] >> 1;
-    atomicAdd(&cov[k], 1u);
-    if (!(new_m_pos[i] & 1u)) atomicAdd(&fwd[k], 1u);
-}
-
-// The same two figures without 8 M atomics on a few thousand hot counters, from the occurrence lists once they are sorted by syncmer: a
-// segment of equal ids ends at i, its start is a binary search away, the forward-strand entries inside are a difference of prefix sums.
 __global__ void ec_fwd_flag_kernel(uint64_t tot, const uint64_t *occ, uint32_t *flag)
 {
     uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -589,17 +578,6 @@ __global__ void ec_cov_sorted_kernel(uint64_t tot, const uint32_t *key_sorted, c
     }
     cov[k] = (uint32_t) (i - lo + 1);
     fwd[k] = fwd_incl[i] - (lo? fwd_incl[lo - 1] : 0u);
-}
-
-__global__ void ec_occ_keys_kernel(uint64_t n_reads, uint64_t sid0, const uint64_t *new_off, const uint64_t *new_k_mer, const uint32_t *new_m_pos,
-                                   uint32_t *key_id, uint64_t *val_occ)
-{
-    uint64_t r = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_reads) return;
-    for (uint64_t i = new_off[r], j = 0; i < new_off[r + 1]; ++i, ++j) {
-        key_id[i] = (uint32_t) (new_k_mer[i] >> 1);
-        val_occ[i] = (sid0 + r) << 32 | j << 1 | (new_m_pos[i] & 1u);
-    }
 }
 
 __global__ void ec_del_kernel(uint64_t n, const uint32_t *fwd, uint8_t *del)
