@@ -289,3 +289,19 @@ def test_a_new_batch_is_merged_again(hip):
     assert np.array_equal(np.concatenate([o[2]["MG_H"] for o in out]), cnt["h"])
     assert np.array_equal(np.concatenate([o[2]["EC_KMER"] for o in out]), want["EC_KMER"])
     assert np.array_equal(np.concatenate([o[2]["MG_EC_COV"] for o in out]), want["EC_SCM_COV"])
+
+
+def test_rccl_branch_with_several_ranks_over_a_mock_library(tmp_path):
+    """RCCL refuses two ranks on one device, so on this box the RCCL branch of the collectives (grouped ncclSend / ncclRecv with the library's offsets,
+    grouped broadcasts, all-gather, all-reduce) only ever runs with a world of one.  tests/c/mock_rccl.cpp implements those entry points for ranks
+    that are threads of one process; a child process loads it through OATK_RCCL_LIB and runs 2 - 4 ranks through oatk_comm_create, an empty shard and
+    forced hash collisions included, against one handle (tests/mock_rccl_run.py)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    lib = str(tmp_path / "libmock_rccl.so")
+    subprocess.run(["hipcc", "-shared", "-fPIC", "-O2", "-o", lib, os.path.join(here, "c", "mock_rccl.cpp")], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    env = dict(os.environ, OATK_RCCL_LIB=lib)
+    p = subprocess.run([sys.executable, os.path.join(here, "mock_rccl_run.py")], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0 and p.stdout.strip().endswith(b"ok 5"), (p.returncode, p.stdout[-300:], p.stderr.decode(errors="replace")[-1500:])
