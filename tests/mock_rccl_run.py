@@ -8,6 +8,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import adversarial as A            # noqa: E402
 import test_gpu_multi_c as M       # noqa: E402
 from oatk_amd import HipSyncasm, _lib  # noqa: E402
