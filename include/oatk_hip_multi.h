@@ -71,6 +71,45 @@ int oatk_hip_ec_sharded(oatk_hip_ctx *ctx, oatk_comm *comm, double max_edist, ui
 
 enum { OATK_BUF_MG_H = 220, OATK_BUF_MG_S, OATK_BUF_MG_COV, OATK_BUF_MG_L2G, OATK_BUF_MG_EC_COV, OATK_BUF_MG_EC_DEL, OATK_BUF_MG_LCOV };
 
+/* ---- up to the graph hand-off -----------------------------------------------------------------------------------------------------------------
+ * What syncasm() does after the count and after the correction consumes properties of ALL reads: one syncmer_db_t whose syncmers carry their
+ * occurrences in (sid, idx) order (syncmer.c:1353-1360; rebuilt by update_syncmer_db, syncerr.c:796-805), the graph of run_syncasm.c:138, the
+ * consensus sums and distance tables behind scg_consensus (syncasm.c:716-823), the statistics of sr_db_stat (syncmer.c:867).  The calls below
+ * produce them from sharded reads; every rank makes the same call; results are bit-identical to one handle holding all the reads
+ * (tests/test_gpu_multi_tail.py).  Per rank, the traffic of each is bounded by what the result itself weighs -- none grows with the number
+ * of ranks the way an all-gather of every shard's chains would.
+ *
+ * oatk_hip_gather_table   the table as it stands -- after oatk_hip_merge_counts: what collect_syncmer_from_reads returns; after
+ *                         oatk_hip_ec_sharded: what update_syncmer_db leaves -- assembled on rank `root` (ids for oatk_hip_buffer, valid there):
+ *                           MG_G_H, MG_G_S u64[n_global]   MG_G_COV u32[n_global]   MG_G_DEL u8[n_global]
+ *                           MG_G_OCC_OFF u64[n_global + 1]   MG_G_OCC u64[sum of coverage]   sid << 32 | idx << 1 | rev, per syncmer in (sid, idx) order
+ *                         The owners' ranges are concatenated; every rank sends its occurrence words with their global ids once (12 bytes per
+ *                         occurrence) and root sorts them stably by id -- the ranks' parts arrive in rank order, which is sid order.  Before the
+ *                         correction every rank also keeps MG_POS_GKID u64[n_occ]: sr_t.k_mer of its own reads as the count leaves it (global
+ *                         id << 1, syncmer.c:1378), slot order of OATK_BUF_SCM_OFF. */
+int oatk_hip_gather_table(oatk_hip_ctx *ctx, oatk_comm *comm, int root);
+/* make_syncmer_graph(sr_db, scm_db, min_k_cov, min_a_cov_f) + asmg_finalize (include/oatk_hip_graph.h) of all reads, after oatk_hip_ec_sharded: the
+ * refreshed coverage and deletion marks are all-gathered from their owners (5 bytes per syncmer); each rank sorts and run-length encodes the
+ * canonical keys of ITS adjacent pairs between two surviving vertices and the (key, count) lists are all-gathered -- a true arc is one entry per
+ * rank however many reads cross it; the same graph is then built on every rank: OATK_BUF_AG_* in global ids. */
+int oatk_hip_asm_graph_sharded(oatk_hip_ctx *ctx, oatk_comm *comm, uint32_t min_k_cov, double min_a_cov_f, uint64_t *n_vtx, uint64_t *n_arc);
+/* oatk_hip_consensus (include/oatk_hip_cons.h) of all reads, after oatk_hip_ec_sharded: every rank adds up the run lengths of its own occurrences of
+ * the selected syncmers (not deleted, coverage over all shards >= min_cov); totals and counts are all-reduced, the first uncorrected occurrence is
+ * the minimum over the ranks (sid in the top bits).  OATK_BUF_CONS_* identical on every rank, CONS_FIRST naming a read of whichever rank. */
+int oatk_hip_consensus_sharded(oatk_hip_ctx *ctx, oatk_comm *comm, uint32_t min_cov);
+/* oatk_hip_overlap_hist of all reads, after oatk_hip_ec_sharded, for the pairs both of whose members are not deleted and seen >= min_cov times (the
+ * only pairs scg_consensus asks about are neighbours in the graph; min_cov = 0: every pair).  Each rank's pairs travel as weighted segments (key,
+ * distance, calls) -- its list sorted by key, stably, so a segment is a run of consecutive add_ovl_count calls (syncasm.c:477-582) -- and the
+ * segments of all ranks in rank order are the calls of one database in read order.  OATK_BUF_OVL_* identical on every rank. */
+int oatk_hip_overlap_hist_sharded(oatk_hip_ctx *ctx, oatk_comm *comm, uint32_t min_cov, uint64_t *n_pairs, uint64_t *n_entries);
+/* oatk_hip_stat (include/oatk_hip_stat.h) of all reads, right after the scans (run_syncasm.c:88) or after oatk_hip_ec_sharded (:131).  The key space
+ * is cut into one range per rank; every rank sorts and run-length encodes its own keys and sends each range's (key, count) entries to its owner,
+ * which merges them and histograms the multiplicities; the 1001-bin histograms and the distinct counts are all-reduced.  `out` identical on every rank. */
+struct oatk_stat_raw_s;
+int oatk_hip_stat_sharded(oatk_hip_ctx *ctx, oatk_comm *comm, struct oatk_stat_raw_s *out);
+
+enum { OATK_BUF_MG_G_H = 230, OATK_BUF_MG_G_S, OATK_BUF_MG_G_COV, OATK_BUF_MG_G_DEL, OATK_BUF_MG_G_OCC_OFF, OATK_BUF_MG_G_OCC, OATK_BUF_MG_POS_GKID };
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,7 @@ extern "C" {
 
 #define OATK_STAT_MAX_DEPTH 1000          /* MAX_DEPTH, syncmer.c:753 */
 
-typedef struct {
+typedef struct oatk_stat_raw_s {
     uint64_t n_reads, n_syncmers;                    /* n, m of syncmer.c:889-904                                                       */
     int64_t sum_dist;                                /* sum of (p1 - p0 - k) over syncmers adjacent on a read, both with a position      */
     uint64_t n_dist;                                 /* number of such pairs                                                             */

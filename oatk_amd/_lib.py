@@ -36,6 +36,7 @@ BUF.update({name: 180 + i for i, name in enumerate([
     "AG_SCM_DEL", "AG_VTX_SCM", "AG_VTX_COV", "AG_IDX_P", "AG_IDX_N", "AG_ARC_V", "AG_ARC_W", "AG_ARC_COV", "AG_ARC_COMP", "AG_ARC_LINK"])})
 # include/oatk_hip_multi.h
 BUF.update({name: 220 + i for i, name in enumerate(["MG_H", "MG_S", "MG_COV", "MG_L2G", "MG_EC_COV", "MG_EC_DEL", "MG_LCOV"])})
+BUF.update({name: 230 + i for i, name in enumerate(["MG_G_H", "MG_G_S", "MG_G_COV", "MG_G_DEL", "MG_G_OCC_OFF", "MG_G_OCC", "MG_POS_GKID"])})
 TIMERS = ["hpc", "syncmer", "syncmer_n", "scan_post", "count_place", "count_sort", "count_group", "kmer_hash", "ec_graph", "ec_mark", "ec_solve", "ec_refresh"]
 
 EXPORTS = [
@@ -43,6 +44,7 @@ EXPORTS = [
     "oatk_hip_stream", "oatk_hip_sync", "oatk_hip_max_k", "oatk_hip_scan", "oatk_hip_scan_host", "oatk_hip_count",
     "oatk_comm_unique_id", "oatk_comm_create", "oatk_comm_group_create", "oatk_comm_group_rank", "oatk_comm_group_destroy", "oatk_comm_destroy",
     "oatk_comm_rank", "oatk_comm_size", "oatk_comm_backend", "oatk_hip_merge_counts", "oatk_hip_multi_range", "oatk_hip_ec_sharded",
+    "oatk_hip_gather_table", "oatk_hip_asm_graph_sharded", "oatk_hip_consensus_sharded", "oatk_hip_overlap_hist_sharded", "oatk_hip_stat_sharded",
     "oatk_hip_scan_begin", "oatk_hip_scan_reserve", "oatk_hip_scan_append", "oatk_hip_device", "oatk_hip_d2d",
     "oatk_hip_info", "oatk_hip_buffer", "oatk_hip_d2h", "oatk_hip_d2h_async", "oatk_hip_h2d_async", "oatk_hip_staging", "oatk_hip_ingest_text_buffer", "oatk_hip_set_timing", "oatk_hip_get_timing",
     "oatk_hip_debug_hash_mask", "oatk_hip_debug_force_general", "oatk_hip_debug_list_cap",
@@ -125,6 +127,11 @@ def load():
     L.oatk_hip_merge_counts.argtypes = [vp, vp, C.POINTER(C.c_uint64)]
     L.oatk_hip_multi_range.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.oatk_hip_ec_sharded.argtypes = [vp, vp, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, vp, C.POINTER(C.c_uint64)]
+    L.oatk_hip_gather_table.argtypes = [vp, vp, C.c_int]
+    L.oatk_hip_asm_graph_sharded.argtypes = [vp, vp, C.c_uint32, C.c_double, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.oatk_hip_consensus_sharded.argtypes = [vp, vp, C.c_uint32]
+    L.oatk_hip_overlap_hist_sharded.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.oatk_hip_stat_sharded.argtypes = [vp, vp, C.POINTER(StatRaw)]
     L.oatk_hip_scan_begin.argtypes = [vp, C.c_uint64, C.c_int, C.c_int]
     L.oatk_hip_scan_reserve.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64]
     L.oatk_hip_scan_append.argtypes = [vp, vp]

@@ -165,6 +165,7 @@ static void t_collect(oatk_hip_ctx *ctx, int first, int last)
 #include "api_ingest.inc"
 #include "api_stat.inc"
 #include "api_multi.inc"
+#include "api_multi_tail.inc"
 
 extern "C" {
 
@@ -737,6 +738,7 @@ int oatk_hip_buffer(oatk_hip_ctx *ctx, int which, const void **d_ptr, uint64_t *
     if (!ctx) return OATK_E_NODEV;
     if (which >= OATK_BUF_INGEST_SEQ && which <= OATK_BUF_INGEST_HDR) return ing_buffer(ctx, which, d_ptr, bytes);      // precedes any scan
     if (which >= OATK_BUF_MG_H && which <= OATK_BUF_MG_LCOV) return multi_buffer(ctx, which, d_ptr, bytes);
+    if (which >= OATK_BUF_MG_G_H && which <= OATK_BUF_MG_POS_GKID) return multi_tail_buffer(ctx, which, d_ptr, bytes);
     if (!ctx->scanned) { ctx->err = "no resident scan"; return OATK_E_STATE; }
     const uint64_t n = ctx->n_reads, occ = ctx->n_occ, ns = ctx->n_scm_total;
     const void *p = nullptr;

@@ -26,6 +26,7 @@
 
 #include "oatk_dropin.h"
 #include "oatk_hip_ec.h"
+#include "oatk_multi.h"
 #include "oatk_syncasm.h"
 
 /* sstream.h:46-51 */
@@ -53,6 +54,8 @@ static const char *F_NAME[F_COUNT_] = {"sr_read", "sr_db_stat", "collect_syncmer
 static struct {
     int init, enabled, log;
     oatk_hip_ctx *ctx;
+    oatk_multi *multi;             /* OATK_DEVICES names several handles: the reads are spread over them (include/oatk_multi.h); ctx is then its handle 0 */
+    int corrected;                 /* the resident chains are read_error_correction's */
     int resident;                  /* the device batch mirrors sr_db (its reads, and every rewrite of their chains since) */
     int counted;                   /* ... and the table collect_syncmer_from_reads returned */
     oatk_scg_t *placeholder;       /* the empty graph handed out for the (0, 0.) call */
@@ -100,8 +103,9 @@ static void at_exit(void)
             fprintf(stderr, "[M::oatk_dropin] %-28s %10lu %10.3f %10lu %10.3f\n", F_NAME[f], (unsigned long) D.served[2 * f], D.secs[2 * f],
                     (unsigned long) D.served[2 * f + 1], D.secs[2 * f + 1]);
     }
-    if (D.ctx) oatk_hip_destroy(D.ctx);
-    D.ctx = 0;
+    if (D.multi) oatk_multi_destroy(D.multi);
+    else if (D.ctx) oatk_hip_destroy(D.ctx);
+    D.ctx = 0, D.multi = 0;
     if (D.log) fprintf(stderr, "[M::oatk_dropin] device context released in %.3f s\n", now() - t_exit);
 }
 
@@ -115,9 +119,26 @@ static void init(void)
     e = getenv("OATK_DROPIN_LOG");
     D.log = e && e[0] && e[0] != '0';
     if (D.enabled) {
-        e = getenv("OATK_DEVICE");
-        D.ctx = oatk_hip_create(e? atoi(e) : 0);
-        if (!D.ctx) fprintf(stderr, "[W::oatk_dropin] no usable MI355X (gfx950) device: every call runs the original body\n");
+        /* OATK_DEVICES=0,1,2,3: one handle per listed ordinal, the reads spread over them (an ordinal may repeat: handles then share a GPU) */
+        int dev[64], nd = 0;
+        e = getenv("OATK_DEVICES");
+        while (e && *e && nd < 64) {
+            char *end = 0;
+            const long v = strtol(e, &end, 10);
+            if (end == e) break;
+            dev[nd++] = (int) v;
+            e = *end == ','? end + 1 : end;
+            if (*end != ',') break;
+        }
+        if (nd > 1) {
+            D.multi = oatk_multi_create(dev, nd);
+            if (D.multi) D.ctx = oatk_multi_ctx(D.multi, 0);
+            else fprintf(stderr, "[W::oatk_dropin] OATK_DEVICES: the %d handles or their communicators could not be made: every call runs the original body\n", nd);
+        } else {
+            e = getenv("OATK_DEVICE");
+            D.ctx = oatk_hip_create(nd == 1? dev[0] : (e? atoi(e) : 0));
+            if (!D.ctx) fprintf(stderr, "[W::oatk_dropin] no usable MI355X (gfx950) device: every call runs the original body\n");
+        }
     }
     e = getenv("OATK_DROPIN_ARENA");
     oatk_host_set_arena(!(e && e[0] == '0'));                            /* this build owns sr_destroy / sr_db_clean / sr_db_destroy (below) */
@@ -133,7 +154,7 @@ void oatk_dropin_counts(uint64_t *out16)
 static const char *why_not(int rc)
 {
     static char buf[512];
-    snprintf(buf, sizeof(buf), "device path declined (code %d: %s)", rc, D.ctx? oatk_hip_last_error(D.ctx) : "no device");
+    snprintf(buf, sizeof(buf), "device path declined (code %d: %s)", rc, D.multi? oatk_multi_last_error(D.multi) : (D.ctx? oatk_hip_last_error(D.ctx) : "no device"));
     return buf;
 }
 
@@ -159,7 +180,7 @@ void sr_read(dropin_sstream_t *s_stream, oatk_sr_db_t *sr_db, size_t mD, int n_t
     const double t0 = now();
     const char *why = 0;
     hooks_off();
-    D.resident = D.counted = 0, D.sr_db = 0, D.scm_db = 0, D.placeholder = 0;
+    D.resident = D.counted = D.corrected = 0, D.sr_db = 0, D.scm_db = 0, D.placeholder = 0;
     if (!D.ctx) why = D.enabled? "no device" : "OATK_DROPIN=0";
     else if (mD != 0) why = "a data cap (-D) cuts the input mid-file: the original reader counts bases as it goes";
     else if (s_stream->n_seq != 0 || s_stream->n != 0) why = "the stream was already read from";
@@ -167,7 +188,8 @@ void sr_read(dropin_sstream_t *s_stream, oatk_sr_db_t *sr_db, size_t mD, int n_t
     if (!why) {
         oatk_host_set_threads(n_threads);                                /* the struct filling uses as many host threads as the caller grants (-t) */
         oatk_sr_db_clean(sr_db);                                         /* syncmer.c:494-495: k and s stay */
-        const int rc = oatk_sr_read_files(D.ctx, sr_db, s_stream->files, s_stream->n_files);
+        const int rc = D.multi? oatk_multi_sr_read_files(D.multi, sr_db, s_stream->files, s_stream->n_files)
+                              : oatk_sr_read_files(D.ctx, sr_db, s_stream->files, s_stream->n_files);
         if (rc == OATK_OK) {
             s_stream->n_seq = sr_db->n;                                  /* what sstream_read would have counted (sstream.c:87) */
             D.resident = 1, D.sr_db = sr_db;
@@ -175,8 +197,8 @@ void sr_read(dropin_sstream_t *s_stream, oatk_sr_db_t *sr_db, size_t mD, int n_t
             return;
         }
         why = why_not(rc);
-        oatk_sr_db_clean(sr_db);
     }
+    oatk_sr_db_clean(sr_db);                                             /* the original's own sr_db_clean (syncmer.c:494) would free() arena members of an earlier device fill */
     orig_sr_read(s_stream, sr_db, mD, n_threads);
     note(F_READ, 1, t0, why);
 }
@@ -190,8 +212,9 @@ void sr_db_stat(oatk_sr_db_t *sr_db, FILE *fo, int verbose)
     const char *why = 0;
     if (!D.resident || sr_db != D.sr_db) why = "no resident batch";
     else if (verbose > 1) why = "the verbose histogram plots are the original's";
+    else if (D.multi && D.counted && !D.corrected) why = "between the count and the correction the handles' k-mer keys are their own ids";
     if (!why) {
-        const int rc = oatk_sr_db_stat(D.ctx, sr_db, fo, verbose);
+        const int rc = D.multi? oatk_multi_sr_db_stat(D.multi, sr_db, fo, verbose) : oatk_sr_db_stat(D.ctx, sr_db, fo, verbose);
         if (rc == OATK_OK) { note(F_STAT, 0, t0, 0); return; }
         why = why_not(rc);
     }
@@ -209,7 +232,8 @@ oatk_syncmer_db_t *collect_syncmer_from_reads(oatk_sr_db_t *sr_db)
     if (!D.resident || sr_db != D.sr_db) why = "no resident batch";
     if (!why) {
         int rc = 0;
-        oatk_syncmer_db_t *db = oatk_collect_syncmer_from_reads(D.ctx, sr_db, &rc);     /* "identical kmers have different smers" exits, as in the original */
+        oatk_syncmer_db_t *db = D.multi? oatk_multi_collect_syncmer_from_reads(D.multi, sr_db, &rc)
+                                       : oatk_collect_syncmer_from_reads(D.ctx, sr_db, &rc);     /* "identical kmers have different smers" exits, as in the original */
         if (rc == OATK_OK) {
             D.counted = 1, D.scm_db = db;
             note(F_COLLECT, 0, t0, 0);
@@ -269,7 +293,8 @@ static int64_t hook_cons(void *sr_db, void *scm, int rev, int64_t beg, void *c_s
 static int hook_ovl(void *m1, uint64_t rc1, void *m2, uint64_t rc2, const int32_t **dist, const uint32_t **cnt, int *tail)
 {
     const oatk_syncmer_t *base = D.scm_db->a;
-    const int n = oatk_overlap_lookup(D.ovl, (uint64_t) ((oatk_syncmer_t *) m1 - base) << 1 | rc1, (uint64_t) ((oatk_syncmer_t *) m2 - base) << 1 | rc2, dist, cnt, tail);
+    int n = oatk_overlap_lookup(D.ovl, (uint64_t) ((oatk_syncmer_t *) m1 - base) << 1 | rc1, (uint64_t) ((oatk_syncmer_t *) m2 - base) << 1 | rc2, dist, cnt, tail);
+    if (D.multi && n == 0) n = -1;                                      /* several handles tabulate the pairs between graph vertices only: anything else is the original walk's */
     D.served[2 * F_OVL + (n < 0)] += 1;
     return n;
 }
@@ -291,9 +316,11 @@ oatk_scg_t *make_syncmer_graph(oatk_sr_db_t *sr_db, oatk_syncmer_db_t *scm_db, u
         note(F_GRAPH, 0, t0, "placeholder: the EC graph is built on the device by read_error_correction");
         return g;
     }
+    if (!why && D.multi && !D.corrected) why = "with several handles the graph of uncorrected reads is the original's (--no-read-ec)";
     if (!why) {
         int rc = 0;
-        oatk_asmg_t *a = oatk_make_syncmer_asmg(D.ctx, scm_db, min_k_cov, min_a_cov_f, &rc);
+        oatk_asmg_t *a = D.multi? oatk_multi_make_syncmer_asmg(D.multi, scm_db, min_k_cov, min_a_cov_f, &rc)
+                                : oatk_make_syncmer_asmg(D.ctx, scm_db, min_k_cov, min_a_cov_f, &rc);
         if (rc == OATK_OK && a) {
             oatk_scg_t *g = (oatk_scg_t *) calloc(1, sizeof(oatk_scg_t));
             g->scm_db = scm_db, g->utg_asmg = a;
@@ -302,10 +329,11 @@ oatk_scg_t *make_syncmer_graph(oatk_sr_db_t *sr_db, oatk_syncmer_db_t *scm_db, u
              * from the device in one fetch each */
             hooks_off();
             int r1 = 0, r2 = 0;
-            D.cons = oatk_consensus_fetch(D.ctx, min_k_cov, sr_db->k, &r1);
-            D.ovl = oatk_overlap_fetch(D.ctx, &r2);
+            D.cons = D.multi? oatk_multi_consensus_fetch(D.multi, min_k_cov, sr_db->k, &r1) : oatk_consensus_fetch(D.ctx, min_k_cov, sr_db->k, &r1);
+            D.ovl = D.multi? oatk_multi_overlap_fetch(D.multi, min_k_cov, &r2) : oatk_overlap_fetch(D.ctx, &r2);
             if (D.cons && !r1) oatk_hook_cons = hook_cons;
             if (D.ovl && !r2) oatk_hook_ovl = hook_ovl;
+            D.placeholder = 0;
             note(F_GRAPH, 0, t0, 0);
             return g;
         }
@@ -350,8 +378,9 @@ void read_error_correction(oatk_sr_db_t *sr_db, oatk_scg_t *g, double max_edist,
     else if (fo) why = "the corrected reads are to be written out (debug build): the original does that";
     if (!why) {
         oatk_host_set_threads(n_threads);
-        int rc = oatk_read_error_correction(D.ctx, sr_db, g->scm_db, placeholder? 0 : g->utg_asmg, max_edist, err_mer_c, max_err_c, err_arc_c, max_arc_f, st);
-        if (rc == OATK_E_SPLIT && placeholder) {
+        int rc = D.multi? (placeholder? oatk_multi_read_error_correction(D.multi, sr_db, g->scm_db, max_edist, err_mer_c, max_err_c, err_arc_c, max_arc_f, st) : OATK_E_ARG)
+                        : oatk_read_error_correction(D.ctx, sr_db, g->scm_db, placeholder? 0 : g->utg_asmg, max_edist, err_mer_c, max_err_c, err_arc_c, max_arc_f, st);
+        if (rc == OATK_E_SPLIT && placeholder && !D.multi) {
             /* the device refuses to ORDER this graph (duplicate arcs of a long tandem repeat, an arc with dozens of distances): the original
              * builds it, the correction itself still runs on the device against that graph */
             if (D.log) fprintf(stderr, "[M::oatk_dropin] read_error_correction: %s; graph from the original make_syncmer_graph + scg_consensus\n", why_not(rc));
@@ -361,13 +390,14 @@ void read_error_correction(oatk_sr_db_t *sr_db, oatk_scg_t *g, double max_edist,
         }
         if (rc == OATK_OK) {
             ec_report(st, verbose);
+            D.corrected = 1, D.placeholder = 0;                         /* (the caller's scg_destroy frees it: a later graph may reuse its address) */
             if (real) scg_destroy(real);
             note(F_EC, 0, t0, real? "device correction against the original's graph" : 0);
             return;
         }
         why = why_not(rc);
     }
-    D.resident = 0;                                                     /* the host rewrites the chains: the device batch is stale */
+    D.resident = 0, D.placeholder = 0;                                  /* the host rewrites the chains: the device batch is stale */
     if (placeholder && !real) {
         real = orig_make_syncmer_graph(sr_db, g->scm_db, 0, 0.);
         scg_consensus(sr_db, real, 1, 1, 0);
@@ -388,9 +418,11 @@ void scg_read_alignment(oatk_sr_db_t *sr_db, oatk_scg_ra_v *ra_v, oatk_scg_t *g,
     const char *why = 0;
     if (!D.resident || !D.counted || sr_db != D.sr_db || !g || g->scm_db != D.scm_db) why = "no resident batch";
     else if (!g->idx_u) why = "the graph carries no syncmer index";
+    else if (D.multi && !D.corrected) why = "with several handles the uncorrected chains on the devices carry the handles' own ids (--no-read-ec)";
     if (!why) {
         uint64_t n_skipped = 0;
-        const int rc = oatk_scg_read_alignment(D.ctx, sr_db, ra_v, g, for_unzip, &n_skipped, 0);     /* all or nothing: ra_v untouched on refusal */
+        const int rc = D.multi? oatk_multi_scg_read_alignment(D.multi, sr_db, ra_v, g, for_unzip, &n_skipped)
+                              : oatk_scg_read_alignment(D.ctx, sr_db, ra_v, g, for_unzip, &n_skipped, 0);     /* all or nothing: ra_v untouched on refusal */
         if (rc == OATK_OK) { note(F_ALIGN, 0, t0, 0); return; }
         why = n_skipped? "reads beyond the device aligner's per-read limits" : why_not(rc);
     }

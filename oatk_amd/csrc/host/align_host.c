@@ -16,6 +16,8 @@
 
 #include "oatk_hip_align.h"
 #include "oatk_syncasm.h"
+#include "host_internal.h"
+#include <pthread.h>
 
 typedef unsigned __int128 u128_t;
 
@@ -41,8 +43,50 @@ static void *fetch(oatk_hip_ctx *ctx, int which, uint64_t *bytes, int *rc)
 int oatk_scg_read_alignment(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, oatk_scg_ra_v *ra_v, oatk_scg_t *g, int for_unzip, uint64_t *n_skipped,
                             uint32_t **skipped)
 {
-    uint64_t i, j, b;
-    int rc = 0;
+    const uint64_t first[2] = {0, sr_db->n};
+    return oatk_host_read_alignment_n(&ctx, first, 1, sr_db, ra_v, g, for_unzip, n_skipped, skipped);
+}
+
+/* one handle's share: its reads against the same graph (reads align independently, include/oatk_hip_align.h) */
+typedef struct {
+    oatk_hip_ctx *ctx;
+    const oatk_ra_graph_t *fg;
+    const int64_t *old_ra;
+    int rc;
+    uint64_t n_aln, n_frg, st[3];
+    uint32_t *a_sid, *f_ub, *f_ue, *f_sb, *f_se, *sk;
+    uint64_t *a_off, *f_uid;
+    double *a_s;
+} ra_part_t;
+
+static void *ra_part_run(void *arg)
+{
+    ra_part_t *p = (ra_part_t *) arg;
+    uint64_t b;
+    int rc = oatk_hip_read_alignment(p->ctx, p->fg, p->old_ra, &p->n_aln, &p->n_frg, p->st);
+    if (!rc) p->a_sid = (uint32_t *) fetch(p->ctx, OATK_BUF_RA_ALN_SID, &b, &rc);
+    if (!rc) p->a_off = (uint64_t *) fetch(p->ctx, OATK_BUF_RA_ALN_OFF, &b, &rc);
+    if (!rc) p->a_s = (double *) fetch(p->ctx, OATK_BUF_RA_ALN_S, &b, &rc);
+    if (!rc) p->f_uid = (uint64_t *) fetch(p->ctx, OATK_BUF_RA_FRG_UID, &b, &rc);
+    if (!rc) p->f_ub = (uint32_t *) fetch(p->ctx, OATK_BUF_RA_FRG_UBEG, &b, &rc);
+    if (!rc) p->f_ue = (uint32_t *) fetch(p->ctx, OATK_BUF_RA_FRG_UEND, &b, &rc);
+    if (!rc) p->f_sb = (uint32_t *) fetch(p->ctx, OATK_BUF_RA_FRG_SBEG, &b, &rc);
+    if (!rc) p->f_se = (uint32_t *) fetch(p->ctx, OATK_BUF_RA_FRG_SEND, &b, &rc);
+    if (!rc && p->st[2]) p->sk = (uint32_t *) fetch(p->ctx, OATK_BUF_RA_SKIPPED, &b, &rc);
+    p->rc = rc;
+    return 0;
+}
+
+static void ra_part_free(ra_part_t *p)
+{
+    free(p->a_sid); free(p->a_off); free(p->a_s); free(p->f_uid); free(p->f_ub); free(p->f_ue); free(p->f_sb); free(p->f_se); free(p->sk);
+}
+
+int oatk_host_read_alignment_n(oatk_hip_ctx **ctx, const uint64_t *first, int n, oatk_sr_db_t *sr_db, oatk_scg_ra_v *ra_v, oatk_scg_t *g, int for_unzip,
+                               uint64_t *n_skipped, uint32_t **skipped)
+{
+    uint64_t i, j;
+    int rc = 0, r;
     if (n_skipped) *n_skipped = 0;
     if (skipped) *skipped = 0;
     oatk_asmg_t *ug = g->utg_asmg;
@@ -83,47 +127,63 @@ int oatk_scg_read_alignment(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, oatk_scg_ra_
     uint8_t *arc_del = (uint8_t *) xmalloc(na);
     for (i = 0; i < na; ++i) arc_w[i] = ug->arc[i].w, arc_ln[i] = ug->arc[i].ln, arc_del[i] = ug->arc[i].del;
     oatk_ra_graph_t fg = {ns, nu, na, su_off, su_uid, su_pos, utg_n, ug->idx_p, ug->idx_n, arc_w, arc_ln, arc_del};
-    uint64_t n_aln = 0, n_frg = 0, st[3] = {0, 0, 0};
-    rc = oatk_hip_read_alignment(ctx, &fg, old_ra, &n_aln, &n_frg, st);
+
+    /* every handle aligns its own reads (the handles of several GPUs side by side: one host thread each) */
+    ra_part_t *part = (ra_part_t *) calloc((size_t) n, sizeof(ra_part_t));
+    pthread_t *th = (pthread_t *) calloc((size_t) n, sizeof(pthread_t));
+    for (r = 0; r < n; ++r) part[r].ctx = ctx[r], part[r].fg = &fg, part[r].old_ra = old_ra + first[r];
+    for (r = 1; r < n; ++r) if (pthread_create(&th[r], 0, ra_part_run, &part[r]) != 0) { ra_part_run(&part[r]); th[r] = 0; }
+    ra_part_run(&part[0]);
+    for (r = 1; r < n; ++r) if (th[r]) pthread_join(th[r], 0);
+    free(th);
     free(su_off); free(su_uid); free(su_pos); free(utg_n); free(arc_w); free(arc_ln); free(arc_del); free(old_ra);
-    if (rc) return rc;
+    uint64_t n_aln = 0, st[3] = {0, 0, 0};
+    for (r = 0; r < n; ++r) {
+        if (part[r].rc && !rc) rc = part[r].rc;
+        n_aln += part[r].n_aln, st[0] += part[r].st[0], st[1] += part[r].st[1], st[2] += part[r].st[2];
+    }
+    if (rc) goto done;
     if (st[2] && !skipped) {                                                       /* a caller that cannot finish the skipped reads itself gets */
         if (n_skipped) *n_skipped = st[2];                                         /* all or nothing: ra_v is still the previous round's        */
-        return OATK_E_SPLIT;
+        rc = OATK_E_SPLIT;
+        goto done;
     }
 
-    uint32_t *a_sid = (uint32_t *) fetch(ctx, OATK_BUF_RA_ALN_SID, &b, &rc); if (rc) return rc;
-    uint64_t *a_off = (uint64_t *) fetch(ctx, OATK_BUF_RA_ALN_OFF, &b, &rc); if (rc) return rc;
-    double *a_s = (double *) fetch(ctx, OATK_BUF_RA_ALN_S, &b, &rc); if (rc) return rc;
-    uint64_t *f_uid = (uint64_t *) fetch(ctx, OATK_BUF_RA_FRG_UID, &b, &rc); if (rc) return rc;
-    uint32_t *f_ub = (uint32_t *) fetch(ctx, OATK_BUF_RA_FRG_UBEG, &b, &rc); if (rc) return rc;
-    uint32_t *f_ue = (uint32_t *) fetch(ctx, OATK_BUF_RA_FRG_UEND, &b, &rc); if (rc) return rc;
-    uint32_t *f_sb = (uint32_t *) fetch(ctx, OATK_BUF_RA_FRG_SBEG, &b, &rc); if (rc) return rc;
-    uint32_t *f_se = (uint32_t *) fetch(ctx, OATK_BUF_RA_FRG_SEND, &b, &rc); if (rc) return rc;
-
-    /* scg_ra_v_clean (alignment.c:47-54), then the new alignments (:650-664) */
+    /* scg_ra_v_clean (alignment.c:47-54), then the new alignments (:650-664): the handles' results in handle order are read order */
     for (i = 0; i < ra_v->n; ++i) free(ra_v->a[i].a);
     free(ra_v->a);
     ra_v->n = ra_v->m = n_aln;
     ra_v->a = (oatk_scg_ra_t *) xmalloc(sizeof(oatk_scg_ra_t) * n_aln);
-    for (i = 0; i < n_aln; ++i) {
-        oatk_scg_ra_t *ra = &ra_v->a[i];
-        const uint64_t o = a_off[i], m = a_off[i + 1] - o;
-        ra->sid = sid0 + a_sid[i], ra->n = (uint32_t) m, ra->s = a_s[i];
-        ra->a = (oatk_ra_frg_t *) xmalloc(sizeof(oatk_ra_frg_t) * m);
-        for (j = 0; j < m; ++j) {
-            oatk_ra_frg_t *f = &ra->a[j];
-            f->uid = f_uid[o + j], f->u_beg = f_ub[o + j], f->u_end = f_ue[o + j], f->s_beg = f_sb[o + j], f->s_end = f_se[o + j];
+    {
+        uint64_t at = 0;
+        for (r = 0; r < n; ++r) {
+            const ra_part_t *p = &part[r];
+            for (i = 0; i < p->n_aln; ++i, ++at) {
+                oatk_scg_ra_t *ra = &ra_v->a[at];
+                const uint64_t o = p->a_off[i], m = p->a_off[i + 1] - o;
+                ra->sid = sid0 + first[r] + p->a_sid[i], ra->n = (uint32_t) m, ra->s = p->a_s[i];
+                ra->a = (oatk_ra_frg_t *) xmalloc(sizeof(oatk_ra_frg_t) * m);
+                for (j = 0; j < m; ++j) {
+                    oatk_ra_frg_t *f = &ra->a[j];
+                    f->uid = p->f_uid[o + j], f->u_beg = p->f_ub[o + j], f->u_end = p->f_ue[o + j], f->s_beg = p->f_sb[o + j], f->s_end = p->f_se[o + j];
+                }
+            }
         }
     }
-    free(a_sid); free(a_off); free(a_s); free(f_uid); free(f_ub); free(f_ue); free(f_sb); free(f_se);
-    uint64_t n_r = 0;
-    for (i = 0; i < sr_db->n; ++i) n_r += sr_db->a[i].n > 0;
-    fprintf(stderr, "[M::%s] %lu mappable reads, %lu mapped (%lu unique mapping)\n", "scg_read_alignment", n_r, st[0], st[1]);      /* :685 */
-    if (st[2]) {
-        uint32_t *sk = (uint32_t *) fetch(ctx, OATK_BUF_RA_SKIPPED, &b, &rc); if (rc) return rc;
-        if (n_skipped) *n_skipped = st[2];
-        if (skipped) *skipped = sk; else free(sk);
+    {
+        uint64_t n_r = 0;
+        for (i = 0; i < sr_db->n; ++i) n_r += sr_db->a[i].n > 0;
+        fprintf(stderr, "[M::%s] %lu mappable reads, %lu mapped (%lu unique mapping)\n", "scg_read_alignment", n_r, st[0], st[1]);      /* :685 */
     }
-    return 0;
+    if (st[2]) {
+        uint32_t *sk = skipped? (uint32_t *) xmalloc(4 * st[2]) : 0;
+        uint64_t at = 0;
+        for (r = 0; r < n && sk; ++r) for (i = 0; i < part[r].st[2]; ++i) sk[at++] = (uint32_t) (first[r] + part[r].sk[i]);
+        if (n_skipped) *n_skipped = st[2];
+        if (skipped) *skipped = sk;
+    }
+done:
+    for (r = 0; r < n; ++r) ra_part_free(&part[r]);
+    free(part);
+    return rc;
 }

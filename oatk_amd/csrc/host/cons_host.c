@@ -11,6 +11,7 @@
 
 #include "oatk_hip_cons.h"
 #include "oatk_syncasm.h"
+#include "host_internal.h"
 
 static void *xmalloc(size_t n)
 {
@@ -33,9 +34,14 @@ static void *fetch(oatk_hip_ctx *ctx, int which, uint64_t *bytes, int *rc)
 
 oatk_consensus_t *oatk_consensus_fetch(oatk_hip_ctx *ctx, uint32_t min_cov, int k, int *rc)
 {
-    uint64_t b;
     *rc = oatk_hip_consensus(ctx, min_cov);
     if (*rc) return 0;
+    return oatk_host_consensus_from_resident(ctx, k, rc);
+}
+
+oatk_consensus_t *oatk_host_consensus_from_resident(oatk_hip_ctx *ctx, int k, int *rc)
+{
+    uint64_t b;
     oatk_consensus_t *c = (oatk_consensus_t *) calloc(1, sizeof(oatk_consensus_t));
     c->k = k;
     c->slot = (uint32_t *) fetch(ctx, OATK_BUF_CONS_SLOT, &b, rc); if (*rc) { oatk_consensus_destroy(c); return 0; }

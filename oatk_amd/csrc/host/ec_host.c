@@ -15,6 +15,7 @@
 
 #include "oatk_hip_ec.h"
 #include "oatk_syncasm.h"
+#include "host_internal.h"
 
 static void *xmalloc(size_t n)
 {
@@ -79,6 +80,29 @@ static void ecw_worker(void *arg, int tid, int n_threads)
     }
 }
 
+void oatk_host_ec_write_back(oatk_sr_db_t *sr_db, oatk_syncmer_db_t *scm_db, const uint32_t *new_n, uint64_t **new_k, uint32_t **new_m, uint64_t **new_s,
+                             const uint32_t *cov, const uint8_t *del, const uint64_t *occ_off, uint64_t **occ)
+{
+    uint64_t i;
+    ecw_job_t job = {sr_db, scm_db, new_n, *new_k, *new_m, *new_s, cov, del, occ_off, *occ, 0, 0};
+    job.new_off = (uint64_t *) xmalloc(8 * (sr_db->n + 1));
+    for (i = 0, job.new_off[0] = 0; i < sr_db->n; ++i) job.new_off[i + 1] = job.new_off[i] + new_n[i];
+    job.adopt = oatk_host_arena();
+    free(scm_db->c); scm_db->c = 0;
+    free(scm_db->h); scm_db->h = 0;
+    oatk_par_run(ecw_worker, &job);
+    if (job.adopt) {
+        /* what the reads and the table pointed into before (their fill-time arenas, the arrays adopted by the count) stays until the
+         * databases are cleaned: a few arrays of the size of the chains, against a free() per read and per syncmer */
+        const size_t tot = (size_t) job.new_off[sr_db->n];
+        oatk_host_arena_adopt(*new_k, 8 * tot, sr_db), *new_k = 0;
+        oatk_host_arena_adopt(*new_m, 4 * tot, sr_db), *new_m = 0;
+        oatk_host_arena_adopt(*new_s, 8 * tot, sr_db), *new_s = 0;
+        oatk_host_arena_adopt(*occ, 8 * tot, scm_db), *occ = 0;
+    }
+    free(job.new_off);
+}
+
 int oatk_read_error_correction(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, oatk_syncmer_db_t *scm_db, oatk_asmg_t *asmg, double max_edist,
                                uint32_t err_mer_c, uint32_t max_err_c, uint32_t err_arc_c, double max_arc_f, uint64_t *stats12)
 {
@@ -136,25 +160,7 @@ int oatk_read_error_correction(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, oatk_sync
     }
 
     /* reads and syncmer table, on the host threads */
-    {
-        ecw_job_t job = {sr_db, scm_db, new_n, new_k, new_m, new_s, cov, del, occ_off, occ, 0, 0};
-        job.new_off = (uint64_t *) xmalloc(8 * (sr_db->n + 1));
-        for (i = 0, job.new_off[0] = 0; i < sr_db->n; ++i) job.new_off[i + 1] = job.new_off[i] + new_n[i];
-        job.adopt = oatk_host_arena();
-        free(scm_db->c); scm_db->c = 0;
-        free(scm_db->h); scm_db->h = 0;
-        oatk_par_run(ecw_worker, &job);
-        if (job.adopt) {
-            /* what the reads and the table pointed into before (their fill-time arenas, the arrays adopted by the count) stays until the
-             * databases are cleaned: a few arrays of the size of the chains, against a free() per read and per syncmer */
-            const size_t tot = (size_t) job.new_off[sr_db->n];
-            oatk_host_arena_adopt(new_k, 8 * tot, sr_db), new_k = 0;
-            oatk_host_arena_adopt(new_m, 4 * tot, sr_db), new_m = 0;
-            oatk_host_arena_adopt(new_s, 8 * tot, sr_db), new_s = 0;
-            oatk_host_arena_adopt(occ, 8 * tot, scm_db), occ = 0;
-        }
-        free(job.new_off);
-    }
+    oatk_host_ec_write_back(sr_db, scm_db, new_n, &new_k, &new_m, &new_s, cov, del, occ_off, &occ);
 done:
     free(arc_v); free(arc_w);
     free(new_n); free(new_k); free(new_m); free(new_s); free(cov); free(del); free(err_del); free(occ_off); free(occ);

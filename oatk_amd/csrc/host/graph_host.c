@@ -13,6 +13,7 @@
 
 #include "oatk_hip_graph.h"
 #include "oatk_syncasm.h"
+#include "host_internal.h"
 
 static void *xcalloc(size_t n, size_t sz)
 {
@@ -42,6 +43,13 @@ oatk_asmg_t *oatk_make_syncmer_asmg(oatk_hip_ctx *ctx, oatk_syncmer_db_t *scm_db
     if (!scm_db || scm_db->n == 0) return 0;                                   /* syncasm.c:205 */
     *rc = oatk_hip_asm_graph(ctx, min_k_cov, min_a_cov_f, &nv, &na);
     if (*rc) return 0;
+    (void) i, (void) b;
+    return oatk_host_asmg_from_resident(ctx, scm_db, nv, na, rc);
+}
+
+oatk_asmg_t *oatk_host_asmg_from_resident(oatk_hip_ctx *ctx, oatk_syncmer_db_t *scm_db, uint64_t nv, uint64_t na, int *rc)
+{
+    uint64_t i, b;
     uint8_t *del = (uint8_t *) fetch(ctx, OATK_BUF_AG_SCM_DEL, &b, rc); if (*rc) return 0;
     if (b != scm_db->n) { free(del); *rc = OATK_E_STATE; return 0; }           /* the table is not the resident batch's */
     uint32_t *vscm = (uint32_t *) fetch(ctx, OATK_BUF_AG_VTX_SCM, &b, rc); if (*rc) return 0;

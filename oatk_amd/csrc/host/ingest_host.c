@@ -19,6 +19,7 @@
 
 #include "oatk_hip_ingest.h"
 #include "oatk_syncasm.h"
+#include "host_internal.h"
 
 #define UP_CHUNK ((uint64_t) 96 << 20)                 /* bytes per upload piece */
 
@@ -250,38 +251,61 @@ static void name_worker(void *arg, int tid, int n_threads)
 static uint64_t g_window = 0;
 void oatk_host_debug_window(uint64_t bytes) { g_window = bytes; }
 
+/* what the stream keeps on one DEVICE: with the reads spread over several handles (include/oatk_multi.h) a window is uploaded to, parsed and scanned on
+ * the device of the handle its reads will be assembled in */
+typedef struct {
+    int dev;
+    oatk_hip_ctx *up;              /* the uploader's handle */
+    oatk_hip_ctx *piece[2];        /* record scan + syncmer scan of one window */
+    uint8_t *d_win[2];             /* where a slot's window goes on the device */
+    uint8_t *stage;                /* the uploader's page-locked pieces */
+} stream_dev_t;
+
 typedef struct {
     pthread_mutex_t mu;
     pthread_cond_t cv;
     int state[2];                  /* 0 free, 1 window uploaded */
     uint64_t g0[2], g1[2];         /* text range of the window in the slot */
     int failed, stop;
-    oatk_hip_ctx *up;              /* the uploader's handle */
-    uint8_t *d_win[2];             /* where a slot's window goes on the device */
+    stream_dev_t *res;             /* one per device in use */
+    int n_res;
+    const int *res_of_rank;        /* [n_rank] */
+    int n_rank;
     const seg_t *seg;
     int n_seg, n_up;
     uint64_t total, win;
 } stream_t;
+
+/* the handle a window's reads go to: by where the window starts in the input, so the ranks hold contiguous ranges of reads of about equal text */
+static int rank_of_window(const stream_t *st, uint64_t g0)
+{
+    if (st->n_rank <= 1 || st->total == 0) return 0;
+    const uint64_t r = (uint64_t) (((unsigned __int128) g0 * (uint64_t) st->n_rank) / st->total);
+    return r >= (uint64_t) st->n_rank? st->n_rank - 1 : (int) r;
+}
 
 static void *uploader(void *arg)
 {
     stream_t *st = (stream_t *) arg;
     const uint64_t chunk = st->win < UP_CHUNK? ((st->win + 63) & ~63ULL) : UP_CHUNK;
     const int direct = st->n_seg == 1 && st->seg[0].pinned;
-    uint8_t *stage = direct? 0 : (uint8_t *) oatk_hip_staging(st->up, 2 * chunk);
     uint64_t g0, w;
-    int rc = stage || direct? OATK_OK : OATK_E_NOMEM;
+    int rc = OATK_OK;
     for (w = 0, g0 = 0; !rc && g0 < st->total; ++w) {
         const int s = (int) (w & 1);
         const uint64_t g1 = g0 + st->win < st->total? g0 + st->win : st->total;
+        stream_dev_t *D = &st->res[st->res_of_rank[rank_of_window(st, g0)]];
+        if (!direct && !D->stage) D->stage = (uint8_t *) oatk_hip_staging(D->up, 2 * chunk);
+        uint8_t *stage = D->stage;
+        if (!direct && !stage) { rc = OATK_E_NOMEM; break; }
         pthread_mutex_lock(&st->mu);
         while (st->state[s] != 0 && !st->stop) pthread_cond_wait(&st->cv, &st->mu);
         const int stop = st->stop;
         pthread_mutex_unlock(&st->mu);
         if (stop) break;
         if (st->n_seg == 1 && st->seg[0].pinned) {                   /* page-locked text: one copy, no staging */
-            rc = oatk_hip_h2d_async(st->up, st->d_win[s], st->seg[0].mem + g0, g1 - g0);
-            if (!rc) rc = oatk_hip_sync(st->up);
+            rc = oatk_hip_h2d_async(D->up, D->d_win[s], st->seg[0].mem + g0, g1 - g0);
+            if (!rc) rc = oatk_hip_sync(D->up);
             pthread_mutex_lock(&st->mu);
             if (rc) st->failed = rc;
             else st->state[s] = 1, st->g0[s] = g0, st->g1[s] = g1;
@@ -297,12 +321,12 @@ static void *uploader(void *arg)
         int which = 0;
         while (!rc && p0 < g1 && !job.failed) {
             const uint64_t p1 = p0 + chunk < g1? p0 + chunk : g1;
-            rc = oatk_hip_h2d_async(st->up, st->d_win[s] + (p0 - g0), stage + (uint64_t) which * chunk, p1 - p0);
+            rc = oatk_hip_h2d_async(D->up, D->d_win[s] + (p0 - g0), stage + (uint64_t) which * chunk, p1 - p0);
             if (!rc && p1 < g1) {
                 job.dst = stage + (uint64_t) (which ^ 1) * chunk, job.g0 = p1, job.g1 = p1 + chunk < g1? p1 + chunk : g1;
                 oatk_par_run_n(up_worker, &job, st->n_up);
             }
-            if (!rc) rc = oatk_hip_sync(st->up);
+            if (!rc) rc = oatk_hip_sync(D->up);
             p0 = p1, which ^= 1;
         }
         if (job.failed) rc = OATK_E_ARG;
@@ -340,36 +364,51 @@ static double now_s(void)
     return (double) t.tv_sec + 1e-9 * (double) t.tv_nsec;
 }
 
-static int sr_read_stream(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, int K, int S, seg_t *seg, int n_files, uint64_t total, uint64_t win)
+/* ctxs[0 .. n_ctx): the handles the reads are assembled in -- one, or one per GPU: then handle r receives the reads of the r-th part of the input
+ * (rank_of_window) and first[0 .. n_ctx] their ranges; sid0 of handle r = first[r] */
+static int sr_read_stream(oatk_hip_ctx **ctxs, int n_ctx, uint64_t *first, oatk_sr_db_t *sr_db, int K, int S, seg_t *seg, int n_files, uint64_t total, uint64_t win)
 {
     const char *lg = getenv("OATK_DROPIN_LOG");
     const int log = lg && lg[0] && lg[0] != '0';
-    const int dev = oatk_hip_device(ctx), threads = oatk_host_threads();
+    const int threads = oatk_host_threads();
     const double t_begin = now_s();
     double t_wait = 0, t_dev = 0, t_fill = 0, t_app = 0;
-    oatk_hip_ctx *piece[2] = {0, 0};
     stream_t st;
+    stream_dev_t res[64];
+    int res_of_rank[64];
     pthread_t th;
-    int rc = OATK_OK, started = 0, i;
+    int rc = OATK_OK, started = 0, i, r, cur = 0, prev_res = -1, prev_slot = 0;
     uint64_t n_done = 0, carry = 0, w, text_done = 0;
     uint64_t *off = 0, *hdr = 0;
+    uint8_t *hop = 0;                                               /* a carried record tail on its way from one device to the next */
     char **names = 0;
     memset(&st, 0, sizeof(st));
+    memset(res, 0, sizeof(res));
+    if (n_ctx < 1 || n_ctx > 64) return OATK_E_ARG;
     pthread_mutex_init(&st.mu, 0);
     pthread_cond_init(&st.cv, 0);
-    st.seg = seg, st.n_seg = n_files, st.total = total, st.win = win;
+    st.seg = seg, st.n_seg = n_files, st.total = total, st.win = win, st.res = res, st.res_of_rank = res_of_rank, st.n_rank = n_ctx;
     st.n_up = threads > 1? threads : 1;            /* readers of the file beside the threads that fill the structs: with the reads in arenas the file is what sr_read waits for */
     { const char *e = getenv("OATK_HOST_UP_THREADS"); if (e && atoi(e) > 0) st.n_up = atoi(e); }
     const int fmt = sniff_format(seg, n_files, total);
-    rc = oatk_hip_scan_begin(ctx, 0, K, S);
-    st.up = rc? 0 : oatk_hip_create(dev);
-    for (i = 0; !rc && i < 2; ++i) {
-        uint8_t *d = 0;
-        piece[i] = oatk_hip_create(dev);
-        if (!piece[i] || !st.up) { rc = OATK_E_NODEV; break; }
-        if (i == 1 && total <= win) break;                        /* one window: one slot */
-        rc = oatk_hip_ingest_text_buffer(piece[i], CARRY_CAP + (win < total? win : total) + 64, &d);
-        st.d_win[i] = d + CARRY_CAP;
+    for (r = 0; r < n_ctx; ++r) {                                   /* one set of working handles per device */
+        const int dev = oatk_hip_device(ctxs[r]);
+        for (i = 0; i < st.n_res && res[i].dev != dev; ++i) {}
+        if (i == st.n_res) res[st.n_res++].dev = dev;
+        res_of_rank[r] = i;
+    }
+    rc = oatk_hip_scan_begin(ctxs[0], 0, K, S);
+    if (first) first[0] = 0;
+    for (r = 0; !rc && r < st.n_res; ++r) {
+        res[r].up = oatk_hip_create(res[r].dev);
+        for (i = 0; !rc && i < 2; ++i) {
+            uint8_t *d = 0;
+            res[r].piece[i] = oatk_hip_create(res[r].dev);
+            if (!res[r].piece[i] || !res[r].up) { rc = OATK_E_NODEV; break; }
+            if (i == 1 && total <= win) break;                        /* one window: one slot */
+            rc = oatk_hip_ingest_text_buffer(res[r].piece[i], CARRY_CAP + (win < total? win : total) + 64, &d);
+            res[r].d_win[i] = d + CARRY_CAP;
+        }
     }
     if (rc) goto done;
     oatk_host_set_threads(threads > 1? threads / 2 : 1);           /* the other half reads the file */
@@ -387,15 +426,33 @@ static int sr_read_stream(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, int K, int S, 
         if (rc) break;
         t_wait += now_s() - t0, t0 = now_s();
         const int final = g1 == total;
-        uint8_t *d_text = st.d_win[s] - carry;
+        const int rank = rank_of_window(&st, g0), ri = res_of_rank[rank];
+        stream_dev_t *D = &res[ri];
+        while (cur < rank) {                                         /* the reads from here on belong to the next handle(s) */
+            ++cur;
+            rc = oatk_hip_scan_begin(ctxs[cur], n_done, K, S);
+            if (rc) break;
+            if (first) first[cur] = n_done;
+        }
+        if (rc) break;
+        if (carry && prev_res >= 0 && prev_res != ri) {
+            /* the record cut by the previous window's end was parked on another device: bring it over through the host (once per change of device) */
+            if (!hop) hop = (uint8_t *) malloc(CARRY_CAP);
+            if (!hop) { rc = OATK_E_NOMEM; break; }
+            rc = oatk_hip_d2h(res[prev_res].piece[prev_slot], hop, res[prev_res].d_win[s] - carry, carry);
+            if (!rc) rc = oatk_hip_h2d_async(D->piece[s], D->d_win[s] - carry, hop, carry);
+            if (!rc) rc = oatk_hip_sync(D->piece[s]);
+            if (rc) break;
+        }
+        uint8_t *d_text = D->d_win[s] - carry;
         const uint64_t len = carry + (g1 - g0);
         uint64_t n = 0, used = 0, b = 0;
-        rc = oatk_hip_ingest(piece[s], d_text, len, fmt, final, &n, &used);
+        rc = oatk_hip_ingest(D->piece[s], d_text, len, fmt, final, &n, &used);
         if (rc) break;
         const uint64_t next_carry = len - used;
         if (!final) {
             if (next_carry > CARRY_CAP || used == 0) { rc = OATK_E_NOMEM; break; }       /* a record longer than a window: the caller retries in one piece */
-            rc = oatk_hip_d2d(piece[s], st.d_win[s ^ 1] - next_carry, d_text + used, next_carry);
+            rc = oatk_hip_d2d(D->piece[s], D->d_win[s ^ 1] - next_carry, d_text + used, next_carry);      /* (moved on above if the next window lands on another device) */
             if (rc) break;
         }
         pthread_mutex_lock(&st.mu);                                 /* the window's text is spent: the uploader may have the slot back */
@@ -403,9 +460,10 @@ static int sr_read_stream(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, int K, int S, 
         pthread_cond_broadcast(&st.cv);
         pthread_mutex_unlock(&st.mu);
         const uint64_t text0 = g0 - carry;                          /* where this piece's text starts in the whole text */
-        carry = next_carry, text_done = g1;
+        carry = next_carry, text_done = g1, prev_res = ri, prev_slot = s;
         if (n == 0) continue;
-        rc = oatk_hip_scan_ingested(piece[s], n_done, K, S);
+        oatk_hip_ctx *ctx = ctxs[cur];
+        rc = oatk_hip_scan_ingested(D->piece[s], n_done, K, S);
         if (rc) break;
         t_dev += now_s() - t0, t0 = now_s();
         /* room for the reads: from the first piece's density, generously; grown when a later piece needs more */
@@ -417,16 +475,21 @@ static int sr_read_stream(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, int K, int S, 
             memset(na + sr_db->m, 0, sizeof(oatk_sr_t) * (m - sr_db->m));
             sr_db->a = na, sr_db->m = m;
         }
-        if (n_done == 0 && !final && used) {                        /* ... and for the assembled batch on the device */
-            oatk_hip_info_t inf;
-            oatk_hip_info(piece[s], &inf);
-            const double scale = (double) total / (double) used * 1.03;
-            rc = oatk_hip_scan_reserve(ctx, (uint64_t) ((double) inf.seq_bytes * scale) + (1 << 20), (uint64_t) ((double) n * scale) + 1024,
-                                       (uint64_t) ((double) inf.n_occ * scale * 1.1) + 4096);
-            if (rc) break;
+        {   /* ... and for the batch assembled in this handle, at its first piece */
+            oatk_hip_info_t have;
+            oatk_hip_info(ctx, &have);
+            if (have.n_reads == 0 && !final && used) {
+                oatk_hip_info_t inf;
+                oatk_hip_info(D->piece[s], &inf);
+                const double share = (double) total / (double) n_ctx, left = (double) (total - text0);
+                const double scale = (share < left? share : left) / (double) used * 1.03 + (n_ctx > 1? 1.0 : 0.0);       /* (a handle's part ends on a window boundary) */
+                rc = oatk_hip_scan_reserve(ctx, (uint64_t) ((double) inf.seq_bytes * scale) + (1 << 20), (uint64_t) ((double) n * scale) + 1024,
+                                           (uint64_t) ((double) inf.n_occ * scale * 1.1) + 4096);
+                if (rc) break;
+            }
         }
         if (!sr_db) {                                               /* the scan only: no structs to fill */
-            rc = oatk_hip_scan_append(ctx, piece[s]);
+            rc = oatk_hip_scan_append(ctx, D->piece[s]);
             if (rc) break;
             t_app += now_s() - t0;
             n_done += n;
@@ -435,23 +498,29 @@ static int sr_read_stream(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, int K, int S, 
         const void *d = 0;
         off = (uint64_t *) malloc(8 * n), hdr = (uint64_t *) malloc(8 * n), names = (char **) calloc(n, sizeof(char *));
         if (!off || !hdr || !names) { rc = OATK_E_NOMEM; break; }
-        rc = oatk_hip_buffer(piece[s], OATK_BUF_INGEST_OFF, &d, &b);
-        if (!rc) rc = oatk_hip_d2h(piece[s], off, d, 8 * n);
-        if (!rc) rc = oatk_hip_buffer(piece[s], OATK_BUF_INGEST_HDR, &d, &b);
-        if (!rc) rc = oatk_hip_d2h(piece[s], hdr, d, 8 * n);
+        rc = oatk_hip_buffer(D->piece[s], OATK_BUF_INGEST_OFF, &d, &b);
+        if (!rc) rc = oatk_hip_d2h(D->piece[s], off, d, 8 * n);
+        if (!rc) rc = oatk_hip_buffer(D->piece[s], OATK_BUF_INGEST_HDR, &d, &b);
+        if (!rc) rc = oatk_hip_d2h(D->piece[s], hdr, d, 8 * n);
         if (rc) break;
         name_job_t nj = {seg, n_files, hdr, text0, n, names};
         oatk_par_run(name_worker, &nj);
-        rc = oatk_sr_db_fill_range(piece[s], sr_db, n_done, off, n, names);
+        rc = oatk_sr_db_fill_range(D->piece[s], sr_db, n_done, off, n, names);
         free(off); free(hdr); free(names);
         off = hdr = 0, names = 0;
         if (rc) break;
         t_fill += now_s() - t0, t0 = now_s();
-        rc = oatk_hip_scan_append(ctx, piece[s]);
+        rc = oatk_hip_scan_append(ctx, D->piece[s]);
         if (rc) break;
         t_app += now_s() - t0;
         n_done += n;
     }
+    while (!rc && cur < n_ctx - 1) {                                /* handles the input did not reach hold no reads */
+        ++cur;
+        rc = oatk_hip_scan_begin(ctxs[cur], n_done, K, S);
+        if (first) first[cur] = n_done;
+    }
+    if (first) first[n_ctx] = n_done;
 done:
     if (started) {
         pthread_mutex_lock(&st.mu);
@@ -461,21 +530,28 @@ done:
         pthread_join(th, 0);
     }
     oatk_host_set_threads(threads);
-    free(off); free(hdr); free(names);
-    for (i = 0; i < 2; ++i) if (piece[i]) oatk_hip_destroy(piece[i]);
-    if (st.up) oatk_hip_destroy(st.up);
+    free(off); free(hdr); free(names); free(hop);
+    for (r = 0; r < st.n_res; ++r) {
+        for (i = 0; i < 2; ++i) if (res[r].piece[i]) oatk_hip_destroy(res[r].piece[i]);
+        if (res[r].up) oatk_hip_destroy(res[r].up);
+    }
     pthread_mutex_destroy(&st.mu);
     pthread_cond_destroy(&st.cv);
     if (!rc && sr_db && sr_db->m > sr_db->n) {                      /* give back what the estimate left over */
         oatk_sr_t *na = (oatk_sr_t *) realloc(sr_db->a, sizeof(oatk_sr_t) * (sr_db->n? sr_db->n : 1));
         if (na) sr_db->a = na, sr_db->m = sr_db->n;
     }
-    if (log) fprintf(stderr, "[M::oatk_sr_read_files] %.2f GB of text in %lu windows, %lu reads: %.3f s (waiting for the uploader %.3f, record + syncmer scan %.3f, "
-                             "structs %.3f, append %.3f)\n", (double) total / 1e9, (unsigned long) w, (unsigned long) n_done, now_s() - t_begin, t_wait, t_dev, t_fill, t_app);
+    if (log) fprintf(stderr, "[M::oatk_sr_read_files] %.2f GB of text in %lu windows, %lu reads into %d handle(s): %.3f s (waiting for the uploader %.3f, record + syncmer scan %.3f, "
+                             "structs %.3f, append %.3f)\n", (double) total / 1e9, (unsigned long) w, (unsigned long) n_done, n_ctx, now_s() - t_begin, t_wait, t_dev, t_fill, t_app);
     return rc;
 }
 
 int oatk_sr_read_files(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, char **files, int n_files)
+{
+    return oatk_host_sr_read_files_n(&ctx, 1, sr_db, files, n_files, 0);
+}
+
+int oatk_host_sr_read_files_n(oatk_hip_ctx **ctxs, int n_ctx, oatk_sr_db_t *sr_db, char **files, int n_files, uint64_t *first)
 {
     uint64_t total = 0;
     int i, rc = OATK_OK;
@@ -486,15 +562,21 @@ int oatk_sr_read_files(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, char **files, int
             seg[i].map = (uint8_t *) mmap(0, (size_t) seg[i].size, PROT_READ, MAP_PRIVATE, seg[i].fd, 0);
             if (seg[i].map == MAP_FAILED) { seg[i].map = 0; rc = OATK_E_NOMEM; }
         }
-    if (!rc && total == 0) rc = oatk_hip_scan_begin(ctx, 0, sr_db->k, sr_db->s);
-    else if (!rc) {
+    if (!rc && total == 0) {
+        for (i = 0; !rc && i < n_ctx; ++i) rc = oatk_hip_scan_begin(ctxs[i], 0, sr_db->k, sr_db->s);
+        for (i = 0; first && i <= n_ctx; ++i) first[i] = 0;
+    } else if (!rc) {
         const char *ew = getenv("OATK_DEBUG_WINDOW");              /* test hook, like oatk_host_debug_window */
         uint64_t win = g_window? g_window : (ew && atoll(ew) > 0? (uint64_t) atoll(ew) : WIN_DEFAULT);
+        if (n_ctx > 1 && !g_window && !(ew && atoll(ew) > 0)) {     /* several handles: at least four windows each, so the parts come out even */
+            const uint64_t even = total / (4 * (uint64_t) n_ctx);
+            if (even < win) win = even > ((uint64_t) 64 << 20)? even : (uint64_t) 64 << 20;
+        }
         if (win < 4096) win = 4096;
-        rc = sr_read_stream(ctx, sr_db, sr_db->k, sr_db->s, seg, n_files, total, win);
+        rc = sr_read_stream(ctxs, n_ctx, first, sr_db, sr_db->k, sr_db->s, seg, n_files, total, win);
         if (rc == OATK_E_NOMEM && win < total) {                    /* a record longer than a window: once more, in one piece */
             oatk_sr_db_clean(sr_db);
-            rc = sr_read_stream(ctx, sr_db, sr_db->k, sr_db->s, seg, n_files, total, total);
+            rc = sr_read_stream(ctxs, n_ctx, first, sr_db, sr_db->k, sr_db->s, seg, n_files, total, total);
         }
     }
     seg_close(seg, n_files);
@@ -517,8 +599,8 @@ int oatk_scan_text(oatk_hip_ctx *ctx, const uint8_t *text, uint64_t n_bytes, int
     else {
         uint64_t win = window? window : WIN_DEFAULT;
         if (win < 4096) win = 4096;
-        rc = sr_read_stream(ctx, 0, k, s, &seg, 1, total, win);
-        if (rc == OATK_E_NOMEM && win < total) rc = sr_read_stream(ctx, 0, k, s, &seg, 1, total, total);
+        rc = sr_read_stream(&ctx, 1, 0, 0, k, s, &seg, 1, total, win);
+        if (rc == OATK_E_NOMEM && win < total) rc = sr_read_stream(&ctx, 1, 0, 0, k, s, &seg, 1, total, total);
     }
     if (!rc && n_reads) { oatk_hip_info_t inf; oatk_hip_info(ctx, &inf); *n_reads = inf.n_reads; }
     return rc;

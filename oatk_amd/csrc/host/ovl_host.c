@@ -15,6 +15,7 @@
 
 #include "oatk_hip_cons.h"
 #include "oatk_syncasm.h"
+#include "host_internal.h"
 
 static void *xmalloc(size_t n)
 {
@@ -38,10 +39,16 @@ static void *fetch(oatk_hip_ctx *ctx, int which, uint64_t *bytes, int *rc)
 oatk_overlap_t *oatk_overlap_fetch(oatk_hip_ctx *ctx, int *rc)
 {
     int r = 0;
-    uint64_t np = 0, ne = 0, b;
+    uint64_t np = 0, ne = 0;
     if (!rc) rc = &r;
     *rc = oatk_hip_overlap_hist(ctx, &np, &ne);
     if (*rc) return 0;
+    return oatk_host_overlap_from_resident(ctx, np, ne, rc);
+}
+
+oatk_overlap_t *oatk_host_overlap_from_resident(oatk_hip_ctx *ctx, uint64_t np, uint64_t ne, int *rc)
+{
+    uint64_t b;
     oatk_overlap_t *o = (oatk_overlap_t *) calloc(1, sizeof(oatk_overlap_t));
     o->n_pairs = np, o->n_entries = ne;
     o->key = (uint64_t *) fetch(ctx, OATK_BUF_OVL_KEY, &b, rc); if (*rc) return 0;

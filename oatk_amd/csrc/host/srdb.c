@@ -19,6 +19,7 @@
 #include <time.h>
 
 #include "oatk_syncasm.h"
+#include "host_internal.h"
 
 static double host_now(void)
 {
@@ -473,20 +474,30 @@ oatk_syncmer_db_t *oatk_collect_syncmer_from_reads(oatk_hip_ctx *ctx, oatk_sr_db
     uint64_t b;
     uint64_t *h = 0, *s = 0, *occ_off = 0, *occ = 0, *kid = 0;
     uint32_t *cov = 0;
+    oatk_syncmer_db_t *db = 0;
     h = (uint64_t *) fetch(ctx, OATK_BUF_SCM_H, &b, &rc); if (rc) goto fail;
     s = (uint64_t *) fetch(ctx, OATK_BUF_SCM_S, &b, &rc); if (rc) goto fail;
     cov = (uint32_t *) fetch(ctx, OATK_BUF_SCM_COV, &b, &rc); if (rc) goto fail;
     occ_off = (uint64_t *) fetch(ctx, OATK_BUF_SCM_OCC_OFF, &b, &rc); if (rc) goto fail;
     occ = (uint64_t *) fetch(ctx, OATK_BUF_SCM_OCC, &b, &rc); if (rc) goto fail;
     kid = (uint64_t *) fetch(ctx, OATK_BUF_POS_KID, &b, &rc); if (rc) goto fail;
+    db = oatk_host_build_syncmer_db(sr_db, inf.n_scm, inf.n_occ, h, s, cov, occ_off, &occ, kid);
+fail:
+    free(h); free(s); free(cov); free(occ_off); free(occ); free(kid);
+    if (rc_out) *rc_out = rc;
+    return db;
+}
 
+oatk_syncmer_db_t *oatk_host_build_syncmer_db(oatk_sr_db_t *sr_db, uint64_t n_scm, uint64_t n_occ, const uint64_t *h, const uint64_t *s, const uint32_t *cov,
+                                              const uint64_t *occ_off, uint64_t **occ, const uint64_t *kid)
+{
     oatk_syncmer_db_t *db = (oatk_syncmer_db_t *) xmalloc(sizeof(oatk_syncmer_db_t));
-    db->n = db->m = inf.n_scm;
-    db->a = (oatk_syncmer_t *) xmalloc(sizeof(oatk_syncmer_t) * inf.n_scm);
-    db->c = (uint16_t *) xmalloc(sizeof(uint16_t) * inf.n_scm);
+    db->n = db->m = n_scm;
+    db->a = (oatk_syncmer_t *) xmalloc(sizeof(oatk_syncmer_t) * n_scm);
+    db->c = (uint16_t *) xmalloc(sizeof(uint16_t) * n_scm);
     db->h = 0;
-    collect_job_t job = {db, sr_db, h, s, cov, occ_off, occ, kid, 0, g_use_arena};
-    /* where each read's ids start in POS_KID: the chain lengths have not changed since the scan */
+    collect_job_t job = {db, sr_db, h, s, cov, occ_off, *occ, kid, 0, g_use_arena};
+    /* where each read's ids start in the id array: the chain lengths have not changed since the scan */
     job.kid_off = (uint64_t *) xmalloc(8 * (sr_db->n + 1));
     {
         uint64_t i;
@@ -494,13 +505,8 @@ oatk_syncmer_db_t *oatk_collect_syncmer_from_reads(oatk_hip_ctx *ctx, oatk_sr_db
     }
     oatk_par_run(collect_worker, &job);
     free(job.kid_off);
-    if (job.adopt) oatk_host_arena_adopt(occ, 8 * (size_t) inf.n_occ, db), occ = 0;
-    free(h); free(s); free(cov); free(occ_off); free(occ); free(kid);
+    if (job.adopt) oatk_host_arena_adopt(*occ, 8 * (size_t) n_occ, db), *occ = 0;
     return db;
-fail:
-    free(h); free(s); free(cov); free(occ_off); free(occ); free(kid);
-    if (rc_out) *rc_out = rc;
-    return 0;
 }
 
 void oatk_sr_db_clean(oatk_sr_db_t *sr_db)

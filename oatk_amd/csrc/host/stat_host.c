@@ -12,6 +12,7 @@
 
 #include "oatk_hip_stat.h"
 #include "oatk_syncasm.h"
+#include "host_internal.h"
 
 #define LOWEST_CUT 5                      /* syncmer.c:754 */
 
@@ -79,13 +80,18 @@ int oatk_sr_db_stat(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, FILE *fo, int verbos
     oatk_stat_raw_t *raw = (oatk_stat_raw_t *) calloc(1, sizeof(oatk_stat_raw_t));
     int rc = oatk_hip_stat(ctx, raw);
     (void) verbose;                                                /* the histogram plots of verbose > 1 are not reproduced */
-    if (rc) { free(raw); return rc; }
+    if (!rc) rc = oatk_host_stat_report(sr_db, raw, fo);
+    free(raw);
+    return rc;
+}
+
+int oatk_host_stat_report(oatk_sr_db_t *sr_db, const oatk_stat_raw_t *raw, FILE *fo)
+{
     oatk_sr_stat_t *st = sr_db->stats;
     if (!st) st = sr_db->stats = (oatk_sr_stat_t *) calloc(1, sizeof(oatk_sr_stat_t));
     const uint64_t m = raw->n_syncmers, n = raw->n_reads;
     if (m == 0) {
         if (fo) fprintf(fo, "[M::%s] empty syncmer collection\n", "sr_db_stat");
-        free(raw);
         return OATK_OK;
     }
     const double dist = (double) raw->sum_dist / (int) raw->n_dist;          /* 0/0 = NaN where the reference divides 0.0 by 0 too */
@@ -112,6 +118,5 @@ int oatk_sr_db_stat(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, FILE *fo, int verbos
     st->syncmer_n = m, st->syncmer_per_read = (double) m / n, st->syncmer_avg_dist = dist;
     st->smer_unique = smeru, st->smer_singleton = smer1, st->smer_avg_cnt = smera, st->smer_peak_hom = s_hom, st->smer_peak_het = s_het;
     st->kmer_unique = kmeru, st->kmer_singleton = kmer1, st->kmer_avg_cnt = kmera, st->kmer_peak_hom = k_hom, st->kmer_peak_het = k_het;
-    free(raw);
     return OATK_OK;
 }

@@ -17,9 +17,13 @@ namespace oatk {
 #define OVH_MAX 64        // distinct distances per pair the kernel keeps (the EC graph's own limit is 48)
 
 // one wave per run of equal keys.  n_out == nullptr: write the entries at out_off[run]; otherwise only count them.
-__global__ __launch_bounds__(64) void ovh_kernel(uint64_t n_runs, const uint64_t *ukeys, const uint32_t *counts, const uint64_t *run_off,
-                                                 const uint32_t *sdist, uint32_t *n_out, const uint64_t *out_off, int32_t *o_dist, uint32_t *o_cnt,
-                                                 uint8_t *o_tail, uint32_t *flags)
+// W: the run is made of weighted segments -- sval[i] = distance | calls << 32 stands for `calls` consecutive add_ovl_count calls with that distance
+// (what shards exchange, include/oatk_hip_multi.h); sdist is then unused.  Order of first appearance, totals and the tail rule are those of the
+// expanded list: the last call is a repeat iff the last segment's distance was counted more than once in all.
+template <bool W>
+__global__ __launch_bounds__(64) void ovh_kernel_t(uint64_t n_runs, const uint64_t *ukeys, const uint32_t *counts, const uint64_t *run_off,
+                                                   const uint32_t *sdist, const uint64_t *sval, uint32_t *n_out, const uint64_t *out_off, int32_t *o_dist,
+                                                   uint32_t *o_cnt, uint8_t *o_tail, uint32_t *flags)
 {
     __shared__ int32_t hk[OVH_MAX];
     __shared__ uint32_t hc[OVH_MAX];
@@ -33,11 +37,19 @@ __global__ __launch_bounds__(64) void ovh_kernel(uint64_t n_runs, const uint64_t
     bool overflow = false;
     for (uint32_t t0 = 0; t0 < cc && !overflow; t0 += 64) {
         const bool in = t0 + lane < cc;
-        const int32_t d = in? (int32_t) sdist[oo + t0 + lane] : 0;
+        const uint64_t sv = W && in? sval[oo + t0 + lane] : 0ULL;
+        const int32_t d = W? (int32_t) (uint32_t) sv : (in? (int32_t) sdist[oo + t0 + lane] : 0);
+        const uint32_t wt = W? (uint32_t) (sv >> 32) : 1u;
+        auto total = [&](uint64_t mask) -> uint32_t {                    // calls behind the lanes of `mask`
+            if (!W) return (uint32_t) __builtin_popcountll(mask);
+            uint32_t v = (mask >> lane & 1ULL)? wt : 0u;
+            for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+            return v;
+        };
         uint64_t rest = __ballot(in);
         for (uint32_t j = 0; j < nd && rest; ++j) {                      // distances seen in earlier chunks
             const uint64_t eq = __ballot(in && d == hk[j]) & rest;
-            if (eq && lane == 0) hc[j] += (uint32_t) __builtin_popcountll(eq);
+            if (eq) { const uint32_t t = total(eq); if (lane == 0) hc[j] += t; }
             rest &= ~eq;
         }
         while (rest) {                                                   // new ones, in the order of their first appearance
@@ -46,7 +58,8 @@ __global__ __launch_bounds__(64) void ovh_kernel(uint64_t n_runs, const uint64_t
             const uint64_t eq = __ballot(in && d == x) & rest;
             rest &= ~eq;
             if (nd == OVH_MAX) { overflow = true; break; }
-            if (lane == 0) hk[nd] = x, hc[nd] = (uint32_t) __builtin_popcountll(eq);
+            const uint32_t t = total(eq);
+            if (lane == 0) hk[nd] = x, hc[nd] = t;
             ++nd;
         }
         __syncthreads();                                                 // lane 0's LDS writes before the next chunk's reads
@@ -58,7 +71,7 @@ __global__ __launch_bounds__(64) void ovh_kernel(uint64_t n_runs, const uint64_t
     if ((uint32_t) lane < nd) o_dist[w0 + lane] = hk[lane], o_cnt[w0 + lane] = hc[lane];
     if (lane == 0 && nd) {
         // the last call was a repeat unless the last distance of the run occurs exactly once (then the call inserted it)
-        const int32_t last = (int32_t) sdist[oo + cc - 1];
+        const int32_t last = W? (int32_t) (uint32_t) sval[oo + cc - 1] : (int32_t) sdist[oo + cc - 1];
         uint32_t c = 0;
         for (uint32_t j = 0; j < nd; ++j) if (hk[j] == last) c = hc[j];
         o_tail[run] = c > 1;

@@ -25,6 +25,7 @@ _DTYPES = {
     "RA_ALN_SID": np.uint32, "RA_ALN_OFF": np.uint64, "RA_ALN_S": np.float64, "RA_FRG_UID": np.uint64, "RA_FRG_UBEG": np.uint32,
     "RA_FRG_UEND": np.uint32, "RA_FRG_SBEG": np.uint32, "RA_FRG_SEND": np.uint32, "RA_SKIPPED": np.uint32,
     "OVL_KEY": np.uint64, "OVL_OFF": np.uint64, "OVL_DIST": np.int32, "OVL_CNT": np.uint32, "OVL_TAIL": np.uint8,
+    "MG_G_H": np.uint64, "MG_G_S": np.uint64, "MG_G_COV": np.uint32, "MG_G_DEL": np.uint8, "MG_G_OCC_OFF": np.uint64, "MG_G_OCC": np.uint64, "MG_POS_GKID": np.uint64,
     "MG_H": np.uint64, "MG_S": np.uint64, "MG_COV": np.uint32, "MG_L2G": np.uint32, "MG_EC_COV": np.uint32, "MG_EC_DEL": np.uint8, "MG_LCOV": np.uint32,
     "AG_SCM_DEL": np.uint8, "AG_VTX_SCM": np.uint32, "AG_VTX_COV": np.uint32, "AG_IDX_P": np.uint64, "AG_IDX_N": np.uint32,
     "AG_ARC_V": np.uint64, "AG_ARC_W": np.uint64, "AG_ARC_COV": np.uint32, "AG_ARC_COMP": np.uint8, "AG_ARC_LINK": np.uint64,
@@ -120,6 +121,29 @@ class HipSyncasm:
         ni = C.c_uint64()
         self._check(self.L.oatk_hip_ec_sharded(self.h, comm, max_edist, c, 10 * c, c, a, st.ctypes.data, C.byref(ni)), "oatk_hip_ec_sharded")
         return st, int(ni.value)
+
+    # ---- sharded reads up to the graph hand-off (include/oatk_hip_multi.h, second half) ----
+    def gather_table(self, comm, root=0):
+        """the merged (after merge_counts) or refreshed (after ec_sharded) table with its occurrence lists on rank `root`: fetch MG_G_* there"""
+        self._check(self.L.oatk_hip_gather_table(self.h, comm, root), "oatk_hip_gather_table")
+
+    def asm_graph_sharded(self, comm, min_k_cov, min_a_cov_f):
+        nv, na = C.c_uint64(), C.c_uint64()
+        self._check(self.L.oatk_hip_asm_graph_sharded(self.h, comm, int(min_k_cov), float(min_a_cov_f), C.byref(nv), C.byref(na)), "oatk_hip_asm_graph_sharded")
+        return int(nv.value), int(na.value)
+
+    def consensus_sharded(self, comm, min_cov=1):
+        self._check(self.L.oatk_hip_consensus_sharded(self.h, comm, int(min_cov)), "oatk_hip_consensus_sharded")
+
+    def overlap_hist_sharded(self, comm, min_cov=0):
+        np_, ne = C.c_uint64(), C.c_uint64()
+        self._check(self.L.oatk_hip_overlap_hist_sharded(self.h, comm, int(min_cov), C.byref(np_), C.byref(ne)), "oatk_hip_overlap_hist_sharded")
+        return int(np_.value), int(ne.value)
+
+    def stat_sharded(self, comm):
+        r = _lib.StatRaw()
+        self._check(self.L.oatk_hip_stat_sharded(self.h, comm, C.byref(r)), "oatk_hip_stat_sharded")
+        return self._stat_dict(r)
 
     # ---- error correction (include/oatk_hip_ec.h) ----
     def ec_graph(self, light_c=0):

@@ -163,3 +163,56 @@ def test_cli_refusals_of_the_device_fall_back_and_stay_identical(tmp_path, refus
         assert tab["calc_syncmer_overlap"][0] == 0 and tab["scg_syncmer_consensus"][0] > 20
     if refuse in (1, 2, 8):
         assert tab["scg_read_alignment"][0] >= 3 and tab["scg_read_alignment"][2] == 0
+
+
+@pytest.mark.parametrize("devices,K,S,cov,err", [("0,0", 1001, 31, 8, 0.0008), ("0,0,0,0", 301, 21, 6, 0.001), ("0,0,0", 101, 11, 5, 0.003)])
+def test_cli_over_several_handles(tmp_path, devices, K, S, cov, err):
+    """OATK_DEVICES names several handles (here all on the test box's one GPU, talking through the in-process group): the reads are spread over them by
+    position in the input, the count tables merged by hash range, the correction sharded, and one syncmer_db_t / one graph / one set of consensus tables
+    / one alignment vector handed to the reference's serial tail (include/oatk_multi.h).  Same GFA bytes as the reference, every call
+    served from the devices."""
+    n = devices.count(",") + 1
+    reads = A.hifi_like(320, 50000, 9000 if K > 500 else (5000 if K > 200 else 2500), seed=K + 5 * n, err=err)
+    fa = str(tmp_path / "reads.fa")
+    R.write_fasta(reads, fa)
+    win = os.path.getsize(fa) // (3 * n) + 1000                          # about three windows per handle, records straddling every boundary
+    tab, log = both(tmp_path, fa, K, S, cov, env={"OATK_DEVICES": devices, "OATK_DEBUG_WINDOW": str(win)})
+    for f in SIX:
+        assert tab[f][0] >= 1 and tab[f][2] == 0, (f, tab[f], log[-3000:])
+    assert tab["make_syncmer_graph"][0] == 2 and tab["sr_db_stat"][0] == 2 and tab["scg_read_alignment"][0] >= 3
+    assert tab["scg_syncmer_consensus"][0] > 20 and tab["scg_syncmer_consensus"][2] == 0
+    assert tab["calc_syncmer_overlap"][0] > 20 and tab["calc_syncmer_overlap"][2] == 0
+    import re
+    assert int(re.search(r"reads into (\d+) handle", log).group(1)) == n
+
+
+def test_cli_over_several_handles_two_files_and_an_idle_handle(tmp_path):
+    """a short input in one window: everything lands on handle 0 and the others hold no reads -- the collectives still run with empty shards; and the
+    same with two files (gzip'ed FASTQ + FASTQ with CRLF) spread over three handles"""
+    reads = A.hifi_like(300, 50000, 5000, seed=19, err=0.0008)
+    fa = str(tmp_path / "reads.fa")
+    R.write_fasta(reads, fa)
+    tab, log = both(tmp_path, fa, 301, 21, 6, env={"OATK_DEVICES": "0,0,0"})
+    for f in SIX:
+        assert tab[f][0] >= 1 and tab[f][2] == 0, (f, tab[f], log[-3000:])
+    f1, f2 = str(tmp_path / "a.fq.gz"), str(tmp_path / "b.fq")
+    with gzip.open(f1, "wb") as f:
+        for i, r in enumerate(reads[:150]):
+            f.write(b"@q%d\n" % i + r + b"\n+\n" + b"I" * len(r) + b"\n")
+    with open(f2, "wb") as f:
+        for i, r in enumerate(reads[150:]):
+            f.write(b"@w%d second file\r\n" % i + r + b"\r\n+\r\n" + b"5" * len(r) + b"\r\n")
+    tab, log = both(tmp_path, [f1, f2], 301, 21, 6, env={"OATK_DEVICES": "0,0,0", "OATK_DEBUG_WINDOW": "400000"})
+    for f in SIX:
+        assert tab[f][0] >= 1 and tab[f][2] == 0, (f, tab[f], log[-3000:])
+
+
+def test_cli_over_several_handles_without_ec_falls_back_after_the_count(tmp_path):
+    """--no-read-ec: the sharded graph is built from corrected chains only, so with several handles the graph and what follows are the original's --
+    on the complete sr_db_t / syncmer_db_t the handles left on the host.  Still the reference's bytes."""
+    reads = A.hifi_like(260, 50000, 5000, seed=5)
+    fa = str(tmp_path / "reads.fa")
+    R.write_fasta(reads, fa)
+    tab, _ = both(tmp_path, fa, 301, 21, 6, extra=["--no-read-ec", "--unzip-round", "0"], env={"OATK_DEVICES": "0,0", "OATK_DEBUG_WINDOW": "300000"})
+    assert tab["sr_read"][0] == 1 and tab["collect_syncmer_from_reads"][0] == 1 and tab["sr_db_stat"][0] == 1
+    assert tab["make_syncmer_graph"][2] == 1
