@@ -10,9 +10,11 @@ timed region starts: run_syncasm.c:81-131 without the file parsing --
     graph  make_syncmer_graph(sr_db, scm_db, 0, 0.) + the hoco arc overlaps of scg_consensus             (run_syncasm.c:109-117)
     ec     read_error_correction (Levenshtein path search per error block) + update_syncmer_db           (syncerr.c:819)
 At N = 1 the workload is BASELINE.json configs[2] (2 M reads x ~15 kb = 30 Gbases, k = 1001, s = 31, -c 30), the configuration
-the metric is quoted on; it occupies ~70 GB of the 288 GB.  For N > 1 (launched by torch.distributed.run, one rank per GPU) reads
-are sharded by record: rank r owns reads [r*R, (r+1)*R) of an N*R-read set ("weak" scaling); the per-GPU syncmer tables are
-merged, the graph is built from everybody's adjacent pairs and every rank corrects its own reads (oatk_amd/multi.py, RCCL).
+the metric is quoted on; it occupies ~70 GB of the 288 GB.  For N > 1 (launched by torch.distributed.run, one rank per GPU) the default
+is BASELINE.json configs[3]: the SAME 2 M reads sharded by record over the N GPUs (rank r owns reads [r*R, (r+1)*R), R = 2 M / N:
+"strong" scaling, so the N = 1 -> 8 ratio reads directly against north_star's ">= 6x"), the per-GPU syncmer tables merged by hash range,
+the graph built from everybody's candidate pairs, every rank correcting its own reads (include/oatk_hip_multi.h over RCCL); the `weak`
+sub-object repeats the step with 2 M reads on EVERY GPU (--scaling weak makes that the headline instead).
 
 Prints ONE JSON line on rank 0.  `value` is the whole step above.  Sub-objects: `scan_count` (the same batch through scan +
 count only), `config2` (BASELINE.json configs[1]: 200 k reads, scan + count, and with the EC round), `results_back` (SURVEY 8d
@@ -50,6 +52,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="config3")
     ap.add_argument("--reads-per-gpu", type=int, default=0, help="override the number of reads each GPU owns")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="at N > 1: strong (default) = the workload's reads divided over the GPUs (BASELINE.json configs[3] for config3); weak = the workload's reads on every GPU")
+    ap.add_argument("--no-weak", action="store_true", help="at N > 1 with strong scaling: skip the `weak` sub-object (the workload's reads on every GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; the contract) or gloo (development: several ranks on ONE GPU)")
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline only: no scan_count / config2 / results_back / ingest / cli legs")
@@ -64,7 +69,7 @@ def parse_args():
     ap.add_argument("--ingest-reads", type=int, default=200000)
     ap.add_argument("--ingest-window", type=int, default=64, help="MiB of text per window of the streamed ingest")
     ap.add_argument("--back-reads", type=int, default=100000)
-    ap.add_argument("--cli-reads", type=int, default=40000)
+    ap.add_argument("--cli-reads", type=int, default=400000)
     ap.add_argument("--cpu-sample-reads", type=int, default=80000)
     ap.add_argument("--cpu-threads", type=int, default=8)
     ap.add_argument("--dist-timeout-s", type=int, default=600, help="a collective that does not complete within this aborts the run instead of hanging it")
@@ -110,11 +115,33 @@ def cpu_baseline(readset, first, n_sample, threads, min_k_cov):
         db.close()
     finally:
         os.unlink(path)
-    return {"value": round(bases / (dt + dt_ec) / 1e9, 4), "unit": "Gbases/s", "cores": threads, "kind": "reference",
+    return {"value": round(bases / (dt + dt_ec) / 1e9, 4), "unit": "Gbases/s", "cores": threads, "threads": threads, "host": host_cores(), "kind": "reference",
             "sample": "first %d reads of the workload (%.2f Gbases) as FASTA through the compiled reference at -t %d: sr_read + collect_syncmer_from_reads "
                       "(parse included; %.1f s, %d syncmers), then make_syncmer_graph + scg_consensus + read_error_correction -c %d (+%.1f s, %s error blocks)"
                       % (n_sample, bases / 1e9, threads, dt, n_scm, min_k_cov, dt_ec, summ.get("total")),
             "scan_count": {"value": round(bases / dt / 1e9, 4), "unit": "Gbases/s"}}
+
+
+def host_cores():
+    """what the box has: physical cores (distinct (physical id, core id) pairs of /proc/cpuinfo), hardware threads, CPU model -- `cores` in cpu_baseline is
+    the number of threads the reference was RUN with (its -t), as the contract defines it; more threads do not help it"""
+    phys, model, logical = set(), None, os.cpu_count()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model is None:
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    return {"physical_cores": len(phys) or None, "hardware_threads": logical, "cpu": model}
 
 
 def pmc_traffic(kernel_name, workload, per_gpu):
@@ -165,7 +192,9 @@ def main():
 
     cfg = dict(CONFIGS[args.workload])
     c = int(cfg.get("min_k_cov", 30))
-    per_gpu = args.reads_per_gpu or cfg["n_reads"]
+    strong = world > 1 and args.scaling == "strong" and not args.reads_per_gpu
+    per_gpu = args.reads_per_gpu or (cfg["n_reads"] // world if strong else cfg["n_reads"])
+    n_workload = cfg["n_reads"]
     cfg["n_reads"] = per_gpu * world
     t_gen = time.perf_counter()
     rs = ReadSet(**cfg)
@@ -308,6 +337,40 @@ def main():
 
     extras = {}
     hip.set_timing(False)
+    if comm and with_ec and not args.no_extras:
+        # ---- what follows the EC round in syncasm() with sharded reads: every rank takes part (include/oatk_hip_multi.h, second half) ----
+        try:
+            after = {}
+
+            def tmax(d):
+                t = torch.tensor([d], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                return float(t.item())
+            d, _ = timed(lambda: hip.gather_table(comm, 0), args.steps)
+            after["gather_table"] = {"ms": round(tmax(d) * 1e3, 3), "workload": "oatk_hip_gather_table: update_syncmer_db's table with every syncmer's occurrences in (sid, idx) order, on rank 0"}
+            d, (nv, na) = timed(lambda: hip.asm_graph_sharded(comm, c, 0.35), args.steps)
+            after["asm_graph"] = {"ms": round(tmax(d) * 1e3, 3), "n_vtx": nv, "n_arc": na, "workload": "oatk_hip_asm_graph_sharded(-c %d, a 0.35): the same graph on every rank" % c}
+            d, _ = timed(lambda: hip.consensus_sharded(comm, c), args.steps)
+            after["consensus"] = {"ms": round(tmax(d) * 1e3, 3), "workload": "oatk_hip_consensus_sharded(-c %d): totals all-reduced" % c}
+            d, (n_p, n_e) = timed(lambda: hip.overlap_hist_sharded(comm, c), args.steps)
+            after["overlap_hist"] = {"ms": round(tmax(d) * 1e3, 3), "pairs": n_p, "workload": "oatk_hip_overlap_hist_sharded(-c %d): tables of the pairs between graph vertices, from weighted segments" % c}
+            d, sraw = timed(lambda: hip.stat_sharded(comm), args.steps)
+            after["sr_db_stat"] = {"ms": round(tmax(d) * 1e3, 3), "kmer_unique": int(sraw["kmer_unique"]), "workload": "oatk_hip_stat_sharded on the corrected chains"}
+            ag = hip.fetch_asm_graph()
+            n_scm_all = len(ag["scm_del"])
+            su_off = np.zeros(n_scm_all + 1, np.uint64)
+            su_off[1:] = np.cumsum(ag["scm_del"] == 0)
+            graph = {"n_scm": n_scm_all, "su_off": su_off, "su_uid": np.arange(nv, dtype=np.uint64) << np.uint64(1), "su_pos": np.zeros(nv, np.uint32),
+                     "utg_n": np.ones(nv, np.uint32), "idx_p": ag["idx_p"], "idx_n": ag["idx_n"].astype(np.uint64), "arc_w": ag["arc_w"],
+                     "arc_ln": np.zeros(na, np.uint64), "arc_del": np.zeros(na, np.uint8)}
+            d, (n_aln, n_frg, ast) = timed(lambda: hip.read_alignment(graph), args.steps)
+            tot = torch.tensor([n_aln, int(ast[0]), int(ast[2])], dtype=torch.int64, device=dev)
+            dist.all_reduce(tot)
+            after["read_alignment"] = {"ms": round(tmax(d) * 1e3, 3), "alignments": int(tot[0]), "reads_aligned": int(tot[1]), "reads_over_limits": int(tot[2]),
+                                       "workload": "scg_read_alignment: every rank its own %d corrected reads against the %d-vertex graph, no exchange" % (per_gpu, nv)}
+            extras["after_syncerr"] = after
+        except Exception as ex:             # noqa: BLE001
+            extras["after_syncerr"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
     if rank == 0 and not args.no_extras:
         # ---- what follows the EC round in syncasm(), on the corrected batch of rank 0 (not part of `value`) ----
         if world == 1 and not multi:
@@ -345,6 +408,36 @@ def main():
                                     "workload": "the same resident batch through scan + count only%s" % (" (no table merge)" if world > 1 else "")}
         except Exception as ex:             # noqa: BLE001   (an extension must never take the headline down)
             extras["scan_count"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+
+    if strong and comm and with_ec and not args.no_extras and not args.no_weak:
+        # ---- weak scaling beside it: the workload's reads on EVERY GPU (N x the reads of the headline) ----
+        try:
+            del d_seq, d_off, d_len
+            wcfg = dict(CONFIGS[args.workload])
+            w_per = wcfg["n_reads"]
+            wcfg["n_reads"] = w_per * world
+            rsw = ReadSet(**wcfg)
+            sq, of, ln = rsw.slice(rank * w_per, w_per)
+            wb = int(ln.sum())
+            t_sq, t_of, t_ln = torch.from_numpy(sq).to(dev), torch.from_numpy(of.view(np.int64)).to(dev), torch.from_numpy(ln.view(np.int32)).to(dev)
+            nbw = int(sq.size)
+            del sq
+
+            def step_weak():
+                scan_count(t_sq, t_of, t_ln, w_per, nbw, rank * w_per)
+                return hip.ec_sharded(comm, 0.02, c, 0.35)[0]
+            step_weak()
+            dw, st_w = timed(step_weak, args.steps)
+            t = torch.tensor([dw], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tbw = torch.tensor([wb], dtype=torch.int64, device=dev)
+            dist.all_reduce(tbw)
+            extras["weak"] = {"value": round(int(tbw.item()) / float(t.item()) / 1e9, 3), "unit": "Gbases/s", "ms_per_step": round(float(t.item()) * 1e3, 3), "scaling": "weak",
+                              "reads_per_gpu": w_per, "error_blocks": int(st_w[0] + st_w[5] + st_w[10]),
+                              "workload": "%s's %d reads on EVERY GPU (%d reads in all): the same sharded step" % (args.workload, w_per, w_per * world)}
+            del t_sq, t_of, t_ln
+        except Exception as ex:             # noqa: BLE001
+            extras["weak"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
 
     if world == 1 and not multi and not args.no_extras:
         # ---- the same step with the other EC graph (light <-> full): what the restriction to usable arcs is worth ----
@@ -473,7 +566,7 @@ def main():
                 sys.path.insert(0, os.path.join(ROOT, "tests"))
                 import cli_util
                 hip.sync()
-                extras["cli"] = cli_util.time_cli(rs, first, min(args.cli_reads, per_gpu), K, S, c, args.cpu_threads)
+                extras["cli"] = cli_util.time_cli(rs, first, min(args.cli_reads, per_gpu), K, S, c, args.cpu_threads, devices="%d,%d" % (local_rank, local_rank))
             except Exception as ex:         # noqa: BLE001
                 extras["cli"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
 
@@ -501,7 +594,8 @@ def main():
                     "valu": {"achieved": round(hoco / 64 * valu_per_64 / (phase_ms["syncmer"] / 1e3) / 1e9, 1), "peak": 614.4, "unit": "G wave-instr/s",
                              "frac": round(hoco / 64 * valu_per_64 / (phase_ms["syncmer"] / 1e3) / 1e9 / 614.4, 3), "valu_per_64_positions": valu_per_64},
                     "scan_bytes_per_base": round((alg_bytes["hpc"] + 28 * n_occ) / bases, 4),
-                    "scan_achieved_GBs": round((alg_bytes["hpc"] + 28 * n_occ) / ((phase_ms["hpc"] + phase_ms["syncmer"]) / 1e3) / 1e9, 2)}
+                    # the scan of SURVEY.md 8(d) is kernel A + kernel B + the k-mer hash
+                    "scan_achieved_GBs": round((alg_bytes["hpc"] + 28 * n_occ) / ((phase_ms["hpc"] + phase_ms["syncmer"] + phase_ms.get("syncmer_n", 0.0) + phase_ms.get("kmer_hash", 0.0)) / 1e3) / 1e9, 2)}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(rs, first, min(args.cpu_sample_reads, per_gpu), args.cpu_threads, c)
@@ -510,9 +604,10 @@ def main():
             "metric": "HiFi Gbases/s through syncasm (%s) at k=1001 s=31" % what,
             "value": round(total_bases * args.steps / dt / 1e9, 3), "unit": "Gbases/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "%s: %d reads x ~%d kb per GPU, k=1001 s=31 -c %d, full hot path of syncasm incl. syncerr (scan + count + EC graph + "
+            "config": {"workload": (("%s sharded over %d GPUs (BASELINE.json configs[3] for config3: %d reads in all), " % (args.workload, world, n_workload)) if strong else "") +
+                                   "%s: %d reads x ~%d kb per GPU, k=1001 s=31 -c %d, full hot path of syncasm incl. syncerr (scan + count + EC graph + "
                                    "read_error_correction with its Levenshtein path search), reads resident in HBM" % (args.workload, per_gpu, cfg["mean_len"] // 1000, c)
                        if with_ec else "%s: %d reads x ~%d kb per GPU, scan + count + table merge" % (args.workload, per_gpu, cfg["mean_len"] // 1000),
                        "ec_graph": ("light: arcs between syncmers seen >= %d times + one flag per oriented vertex for the rest (include/oatk_hip_ec.h); same corrected reads "

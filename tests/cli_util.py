@@ -38,7 +38,9 @@ def served_table(stderr_text):
     return out
 
 
-def time_cli(readset, first, n_reads, k, s, c, threads, workdir=None):
+def time_cli(readset, first, n_reads, k, s, c, threads, workdir=None, strict=True, devices=None):
+    """strict: the leg FAILS (raises) when the two GFA files differ or when any of the six hot-path calls was served by its original body -- a drop-in
+    number is only worth reporting when the device did the work and the bytes are the reference's"""
     if not available():
         return {"skipped": "the CLI binaries are built only where the reference's sources are (make ref ref_dropin)"}
     seq, off, lens = readset.slice(first, n_reads)
@@ -56,7 +58,24 @@ def time_cli(readset, first, n_reads, k, s, c, threads, workdir=None):
         t_dev, err = run_cli(CLI_DROPIN, fa, os.path.join(d, "dev"), k, c, threads, {"OATK_DROPIN_LOG": "1"})
         same = all(filecmp.cmp(os.path.join(d, "ref" + x), os.path.join(d, "dev" + x), shallow=False) for x in (".utg.gfa", ".utg.final.gfa"))
         tab = served_table(err)
-        return {"reads": n_reads, "gbases": round(bases / 1e9, 3), "threads": threads,
+        if strict:
+            six = ("sr_read", "sr_db_stat", "collect_syncmer_from_reads", "make_syncmer_graph", "read_error_correction", "scg_read_alignment")
+            fell_back = {f: tab[f][2] for f in six if f in tab and tab[f][2] > 0}
+            missing = [f for f in six if f not in tab or tab[f][0] == 0]
+            if not same or fell_back or missing:
+                raise RuntimeError("drop-in CLI run rejected: gfa_identical=%s, calls served by their original bodies %s, calls the device never served %s"
+                                   % (same, fell_back, missing))
+        multi = None
+        if devices:
+            # the same file once more with the reads spread over several handles (OATK_DEVICES; include/oatk_multi.h)
+            t_m, err_m = run_cli(CLI_DROPIN, fa, os.path.join(d, "mul"), k, c, threads, {"OATK_DROPIN_LOG": "1", "OATK_DEVICES": devices})
+            same_m = all(filecmp.cmp(os.path.join(d, "ref" + x), os.path.join(d, "mul" + x), shallow=False) for x in (".utg.gfa", ".utg.final.gfa"))
+            tab_m = served_table(err_m)
+            orig_m = {f: v[2] for f, v in tab_m.items() if v[2] > 0}
+            if strict and (not same_m or orig_m):
+                raise RuntimeError("drop-in CLI run over OATK_DEVICES=%s rejected: gfa_identical=%s, original bodies %s" % (devices, same_m, orig_m))
+            multi = {"devices": devices, "dropin_s": round(t_m, 2), "speedup": round(t_ref / t_m, 2), "gfa_identical": bool(same_m)}
+        return {"reads": n_reads, "gbases": round(bases / 1e9, 3), "threads": threads, "several_handles": multi,
                 "reference_s": round(t_ref, 2), "dropin_s": round(t_dev, 2), "speedup": round(t_ref / t_dev, 2), "gfa_identical": bool(same),
                 "dropin_value": round(bases / t_dev / 1e9, 3), "reference_value": round(bases / t_ref / 1e9, 3), "unit": "Gbases/s",
                 "served": {f: {"device_calls": v[0], "device_s": v[1], "original_calls": v[2], "original_s": v[3]} for f, v in tab.items()},
