@@ -71,12 +71,30 @@ def test_config2_scan_count_graph_ec_equal_the_compiled_reference(hip, tmp_path)
     assert int(stats[0] + stats[5] + stats[10]) == summ["total"] and int(stats[2] + stats[7]) == summ["corrected"]
     assert int(stats[1] + stats[6]) == summ["uncorrected"] and int(stats[3] + stats[8]) == summ["ambiseq"] and int(stats[4] + stats[9]) == summ["ambipath"]
     assert summ["total"] > 100000
+    full_stat1 = hip.stat_raw()
+
+    # ---- the same round through the LIGHT graph -- the headline path of bench.py and the drop-in (include/oatk_hip_ec.h) -- against the reference directly ----
+    hip.scan_host(seq, off, lens, K, S)
+    hip.count()
+    hip.ec_graph(light_c=c)
+    kept = hip.fetch("EG_ARC_V").astype(np.uint64)
+    rcov = r_cnt["cov"].astype(np.int64)
+    both = (rcov[(G["arc_v"][:na] >> np.uint64(1)).astype(np.int64)] >= c) & (rcov[(G["arc_w"][:na] >> np.uint64(1)).astype(np.int64)] >= c)
+    for name, key in (("EG_ARC_V", "arc_v"), ("EG_ARC_W", "arc_w"), ("EG_ARC_COV", "arc_cov"), ("EG_ARC_LS", "arc_ls"), ("EG_ARC_COMP", "arc_comp")):
+        assert np.array_equal(hip.fetch(name).astype(np.uint64), G[key][:na][both].astype(np.uint64)), "light EC graph = the reference's arcs between candidates: " + key
+    assert 0 < len(kept) < na
+    stats_l = hip.ec(0.02, c, 0.35)
+    for name, key in (("EC_N_SCM", "n_scm"), ("EC_KMER", "k_mer"), ("EC_MPOS", "m_pos"), ("EC_SMER", "s_mer")):
+        assert np.array_equal(hip.fetch(name), r_ec[key]), "light graph, corrected chains: " + key
+    assert np.array_equal(hip.fetch("EC_SCM_COV"), r_tab["cov"]) and np.array_equal(hip.fetch("EC_SCM_DEL"), r_tab["del"])
+    assert np.array_equal(hip.fetch("EC_SCM_OCC"), r_tab["occ"])
+    assert list(stats_l[:11]) == list(stats[:11])
 
     # ---- sr_db_stat before the count and after the correction (run_syncasm.c:88, :131) ----
     import test_gpu_dropin as TD
     H = TD.host_lib()
     H.oatk_stat_peaks.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
-    for raw, (i8, d5) in ((st, r_stat0), (hip.stat_raw(), r_stat1)):
+    for raw, (i8, d5) in ((st, r_stat0), (full_stat1, r_stat1), (hip.stat_raw(), r_stat1)):
         assert raw["n_syncmers"] == int(d5[0]) and raw["smer_unique"] == i8[0] and raw["kmer_unique"] == i8[4]
         assert raw["smer_cnt"][1] == i8[1] and raw["kmer_cnt"][1] == i8[5]
         for cnt, hom, het in ((raw["smer_cnt"], i8[2], i8[3]), (raw["kmer_cnt"], i8[6], i8[7])):
