@@ -105,6 +105,58 @@ def test_full_size_sample_against_oracle(hip, batch):
     assert np.array_equal(m_pos[sel], want["m_pos"]) and np.array_equal(s_mer[sel], want["s_mer"]) and np.array_equal(k_mer[sel], want["k_mer"])
 
 
+def test_full_size_ec_sample_against_oracle(hip, batch):
+    """the correction at full size against the CPU restatement (oracle/ec.c: the block finder, the DFS over the graph, the wavefront edit distance,
+    the splice) on reads sampled from the full batch.  The oracle corrects the sampled reads against the device's own graph of ALL reads -- the light
+    graph's arcs with the marks of find_error_syncmers, the k-mer of every live vertex cut out of the hoco string of its first occurrence -- so what is
+    compared is every decision the solver made for those reads: which blocks, which path, which ambiguity, the spliced chains."""
+    import ec_util as E
+    cfg, seq, off, lens = batch
+    c = cfg["min_k_cov"]
+    hip.scan_host(seq, off, lens, K, S)
+    hip.count()
+    hip.ec_graph(light_c=c)
+    hip.ec(0.02, c, 0.35)
+    ns = hip.info()["n_scm"]
+    err_del = hip.fetch("EC_ERR_DEL")
+    av, aw = hip.fetch("EG_ARC_V"), hip.fetch("EG_ARC_W")
+    idx_n = hip.fetch("EG_IDX_N").astype(np.uint64)
+    G = {"n_vtx": ns, "n_arc": len(av), "vtx_len": np.full(ns, K, np.uint64), "vtx_del": err_del.copy(), "vtx_seq_off": np.zeros(ns, np.uint64),
+         "arc_w": aw, "arc_ls": hip.fetch("EG_ARC_LS").astype(np.uint64), "arc_cov": hip.fetch("EG_ARC_COV"),
+         "arc_del": (err_del[(av >> np.uint64(1)).astype(np.int64)] | err_del[(aw >> np.uint64(1)).astype(np.int64)]).astype(np.uint8) if len(av) else np.zeros(1, np.uint8),
+         "idx_p": np.where(idx_n > 0, hip.fetch("EG_IDX_P"), 0).astype(np.uint64), "idx_n": idx_n}
+    # vertex strings of the live vertices: the oriented k-mer of the syncmer's first occurrence (syncasm.c:910-940), one base letter per byte
+    hoco_l, n_scm, scm_off = hip.fetch("HOCO_L"), hip.fetch("N_SCM"), hip.fetch("SCM_OFF").astype(np.int64)
+    m_pos, s_mer, kid = hip.fetch("POS_MPOS"), hip.fetch("POS_SMER"), hip.fetch("POS_KID")
+    hoco_s = hip.fetch("HOCO_S")
+    occ_off, occ = hip.fetch("SCM_OCC_OFF").astype(np.int64), hip.fetch("SCM_OCC")
+    live = np.nonzero(err_del == 0)[0]
+    assert 0 < len(live) < 200000
+    nt = np.frombuffer(b"ACGT", np.uint8)
+    seqs = np.zeros(len(live) * K, np.uint8)
+    for t, v in enumerate(live):
+        o = int(occ[occ_off[v]])
+        rd, idx = o >> 32, (o >> 1) & 0x7FFFFFFF
+        mp = int(m_pos[scm_off[rd] + idx])
+        p = (mp >> 1) + np.arange(K)
+        codes = (hoco_s[int(off[rd]) // 4 + (p >> 2)] >> (((p & 3) ^ 3) << 1)) & 3
+        seqs[t * K:(t + 1) * K] = nt[(3 - codes[::-1]) if mp & 1 else codes]
+        G["vtx_seq_off"][v] = t * K
+    G["seq"] = seqs
+    # the sampled reads as a little sr_db of their own (ids stay global)
+    pick = np.sort(np.random.default_rng(11).choice(len(off), 400, replace=False))
+    sel = np.concatenate([np.arange(scm_off[i], scm_off[i + 1]) for i in pick])
+    sr = {"hoco_l": hoco_l[pick], "n_scm": n_scm[pick], "k_mer": kid[sel], "m_pos": m_pos[sel], "s_mer": s_mer[sel],
+          "hoco_s": np.concatenate([hoco_s[int(off[i]) // 4:int(off[i]) // 4 + (int(hoco_l[i]) + 3) // 4] for i in pick])}
+    want = E.oracle_ec_reads(G, err_del.copy(), hip.fetch("SCM_S"), K, 0.02, sr)
+    new_n, new_off = hip.fetch("EC_N_SCM"), hip.fetch("EC_SCM_OFF").astype(np.int64)
+    assert np.array_equal(new_n[pick], want["n_scm"])
+    nsel = np.concatenate([np.arange(new_off[i], new_off[i + 1]) for i in pick])
+    for name, key in (("EC_KMER", "k_mer"), ("EC_MPOS", "m_pos"), ("EC_SMER", "s_mer")):
+        assert np.array_equal(hip.fetch(name)[nsel], want[key]), key
+    assert int(want["stats"][2] + want["stats"][7]) > 100            # the sample did hold blocks that were corrected
+
+
 def test_strand_symmetry(hip, batch):
     """a read and its reverse complement select the same k-mers: same hashes in reverse order, mirrored positions, flipped strands"""
     cfg, seq, off, lens = batch
