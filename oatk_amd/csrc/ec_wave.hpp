@@ -48,6 +48,21 @@ __device__ __forceinline__ uint32_t ecw_gather16(const uint8_t *hs, int64_t star
     const int64_t lo = start - 15;
     return ~(lo >= 0? ecw_rev16(ecw_src16(hs, (uint32_t) lo)) : ecw_rev16(ecw_src16(hs, 0)) >> ((uint32_t) (-lo) << 1));
 }
+// the same in two halves, so that a loop can have the loads of several windows in flight before it finishes the first: where to read ...
+__device__ __forceinline__ uint32_t ecw_gather16_at(int64_t start, bool desc)
+{
+    const int64_t p = desc? start - 15 : start;
+    return p >= 0? (uint32_t) p : 0u;
+}
+// ... and what to make of the two words w[p >> 4], w[(p >> 4) + 1]
+__device__ __forceinline__ uint32_t ecw_gather16_fin(uint32_t w0, uint32_t w1, uint32_t p, int64_t start, bool desc)
+{
+    const uint64_t v = (uint64_t) ecw_rev_in_bytes(w1) << 32 | ecw_rev_in_bytes(w0);
+    const uint32_t x = (uint32_t) (v >> ((p & 15u) << 1));
+    if (!desc) return start >= 0? x : x << ((uint32_t) (-start) << 1);
+    const int64_t lo = start - 15;
+    return ~(lo >= 0? ecw_rev16(x) : ecw_rev16(x) >> ((uint32_t) (-lo) << 1));
+}
 // sixteen fields starting at base p of a packed array (one pad word behind the data)
 __device__ __forceinline__ uint32_t ecw_win16(const uint32_t *W, int32_t p)
 {
@@ -102,7 +117,7 @@ struct EcwScratch {
 
 struct EcwFrame {                 // state at the entry of one DFS level (syncerr.c:158-171), followed by k[n]
     uint32_t arc_i, arc_end;
-    int32_t l0, score, t_end, q_end, n, d0, prev_off, pad;
+    int32_t l0, score, t_end, q_end, n, d0, prev_off, depth;
 };
 
 struct EcwWave {                  // the working wavefront: diagonals d0 .. d0 + n - 1, furthest target index per diagonal in k[]
@@ -246,8 +261,23 @@ __device__ bool ecw_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
     if (wk.ln) pre = ecw_arc_load(lv.arc, wk.lp), pre_idx = wk.lp;
     // target: the read segment, reverse-complemented for a leading block (get_kmer_dna_seq, syncmer.c:1237)
     const uint8_t *hs = rd.hoco_s + ((uint64_t) wk.hs16 << 4);
-    for (int32_t wi = lane; (wi << 4) < tl; wi += 64)
-        s.ts[wi] = wk.r? ecw_gather16(hs, (int64_t) wk.beg_pos + tl - 1 - (wi << 4), true) : ecw_gather16(hs, (int64_t) wk.beg_pos + (wi << 4), false);
+    for (int32_t wb = 0; (wb << 4) < tl; wb += 256) {  // four windows per lane with their loads in flight together (a first-tier block: one turn)
+        uint32_t w0[4], w1[4], pp[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int32_t wi = wb + lane + 64 * u;
+            const int64_t start = wk.r? (int64_t) wk.beg_pos + tl - 1 - (wi << 4) : (int64_t) wk.beg_pos + (wi << 4);
+            pp[u] = ecw_gather16_at(start, wk.r != 0);
+            w0[u] = w1[u] = 0;
+            if ((wi << 4) < tl) { const uint32_t *q = (const uint32_t *) hs + (pp[u] >> 4); w0[u] = q[0], w1[u] = q[1]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int32_t wi = wb + lane + 64 * u;
+            const int64_t start = wk.r? (int64_t) wk.beg_pos + tl - 1 - (wi << 4) : (int64_t) wk.beg_pos + (wi << 4);
+            if ((wi << 4) < tl) s.ts[wi] = ecw_gather16_fin(w0[u], w1[u], pp[u], start, wk.r != 0);
+        }
+    }
     ECW_T(0);                                          // 0: target gather
     int32_t status = EC_FAILURE, n_path = 0, edist = INT32_MAX, s_edist = INT32_MAX;
     int32_t c_len = 0, o_len = 0, np = 0;
@@ -256,15 +286,21 @@ __device__ bool ecw_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
     wv.k = s.ka, wv.spare = s.kb, wv.n = 1, wv.d0 = 0;
     if (lane == 0) s.ka[0] = -1, s.c_path[0] = wk.beg_utg;
     int32_t fsz = 0, top = -1, nfr = 0;
+    // A level with ONE arc needs no frame: nothing has to be restored for a sibling, and when its only child returns the level is exhausted, so the
+    // return goes straight to the nearest level that does have siblings.  The search then simply carries on with the state it is in (vpend: the arc
+    // to take next, at depth v_depth).  After the marking the graph of HiFi reads is a line almost everywhere, so most blocks never build a frame.
+    bool vpend = false;
+    uint32_t v_arc = 0;
+    int32_t v_depth = 0;
     __syncthreads();
 
-    auto push_frame = [&](uint32_t lp, uint32_t ln) -> bool {
+    auto push_frame = [&](uint32_t lp, uint32_t ln, int32_t depth) -> bool {
         const int32_t need = ((int32_t) sizeof(EcwFrame) + 4 * wv.n + 7) & ~7;
         if (fsz + need > s.cap_f) return false;
         EcwFrame *f = (EcwFrame *) (s.frames + fsz);
         if (lane == 0) {
             f->arc_i = lp, f->arc_end = lp + ln;
-            f->l0 = c_len, f->score = score, f->t_end = t_end, f->q_end = q_end, f->n = wv.n, f->d0 = wv.d0, f->prev_off = top;
+            f->l0 = c_len, f->score = score, f->t_end = t_end, f->q_end = q_end, f->n = wv.n, f->d0 = wv.d0, f->prev_off = top, f->depth = depth;
         }
         int32_t *sv = (int32_t *) (f + 1);
         for (int32_t j = lane; j < wv.n; j += 64) sv[j] = wv.k[j];
@@ -273,33 +309,40 @@ __device__ bool ecw_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
         ++nfr;
         return true;
     };
-    if (!push_frame(wk.lp, wk.ln)) { ECW_C(12, 1); return false; }
+    if (wk.ln == 1) vpend = true, v_arc = wk.lp, v_depth = 0;
+    else if (!push_frame(wk.lp, wk.ln, 0)) { ECW_C(12, 1); return false; }
 
-    while (nfr > 0) {
+    while (nfr > 0 || vpend) {
         __syncthreads();
-        EcwFrame *f = (EcwFrame *) (s.frames + top);
-        const int32_t depth = nfr - 1;
-        const uint32_t a = ecw_uniu(f->arc_i), a_end = ecw_uniu(f->arc_end);
-        if (a == a_end) {                             // level exhausted: return to the parent
-            fsz = top;
-            top = ecw_uni(f->prev_off);
-            --nfr;
-            ECW_T(1);                                  // 1: pops
-            continue;
+        uint32_t a;
+        int32_t depth;
+        if (vpend) {                                  // carry on where the search stands: nothing to restore
+            vpend = false;
+            a = v_arc, depth = v_depth;
+        } else {
+            EcwFrame *f = (EcwFrame *) (s.frames + top);
+            a = ecw_uniu(f->arc_i);
+            const uint32_t a_end = ecw_uniu(f->arc_end);
+            if (a == a_end) {                         // level exhausted: return to the nearest level with siblings left
+                fsz = top;
+                top = ecw_uni(f->prev_off);
+                --nfr;
+                ECW_T(1);                              // 1: pops
+                continue;
+            }
+            if (lane == 0) f->arc_i = a + 1;
+            // restore the state this level was entered with (syncerr.c:277-284)
+            depth = ecw_uni(f->depth);
+            c_len = ecw_uni(f->l0), score = ecw_uni(f->score), t_end = ecw_uni(f->t_end), q_end = ecw_uni(f->q_end);
+            wv.n = ecw_uni(f->n), wv.d0 = ecw_uni(f->d0), wv.k = s.ka, wv.spare = s.kb;
+            const int32_t *sv = (const int32_t *) (f + 1);
+            for (int32_t j = lane; j < wv.n; j += 64) s.ka[j] = sv[j];
         }
-        if (lane == 0) f->arc_i = a + 1;
         ECW_C(8, 1);                                   // 8: arcs tried
         if (pre_idx != a) pre = ecw_arc_load(lv.arc, a);
         const uint64_t w = ecw_uniu(pre.a.x);
         const int32_t ls = (int32_t) ecw_uniu(pre.a.y), ext = K - ls;
         const uint32_t w_hs16 = ecw_uniu(pre.a.z), w_mpos = ecw_uniu(pre.a.w), w_lp = ecw_uniu(pre.b.x), w_ln = ecw_uniu(pre.b.y);
-        // restore the state this level was entered with (syncerr.c:277-284)
-        c_len = ecw_uni(f->l0), score = ecw_uni(f->score), t_end = ecw_uni(f->t_end), q_end = ecw_uni(f->q_end);
-        wv.n = ecw_uni(f->n), wv.d0 = ecw_uni(f->d0), wv.k = s.ka, wv.spare = s.kb;
-        {
-            const int32_t *sv = (const int32_t *) (f + 1);
-            for (int32_t j = lane; j < wv.n; j += 64) s.ka[j] = sv[j];
-        }
         const int32_t t_end0 = t_end;
         if (depth + 2 > s.cap_path || c_len + ext > s.cap_c) { ECW_C(depth + 2 > s.cap_path? 13 : 14, 1); return false; }
         if (lane == 0) s.c_path[depth + 1] = w;
@@ -379,7 +422,8 @@ __device__ bool ecw_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
         }
         if (score <= bw && ql - K <= tl + bw && ((wk.end_utg != EC_NONE && wk.end_utg != w) || t_end < tl)) {
             if (n_path < EC_MAX_DFS_PATH) {           // the callee would return at once otherwise (syncerr.c:146-148)
-                if (!push_frame(w_lp, w_ln)) { ECW_C(12, 1); return false; }
+                if (w_ln == 1) vpend = true, v_arc = w_lp, v_depth = depth + 1;
+                else if (w_ln > 1 && !push_frame(w_lp, w_ln, depth + 1)) { ECW_C(12, 1); return false; }      // (no arcs: the callee's loop does not run)
             }
         } else {
             ++n_path;
@@ -459,13 +503,14 @@ __global__ __launch_bounds__(64) void ec_wave_kernel(EcwArgs a)
     const int lane = threadIdx.x;
     EcwScratch s;
     s.cap_t = a.cap_t, s.cap_c = a.cap_c, s.cap_w = a.cap_w, s.cap_path = a.cap_path, s.cap_f = a.cap_f;
-    uint32_t *p = BIG? (uint32_t *) (a.slabs + (uint64_t) blockIdx.x * a.slab_bytes) : ecw_lds;
+    uint32_t *const p0 = BIG? (uint32_t *) (a.slabs + (uint64_t) blockIdx.x * a.slab_bytes) : ecw_lds;
+    uint32_t *p = p0;
     s.ts = p, p += ecw_words(a.cap_t);
     s.cs = p, p += ecw_words(a.cap_c);
     s.os = p, p += ecw_words(a.cap_c);
     s.ka = (int32_t *) p, p += a.cap_w + 2;
     s.kb = (int32_t *) p, p += a.cap_w + 2;
-    p = (uint32_t *) (((uintptr_t) p + 7) & ~(uintptr_t) 7);
+    p += (p - p0) & 1;                 // (the base is 8-byte aligned; no detour through an integer, which would turn every access behind it into a flat one)
     s.c_path = (uint64_t *) p, p += 2 * a.cap_path;
     s.o_path = (uint64_t *) p, p += 2 * a.cap_path;
     s.frames = (uint8_t *) p;

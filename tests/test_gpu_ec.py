@@ -144,7 +144,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("graph", ["host", "device", "device-tiers", "device-tiers-serial"])
+@pytest.mark.parametrize("graph", ["host", "device", "device-tiers", "device-tiers-serial", "device-rows4", "device-rows2"])
 @pytest.mark.parametrize("case", range(len(CASES)))
 def test_device_ec_matches_reference(hip, case, graph, monkeypatch):
     K, S, c, mk = CASES[case]
@@ -153,6 +153,8 @@ def test_device_ec_matches_reference(hip, case, graph, monkeypatch):
     # or (serial) found too long by each tier in turn
     t0, t1 = (48, 160) if graph.startswith("device-tiers") else (0, 0)
     monkeypatch.setenv("OATK_DEBUG_EC_SERIAL_TIERS", "1" if graph == "device-tiers-serial" else "0")
+    # the first tier with several blocks per wave, a row of 16 or 32 lanes each (ec_quad.hpp; measured, not the default: profiles/r03b_solver_ab.txt)
+    monkeypatch.setenv("OATK_DEBUG_EC_QUAD", {"device-rows4": "1", "device-rows2": "2"}.get(graph, "0"))
     hip._check(hip.L.oatk_hip_debug_ec_tiers(hip.h, t0, t1), "oatk_hip_debug_ec_tiers")
     db, scm = device_dbs(hip, reads, K, S)                  # reference-layout structs built from the device scan + count
     L = R.lib()
