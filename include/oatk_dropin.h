@@ -20,7 +20,7 @@
  * new definitions and the original bodies stay reachable):  run_syncasm.c, the CLI and everything downstream are untouched.
  *
  * Every function falls back to its ORIGINAL body -- the maintainer's code, never a CPU restatement of ours -- when the device
- * path does not apply or refuses: no gfx950 device, OATK_DROPIN=0, a -D data cap, wrapped FASTQ, k beyond oatk_hip_max_k(),
+ * path does not apply or refuses: no gfx950 device, OATK_DROPIN=0, k beyond oatk_hip_max_k(), text kseq itself would stop in (a quality string longer than its sequence),
  * OATK_E_SPLIT (duplicate arcs / oversized hash groups), reads beyond the aligner's per-read limits.  After a fallback that
  * changes the reads or the table on the host the device batch is stale and the later calls fall back as well.
  *

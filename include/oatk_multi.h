@@ -37,6 +37,7 @@ const char *oatk_multi_last_error(oatk_multi *m);
 
 /* sr_read (syncmer.c:487): the files' text streams through the devices in windows, consecutive parts of the input to consecutive handles */
 int oatk_multi_sr_read_files(oatk_multi *m, oatk_sr_db_t *sr_db, char **files, int n_files);
+int oatk_multi_sr_read_files_capped(oatk_multi *m, oatk_sr_db_t *sr_db, char **files, int n_files, uint64_t m_data);      /* with sr_read's data cap (-D), 0 = none */
 /* sr_db_stat (syncmer.c:867), after the read and after the correction */
 int oatk_multi_sr_db_stat(oatk_multi *m, oatk_sr_db_t *sr_db, FILE *fo, int verbose);
 /* collect_syncmer_from_reads (syncmer.c:1397): local counts, the table merge, the table gathered into the reference's struct */

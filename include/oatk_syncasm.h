@@ -93,6 +93,8 @@ int oatk_sr_db_fill_resident(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, const uint6
 /* sr_read (syncmer.c:487) for files (plain or gzip'ed FASTA / four-line FASTQ), without kseq: text to the device (oatk_ingest_files), record
  * scan and syncmer scan there, sr_db filled from the resident results, snames cut out of the headers */
 int oatk_sr_read_files(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, char **files, int n_files);
+/* the same with sr_read's data cap (-D, syncmer.c:537-541): reading stops behind the read that takes the total of raw bases to m_data (0 = no cap) */
+int oatk_sr_read_files_capped(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, char **files, int n_files, uint64_t m_data);
 /* the device half of the above for text that is already in host memory: streamed through the device in windows (upload of window i + 1 beside
  * the record scan and syncmer scan of window i), the scanned pieces assembled in ctx; nothing is copied back.  pinned != 0: the text is
  * page-locked and goes over PCIe as it lies.  window = 0: default. */

@@ -182,14 +182,13 @@ void sr_read(dropin_sstream_t *s_stream, oatk_sr_db_t *sr_db, size_t mD, int n_t
     hooks_off();
     D.resident = D.counted = D.corrected = 0, D.sr_db = 0, D.scm_db = 0, D.placeholder = 0;
     if (!D.ctx) why = D.enabled? "no device" : "OATK_DROPIN=0";
-    else if (mD != 0) why = "a data cap (-D) cuts the input mid-file: the original reader counts bases as it goes";
     else if (s_stream->n_seq != 0 || s_stream->n != 0) why = "the stream was already read from";
     else if (sr_db->k > oatk_hip_max_k()) why = "k beyond the device scan's window";
     if (!why) {
         oatk_host_set_threads(n_threads);                                /* the struct filling uses as many host threads as the caller grants (-t) */
         oatk_sr_db_clean(sr_db);                                         /* syncmer.c:494-495: k and s stay */
-        const int rc = D.multi? oatk_multi_sr_read_files(D.multi, sr_db, s_stream->files, s_stream->n_files)
-                              : oatk_sr_read_files(D.ctx, sr_db, s_stream->files, s_stream->n_files);
+        const int rc = D.multi? oatk_multi_sr_read_files_capped(D.multi, sr_db, s_stream->files, s_stream->n_files, (uint64_t) mD)
+                              : oatk_sr_read_files_capped(D.ctx, sr_db, s_stream->files, s_stream->n_files, (uint64_t) mD);
         if (rc == OATK_OK) {
             s_stream->n_seq = sr_db->n;                                  /* what sstream_read would have counted (sstream.c:87) */
             D.resident = 1, D.sr_db = sr_db;

@@ -27,6 +27,6 @@ int oatk_host_stat_report(oatk_sr_db_t *sr_db, const oatk_stat_raw_t *raw, FILE 
 int oatk_host_read_alignment_n(oatk_hip_ctx **ctx, const uint64_t *first, int n, oatk_sr_db_t *sr_db, oatk_scg_ra_v *ra_v, oatk_scg_t *g, int for_unzip,
                                uint64_t *n_skipped, uint32_t **skipped);
 /* sr_read (syncmer.c:487) for files with the reads spread over n handles by position in the input: first[0 .. n] receives the read ranges */
-int oatk_host_sr_read_files_n(oatk_hip_ctx **ctx, int n, oatk_sr_db_t *sr_db, char **files, int n_files, uint64_t *first);
+int oatk_host_sr_read_files_n(oatk_hip_ctx **ctx, int n, oatk_sr_db_t *sr_db, char **files, int n_files, uint64_t *first, uint64_t m_data);
 
 #endif

@@ -366,7 +366,9 @@ static double now_s(void)
 
 /* ctxs[0 .. n_ctx): the handles the reads are assembled in -- one, or one per GPU: then handle r receives the reads of the r-th part of the input
  * (rank_of_window) and first[0 .. n_ctx] their ranges; sid0 of handle r = first[r] */
-static int sr_read_stream(oatk_hip_ctx **ctxs, int n_ctx, uint64_t *first, oatk_sr_db_t *sr_db, int K, int S, seg_t *seg, int n_files, uint64_t total, uint64_t win)
+/* m_data: sr_read's data cap (syncmer.c:537-541; 0 = none): the read that takes the total of raw bases to the cap is the last one taken */
+static int sr_read_stream(oatk_hip_ctx **ctxs, int n_ctx, uint64_t *first, oatk_sr_db_t *sr_db, int K, int S, seg_t *seg, int n_files, uint64_t total, uint64_t win,
+                          uint64_t m_data)
 {
     const char *lg = getenv("OATK_DROPIN_LOG");
     const int log = lg && lg[0] && lg[0] != '0';
@@ -390,7 +392,9 @@ static int sr_read_stream(oatk_hip_ctx **ctxs, int n_ctx, uint64_t *first, oatk_
     st.seg = seg, st.n_seg = n_files, st.total = total, st.win = win, st.res = res, st.res_of_rank = res_of_rank, st.n_rank = n_ctx;
     st.n_up = threads > 1? threads : 1;            /* readers of the file beside the threads that fill the structs: with the reads in arenas the file is what sr_read waits for */
     { const char *e = getenv("OATK_HOST_UP_THREADS"); if (e && atoi(e) > 0) st.n_up = atoi(e); }
-    const int fmt = sniff_format(seg, n_files, total);
+    int fmt = sniff_format(seg, n_files, total);
+    uint64_t n_bases = 0;                                           /* raw bases taken so far */
+    int capped = 0;
     for (r = 0; r < n_ctx; ++r) {                                   /* one set of working handles per device */
         const int dev = oatk_hip_device(ctxs[r]);
         for (i = 0; i < st.n_res && res[i].dev != dev; ++i) {}
@@ -448,9 +452,29 @@ static int sr_read_stream(oatk_hip_ctx **ctxs, int n_ctx, uint64_t *first, oatk_
         const uint64_t len = carry + (g1 - g0);
         uint64_t n = 0, used = 0, b = 0;
         rc = oatk_hip_ingest(D->piece[s], d_text, len, fmt, final, &n, &used);
+        if (rc == OATK_E_SPLIT && fmt != OATK_FMT_KSEQ) {
+            /* not what the two device-only formats take (wrapped FASTQ; FASTQ records among FASTA ones): kseq's own reading from here on, line by line */
+            fmt = OATK_FMT_KSEQ;
+            rc = oatk_hip_ingest(D->piece[s], d_text, len, fmt, final, &n, &used);
+        }
         if (rc) break;
+        if (m_data && n) {                                           /* the cap: count the raw bases of this piece's reads */
+            uint32_t *ln = (uint32_t *) malloc(4 * n);
+            const void *dl = 0;
+            uint64_t bb = 0, i2;
+            if (!ln) { rc = OATK_E_NOMEM; break; }
+            rc = oatk_hip_buffer(D->piece[s], OATK_BUF_INGEST_LEN, &dl, &bb);
+            if (!rc) rc = oatk_hip_d2h(D->piece[s], ln, dl, 4 * n);
+            for (i2 = 0; !rc && i2 < n; ++i2) {
+                n_bases += ln[i2];
+                if (n_bases >= m_data) { capped = 1; break; }
+            }
+            free(ln);
+            if (rc) break;
+            if (capped) { n = i2 + 1; rc = oatk_hip_ingest_truncate(D->piece[s], n); if (rc) break; }
+        }
         const uint64_t next_carry = len - used;
-        if (!final) {
+        if (!final && !capped) {
             if (next_carry > CARRY_CAP || used == 0) { rc = OATK_E_NOMEM; break; }       /* a record longer than a window: the caller retries in one piece */
             rc = oatk_hip_d2d(D->piece[s], D->d_win[s ^ 1] - next_carry, d_text + used, next_carry);      /* (moved on above if the next window lands on another device) */
             if (rc) break;
@@ -460,7 +484,7 @@ static int sr_read_stream(oatk_hip_ctx **ctxs, int n_ctx, uint64_t *first, oatk_
         pthread_cond_broadcast(&st.cv);
         pthread_mutex_unlock(&st.mu);
         const uint64_t text0 = g0 - carry;                          /* where this piece's text starts in the whole text */
-        carry = next_carry, text_done = g1, prev_res = ri, prev_slot = s;
+        carry = next_carry, text_done = capped? total : g1, prev_res = ri, prev_slot = s;
         if (n == 0) continue;
         oatk_hip_ctx *ctx = ctxs[cur];
         rc = oatk_hip_scan_ingested(D->piece[s], n_done, K, S);
@@ -469,7 +493,7 @@ static int sr_read_stream(oatk_hip_ctx **ctxs, int n_ctx, uint64_t *first, oatk_
         /* room for the reads: from the first piece's density, generously; grown when a later piece needs more */
         if (sr_db && sr_db->m < n_done + n) {
             uint64_t m = n_done + n;
-            if (!final && used) m = n_done + (uint64_t) ((double) n * ((double) (total - text0) / (double) used) * 1.05) + 1024;
+            if (!final && !capped && used) m = n_done + (uint64_t) ((double) n * ((double) (total - text0) / (double) used) * 1.05) + 1024;
             oatk_sr_t *na = (oatk_sr_t *) realloc(sr_db->a, sizeof(oatk_sr_t) * m);
             if (!na) { rc = OATK_E_NOMEM; break; }
             memset(na + sr_db->m, 0, sizeof(oatk_sr_t) * (m - sr_db->m));
@@ -478,7 +502,7 @@ static int sr_read_stream(oatk_hip_ctx **ctxs, int n_ctx, uint64_t *first, oatk_
         {   /* ... and for the batch assembled in this handle, at its first piece */
             oatk_hip_info_t have;
             oatk_hip_info(ctx, &have);
-            if (have.n_reads == 0 && !final && used) {
+            if (have.n_reads == 0 && !final && !capped && used) {
                 oatk_hip_info_t inf;
                 oatk_hip_info(D->piece[s], &inf);
                 const double share = (double) total / (double) n_ctx, left = (double) (total - text0);
@@ -521,6 +545,7 @@ static int sr_read_stream(oatk_hip_ctx **ctxs, int n_ctx, uint64_t *first, oatk_
         if (first) first[cur] = n_done;
     }
     if (first) first[n_ctx] = n_done;
+    if (capped && !rc) fprintf(stderr, "[M::%s] data limit (%lu) reached. Discard the remaining sequences...\n", "sr_read", (unsigned long) m_data);       /* syncmer.c:539 */
 done:
     if (started) {
         pthread_mutex_lock(&st.mu);
@@ -548,10 +573,15 @@ done:
 
 int oatk_sr_read_files(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, char **files, int n_files)
 {
-    return oatk_host_sr_read_files_n(&ctx, 1, sr_db, files, n_files, 0);
+    return oatk_host_sr_read_files_n(&ctx, 1, sr_db, files, n_files, 0, 0);
 }
 
-int oatk_host_sr_read_files_n(oatk_hip_ctx **ctxs, int n_ctx, oatk_sr_db_t *sr_db, char **files, int n_files, uint64_t *first)
+int oatk_sr_read_files_capped(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, char **files, int n_files, uint64_t m_data)
+{
+    return oatk_host_sr_read_files_n(&ctx, 1, sr_db, files, n_files, 0, m_data);
+}
+
+int oatk_host_sr_read_files_n(oatk_hip_ctx **ctxs, int n_ctx, oatk_sr_db_t *sr_db, char **files, int n_files, uint64_t *first, uint64_t m_data)
 {
     uint64_t total = 0;
     int i, rc = OATK_OK;
@@ -573,10 +603,10 @@ int oatk_host_sr_read_files_n(oatk_hip_ctx **ctxs, int n_ctx, oatk_sr_db_t *sr_d
             if (even < win) win = even > ((uint64_t) 64 << 20)? even : (uint64_t) 64 << 20;
         }
         if (win < 4096) win = 4096;
-        rc = sr_read_stream(ctxs, n_ctx, first, sr_db, sr_db->k, sr_db->s, seg, n_files, total, win);
+        rc = sr_read_stream(ctxs, n_ctx, first, sr_db, sr_db->k, sr_db->s, seg, n_files, total, win, m_data);
         if (rc == OATK_E_NOMEM && win < total) {                    /* a record longer than a window: once more, in one piece */
             oatk_sr_db_clean(sr_db);
-            rc = sr_read_stream(ctxs, n_ctx, first, sr_db, sr_db->k, sr_db->s, seg, n_files, total, total);
+            rc = sr_read_stream(ctxs, n_ctx, first, sr_db, sr_db->k, sr_db->s, seg, n_files, total, total, m_data);
         }
     }
     seg_close(seg, n_files);
@@ -599,8 +629,8 @@ int oatk_scan_text(oatk_hip_ctx *ctx, const uint8_t *text, uint64_t n_bytes, int
     else {
         uint64_t win = window? window : WIN_DEFAULT;
         if (win < 4096) win = 4096;
-        rc = sr_read_stream(&ctx, 1, 0, 0, k, s, &seg, 1, total, win);
-        if (rc == OATK_E_NOMEM && win < total) rc = sr_read_stream(&ctx, 1, 0, 0, k, s, &seg, 1, total, total);
+        rc = sr_read_stream(&ctx, 1, 0, 0, k, s, &seg, 1, total, win, 0);
+        if (rc == OATK_E_NOMEM && win < total) rc = sr_read_stream(&ctx, 1, 0, 0, k, s, &seg, 1, total, total, 0);
     }
     if (!rc && n_reads) { oatk_hip_info_t inf; oatk_hip_info(ctx, &inf); *n_reads = inf.n_reads; }
     return rc;

@@ -157,10 +157,12 @@ static void *fetch(oatk_hip_ctx *ctx, int which, uint64_t *bytes, int *rc)
 
 /* ---------------------------------------------------------------- sr_read ---------------------------------------------------------------- */
 
-int oatk_multi_sr_read_files(oatk_multi *m, oatk_sr_db_t *sr_db, char **files, int n_files)
+int oatk_multi_sr_read_files(oatk_multi *m, oatk_sr_db_t *sr_db, char **files, int n_files) { return oatk_multi_sr_read_files_capped(m, sr_db, files, n_files, 0); }
+
+int oatk_multi_sr_read_files_capped(oatk_multi *m, oatk_sr_db_t *sr_db, char **files, int n_files, uint64_t m_data)
 {
     m->have_reads = 0;
-    const int rc = oatk_host_sr_read_files_n(m->ctx, m->n, sr_db, files, n_files, m->first);
+    const int rc = oatk_host_sr_read_files_n(m->ctx, m->n, sr_db, files, n_files, m->first, m_data);
     if (rc) { int r; for (r = 0; r < m->n; ++r) if (oatk_hip_last_error(m->ctx[r])[0]) { note_err(m, r, rc); break; } }
     else m->have_reads = 1;
     return rc;

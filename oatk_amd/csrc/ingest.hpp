@@ -62,16 +62,39 @@ __device__ __forceinline__ uint64_t ing_line_end(const IngLines &l, uint64_t i) 
     return e;
 }
 
-// FASTA: is_hdr[i], seq_len[i] (both widened to u64 for the scans; entry n_lines = 0)
-__global__ void ing_line_kernel(IngLines l, uint64_t *is_hdr, uint64_t *seq_len)
+// FASTA: is_hdr[i], seq_len[i] (both widened to u64 for the scans; entry n_lines = 0).  A sequence line that starts with '+' is where kseq
+// switches to a quality string (kseq.h:207): such text is not plain FASTA and is left to the line-by-line reading below (flags[2]).
+__global__ void ing_line_kernel(IngLines l, uint64_t *is_hdr, uint64_t *seq_len, uint32_t *flags)
 {
     uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i > l.n_lines) return;
     if (i == l.n_lines) { is_hdr[i] = 0, seq_len[i] = 0; return; }
     const uint64_t s = ing_line_start(l, i), e = ing_line_end(l, i);
     const bool h = e > s && (l.text[s] == '>' || l.text[s] == '@');
+    if (e > s && l.text[s] == '+') flags[2] = 1u;
     is_hdr[i] = h;
     seq_len[i] = h? 0 : e - s;
+}
+// kseq's reading line by line (kseq.h:192-235), for text that is neither plain FASTA nor four-line FASTQ -- wrapped FASTQ, FASTA and FASTQ records
+// in one stream: what a line IS depends on the lines before it (inside a quality string a line that starts with '@' is quality), so the classification
+// is a serial walk; it runs on the host over three numbers per line that this kernel extracts: first character (0 for an empty line), length with
+// the CR stripped, and whether a '>' or '@' sits anywhere behind the first character (kseq looks for the next header character by character, so
+// such a line inside skipped text would start a record in the middle of a line: refused)
+struct __attribute__((packed)) IngLineInfo { uint32_t len; uint8_t c0, mid; };
+__global__ __launch_bounds__(256) void ing_line_info_kernel(IngLines l, IngLineInfo *info)
+{
+    const uint64_t i = (uint64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    if (i >= l.n_lines) return;
+    const uint64_t s = ing_line_start(l, i), e = ing_line_end(l, i);
+    bool m = false;
+    for (uint64_t j = 1 + lane; j < e - s; j += 64) { const uint8_t ch = l.text[s + j]; m |= ch == '>' || ch == '@'; }
+    const bool mid = e > s && __ballot(m) != 0;
+    if (lane == 0) {
+        IngLineInfo x;
+        x.len = e - s > 0xFFFFFFFFULL? 0xFFFFFFFFu : (uint32_t) (e - s), x.c0 = e > s? l.text[s] : 0, x.mid = mid;
+        info[i] = x;
+    }
 }
 // header lines by rank
 __global__ void ing_hdr_lines_kernel(uint64_t n_lines, const uint64_t *is_hdr, const uint64_t *hdr_rank, uint64_t *hdr_line)
@@ -94,7 +117,7 @@ __global__ void ing_record_kernel(IngLines l, uint64_t n_rec, const uint64_t *hd
     hdr_off[r] = ing_line_start(l, h);
 }
 // one wave per line of text: copy sequence lines to their place
-__global__ __launch_bounds__(256) void ing_copy_fasta_kernel(IngLines l, uint64_t line_end, const uint64_t *is_hdr, const uint64_t *hdr_rank,
+__global__ __launch_bounds__(256) void ing_copy_fasta_kernel(IngLines l, uint64_t line_end, const uint64_t *is_hdr, const uint64_t *seq_len, const uint64_t *hdr_rank,
                                                              const uint64_t *hdr_line, const uint64_t *seq_before, const uint64_t *off, uint8_t *seq)
 {
     const uint64_t i = (uint64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -102,9 +125,9 @@ __global__ __launch_bounds__(256) void ing_copy_fasta_kernel(IngLines l, uint64_
     if (i >= line_end || is_hdr[i]) return;
     const uint64_t rk = hdr_rank[i];                                // headers before this line
     if (rk == 0) return;                                            // text in front of the first header (kseq skips it)
-    const uint64_t r = rk - 1, s = ing_line_start(l, i), e = ing_line_end(l, i);
+    const uint64_t r = rk - 1, s = ing_line_start(l, i), n = seq_len[i];       // (0 for a line that carries no sequence: '+', quality, skipped text)
     uint8_t *dst = seq + off[r] + (seq_before[i] - seq_before[hdr_line[r]]);
-    for (uint64_t j = lane; j < e - s; j += 64) dst[j] = l.text[s + j];
+    for (uint64_t j = lane; j < n; j += 64) dst[j] = l.text[s + j];
 }
 
 // FASTQ, four lines per record

@@ -50,6 +50,18 @@ sr_db_t *refx_scan(char **files, int n_files, int k, int s, int n_threads)
     return db;
 }
 
+/* the same with sr_read's data cap (run_syncasm.c:81: m_data) */
+sr_db_t *refx_scan_cap(char **files, int n_files, int k, int s, int n_threads, size_t m_data)
+{
+    sstream_t *rdr = sstream_open(files, n_files);
+    if (!rdr) return 0;
+    sr_db_t *db = (sr_db_t *) malloc(sizeof(sr_db_t));
+    sr_db_init(db, k, s);
+    sr_read(rdr, db, m_data, n_threads);
+    sstream_close(rdr);
+    return db;
+}
+
 void refx_srdb_destroy(sr_db_t *db) { sr_db_destroy(db); }
 uint64_t refx_srdb_n(sr_db_t *db) { return db->n; }
 int refx_srdb_validate(sr_db_t *db) { return sr_db_validate(db); }

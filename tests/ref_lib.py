@@ -84,9 +84,15 @@ def _files_arg(paths):
 class SrDb:
     """reference sr_db_t built by sr_read (syncmer.c:487) from FASTA files"""
 
-    def __init__(self, paths, K, S, threads=1):
+    def __init__(self, paths, K, S, threads=1, m_data=0):
         self.K, self.S = K, S
-        self._h = lib().refx_scan(_files_arg(paths), len(paths), K, S, threads)
+        if m_data:
+            L = lib()
+            L.refx_scan_cap.restype = C.c_void_p
+            L.refx_scan_cap.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t]
+            self._h = L.refx_scan_cap(_files_arg(paths), len(paths), K, S, threads, m_data)
+        else:
+            self._h = lib().refx_scan(_files_arg(paths), len(paths), K, S, threads)
         if not self._h:
             raise RuntimeError("reference failed to open input")
 

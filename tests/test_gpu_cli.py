@@ -103,37 +103,59 @@ def test_cli_auto_coverage(tmp_path):
         assert tab[f][2] == 0, (f, tab[f])
 
 
-def test_cli_declined_inputs_fall_back_to_the_original_bodies(tmp_path):
+def test_cli_inputs_the_reader_used_to_decline(tmp_path):
+    """a data cap (-D), wrapped FASTQ, FASTQ and FASTA records in one stream: all read on the device now (OATK_FMT_KSEQ: kseq's own line-by-line reading
+    with the classification walked on the host over three numbers per line; the cap by counting the bases of the records as the windows come in) --
+    the reference's bytes, nothing from an original body.  What is still declined: k beyond the device scan's window."""
     reads = A.hifi_like(260, 50000, 5000, seed=13, err=0.001)
     fa = str(tmp_path / "reads.fa")
     R.write_fasta(reads, fa)
-    # a data cap stops the reader mid-file: the original sr_read, and with it everything behind it
-    tab, log = both(tmp_path, fa, 301, 21, 6, extra=["-D", "600000"])
-    assert tab["sr_read"] [0] == 0 and tab["sr_read"][2] == 1 and "data cap" in log
+    # a data cap stops the reader behind the read that takes the total to the cap (syncmer.c:537-541)
+    for cap, win in (("600000", None), ("700k", "150000")):
+        env = {"OATK_DEBUG_WINDOW": win} if win else None
+        tab, log = both(tmp_path, fa, 301, 21, 6, extra=["-D", cap], env=env)
+        assert "data limit" in log
+        for f in SIX:
+            assert tab[f][0] >= 1 and tab[f][2] == 0, (f, tab[f], log[-2000:])
+    # ... and with several handles
+    tab, log = both(tmp_path, fa, 301, 21, 6, extra=["-D", "600000"], env={"OATK_DEVICES": "0,0", "OATK_DEBUG_WINDOW": "200000"})
     for f in SIX:
-        assert tab[f][0] == 0, f
+        assert tab[f][0] >= 1 and tab[f][2] == 0, (f, tab[f], log[-2000:])
+    # wrapped FASTQ: sequence and quality over several lines, quality lines that start with '@' and '>'
+    fq = str(tmp_path / "w.fq")
+    with open(fq, "wb") as f:
+        for i, r in enumerate(reads):
+            h = len(r) // 3
+            q = (b"@" + b"I" * (h - 1), b">" + b"5" * (h - 1), b"+" * (len(r) - 2 * h))
+            f.write(b"@q%d wrapped\n" % i + r[:h] + b"\n" + r[h:2 * h] + b"\n\n" + r[2 * h:] + b"\n+q%d\n" % i + q[0] + b"\n" + q[1] + b"\n" + q[2] + b"\n")
+    for win in (None, "170000"):
+        tab, log = both(tmp_path, fq, 301, 21, 6, env={"OATK_DEBUG_WINDOW": win} if win else None)
+        for f in SIX:
+            assert tab[f][0] >= 1 and tab[f][2] == 0, (f, tab[f], log[-2000:])
+    # a FASTQ file followed by a FASTA file, and FASTA first with FASTQ records in the middle: kseq decides per record
+    f1, f2, f3 = str(tmp_path / "m.fq"), str(tmp_path / "m.fa"), str(tmp_path / "m2.fa")
+    with open(f1, "wb") as f:
+        for i, r in enumerate(reads[:130]):
+            f.write(b"@q%d\n" % i + r + b"\n+\n" + b"I" * len(r) + b"\n")
+    R.write_fasta(reads[130:], f2)
+    tab, log = both(tmp_path, [f1, f2], 301, 21, 6, env={"OATK_DEBUG_WINDOW": "300000"})
+    for f in SIX:
+        assert tab[f][0] >= 1 and tab[f][2] == 0, (f, tab[f], log[-2000:])
+    with open(f3, "wb") as f:
+        for i, r in enumerate(reads):
+            if i % 3 == 1:
+                f.write(b"@q%d\r\n" % i + r + b"\r\n+\r\n" + b"I" * len(r) + b"\r\n")
+            else:
+                f.write(b">a%d\n" % i + r[:2000] + b"\n" + r[2000:] + b"\n")
+    tab, log = both(tmp_path, f3, 301, 21, 6)
+    for f in SIX:
+        assert tab[f][0] >= 1 and tab[f][2] == 0, (f, tab[f], log[-2000:])
     # k beyond the device scan's window (oatk_hip_max_k() = 4016): the original reads and analyses
     long_reads = A.hifi_like(120, 60000, 20000, seed=17, err=0.0)
     fl = str(tmp_path / "long.fa")
     R.write_fasta(long_reads, fl)
     tab, log = both(tmp_path, fl, 4101, 31, 3)
     assert tab["sr_read"][0] == 0 and tab["sr_read"][2] == 1 and "beyond the device" in log
-    # wrapped FASTQ: the device reader refuses, kseq reads it
-    fq = str(tmp_path / "w.fq")
-    with open(fq, "wb") as f:
-        for i, r in enumerate(reads):
-            h = len(r) // 2
-            f.write(b"@q%d\n" % i + r[:h] + b"\n" + r[h:] + b"\n+\n" + b"I" * h + b"\n" + b"I" * (len(r) - h) + b"\n")
-    tab, log = both(tmp_path, fq, 301, 21, 6)
-    assert tab["sr_read"][0] == 0 and tab["sr_read"][2] == 1
-    # a FASTQ file followed by a FASTA file: kseq decides per record, the device reader per input -- the original reads it
-    f1, f2 = str(tmp_path / "m.fq"), str(tmp_path / "m.fa")
-    with open(f1, "wb") as f:
-        for i, r in enumerate(reads[:130]):
-            f.write(b"@q%d\n" % i + r + b"\n+\n" + b"I" * len(r) + b"\n")
-    R.write_fasta(reads[130:], f2)
-    tab, log = both(tmp_path, [f1, f2], 301, 21, 6)
-    assert tab["sr_read"][0] == 0 and tab["sr_read"][2] == 1
 
 
 @pytest.mark.parametrize("refuse,originals", [(1, {"read_error_correction": 0, "make_syncmer_graph": 0}),      # EC graph refused: the original BUILDS it, the device still corrects

@@ -136,6 +136,149 @@ def test_file_through_device_ingest_equals_reference_sr_read(hip, tmp_path):
     db.close()
 
 
+def wrapped_mixed(reads, eol=b"\n", seed=3):
+    """records of every kind kseq reads: FASTA (one line, wrapped), four-line FASTQ, FASTQ with sequence AND quality over several lines whose quality
+    lines start with '@', '>' and '+', blank lines inside sequences, text between a finished FASTQ record and the next header"""
+    rng = np.random.default_rng(seed)
+    t = b"text before the first header" + eol + eol
+    for i, r in enumerate(reads):
+        kind = i % 4
+        if kind == 0:
+            t += b">fa%d one line" % i + eol + r + eol
+        elif kind == 1:
+            w = int(rng.integers(1, 200))
+            t += b">fw%d" % i + eol + eol.join(r[j:j + w] for j in range(0, len(r), w)) + eol + eol
+        elif kind == 2:
+            t += b"@fq%d four lines" % i + eol + r + eol + b"+" + eol + bytes([64]) * len(r) + eol + b"skipped text" + eol
+        else:
+            a, b = len(r) // 3, 2 * len(r) // 3
+            qual = [b"@" + b"I" * (a - 1) if a else b"", b">" * (b - a), b"+" + b"5" * (len(r) - b - 1) if len(r) - b else b""]
+            t += b"@fm%d wrapped" % i + eol + r[:a] + eol + eol + r[a:b] + eol + r[b:] + eol + b"+fm%d" % i + eol + eol.join(q for q in qual) + eol
+    return t
+
+
+def kseq_exact(text: bytes):
+    """kseq_read itself, character by character as kseq.h:192-235 is written (headers found anywhere; '+' switches to quality; quality read by whole
+    lines until it is at least as long as the sequence; -2 on a length mismatch ends the stream)"""
+    out, p, n, last = [], 0, len(text), 0
+
+    def line_end(q):
+        e = text.find(b"\n", q)
+        return n if e < 0 else e
+
+    while True:
+        if last == 0:
+            while p < n and text[p:p + 1] not in (b">", b"@"):
+                p += 1
+            if p >= n:
+                return out
+            p += 1
+        e = line_end(p)                                # the header line: name up to white space
+        p = min(e + 1, n)
+        seq = b""
+        c = b""
+        while p < n:
+            c = text[p:p + 1]
+            if c in (b">", b"+", b"@"):
+                break
+            e = line_end(p)
+            ln = text[p:e]
+            if ln.endswith(b"\r") and len(seq) + len(ln) > 1:
+                ln = ln[:-1]
+            seq += ln
+            p = min(e + 1, n)
+            c = b""
+        if c in (b">", b"@"):
+            last = 1
+            p += 1
+        else:
+            last = 0
+        if c != b"+":
+            out.append(seq)
+            if p >= n and c == b"":
+                return out
+            continue
+        p = min(line_end(p) + 1, n)
+        q = 0
+        while True:
+            if p >= n:
+                break
+            e = line_end(p)
+            ln = text[p:e]
+            if ln.endswith(b"\r") and q + len(ln) > 1:
+                ln = ln[:-1]
+            q += len(ln)
+            p = min(e + 1, n)
+            if q >= len(seq):
+                break
+        if q != len(seq):
+            return out                                 # -2: the reader stops
+        out.append(seq)
+
+
+@pytest.mark.parametrize("eol", [b"\n", b"\r\n"])
+def test_kseq_format_reads_wrapped_fastq_and_mixed_records(hip, eol):
+    """OATK_FMT_KSEQ (3): kseq's own reading line by line -- the device extracts first character, length and "a header character inside" per line, the
+    classification is walked on the host, lengths / offsets / copy stay on the device -- against kseq_read restated character by character, whole and
+    fed in chunks cut at random places; and the two device-only formats answer OATK_E_SPLIT (5) for such text instead of misreading it"""
+    t = wrapped_mixed(READS[:37], eol)
+    want = kseq_exact(t)
+    assert len(want) == 37 and want == [r for r in READS[:37]]
+    assert device_reads(hip, t, 3) == want
+    rng = np.random.default_rng(8)
+    got, pos, carry = [], 0, b""
+    cuts = sorted(set(rng.integers(1, len(t) - 1, 12).tolist())) + [len(t)]
+    for c in cuts:
+        chunk = carry + t[pos:c]
+        n, used = hip.ingest_host(chunk, 3, c == len(t))
+        seq, off, lens = hip.fetch("INGEST_SEQ"), hip.fetch("INGEST_OFF"), hip.fetch("INGEST_LEN")
+        got += [seq[int(o):int(o) + int(l)].tobytes() for o, l in zip(off, lens)]
+        carry, pos = chunk[used:], c
+    assert got == want
+    for fmt in (1, 2):
+        with pytest.raises(OatkHipError, match="code 5"):
+            hip.ingest_host(t, fmt, True)
+    # a quality string longer than its sequence: kseq stops there (-2), the device refuses the text
+    with pytest.raises(OatkHipError):
+        hip.ingest_host(b"@a" + eol + b"ACGT" + eol + b"+" + eol + b"IIIII" + eol, 3, True)
+
+
+@pytest.mark.skipif(not R.available(), reason="oracle/_ref not built")
+def test_wrapped_mixed_file_and_data_cap_equal_reference_sr_read(hip, tmp_path):
+    """a file of wrapped FASTQ and FASTA records through the streamed reader (small windows) against the compiled reference's sr_read of the same file,
+    without and with a data cap (syncmer.c:537-541: the read that takes the total to the cap is the last one)"""
+    import ctypes as C
+    from test_gpu_dropin import host_lib
+    K, S = 301, 21
+    reads = A.hifi_like(150, 30000, 4000, seed=23)
+    path = str(tmp_path / "mixed.fq")
+    with open(path, "wb") as f:
+        f.write(wrapped_mixed(reads))
+    H = host_lib()
+    H.oatk_sr_read_files_capped.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_char_p), C.c_int, C.c_uint64]
+    H.oatk_host_debug_window.argtypes = [C.c_uint64]
+    total = sum(len(r) for r in reads)
+    for cap in (0, total // 3, 1):
+        db = R.SrDb([path], K, S, 2, m_data=cap)
+        want = db.flatten()
+        mine = H.oatk_sr_db_new(K, S)
+        files = (C.c_char_p * 1)(path.encode())
+        H.oatk_host_debug_window(70000)
+        try:
+            rc = H.oatk_sr_read_files_capped(hip.h, mine, files, 1, cap)
+        finally:
+            H.oatk_host_debug_window(0)
+        assert rc == 0, hip.L.oatk_hip_last_error(hip.h)
+        got_db = R.SrDb.__new__(R.SrDb)
+        got_db.K, got_db.S, got_db._h = K, S, mine
+        got = got_db.flatten()
+        assert got_db.n() == db.n() and (cap == 0) == (db.n() == len(reads)) and (cap != 1 or db.n() == 1)
+        for f in ["hoco_l", "n_scm", "sid", "hoco_s", "ho_rl", "m_pos", "s_mer", "k_mer"]:
+            assert np.array_equal(got[f], want[f]), (cap, f)
+        got_db.close()
+        db.close()
+
+
 def test_empty_and_headers_only(hip):
     assert hip.ingest_host(b"", 0, True) == (0, 0)
     assert device_reads(hip, b">a\n>b\nACGT\n>c\n", 1) == [b"", b"ACGT", b""]
