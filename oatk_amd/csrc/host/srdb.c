@@ -92,6 +92,11 @@ typedef struct {
 } fill_job_t;
 
 static uint8_t *g_heap_top = 0;                       /* where the last large block ended: survives from one call to the next */
+static int heap_tune_wanted(void)
+{
+    const char *e = getenv("OATK_HOST_HEAP_TUNE");
+    return e && e[0] == '1';
+}
 
 /* ---- arenas (opt-in: oatk_host_set_arena) --------------------------------------------------------------------------------------------------
  * The reference frees every member array of every read with free() (sr_destroy, syncmer.c:1047-1058) and reallocs the chains in
@@ -254,7 +259,7 @@ static void fill_alloc(fill_job_t *j)
 static void fill_prefault_plan(fill_job_t *j)
 {
     j->pre0 = j->pre1 = 0;
-    if (g_use_arena || !g_heap_top || j->a1 <= j->a0) return;          /* (an arena is a fresh mapping: its pages are touched by the copies themselves) */
+    if (g_use_arena || !g_heap_top || j->a1 <= j->a0 || !heap_tune_wanted()) return;          /* (an arena is a fresh mapping: its pages are touched by the copies themselves) */
     if ((pid_t) syscall(SYS_gettid) != getpid()) return;       /* the main heap is the main thread's arena: only there do the next blocks come from its top */
     uint64_t need = 0, i;
     for (i = j->a0; i < j->a1; ++i) need += (uint64_t) j->hoco_l[i] + ((uint64_t) j->hoco_l[i] + 3) / 4 + 20 * (j->scm_off[i + 1] - j->scm_off[i]) + 160;
@@ -329,10 +334,11 @@ int oatk_sr_db_fill_range(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, uint64_t first
     int rc = 0;
     if (n_reads == 0) return OATK_OK;
     if (!sr_db->a || sr_db->m < first + n_reads) return OATK_E_ARG;
-    {   /* gigabytes of small blocks are about to be allocated: let the heap grow in large steps and never shrink in between */
-        static int tuned = 0;
-        if (!tuned) { (void) mallopt(M_TOP_PAD, 1 << 30); (void) mallopt(M_TRIM_THRESHOLD, 1 << 30); tuned = 1; }
-    }
+    /* One malloc'ed block per member array (no arenas): gigabytes of small blocks are about to be allocated.  Letting the heap grow in 1 GiB steps and
+     * touching the fresh pages from the copying threads (fill_prefault) is worth 2x on this path, but it changes the HOST PROGRAM's allocator settings and
+     * leans on glibc internals (a contiguous main arena), so it is opt-in: OATK_HOST_HEAP_TUNE=1.  The arena mode needs neither. */
+    const int heap_tune = !g_use_arena && heap_tune_wanted();
+    if (heap_tune) { (void) mallopt(M_TOP_PAD, 1 << 30); (void) mallopt(M_TRIM_THRESHOLD, 1 << 30); }
     const double t_begin = host_now();
     double t_copy = 0, t_wait = 0, t_setup = 0;
     fill_job_t job;
@@ -422,6 +428,7 @@ int oatk_sr_db_fill_range(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, uint64_t first
     }
 done:
     free(hoco_l); free(n_nn); free(n_lrl); free(nn_key); free(lrl_val); free(scm_off); free(o_nn); free(o_lrl);
+    if (heap_tune) { (void) mallopt(M_TOP_PAD, 128 * 1024); (void) mallopt(M_TRIM_THRESHOLD, 128 * 1024); }      /* glibc's defaults back: the host program's heap is its own again */
     if (host_log()) fprintf(stderr, "[M::%s] %lu reads into sr_db_t: %.3f s on %d host threads (setup %.3f, block allocation %.3f beside copying %.3f, waiting for PCIe %.3f)\n",
                             __func__, (unsigned long) n_reads, host_now() - t_begin, oatk_host_threads(), t_setup, job.t_alloc, t_copy, t_wait);
     return rc;
