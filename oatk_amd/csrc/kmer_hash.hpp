@@ -23,32 +23,92 @@ struct KmerHashArgs {
 };
 
 #define KMH_REC 16                // records per wave: most lanes idle in the short chain phase, but four times the waves fit a CU's LDS (64: 1.12 ms, 32: 0.75, 16: 0.56, 8: 0.67)
+#define KMH_WPL 8                 // Murmur blocks a lane prepares in one go (their source words are loaded together)
+
+// r03: FOUR LANES PER RECORD, each preparing a run of consecutive 8-byte Murmur blocks of its record.  A run of blocks is a run of consecutive source
+// words, so a lane loads 2 n + 1 dwords for n blocks (three per block before) with no division, no shuffles and no per-block address arithmetic in
+// front of them (the old loop spent ~100 instructions per block: `it / NW` at run time, two ds_bpermute, three guarded loads, three byte swaps, a
+// 64-bit funnel shift with a special case, revcomp32 and a second byte swap).  The Murmur block of a REVERSE occurrence needs no reversal of the
+// word at all: revcomp32 followed by the byte swap that turns the MSB-first string into the little-endian word Murmur reads is the complement with
+// the four fields of every BYTE reversed, bytes staying where they are.
+__device__ __forceinline__ uint32_t kmh_rev_in_bytes(uint32_t x)
+{
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    return ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+}
 
 __global__ __launch_bounds__(64) void kmer_hash_kernel(KmerHashArgs a)
 {
     extern __shared__ uint64_t kmix[];          // KMH_REC records x (NW + 1)
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x, rr = lane >> 2, q = lane & 3u;
     const uint32_t base = blockIdx.x * (uint32_t) KMH_REC;
     const int K = a.K;
     const int nbytes = (K - 1) / 4 + 1, nfull = nbytes >> 3, nrem = nbytes & 7, NW = nfull + (nrem? 1 : 0);
     const int stride = NW + 1;
     const uint32_t nrec = a.n_rec - base < (uint32_t) KMH_REC? a.n_rec - base : (uint32_t) KMH_REC;
-    const uint32_t items = nrec * (uint32_t) NW;
-    // where record `lane` lives: fetched once, handed to the lanes that read its words by ds_bpermute (three dependent gathers
-    // in front of every word otherwise)
-    uint32_t my_mp = 0, my_hsw = 0;
-    if (lane < nrec) {
-        my_mp = a.rec_mpos[base + lane];
-        my_hsw = (uint32_t) (a.off[(a.rec_lo[base + lane] >> 32) - a.sid0] >> 4);      // 32-bit word index of the read's hoco string
-    }
-    const uint32_t *hs32 = (const uint32_t *) a.hoco_s;
-    for (uint32_t it = lane; it < ((items + 63u) & ~63u); it += 64u) {
-        const uint32_t rr0 = it / (uint32_t) NW, rr = rr0 < nrec? rr0 : 0u, wd = it - rr0 * (uint32_t) NW;
-        const uint32_t mp = __shfl(my_mp, (int) rr);
-        const uint32_t *hs = hs32 + __shfl(my_hsw, (int) rr);
-        if (it >= items) continue;
-        uint64_t word = bswap64(kmer_word_global(hs, mp >> 1, mp & 1u, K, (int) wd));
-        kmix[rr * (uint32_t) stride + wd] = (int) wd < nfull? murmur_mix_word(word) : word;
+    if (rr < nrec) {
+        const uint32_t mp = a.rec_mpos[base + rr], rev = mp & 1u, pos = mp >> 1;      // (four lanes, one address)
+        const int64_t hsw = (int64_t) (a.off[(a.rec_lo[base + rr] >> 32) - a.sid0] >> 4);      // 32-bit word index of the read's hoco string
+        const uint32_t *hs32 = (const uint32_t *) a.hoco_s;
+        uint64_t *out = &kmix[rr * (uint32_t) stride];
+        const int per = (NW + 3) >> 2;                                        // blocks per lane
+        for (int w0 = (int) q * per; w0 < (int) (q + 1) * per && w0 < NW; w0 += KMH_WPL) {
+            const int nwd = (int) (q + 1) * per - w0 < KMH_WPL? (int) (q + 1) * per - w0 : KMH_WPL;
+            const int n = w0 + nwd > NW? NW - w0 : nwd;                       // blocks w0 .. w0 + n - 1
+            // their source bases: [t_lo, t_lo + 32 n) of the hoco string -- the oriented bases 32 w0 .. for a forward occurrence, the mirror image
+            // (block w0 + j from the chunk n - 1 - j) for a reverse one; bases in front of the k-mer (a reverse occurrence's last block) are masked below
+            const int32_t t_lo = rev? (int32_t) pos + K - 32 * (w0 + n) : (int32_t) pos + 32 * w0;
+            const int32_t wi = t_lo >> 4;                                     // (arithmetic shift: t_lo may be negative by less than 32)
+            const uint32_t sh = ((uint32_t) t_lo & 15u) * 2u;
+            // the 2 n + 1 source words, in the order the blocks use them: ascending for a forward occurrence, descending for a reverse one (whose
+            // block j is made of chunk n - 1 - j) -- so block j always finds its three words at d[2j], d[2j + 1], d[2j + 2].  A full run (n = 8, every
+            // lane at K = 1001) fetches them as four 16-byte loads and one dword: seventeen single-dword loads touch 64 cache lines EACH (the lanes of
+            // a wave sit 64 bytes apart) and the vector cache looks up every line of every load -- that, not arithmetic, was the kernel's run time.
+            uint32_t d[2 * KMH_WPL + 1];
+            const int64_t gbase = hsw + wi;
+            if (n == KMH_WPL && gbase >= 0) {
+                struct __attribute__((packed, aligned(4))) W4 { uint32_t a, b, c, e; };
+                const W4 *src = (const W4 *) (hs32 + gbase);
+                const W4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+                const uint32_t v4 = hs32[gbase + 16];
+                const uint32_t asc[17] = {v0.a, v0.b, v0.c, v0.e, v1.a, v1.b, v1.c, v1.e, v2.a, v2.b, v2.c, v2.e, v3.a, v3.b, v3.c, v3.e, v4};
+#pragma unroll
+                for (int j = 0; j < 17; ++j) d[j] = __builtin_bswap32(rev? asc[16 - j] : asc[j]);
+            } else {
+                const int64_t g0 = gbase + (rev? 2 * n : 0);
+#pragma unroll
+                for (int j = 0; j < 2 * KMH_WPL + 1; ++j) {
+                    int64_t gi = rev? g0 - j : g0 + j;
+                    gi = gi < 0? 0 : gi;                                      // (only the very first read of a slab: what is read there is masked)
+                    d[j] = j < 2 * n + 1? __builtin_bswap32(hs32[gi]) : 0u;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < KMH_WPL; ++j) {
+                if (j >= n) break;
+                // sixty-four bits from bit offset sh of the chunk's three words (first, middle, last in string order)
+                const uint32_t x0 = rev? d[2 * j + 2] : d[2 * j], x1 = d[2 * j + 1], x2 = rev? d[2 * j] : d[2 * j + 2];
+                const uint32_t hi = (uint32_t) (((uint64_t) x0 << 32 | x1) >> (32u - sh));
+                const uint32_t lo = (uint32_t) (((uint64_t) x1 << 32 | x2) >> (32u - sh));
+                const int wd = w0 + j;
+                int nb = K - 32 * wd;
+                nb = nb > 32? 32 : nb;
+                uint64_t word;
+                if (rev) {
+                    // the oriented block is revcomp32 of the chunk; bases of the chunk in FRONT of the k-mer (its first 32 - nb) fall behind K
+                    uint64_t V = (uint64_t) hi << 32 | lo;
+                    if (nb < 32) V &= ~0ULL >> (64 - 2 * nb);                 // keep the chunk's LAST nb bases
+                    const uint64_t R = revcomp32(V);                          // (rare tail aside, the two lines below are all a reverse block costs)
+                    word = nb < 32? bswap64(R & (~0ULL << (64 - 2 * nb)))
+                                  : ~((uint64_t) kmh_rev_in_bytes(hi) << 32 | kmh_rev_in_bytes(lo));
+                } else {
+                    uint64_t V = (uint64_t) hi << 32 | lo;
+                    if (nb < 32) V &= ~0ULL << (64 - 2 * nb);
+                    word = bswap64(V);
+                }
+                out[wd] = wd < nfull? murmur_mix_word(word) : word;
+            }
+        }
     }
     __syncthreads();
     if (lane < nrec) {
