@@ -229,6 +229,68 @@ __global__ __launch_bounds__(64) void ecw_wf_ed_kernel(const uint32_t *tw, const
     }
 }
 
+// ---- Myers' bit-vector edit distance (north_star names it; SURVEY.md 7-5: "benchmark both") ----
+// Measured beside the wavefront routine, not used by the correction (the search RESUMES an alignment after every appended k-mer, saves
+// it at a branch and restores it, and its results are defined on wavefronts; a column-wise bit-vector DP can do neither cheaply).  One LANE per pair --
+// "batching reads per wavefront" -- with the bit-vectors over the TARGET, sixty-four pairs per wave, the vectors of a wave interleaved in an HBM slab
+// (word w of lane l at w * 64 + l: every access of the wave is one coalesced 512-byte row).  Global alignment (the first row counts up: carry-in +1
+// per column), Hyyro's block formulation with the horizontal delta handed from word to word.  The result is the closed form wf_ed equals
+// (oracle/levdist.c: orc_ed_bruteforce): the minimum over the last row, then the last column upwards, first minimum wins = smallest diagonal;
+// beyond the band (bw >= 0 and minimum > bw): score bw + 1 with both ends 0, as wf_ed_core leaves them.
+__global__ __launch_bounds__(64) void myers_ed_kernel(uint64_t n_jobs, const uint32_t *tw, const uint64_t *tw_off, const int32_t *tl, const uint32_t *qw, const uint64_t *qw_off,
+                                                      const int32_t *ql_, const int32_t *bw, uint64_t *slab, uint64_t slab_words, int32_t *out3)
+{
+    const uint64_t j = (uint64_t) blockIdx.x * 64 + threadIdx.x;
+    if (j >= n_jobs) return;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t *ts = tw + tw_off[j], *qs = qw + qw_off[j];
+    const int32_t T = tl[j], Q = ql_[j], nw = (T + 63) >> 6;
+    uint64_t *S = slab + (uint64_t) blockIdx.x * slab_words;        // per wave: Peq[4][nw], Pv[nw], Mv[nw], all interleaved over the lanes
+    auto at = [&](int32_t plane, int32_t w) -> uint64_t & { return S[((uint64_t) plane * (uint64_t) (slab_words / (6 * 64)) + (uint64_t) w) * 64 + lane]; };
+    for (int32_t w = 0; w < nw; ++w) {
+        uint64_t eq[4] = {0, 0, 0, 0};
+        for (int32_t b = 0; b < 64 && 64 * w + b < T; ++b) {
+            const int32_t p = 64 * w + b;
+            eq[(ts[p >> 4] >> ((p & 15) << 1)) & 3u] |= 1ULL << b;
+        }
+        for (int c = 0; c < 4; ++c) at(c, w) = eq[c];
+        at(4, w) = ~0ULL, at(5, w) = 0ULL;                             // Pv = all ones (the first column counts up), Mv = 0
+    }
+    const int32_t lastw = nw - 1;
+    const uint64_t lastbit = 1ULL << ((T - 1) & 63);
+    int32_t score = T, best = T, bi = T, bj = 0;                        // last row, j = 0: D[T][0] = T
+    for (int32_t col = 0; col < Q; ++col) {
+        const uint32_t c = (qs[col >> 4] >> ((col & 15) << 1)) & 3u;
+        int hin = 1;
+        for (int32_t w = 0; w < nw; ++w) {
+            uint64_t Eq = at((int32_t) c, w), Pv = at(4, w), Mv = at(5, w);
+            const uint64_t Xv = Eq | Mv;
+            if (hin < 0) Eq |= 1ULL;
+            const uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+            uint64_t Ph = Mv | ~(Xh | Pv), Mh = Pv & Xh;
+            const uint64_t top = w == lastw? lastbit : 1ULL << 63;
+            const int hout = (Ph & top? 1 : 0) - (Mh & top? 1 : 0);
+            Ph <<= 1, Mh <<= 1;
+            if (hin < 0) Mh |= 1ULL; else if (hin > 0) Ph |= 1ULL;
+            at(4, w) = Mh | ~(Xv | Ph);
+            at(5, w) = Ph & Xv;
+            hin = hout;
+        }
+        score += hin;
+        if (score < best) best = score, bi = T, bj = col + 1;
+    }
+    // the last column upwards: D[i][Q] = D[T][Q] - sum of the vertical deltas of rows i + 1 .. T
+    int32_t v = score;
+    for (int32_t i = T - 1; i >= 0; --i) {
+        const uint64_t bit = 1ULL << (i & 63);
+        v -= (at(4, i >> 6) & bit? 1 : 0) - (at(5, i >> 6) & bit? 1 : 0);
+        if (v < best) best = v, bi = i, bj = Q;
+    }
+    const int32_t band = bw[j];
+    if (band >= 0 && best > band) best = band + 1, bi = 0, bj = 0;
+    out3[3 * j] = best, out3[3 * j + 1] = bi, out3[3 * j + 2] = bj;
+}
+
 // a live-arc record in flight: issued as two loads, made uniform only where it is used
 struct EcwArcRegs {
     uint4 a;                      // w, ls, hs16, mpos

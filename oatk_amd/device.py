@@ -193,6 +193,27 @@ class HipSyncasm:
                                                 ql.ctypes.data, s_off.ctypes.data, out.ctypes.data), "oatk_hip_debug_wf_ed")
         return [[tuple(int(v) for v in out[s]) for s in range(int(s_off[j]), int(s_off[j + 1]))] for j in range(len(jobs))]
 
+    def ed_ab(self, pairs, myers):
+        """SURVEY 7-5's A/B (oatk_hip_debug_ed_ab): pairs = [(target, query, bw), ...] through the wavefront routine (myers = False) or Myers' bit-vector
+        algorithm, one lane per pair (True); returns ([(score, t_end, q_end), ...], kernel milliseconds)"""
+        code = np.full(256, 255, np.uint8)
+        for i, ch in enumerate(b"ACGT"):
+            code[ch] = code[ch + 32] = i
+        n = len(pairs)
+        t_off, q_off = np.zeros(n + 1, np.uint64), np.zeros(n + 1, np.uint64)
+        t_off[1:] = np.cumsum([len(p[0]) for p in pairs])
+        q_off[1:] = np.cumsum([len(p[1]) for p in pairs])
+        tc = np.ascontiguousarray(code[np.frombuffer(b"".join(p[0] for p in pairs), np.uint8)])
+        qc = np.ascontiguousarray(code[np.frombuffer(b"".join(p[1] for p in pairs), np.uint8)])
+        if (tc == 255).any() or (qc == 255).any():
+            raise ValueError("ed_ab: the device alphabet is ACGT")
+        bw = np.array([p[2] for p in pairs], np.int32)
+        out = np.zeros((n, 3), np.int32)
+        ms = C.c_float()
+        self._check(self.L.oatk_hip_debug_ed_ab(self.h, 1 if myers else 0, n, tc.ctypes.data, t_off.ctypes.data, qc.ctypes.data, q_off.ctypes.data, bw.ctypes.data,
+                                                out.ctypes.data, C.byref(ms)), "oatk_hip_debug_ed_ab")
+        return [tuple(int(v) for v in r) for r in out], float(ms.value)
+
     def ec_stats(self):
         st = np.zeros(12, np.uint64)
         self._check(self.L.oatk_hip_ec_stats(self.h, st.ctypes.data), "oatk_hip_ec_stats")

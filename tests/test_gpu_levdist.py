@@ -109,6 +109,33 @@ def test_fresh_jobs_against_the_oracle(hip):
     assert n_wide > 10                                                                      # wavefronts wider than one lane group per diagonal
 
 
+def test_myers_bit_vector_variant_gives_the_same_distances(hip):
+    """north_star names a bit-parallel (Myers) kernel, SURVEY 7-5 asks to benchmark both: the bit-vector algorithm with one lane per pair
+    (ec_wave.hpp: myers_ed_kernel) returns wf_ed's (score, t_end, q_end) on every golden pair and on fresh ones, band cut-offs included -- the
+    closed form the wavefront equals (minimum over last row and last column, smallest diagonal first).  tools/edbench.py times the two."""
+    g = G.load("levdist")
+    pairs, want = [], []
+    for ts, qs, bw, out in list(zip(g["pairs_t"], g["pairs_q"], g["pairs_bw"], g["pairs_out"]))[1:]:
+        pairs.append((ts, qs, int(bw))), want.append(tuple(int(v) for v in out))
+    rng = np.random.default_rng(77)
+    for it in range(300):
+        tl = int(rng.integers(1, 2500 if it % 10 == 0 else 260))
+        ts = A.rand_dna(rng, tl)
+        q = mutate(rng, ts, int(rng.integers(0, 1 + tl // 15)))
+        if it % 3 == 0:
+            q = q + A.rand_dna(rng, int(rng.integers(1, 80)))
+        bw = [-1, 3, 8, 40][it % 4]
+        w = O.Wavefront(ts, bw)
+        want.append(w.step(q))
+        w.close()
+        pairs.append((ts, q, bw))
+    for myers in (False, True):
+        got, ms = hip.ed_ab(pairs, myers)
+        for j, (a, b) in enumerate(zip(got, want)):
+            assert a == b, (myers, j, pairs[j][2], len(pairs[j][0]), len(pairs[j][1]), a, b)
+        assert ms > 0
+
+
 def test_bad_arguments_are_refused(hip):
     from oatk_amd import OatkHipError
     with pytest.raises(OatkHipError):
