@@ -75,7 +75,9 @@ def time_cli(readset, first, n_reads, k, s, c, threads, workdir=None, strict=Tru
             if strict and (not same_m or orig_m):
                 raise RuntimeError("drop-in CLI run over OATK_DEVICES=%s rejected: gfa_identical=%s, original bodies %s" % (devices, same_m, orig_m))
             multi = {"devices": devices, "dropin_s": round(t_m, 2), "speedup": round(t_ref / t_m, 2), "gfa_identical": bool(same_m)}
-        return {"reads": n_reads, "gbases": round(bases / 1e9, 3), "threads": threads, "several_handles": multi,
+        m = re.search(r"device context ready after ([\d.]+) s; exit handlers reached at \+([\d.]+) s", err)
+        phases = {"device_context_ready_s": float(m.group(1)), "exit_handlers_at_s": float(m.group(2))} if m else None
+        return {"reads": n_reads, "gbases": round(bases / 1e9, 3), "threads": threads, "several_handles": multi, "dropin_phases": phases,
                 "reference_s": round(t_ref, 2), "dropin_s": round(t_dev, 2), "speedup": round(t_ref / t_dev, 2), "gfa_identical": bool(same),
                 "dropin_value": round(bases / t_dev / 1e9, 3), "reference_value": round(bases / t_ref / 1e9, 3), "unit": "Gbases/s",
                 "served": {f: {"device_calls": v[0], "device_s": v[1], "original_calls": v[2], "original_s": v[3]} for f, v in tab.items()},
