@@ -584,6 +584,13 @@ def main():
         achieved = alg_bytes[dom] / dur_s / 1e9 if dur_s > 0 else 0.0
         traffic, traffic_src = pmc_traffic({"hpc": "oatk::hpc_pack_kernel", "syncmer": "void oatk::syncmer_fast_kernel"}[dom], args.workload, per_gpu)
         valu_per_64 = float(os.environ.get("OATK_VALU_PER_64", "0")) or VALU_PER_64
+        # cycles per wave64 VALU instruction weighted by the opcode mix of kernel B's tile loop (tools/isa_mix.py over `hipcc -S`, per-opcode rates measured
+        # on the box: profiles/r02c_valu_rates.txt) -- 2.9 for the simple 32-bit forms, 4.5 - 5.5 for 64-bit shifts, v_mad_u64_u32, v_alignbit
+        import glob
+        mix_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_isa_mix_syncmer_fast.json")))
+        mix = json.load(open(mix_files[-1])) if mix_files else None
+        cpi = float(mix["cycles_per_valu_instruction_mix"]) if mix else 4.0
+        valu_rate = hoco / 64 * valu_per_64 / (phase_ms["syncmer"] / 1e3) / 1e9           # G wave-instructions / s
         roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": alg_bytes[dom], "avg_launch_ms": round(phase_ms[dom], 4),
@@ -591,8 +598,11 @@ def main():
                     "note": "kernel B reads 0.25 B and hashes one 31-mer per hoco position: it is integer-VALU issue bound, not HBM bound (DESIGN.md 5); "
                             "`valu` prices it against the bound that binds",
                     # wave-instructions issued (PMC count per 64 positions, profiles/) against 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction
-                    "valu": {"achieved": round(hoco / 64 * valu_per_64 / (phase_ms["syncmer"] / 1e3) / 1e9, 1), "peak": 614.4, "unit": "G wave-instr/s",
-                             "frac": round(hoco / 64 * valu_per_64 / (phase_ms["syncmer"] / 1e3) / 1e9 / 614.4, 3), "valu_per_64_positions": valu_per_64},
+                    "valu": {"achieved": round(valu_rate, 1), "peak": 614.4, "unit": "G wave-instr/s",
+                             "frac": round(valu_rate / 614.4, 3), "valu_per_64_positions": valu_per_64,
+                             # the same against the ceiling of THIS opcode mix: 1024 SIMDs x 2.4 GHz / (mix-weighted cycles per instruction)
+                             "cycles_per_instr_mix": cpi, "peak_mix": round(1024 * 2.4 / cpi, 1), "frac_mix": round(valu_rate * cpi / (1024 * 2.4), 3),
+                             "mix_source": os.path.basename(mix_files[-1]) if mix_files else None},
                     "scan_bytes_per_base": round((alg_bytes["hpc"] + 28 * n_occ) / bases, 4),
                     # the scan of SURVEY.md 8(d) is kernel A + kernel B + the k-mer hash
                     "scan_achieved_GBs": round((alg_bytes["hpc"] + 28 * n_occ) / ((phase_ms["hpc"] + phase_ms["syncmer"] + phase_ms.get("syncmer_n", 0.0) + phase_ms.get("kmer_hash", 0.0)) / 1e3) / 1e9, 2)}
