@@ -60,6 +60,20 @@ def main():
     for key, ref in (("MG_H", cnt["h"]), ("MG_S", cnt["s"]), ("MG_COV", cnt["cov"])):
         assert np.array_equal(np.concatenate([o[1][key] for o in out]), ref), key
     assert np.array_equal(np.concatenate([o[5]["EC_KMER"] for o in out]), want["EC_KMER"])
+    # the graph hand-off (include/oatk_hip_multi.h, second half) over the same mock: gather to root by grouped send / receive, the all-gathers of
+    # coverage, keys and segments, the all-reduces of the consensus totals, the personalised exchange of the statistics
+    import test_gpu_multi_tail as T
+    for case in (0, 2, 3):
+        K, S, c, mk, frac = T.CASES[case]
+        reads = mk()
+        bounds = [int(round(f * len(reads))) for f in frac]
+        world = len(bounds) - 1
+        root = world - 1 if case == 3 else 0
+        uid = (C.c_uint8 * 128)()
+        assert L.oatk_comm_unique_id(uid) == 0
+        out = T.run_ranks(world, None, reads, bounds, K, S, c, 0.35, root, make_comm=lambda r, uid=uid, world=world: L.oatk_comm_create(uid, r, world, 0))
+        T.check(out, T.single(hip, reads, K, S, c, 0.35), c, root)
+        done += 1
     print("ok %d" % (done + 1))
 
 

@@ -304,4 +304,4 @@ def test_rccl_branch_with_several_ranks_over_a_mock_library(tmp_path):
     subprocess.run(["hipcc", "-shared", "-fPIC", "-O2", "-o", lib, os.path.join(here, "c", "mock_rccl.cpp")], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     env = dict(os.environ, OATK_RCCL_LIB=lib)
     p = subprocess.run([sys.executable, os.path.join(here, "mock_rccl_run.py")], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
-    assert p.returncode == 0 and p.stdout.strip().endswith(b"ok 5"), (p.returncode, p.stdout[-300:], p.stderr.decode(errors="replace")[-1500:])
+    assert p.returncode == 0 and p.stdout.strip().endswith(b"ok 8"), (p.returncode, p.stdout[-300:], p.stderr.decode(errors="replace")[-1500:])

@@ -63,14 +63,15 @@ def single(hip, reads, K, S, c, a):
     return out
 
 
-def run_ranks(world, grp, reads, bounds, K, S, c, a, root=0):
+def run_ranks(world, grp, reads, bounds, K, S, c, a, root=0, make_comm=None):
+    """make_comm(rank): another communicator factory than the in-process group (tests/mock_rccl_run.py: the RCCL branch over a mock library)"""
     L = _lib.load()
     out, errs = [None] * world, []
 
     def work(rank):
         try:
             h = HipSyncasm(0)
-            comm = L.oatk_comm_group_rank(grp, rank)
+            comm = make_comm(rank) if make_comm else L.oatk_comm_group_rank(grp, rank)
             lo, hi = bounds[rank], bounds[rank + 1]
             seq, off, lens = pack_reads(reads[lo:hi])
             h.scan_host(seq, off, lens, K, S, sid0=lo)
@@ -122,22 +123,8 @@ def ovl_subset(ref, keep_vtx):
     return {"OVL_KEY": key[sel], "OVL_OFF": new_off, "OVL_DIST": ref["OVL_DIST"][idx], "OVL_CNT": ref["OVL_CNT"][idx], "OVL_TAIL": ref["OVL_TAIL"][sel]}
 
 
-@pytest.mark.parametrize("case", range(len(CASES)))
-def test_sharded_tail_equals_one_handle(hip, case):
-    K, S, c, mk, frac = CASES[case]
-    a = 0.35
-    reads = mk()
-    bounds = [int(round(f * len(reads))) for f in frac]
-    world = len(bounds) - 1
-    root = world - 1 if case == 3 else 0
-    L = _lib.load()
-    grp = L.oatk_comm_group_create(world)
-    assert grp
-    try:
-        out = run_ranks(world, grp, reads, bounds, K, S, c, a, root)
-    finally:
-        L.oatk_comm_group_destroy(grp)
-    ref = single(hip, reads, K, S, c, a)
+def check(out, ref, c, root):
+    """every array of the sharded run against one handle's"""
     cnt = ref["cnt"]
     # statistics right after the scan and after the correction: the same on every rank, and one handle's
     for r in out:
@@ -168,6 +155,25 @@ def test_sharded_tail_equals_one_handle(hip, case):
             assert np.array_equal(r["ovl"][k], ovl_kept[k]), k
             assert np.array_equal(r["ovl_all"][k], ref["ovl"][k]), k
         assert r["ovl_dims"] == (len(ovl_kept["OVL_KEY"]), len(ovl_kept["OVL_DIST"]))
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_sharded_tail_equals_one_handle(hip, case):
+    K, S, c, mk, frac = CASES[case]
+    a = 0.35
+    reads = mk()
+    bounds = [int(round(f * len(reads))) for f in frac]
+    world = len(bounds) - 1
+    root = world - 1 if case == 3 else 0
+    L = _lib.load()
+    grp = L.oatk_comm_group_create(world)
+    assert grp
+    try:
+        out = run_ranks(world, grp, reads, bounds, K, S, c, a, root)
+    finally:
+        L.oatk_comm_group_destroy(grp)
+    ref = single(hip, reads, K, S, c, a)
+    check(out, ref, c, root)
 
 
 def test_stat_without_singletons_replays_the_count_table(hip):
