@@ -192,7 +192,7 @@ def main():
 
     cfg = dict(CONFIGS[args.workload])
     c = int(cfg.get("min_k_cov", 30))
-    strong = world > 1 and args.scaling == "strong" and not args.reads_per_gpu
+    strong = (world > 1 or bool(os.environ.get("OATK_BENCH_FORCE_STRONG"))) and args.scaling == "strong" and not args.reads_per_gpu      # (the env switch: exercise the strong-scaling legs with a world of one)
     per_gpu = args.reads_per_gpu or (cfg["n_reads"] // world if strong else cfg["n_reads"])
     n_workload = cfg["n_reads"]
     cfg["n_reads"] = per_gpu * world
