@@ -25,6 +25,7 @@ ap.add_argument("--threads", type=int, default=8)
 ap.add_argument("--workload", default="config3")
 ap.add_argument("--dir", default="/dev/shm")
 ap.add_argument("--keep", action="store_true")
+ap.add_argument("--devices", default="", help="also run the drop-in over several handles (OATK_DEVICES, e.g. 0,0)")
 args = ap.parse_args()
 
 cfg = dict(CONFIGS[args.workload])
@@ -81,6 +82,11 @@ r, err = run("syncasm_dropin", "dev", {"OATK_DROPIN_LOG": "1"})
 report["dropin"] = r
 report["dropin_log"] = [l for l in err.splitlines() if "oatk_dropin]" in l or "oatk_sr_read_files]" in l]
 print("\n".join(l for l in err.splitlines() if "oatk_" in l), flush=True)
+if args.devices:
+    rm, errm = run("syncasm_dropin", "mul", {"OATK_DROPIN_LOG": "1", "OATK_DEVICES": args.devices})
+    report["dropin_several_handles"] = dict(rm, devices=args.devices, same_gfa_as_one_handle=all(rm.get(k) == r.get(k) and rm.get(k) for k in ("md5.utg.gfa", "md5.utg.final.gfa")))
+    report["dropin_several_handles_log"] = [l for l in errm.splitlines() if "oatk_dropin]" in l or "oatk_sr_read_files]" in l]
+    print("\n".join(l for l in errm.splitlines() if "oatk_" in l), flush=True)
 if args.ref:
     r2, _ = run("syncasm", "ref")
     report["reference"] = r2
