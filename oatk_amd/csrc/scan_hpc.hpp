@@ -54,6 +54,26 @@ struct HpcSqueezeTab {
 };
 __device__ const HpcSqueezeTab hpc_squeeze_tab = HpcSqueezeTab();
 
+// gap table: index = eight run-start bits; byte k of the value = positions between the k-th start and the one before it (the run the k-th
+// start finishes is that much longer than one base); byte 0 is 0 -- the run the first start finishes began somewhere else
+struct HpcGapTab {
+    uint64_t v[256];
+    constexpr HpcGapTab() : v()
+    {
+        for (int m = 0; m < 256; ++m) {
+            uint64_t out = 0;
+            int k = 0, prev = -1;
+            for (int i = 0; i < 8; ++i)
+                if (m >> i & 1) {
+                    if (prev >= 0) out |= (uint64_t) (i - prev - 1) << (8 * k);
+                    prev = i, ++k;
+                }
+            v[m] = out;
+        }
+    }
+};
+__device__ const HpcGapTab hpc_gap_tab = HpcGapTab();
+
 struct HpcArgs {
     const uint8_t *seq;       // packed read stream, read r at off[r] (64-byte aligned), len[r] bytes
     const uint64_t *off;
@@ -108,6 +128,7 @@ __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
     __shared__ uint4 ring_hs4[HPC_RING / 64];      // 2-bit codes, 16 per word, MSB-first words (byte-swapped on the way out)
     __shared__ uint8_t lut[256];
     __shared__ uint4 sq4[HPC_NT];                   // the squeeze table, 4 KiB
+    __shared__ uint64_t gap8[256];                  // the gap table, 2 KiB
     __shared__ uint32_t w_cnt[HPC_NT / OATK_WAVE];
     __shared__ int32_t w_max[HPC_NT / OATK_WAVE];
     __shared__ uint32_t s_nn, s_lrl;
@@ -118,6 +139,7 @@ __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
     const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     lut[tid] = (uint8_t) nt4_code(tid);
     sq4[tid] = ((const uint4 *) hpc_squeeze_tab.v)[tid];
+    gap8[tid] = hpc_gap_tab.v[tid];
     const uint8_t *sq = (const uint8_t *) sq4;
     for (uint32_t i = tid; i < HPC_RING / 16; i += HPC_NT) ring_hs[i] = 0;
     for (uint32_t i = tid; i < HPC_RING / 16; i += HPC_NT) ring_rl4[i] = make_uint4(0, 0, 0, 0);      // runs of one base (most) never write their 0
@@ -328,21 +350,40 @@ __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
                 if (low) atomicOr(&ring_hs[(w0 + 1) & (HPC_RING / 16 - 1)], low);
                 // the run that enters the lane from the left ends at the lane's first start: the only one that can be long
                 const uint32_t bf = (uint32_t) __builtin_ctz(smask);
+                uint32_t first = 0;                                        // its length - 1, clamped (0 for the start at position 0 of the read)
                 if ((fin >> bf) & 1u) {
                     const uint32_t rl = (uint32_t) ((int32_t) (b0 + bf) - ls);
-                    if (rl > 1u) {
-                        ring_rl[(n - 1u) & (HPC_RING - 1)] = (uint8_t) ((rl > 256u? 256u : rl) - 1u);
-                        special |= rl > 255u;
-                    }
+                    first = (rl > 256u? 256u : rl) - 1u;
+                    special |= rl > 255u;
                 }
-                // runs longer than one base inside the lane (2 .. 15): finishing starts whose previous byte is not a start
-                uint32_t lng = fin & ~(smask << 1) & ~(1u << bf);
-                while (lng) {
-                    const uint32_t b = (uint32_t) __builtin_ctz(lng);
-                    lng &= lng - 1;
-                    const uint32_t below = smask & ((1u << b) - 1u);       // never empty: the lane's first start is below b
-                    const uint32_t h = n + (uint32_t) __builtin_popcount(below) - 1u;
-                    ring_rl[h & (HPC_RING - 1)] = (uint8_t) (b + (uint32_t) __builtin_clz(below) - 32u);     // b - top(below) - 1
+                // runs longer than one base inside the lane (2 .. 15) -- no loop (one that visits them start by start runs as long as the
+                // unluckiest lane of the wave: seven turns for a mean of three).  The k-th start of the lane finishes hoco position n - 1 + k, so
+                // the lengths (minus one) of everything the lane finishes are consecutive BYTES of the ring: eight starts at a time through the
+                // gap table, the first start of the upper half fixed up with the zeros that end the lower half, both halves shifted to their
+                // place and OR-ed into the (zeroed) ring as whole words.  Byte 0 is the run that came in from the left.
+                {
+                    const uint32_t slo = smask & 0xFFu, shi = smask >> 8;
+                    uint64_t glo = gap8[slo], ghi = gap8[shi];
+                    const uint32_t between = (uint32_t) (__ffs((int) shi) + __clz((int) slo)) - 25u;     // ctz(shi) + 7 - top(slo)
+                    glo |= slo? first : 0u;
+                    ghi |= slo? (shi? between : 0u) : first;
+                    const uint32_t h0 = n - 1u;
+                    const uint32_t sl = (h0 & 3u) * 8u, shh = sl + (uint32_t) __builtin_popcount(slo) * 8u;       // bit shifts of the two halves: 0 .. 24, 0 .. 88
+                    const uint32_t t = shh & 31u, q4 = (shh >> 5) * 4u;
+                    const uint64_t L0 = (uint64_t) (uint32_t) glo << sl, L1 = (glo >> 32) << sl;
+                    const uint64_t H0 = (uint64_t) (uint32_t) ghi << t, H1 = (ghi >> 32) << t;
+                    const uint32_t l0 = (uint32_t) L0, l1 = (uint32_t) (L0 >> 32) | (uint32_t) L1, l2 = (uint32_t) (L1 >> 32);
+                    const uint32_t g0 = (uint32_t) H0, g1 = (uint32_t) (H0 >> 32) | (uint32_t) H1, g2 = (uint32_t) (H1 >> 32);
+                    const uint32_t ab = h0 & (uint32_t) (HPC_RING - 1) & ~3u;                              // byte address of the first word
+                    if (ab <= (uint32_t) HPC_RING - 24u) {                                                 // (five words at most)
+                        uint32_t *pl = (uint32_t *) ((char *) ring_rl4 + ab), *ph = (uint32_t *) ((char *) ring_rl4 + ab + q4);
+                        atomicOr(pl, l0), atomicOr(pl + 1, l1), atomicOr(pl + 2, l2);
+                        atomicOr(ph, g0), atomicOr(ph + 1, g1), atomicOr(ph + 2, g2);
+                    } else {                                                                                // ... that wrap around the ring
+                        auto at = [&](uint32_t b) -> uint32_t * { return (uint32_t *) ((char *) ring_rl4 + (b & (uint32_t) (HPC_RING - 1))); };
+                        atomicOr(at(ab), l0), atomicOr(at(ab + 4u), l1), atomicOr(at(ab + 8u), l2);
+                        atomicOr(at(ab + q4), g0), atomicOr(at(ab + q4 + 4u), g1), atomicOr(at(ab + q4 + 8u), g2);
+                    }
                 }
             }
             if (special) {                                             // ambiguous bases / very long runs: walk again, slowly
