@@ -20,6 +20,7 @@
 // end, with only the diagonals below it extended (levdist.c:166-180); ties between optimum paths compare the consensus
 // and then the path (syncerr.c:216-243).
 #pragma once
+#include <type_traits>
 #include "ec.hpp"
 
 namespace oatk {
@@ -69,8 +70,19 @@ __device__ __forceinline__ uint32_t ecw_win16(const uint32_t *W, int32_t p)
     const int32_t i = p >> 4;
     return (uint32_t) (((uint64_t) W[i + 1] << 32 | W[i]) >> ((p & 15) << 1));
 }
+// The solver's waves work on their own: what one lane wrote is read by another lane of the SAME wave, never by another wave.  A wave's memory
+// instructions are issued in order, so all it takes is that the compiler does not move accesses across this point (and, for the HBM slabs, that
+// the stores have left).  No s_barrier: a workgroup may hold several waves (the hardware places at most sixteen workgroups on a CU, whatever their
+// size -- with one wave each, sixteen waves per CU was all this latency-bound kernel ever got), and they are at different blocks.
+__device__ __forceinline__ void ecw_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 __device__ __forceinline__ int32_t ecw_uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t ecw_uniu(uint32_t v) { return (uint32_t) __builtin_amdgcn_readfirstlane((int32_t) v); }
+__device__ __forceinline__ uint32_t ecw_lane(uint32_t v, int l) { return (uint32_t) __builtin_amdgcn_readlane((int32_t) v, l); }      // l uniform
 __device__ __forceinline__ uint64_t ecw_uni64(uint64_t v) { return (uint64_t) ecw_uniu((uint32_t) (v >> 32)) << 32 | ecw_uniu((uint32_t) v); }
 
 // sharded reads: the k-mer of vertex ids[i] as a stand-alone hoco string (base 0 = first base as read, same byte layout),
@@ -97,11 +109,14 @@ __global__ void ecw_import_kmer_kernel(uint64_t n, const uint32_t *ids, const ui
 }
 
 #ifdef ECW_PROF
+__device__ unsigned long long ecw_dyn[16];          // dynamic counts of the loops of ecw_step (development builds only)
+#define ECW_D(i) do { if ((threadIdx.x & 63) == 0) atomicAdd(&ecw_dyn[i], 1ULL); } while (0)
 #define ECW_T(i) do { const unsigned long long _t = __builtin_readcyclecounter(); s.prof[i] += _t - s.t_last; s.t_last = _t; } while (0)
 #define ECW_C(i, v) do { s.prof[i] += (v); } while (0)
 #else
 #define ECW_T(i) do {} while (0)
 #define ECW_C(i, v) do {} while (0)
+#define ECW_D(i) do {} while (0)
 #endif
 
 struct EcwScratch {
@@ -129,37 +144,44 @@ struct EcwWave {                  // the working wavefront: diagonals d0 .. d0 +
 __device__ int ecw_step(const uint32_t *ts, int32_t tl, const uint32_t *qs, int32_t ql, int32_t bw, EcwWave &wv, int32_t *buf_a, int32_t *buf_b,
                         int32_t &t_end, int32_t &q_end)
 {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int32_t n = wv.n, d0 = wv.d0;
     int32_t *k = wv.k;
     t_end = q_end = -1;
+    ECW_D(0);
+    if (n == 1) ECW_D(6); else if (n <= 2) ECW_D(7); else if (n <= 4) ECW_D(8); else if (n <= 8) ECW_D(9); else if (n <= 16) ECW_D(10); else ECW_D(11);
     int lg = 0;                                        // lanes per diagonal = 1 << lg
     if (n <= 32) lg = n <= 1? 6 : __builtin_clz((uint32_t) (n - 1)) - 26;      // 64 / next_pow2(n)
     const int G = 1 << lg, c = lane & (G - 1), gbase = lane & ~(G - 1);
     const uint64_t gmask = G == 64? ~0ULL : (1ULL << G) - 1ULL;
     for (int32_t base = 0; base < n; base += 64) {
         const int32_t j = base + (lane >> lg);
+        ECW_D(1);
         const bool valid = j < n;
         int32_t kk = valid? k[j] : 0;
-        const int32_t dd = d0 + j;
+        const int32_t dd = valid? d0 + j : 0;          // (0: lanes without a diagonal read, harmlessly, inside the strings)
         const bool act0 = valid && !(kk >= tl || kk + dd >= ql);
         bool act = act0;
         const int32_t lim = (ql - dd < tl? ql - dd : tl) - 1;
-        while (__ballot(act)) {
-            const int32_t rem = lim - kk, o = c << 4;
-            int32_t m = 0;
-            if (act && o < rem) {
-                const uint32_t x = ecw_win16(ts, kk + 1 + o) ^ ecw_win16(qs, kk + dd + 1 + o);
-                m = x? __builtin_ctz(x) >> 1 : 16;
-                if (m > rem - o) m = rem - o;
-            }
-            const bool full = act && m == 16;
-            const uint64_t gb = (__ballot(!full) >> gbase) & gmask;
-            const int first = gb? __builtin_ctzll(gb) : 0;
-            const int32_t mm = __shfl(m, gbase + first);
-            if (act) {
-                if (gb == 0) kk += G << 4;
-                else kk += (first << 4) + mm, act = false;
+        // (straight-line turns: a taken branch costs this kernel more than the handful of instructions it skips -- 64 extra taken branches per
+        //  arc measured +22 %, 64 extra scalar or vector instructions +1.5 % / +1 % -- so lanes that have nothing to compare compare anyway)
+        if (__ballot(act)) {
+            const int32_t o = c << 4;
+            for (;;) {
+                ECW_D(2);
+                const int32_t r = lim - kk - o;                 // bases left from this lane's window on
+                const int32_t oo = r > 0? o : 0;                // (a window behind the end is not read: the strings may lie in HBM, at the end of a buffer)
+                const uint32_t x = ecw_win16(ts, kk + 1 + oo) ^ ecw_win16(qs, kk + dd + 1 + oo);
+                int32_t m = x? __builtin_ctz(x) >> 1 : 16;
+                m = m < r? m : r;
+                m = act && r > 0? m : 0;
+                const uint64_t gb = (__ballot(m != 16) >> gbase) & gmask;      // lanes of the group that did not match all sixteen
+                const int first = gb? __builtin_ctzll(gb) : 0;
+                const int32_t mm = __shfl(m, gbase + first);
+                const int32_t adv = gb? (first << 4) + mm : G << 4;
+                kk += act? adv : 0;
+                act = act && gb == 0;
+                if (!__ballot(act)) break;
             }
         }
         const bool reached = act0 && (kk + dd == ql - 1 || kk == tl - 1);
@@ -168,16 +190,18 @@ __device__ int ecw_step(const uint32_t *ts, int32_t tl, const uint32_t *qs, int3
             const int fl = __builtin_ctzll(rmask);
             const int32_t jf = base + (fl >> lg);
             if (act0 && c == 0 && j < jf) k[j] = kk;
-            t_end = ecw_uni(__shfl(kk, fl));
+            t_end = (int32_t) ecw_lane((uint32_t) kk, fl);
             q_end = t_end + d0 + jf;
-            __syncthreads();
+            ECW_D(3);
+            ecw_sync();
             return 1;
         }
         if (act0 && c == 0) k[j] = kk;
     }
-    __syncthreads();
+    ecw_sync();
     // next wavefront: diagonals d0 - 1 .. d0 + n (levdist.c:183-205)
     int32_t *nk = wv.spare;
+    ECW_D(4);
     for (int32_t i = lane; i < n + 2; i += 64) {
         const int32_t jj = i - 1;
         int32_t v = INT32_MIN;
@@ -199,7 +223,7 @@ __device__ int ecw_step(const uint32_t *ts, int32_t tl, const uint32_t *qs, int3
     wv.n = en - st, wv.d0 = nd0 + st;
     wv.k = nk + st;
     wv.spare = nk == buf_a? buf_b : buf_a;
-    __syncthreads();
+    ecw_sync();
     return 0;
 }
 
@@ -216,7 +240,7 @@ __global__ __launch_bounds__(64) void ecw_wf_ed_kernel(const uint32_t *tw, const
     EcwWave wv;
     wv.k = ka, wv.spare = kb, wv.n = 1, wv.d0 = 0;              // the caller's initial state: diagonal 0, nothing matched, score 0 (syncerr.c:465-482)
     if (threadIdx.x == 0) ka[0] = -1;
-    __syncthreads();
+    ecw_sync();
     int32_t score = 0, t_end = -1, q_end = -1;
     for (uint64_t s = step_off[j]; s < step_off[j + 1]; ++s) {
         const int32_t ql = step_ql[s];
@@ -309,7 +333,7 @@ __device__ __forceinline__ EcwArcRegs ecw_arc_load(const EcLiveArc *arc, uint32_
 __device__ bool ecw_solve_block(const EcLive &lv, const EcReads &rd, const EcWork &wk, const EcwScratch &s, double max_edist,
                                 uint32_t &status_out, uint32_t &np_out)
 {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int K = rd.K;
     const int32_t tl = wk.l;
     int32_t bw = (int32_t) ceil((double) tl * max_edist);
@@ -323,23 +347,33 @@ __device__ bool ecw_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
     if (wk.ln) pre = ecw_arc_load(lv.arc, wk.lp), pre_idx = wk.lp;
     // target: the read segment, reverse-complemented for a leading block (get_kmer_dna_seq, syncmer.c:1237)
     const uint8_t *hs = rd.hoco_s + ((uint64_t) wk.hs16 << 4);
-    for (int32_t wb = 0; (wb << 4) < tl; wb += 256) {  // four windows per lane with their loads in flight together (a first-tier block: one turn)
-        uint32_t w0[4], w1[4], pp[4];
+    // (a wave's 64 windows are 1024 bases and two blocks in three are shorter than that: the common case is one window per lane, and the
+    //  arithmetic of windows that lie behind the target -- a uniform condition -- is skipped, not just their loads)
+    auto gather_target = [&](auto nwin, auto rev, int32_t wb) __attribute__((always_inline)) {
+        constexpr int NW = decltype(nwin)::value;
+        constexpr bool R = decltype(rev)::value;
+        uint32_t w0[NW], w1[NW], pp[NW];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NW; ++u) {
             const int32_t wi = wb + lane + 64 * u;
-            const int64_t start = wk.r? (int64_t) wk.beg_pos + tl - 1 - (wi << 4) : (int64_t) wk.beg_pos + (wi << 4);
-            pp[u] = ecw_gather16_at(start, wk.r != 0);
+            const int64_t start = R? (int64_t) wk.beg_pos + tl - 1 - (wi << 4) : (int64_t) wk.beg_pos + (wi << 4);
+            pp[u] = ecw_gather16_at(start, R);
             w0[u] = w1[u] = 0;
             if ((wi << 4) < tl) { const uint32_t *q = (const uint32_t *) hs + (pp[u] >> 4); w0[u] = q[0], w1[u] = q[1]; }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NW; ++u) {
             const int32_t wi = wb + lane + 64 * u;
-            const int64_t start = wk.r? (int64_t) wk.beg_pos + tl - 1 - (wi << 4) : (int64_t) wk.beg_pos + (wi << 4);
-            if ((wi << 4) < tl) s.ts[wi] = ecw_gather16_fin(w0[u], w1[u], pp[u], start, wk.r != 0);
+            const int64_t start = R? (int64_t) wk.beg_pos + tl - 1 - (wi << 4) : (int64_t) wk.beg_pos + (wi << 4);
+            if ((wi << 4) < tl) s.ts[wi] = ecw_gather16_fin(w0[u], w1[u], pp[u], start, R);
         }
-    }
+    };
+    auto gather_all = [&](auto rev) __attribute__((always_inline)) {
+        if (tl <= 1024) gather_target(std::integral_constant<int, 1>(), rev, 0);
+        else if (tl <= 2048) gather_target(std::integral_constant<int, 2>(), rev, 0);
+        else for (int32_t wb = 0; (wb << 4) < tl; wb += 256) gather_target(std::integral_constant<int, 4>(), rev, wb);   // four windows per lane with their loads in flight together
+    };
+    if (wk.r) gather_all(std::true_type()); else gather_all(std::false_type());
     ECW_T(0);                                          // 0: target gather
     int32_t status = EC_FAILURE, n_path = 0, edist = INT32_MAX, s_edist = INT32_MAX;
     int32_t c_len = 0, o_len = 0, np = 0;
@@ -354,7 +388,7 @@ __device__ bool ecw_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
     bool vpend = false;
     uint32_t v_arc = 0;
     int32_t v_depth = 0;
-    __syncthreads();
+    ecw_sync();
 
     auto push_frame = [&](uint32_t lp, uint32_t ln, int32_t depth) -> bool {
         const int32_t need = ((int32_t) sizeof(EcwFrame) + 4 * wv.n + 7) & ~7;
@@ -375,7 +409,7 @@ __device__ bool ecw_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
     else if (!push_frame(wk.lp, wk.ln, 0)) { ECW_C(12, 1); return false; }
 
     while (nfr > 0 || vpend) {
-        __syncthreads();
+        ecw_sync();
         uint32_t a;
         int32_t depth;
         if (vpend) {                                  // carry on where the search stands: nothing to restore
@@ -421,6 +455,7 @@ __device__ bool ecw_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
             const bool asc = (uint32_t) (w & 1ULL) == (w_mpos & 1u);
             const int32_t w0 = c_len >> 4, w1 = (c_len + ext - 1) >> 4;
             for (int32_t wi = w0 + lane; wi <= w1; wi += 64) {
+                ECW_D(5);
                 const int32_t t0 = (wi << 4) - c_len;
                 uint32_t x = asc? ecw_gather16(vs, (int64_t) pos + ls + t0, false) : ecw_gather16(vs, (int64_t) pos + K - 1 - ls - t0, true);
                 if (t0 < 0) {
@@ -431,8 +466,21 @@ __device__ bool ecw_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
             }
             c_len += ext;
         }
-        __syncthreads();
+        ecw_sync();
         ECW_T(4);                                      // 4: consensus append
+        // A vertex on an unbranched stretch that cannot be the end of the path needs no alignment of its own.  wf_ed_core RESUMES: run on the
+        // consensus up to w and then on the consensus up to w's successor, it leaves the wavefront (and score, ends) that a single run on the longer
+        // consensus leaves -- extending a diagonal in two goes or in one is the same run of matches, and a step that ends early stores nothing
+        // for the diagonals it did not finish.  What the level would have decided besides is reproduced here: no success is possible (w is not the
+        // end vertex), the search goes on iff the score is in the band -- if it is not, the next level finds that out, counts the one dead end and
+        // returns just the same -- and the length test is plain arithmetic.  Two things do depend on the shorter query and keep the level: a
+        // consensus shorter than the band (the next wavefront is trimmed by the query's length, levdist.c:183-205), and `t_end0` of the next level
+        // once an optimum exists (syncerr.c:211).  Most blocks are source - two or three such vertices - sink: one alignment instead of three or four.
+        if (edist == INT32_MAX && wk.end_utg != EC_NONE && wk.end_utg != w && w_ln == 1 && n_path < EC_MAX_DFS_PATH && c_len - K <= tl + bw && c_len >= bw + 3) {
+            vpend = true, v_arc = w_lp, v_depth = depth + 1;
+            ECW_C(15, 1);                              // 15: levels without an alignment
+            continue;
+        }
         // wf_ed_core (levdist.c:265-310)
         for (;;) {
             if (ecw_step(s.ts, tl, s.cs, c_len, bw, wv, s.ka, s.kb, t_end, q_end)) break;
@@ -444,6 +492,7 @@ __device__ bool ecw_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
         t_end += 1, q_end += 1;
         const int32_t ql = c_len;
         const int32_t sc = score + tl - t_end;        // syncerr.c:209
+        bool new_opt = false;
         if (sc <= bw && (wk.end_utg == EC_NONE || wk.end_utg == w)) {
             status = EC_SUCCESS;
             if (sc <= edist) {
@@ -473,8 +522,8 @@ __device__ bool ecw_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
                         if (pd) status = EC_AMBISNQ;
                     }
                 }
-                __syncthreads();
-                for (int32_t wi = lane; wi < ((q_end + 15) >> 4); wi += 64) s.os[wi] = s.cs[wi];
+                ecw_sync();
+                new_opt = true;
                 o_len = q_end;
                 for (int32_t i = lane; i < cn; i += 64) s.o_path[i] = s.c_path[i];
                 np = cn;
@@ -490,13 +539,21 @@ __device__ bool ecw_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
         } else {
             ++n_path;
         }
+        // the optimum consensus is only ever compared with a LATER path's (a tie): when the search ends here -- the usual case, a block with one
+        // path -- nobody reads it and the copy is left out
+        if (new_opt && (nfr > 0 || vpend)) {
+            for (int32_t wi = lane; wi < ((o_len + 15) >> 4); wi += 64) s.os[wi] = s.cs[wi];
+        }
         ECW_T(6);                                      // 6: result handling + push
     }
-    __syncthreads();
+    ecw_sync();
     status_out = (uint32_t) status, np_out = (uint32_t) np;
     return true;
 }
 
+#ifndef ECW_WPB
+#define ECW_WPB 2                 // waves per workgroup of the LDS tiers (independent of each other: ecw_sync)
+#endif
 #define ECW_BATCH 8               // blocks taken from the queue per atomic
 #define ECW_POOL_CHUNK 512        // path-pool entries taken per atomic
 
@@ -510,6 +567,8 @@ struct EcwArgs {
     double max_edist;
     uint8_t *slabs;               // BIG: one HBM slab per wave with every array
     uint64_t slab_bytes;
+    uint32_t *os_slabs;           // LDS tiers: the optimum consensus of every wave, os_words apart
+    uint64_t os_words;
     int32_t cap_t, cap_c, cap_w, cap_path, cap_f;
     EcBlockOut *out;              // [n_work]
     uint64_t *path_pool;          // optimum paths; bump-allocated in chunks
@@ -553,23 +612,29 @@ __global__ void ec_route_kernel(const EcWork *work, uint64_t n_work, EcRoute rt)
 
 __host__ __device__ inline uint32_t ecw_words(int32_t bases) { return (uint32_t) ((bases + 15) / 16 + 2); }
 // 32-bit words of one wave's carve-up: ts, cs, os, two wavefronts, two paths, frames
-__host__ __device__ inline uint32_t ecw_scratch_words(int32_t cap_t, int32_t cap_c, int32_t cap_w, int32_t cap_path, int32_t cap_f)
+// (os_too: the optimum consensus as well -- the HBM slabs of the last tier; the LDS tiers keep theirs in a slab of its own, EcwArgs::os_slabs)
+__host__ __device__ inline uint32_t ecw_scratch_words(int32_t cap_t, int32_t cap_c, int32_t cap_w, int32_t cap_path, int32_t cap_f, bool os_too = true)
 {
-    return ((ecw_words(cap_t) + 2u * ecw_words(cap_c) + 2u * (uint32_t) (cap_w + 2) + 1u) & ~1u) + 4u * (uint32_t) cap_path + (uint32_t) cap_f / 4u;
+    return ((ecw_words(cap_t) + (os_too? 2u : 1u) * ecw_words(cap_c) + 2u * (uint32_t) (cap_w + 2) + 1u) & ~1u) + 4u * (uint32_t) cap_path + (uint32_t) cap_f / 4u;
 }
 
-template <bool BIG>
-__global__ __launch_bounds__(64) void ec_wave_kernel(EcwArgs a)
+template <bool BIG, int WPB = 1>
+__global__ __launch_bounds__(64 * WPB) void ec_wave_kernel(EcwArgs a)
 {
     extern __shared__ uint32_t ecw_lds[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * (uint32_t) WPB + ecw_uniu(threadIdx.x >> 6);      // the waves of a workgroup share nothing but the launch
     EcwScratch s;
     s.cap_t = a.cap_t, s.cap_c = a.cap_c, s.cap_w = a.cap_w, s.cap_path = a.cap_path, s.cap_f = a.cap_f;
-    uint32_t *const p0 = BIG? (uint32_t *) (a.slabs + (uint64_t) blockIdx.x * a.slab_bytes) : ecw_lds;
+    uint32_t *const p0 = BIG? (uint32_t *) (a.slabs + (uint64_t) wave * a.slab_bytes)
+                            : ecw_lds + (WPB > 1? ecw_uniu(threadIdx.x >> 6) * ecw_scratch_words(a.cap_t, a.cap_c, a.cap_w, a.cap_path, a.cap_f, false) : 0u);
     uint32_t *p = p0;
     s.ts = p, p += ecw_words(a.cap_t);
     s.cs = p, p += ecw_words(a.cap_c);
-    s.os = p, p += ecw_words(a.cap_c);
+    // The optimum consensus is written when a second path may follow and read when one ties with the first -- hardly ever (a block with one path
+    // does neither): in the LDS tiers it lives in HBM, and its 1.4 KB (first tier) buy four more waves per CU.
+    if (BIG) s.os = p, p += ecw_words(a.cap_c);
+    else s.os = a.os_slabs + (uint64_t) wave * a.os_words;
     s.ka = (int32_t *) p, p += a.cap_w + 2;
     s.kb = (int32_t *) p, p += a.cap_w + 2;
     p += (p - p0) & 1;                 // (the base is 8-byte aligned; no detour through an integer, which would turn every access behind it into a flat one)
@@ -599,12 +664,12 @@ __global__ __launch_bounds__(64) void ec_wave_kernel(EcwArgs a)
         }
         for (int i = 0; i < cnt; ++i) {
             EcWork wk;
-            const uint64_t wi = ecw_uni64(__shfl(my_wi, i));
-            wk.beg_utg = (uint64_t) ecw_uniu(__shfl(m0.y, i)) << 32 | ecw_uniu(__shfl(m0.x, i));
-            wk.end_utg = (uint64_t) ecw_uniu(__shfl(m0.w, i)) << 32 | ecw_uniu(__shfl(m0.z, i));
-            wk.read = ecw_uniu(__shfl(m1.x, i)), wk.beg_pos = ecw_uniu(__shfl(m1.y, i));
-            wk.l = (int32_t) ecw_uniu(__shfl(m1.z, i)), wk.r = (int32_t) ecw_uniu(__shfl(m1.w, i));
-            wk.hs16 = ecw_uniu(__shfl(m2.x, i)), wk.lp = ecw_uniu(__shfl(m2.y, i)), wk.ln = ecw_uniu(__shfl(m2.z, i)), wk.pad = 0;
+            const uint64_t wi = (uint64_t) ecw_lane((uint32_t) (my_wi >> 32), i) << 32 | ecw_lane((uint32_t) my_wi, i);
+            wk.beg_utg = (uint64_t) ecw_lane(m0.y, i) << 32 | ecw_lane(m0.x, i);
+            wk.end_utg = (uint64_t) ecw_lane(m0.w, i) << 32 | ecw_lane(m0.z, i);
+            wk.read = ecw_lane(m1.x, i), wk.beg_pos = ecw_lane(m1.y, i);
+            wk.l = (int32_t) ecw_lane(m1.z, i), wk.r = (int32_t) ecw_lane(m1.w, i);
+            wk.hs16 = ecw_lane(m2.x, i), wk.lp = ecw_lane(m2.y, i), wk.ln = ecw_lane(m2.z, i), wk.pad = 0;
             if (wk.l > a.skip_l) continue;
             EcBlockOut o;
             o.status = EC_FAILURE, o.np = 0, o.path_off = 0, o.flags = 0, o.short_block = 0;
@@ -631,7 +696,7 @@ __global__ __launch_bounds__(64) void ec_wave_kernel(EcwArgs a)
                 }
             }
             if (lane == 0) a.out[wi] = o;
-            __syncthreads();
+            ecw_sync();
             ECW_C(10, 1);                              // 10: blocks
         }
     }
