@@ -118,6 +118,9 @@ __device__ unsigned long long ecw_dyn[16];          // dynamic counts of the loo
 #define ECW_C(i, v) do {} while (0)
 #define ECW_D(i) do {} while (0)
 #endif
+// block placement: the usual path of the search falls through (a taken branch is what costs here)
+#define ECW_LIKELY(x) __builtin_expect(!!(x), 1)
+#define ECW_RARE(x) __builtin_expect(!!(x), 0)
 
 struct EcwScratch {
     uint32_t *ts, *cs, *os;       // target, consensus, optimum consensus (packed)
@@ -202,17 +205,19 @@ __device__ int ecw_step(const uint32_t *ts, int32_t tl, const uint32_t *qs, int3
     // next wavefront: diagonals d0 - 1 .. d0 + n (levdist.c:183-205)
     int32_t *nk = wv.spare;
     ECW_D(4);
-    for (int32_t i = lane; i < n + 2; i += 64) {
-        const int32_t jj = i - 1;
-        int32_t v = INT32_MIN;
-        if (jj - 1 >= 0) v = k[jj - 1];
-        if (jj >= 0 && jj < n) { const int32_t u = k[jj] + 1; v = u > v? u : v; }
-        if (jj + 1 < n) { const int32_t u = k[jj + 1] + 1; v = u > v? u : v; }
-        nk[i] = v;
+    for (int32_t ib = 0; ib < n + 2; ib += 64) {      // (a uniform trip count -- one turn up to 62 diagonals -- and no branches inside: reads with clamped indices, selects)
+        const int32_t i = ib + lane, jj = i - 1;
+        const int32_t ja = jj - 1 < 0? 0 : (jj - 1 < n? jj - 1 : n - 1), jb = jj < 0? 0 : (jj < n? jj : n - 1), jc = jj + 1 < n? jj + 1 : n - 1;
+        const int32_t ka = k[ja], kb = k[jb], kc = k[jc];
+        int32_t v = jj - 1 >= 0? ka : INT32_MIN;
+        const int32_t ub = kb + 1, uc = kc + 1;
+        v = jj >= 0 && jj < n && ub > v? ub : v;
+        v = jj + 1 < n && uc > v? uc : v;
+        if (i < n + 2) nk[i] = v;
     }
     int32_t st = 0, en = n + 2;
     const int32_t nd0 = d0 - 1;
-    if (bw < 0 || n < 2 * bw + 1) {
+    if (ECW_LIKELY(bw < 0 || n < 2 * bw + 1)) {
         if (nd0 < -tl) ++st;
         if (nd0 + n + 1 > ql) --en;
     } else {
@@ -339,7 +344,7 @@ __device__ bool ecw_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
     int32_t bw = (int32_t) ceil((double) tl * max_edist);
     if (bw < EC_MIN_ERR_BASE) bw = EC_MIN_ERR_BASE;
     ECW_C(16 + (31 - __builtin_clz((uint32_t) tl | 1u)), 1);                  // 16..: histogram of log2(tl)
-    if (tl > s.cap_t || 2 * bw + 8 > s.cap_w) { ECW_C(11, 1); return false; }
+    if (ECW_RARE(tl > s.cap_t || 2 * bw + 8 > s.cap_w)) { ECW_C(11, 1); return false; }
     // the first arc out of the source is fetched while the target is gathered
     EcwArcRegs pre;
     pre.a = make_uint4(0, 0, 0, 0), pre.b = make_uint2(0, 0);
@@ -405,21 +410,21 @@ __device__ bool ecw_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
         ++nfr;
         return true;
     };
-    if (wk.ln == 1) vpend = true, v_arc = wk.lp, v_depth = 0;
+    if (ECW_LIKELY(wk.ln == 1)) vpend = true, v_arc = wk.lp, v_depth = 0;
     else if (!push_frame(wk.lp, wk.ln, 0)) { ECW_C(12, 1); return false; }
 
     while (nfr > 0 || vpend) {
         ecw_sync();
         uint32_t a;
         int32_t depth;
-        if (vpend) {                                  // carry on where the search stands: nothing to restore
+        if (ECW_LIKELY(vpend)) {                      // carry on where the search stands: nothing to restore
             vpend = false;
             a = v_arc, depth = v_depth;
         } else {
             EcwFrame *f = (EcwFrame *) (s.frames + top);
             a = ecw_uniu(f->arc_i);
             const uint32_t a_end = ecw_uniu(f->arc_end);
-            if (a == a_end) {                         // level exhausted: return to the nearest level with siblings left
+            if (ECW_RARE(a == a_end)) {                         // level exhausted: return to the nearest level with siblings left
                 fsz = top;
                 top = ecw_uni(f->prev_off);
                 --nfr;
@@ -435,17 +440,17 @@ __device__ bool ecw_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
             for (int32_t j = lane; j < wv.n; j += 64) s.ka[j] = sv[j];
         }
         ECW_C(8, 1);                                   // 8: arcs tried
-        if (pre_idx != a) pre = ecw_arc_load(lv.arc, a);
+        if (ECW_RARE(pre_idx != a)) pre = ecw_arc_load(lv.arc, a);
         const uint64_t w = ecw_uniu(pre.a.x);
         const int32_t ls = (int32_t) ecw_uniu(pre.a.y), ext = K - ls;
         const uint32_t w_hs16 = ecw_uniu(pre.a.z), w_mpos = ecw_uniu(pre.a.w), w_lp = ecw_uniu(pre.b.x), w_ln = ecw_uniu(pre.b.y);
         const int32_t t_end0 = t_end;
-        if (depth + 2 > s.cap_path || c_len + ext > s.cap_c) { ECW_C(depth + 2 > s.cap_path? 13 : 14, 1); return false; }
+        if (ECW_RARE(depth + 2 > s.cap_path || c_len + ext > s.cap_c)) { ECW_C(depth + 2 > s.cap_path? 13 : 14, 1); return false; }
         if (lane == 0) s.c_path[depth + 1] = w;
         int32_t cn = depth + 2;                       // entries in c_path
         // the arc most likely to be tried next: the first one out of w (in flight during the gather and the alignment)
         pre_idx = 0xFFFFFFFFu;
-        if (w_ln) pre = ecw_arc_load(lv.arc, w_lp), pre_idx = w_lp;
+        if (ECW_LIKELY(w_ln)) pre = ecw_arc_load(lv.arc, w_lp), pre_idx = w_lp;
         ECW_T(3);                                      // 3: restore + arc fetch
         {   // append the part of w's k-mer that lies beyond the overlap (syncerr.c:186-190).  With F the vertex's forward
             // string, base t of the extension is F[ls + t] for a forward w and comp(F[K - ls - 1 - t]) for a reverse one; F itself is
@@ -454,7 +459,9 @@ __device__ bool ecw_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
             const uint32_t pos = w_mpos >> 1;
             const bool asc = (uint32_t) (w & 1ULL) == (w_mpos & 1u);
             const int32_t w0 = c_len >> 4, w1 = (c_len + ext - 1) >> 4;
-            for (int32_t wi = w0 + lane; wi <= w1; wi += 64) {
+            for (int32_t wb = w0; wb <= w1; wb += 64) {             // (uniform trip count: one turn for an extension of up to 1000 bases)
+                const int32_t wi = wb + lane;
+                if (wi > w1) continue;
                 ECW_D(5);
                 const int32_t t0 = (wi << 4) - c_len;
                 uint32_t x = asc? ecw_gather16(vs, (int64_t) pos + ls + t0, false) : ecw_gather16(vs, (int64_t) pos + K - 1 - ls - t0, true);
@@ -486,7 +493,7 @@ __device__ bool ecw_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
             if (ecw_step(s.ts, tl, s.cs, c_len, bw, wv, s.ka, s.kb, t_end, q_end)) break;
             ++score;
             ECW_C(9, 1);                               // 9: wavefront steps beyond the first
-            if (score > bw) break;
+            if (ECW_RARE(score > bw)) break;
         }
         ECW_T(5);                                      // 5: wavefront steps
         t_end += 1, q_end += 1;
@@ -499,7 +506,7 @@ __device__ bool ecw_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
                 if (t_end > t_end0) s_edist = edist;
                 edist = sc;
                 if (wk.end_utg == EC_NONE && q_end < ql) --cn;
-                if (edist == s_edist) {
+                if (ECW_RARE(edist == s_edist)) {
                     bool diff = q_end != o_len;
                     if (!diff) {
                         bool d = false;
@@ -533,7 +540,7 @@ __device__ bool ecw_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
         }
         if (score <= bw && ql - K <= tl + bw && ((wk.end_utg != EC_NONE && wk.end_utg != w) || t_end < tl)) {
             if (n_path < EC_MAX_DFS_PATH) {           // the callee would return at once otherwise (syncerr.c:146-148)
-                if (w_ln == 1) vpend = true, v_arc = w_lp, v_depth = depth + 1;
+                if (ECW_LIKELY(w_ln == 1)) vpend = true, v_arc = w_lp, v_depth = depth + 1;
                 else if (w_ln > 1 && !push_frame(w_lp, w_ln, depth + 1)) { ECW_C(12, 1); return false; }      // (no arcs: the callee's loop does not run)
             }
         } else {
@@ -670,20 +677,20 @@ __global__ __launch_bounds__(64 * WPB) void ec_wave_kernel(EcwArgs a)
             wk.read = ecw_lane(m1.x, i), wk.beg_pos = ecw_lane(m1.y, i);
             wk.l = (int32_t) ecw_lane(m1.z, i), wk.r = (int32_t) ecw_lane(m1.w, i);
             wk.hs16 = ecw_lane(m2.x, i), wk.lp = ecw_lane(m2.y, i), wk.ln = ecw_lane(m2.z, i), wk.pad = 0;
-            if (wk.l > a.skip_l) continue;
+            if (ECW_RARE(wk.l > a.skip_l)) continue;
             EcBlockOut o;
             o.status = EC_FAILURE, o.np = 0, o.path_off = 0, o.flags = 0, o.short_block = 0;
-            if (wk.l < EC_MIN_ERR_SEQ_LEN) {
+            if (ECW_RARE(wk.l < EC_MIN_ERR_SEQ_LEN)) {
                 o.short_block = 1;                     // syncerr.c:502-504
             } else {
                 uint32_t st = 0, np = 0;
-                if (!ecw_solve_block(a.lv, a.rd, wk, s, a.max_edist, st, np)) {
+                if (ECW_RARE(!ecw_solve_block(a.lv, a.rd, wk, s, a.max_edist, st, np))) {
                     o.flags = 1;
                     if (lane == 0) a.todo_out[atomicAdd(a.todo_cnt, 1ULL)] = (uint32_t) wi;
                 } else {
                     o.status = st, o.np = np;
                     if (st == EC_SUCCESS && np) {
-                        if (pool_at + np > pool_end) {
+                        if (ECW_RARE(pool_at + np > pool_end)) {
                             const unsigned long long want = np > ECW_POOL_CHUNK? np : ECW_POOL_CHUNK;
                             unsigned long long off = 0;
                             if (lane == 0) off = atomicAdd(a.pool_cursor, want);
