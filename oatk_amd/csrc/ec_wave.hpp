@@ -264,7 +264,7 @@ __global__ __launch_bounds__(64) void ecw_wf_ed_kernel(const uint32_t *tw, const
 // "batching reads per wavefront" -- with the bit-vectors over the TARGET, sixty-four pairs per wave, the vectors of a wave interleaved in an HBM slab
 // (word w of lane l at w * 64 + l: every access of the wave is one coalesced 512-byte row).  Global alignment (the first row counts up: carry-in +1
 // per column), Hyyro's block formulation with the horizontal delta handed from word to word.  The result is the closed form wf_ed equals
-// (oracle/levdist.c: orc_ed_bruteforce): the minimum over the last row, then the last column upwards, first minimum wins = smallest diagonal;
+// (the full-matrix DP of the test suite): the minimum over the last row, then the last column upwards, first minimum wins = smallest diagonal;
 // beyond the band (bw >= 0 and minimum > bw): score bw + 1 with both ends 0, as wf_ed_core leaves them.
 __global__ __launch_bounds__(64) void myers_ed_kernel(uint64_t n_jobs, const uint32_t *tw, const uint64_t *tw_off, const int32_t *tl, const uint32_t *qw, const uint64_t *qw_off,
                                                       const int32_t *ql_, const int32_t *bw, uint64_t *slab, uint64_t slab_words, int32_t *out3)
