@@ -654,12 +654,20 @@ __global__ __launch_bounds__(64 * WPB) void ec_wave_kernel(EcwArgs a)
 #endif
     const uint64_t total = a.todo? a.n_todo : a.n_work;
     uint64_t pool_at = 0, pool_end = 0;                // this wave's chunk of the path pool
+    ECW_D(13);                                         // 13: waves launched, 12: waves that found work, 14: batches
+#ifdef ECW_PROF
+    bool first_batch = true;
+#endif
     for (;;) {
         ECW_T(7);                                      // 7: queue + output
         unsigned long long t0 = 0;
         if (lane == 0) t0 = atomicAdd(a.next, (unsigned long long) ECW_BATCH);
         t0 = ecw_uni64(t0);
         if (t0 >= total) break;
+#ifdef ECW_PROF
+        if (first_batch) { ECW_D(12); first_batch = false; }
+        ECW_D(14);
+#endif
         const int cnt = total - t0 < ECW_BATCH? (int) (total - t0) : ECW_BATCH;
         // lane i holds block i of the batch
         uint64_t my_wi = 0;
