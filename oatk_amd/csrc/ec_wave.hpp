@@ -118,6 +118,9 @@ __device__ unsigned long long ecw_dyn[16];          // dynamic counts of the loo
 #define ECW_C(i, v) do {} while (0)
 #define ECW_D(i) do {} while (0)
 #endif
+#ifdef ECW_CENSUS                                    // development builds: how many of the launched waves were resident early enough to find work
+__device__ unsigned long long ecw_census[2];
+#endif
 // block placement: the usual path of the search falls through (a taken branch is what costs here)
 #define ECW_LIKELY(x) __builtin_expect(!!(x), 1)
 #define ECW_RARE(x) __builtin_expect(!!(x), 0)
@@ -655,8 +658,11 @@ __global__ __launch_bounds__(64 * WPB) void ec_wave_kernel(EcwArgs a)
     const uint64_t total = a.todo? a.n_todo : a.n_work;
     uint64_t pool_at = 0, pool_end = 0;                // this wave's chunk of the path pool
     ECW_D(13);                                         // 13: waves launched, 12: waves that found work, 14: batches
-#ifdef ECW_PROF
+#if defined(ECW_PROF) || defined(ECW_CENSUS)
     bool first_batch = true;
+#endif
+#ifdef ECW_CENSUS
+    if (lane == 0) atomicAdd(&ecw_census[0], 1ULL);
 #endif
     for (;;) {
         ECW_T(7);                                      // 7: queue + output
@@ -664,6 +670,10 @@ __global__ __launch_bounds__(64 * WPB) void ec_wave_kernel(EcwArgs a)
         if (lane == 0) t0 = atomicAdd(a.next, (unsigned long long) ECW_BATCH);
         t0 = ecw_uni64(t0);
         if (t0 >= total) break;
+#ifdef ECW_CENSUS
+        if (first_batch && lane == 0) atomicAdd(&ecw_census[1], 1ULL);
+        first_batch = false;
+#endif
 #ifdef ECW_PROF
         if (first_batch) { ECW_D(12); first_batch = false; }
         ECW_D(14);
