@@ -77,9 +77,16 @@ __device__ __forceinline__ uint64_t kmer_word_global(const uint32_t *hs32, uint3
     nb = nb > 32? 32 : nb;
     int32_t wi = t >> 4;
     uint32_t sh = ((uint32_t) t & 15u) * 2u;
-    uint32_t w0 = wi >= 0? __builtin_bswap32(hs32[wi]) : 0u;
-    uint32_t w1 = wi + 1 >= 0? __builtin_bswap32(hs32[wi + 1]) : 0u;
-    uint32_t w2 = wi + 2 >= 0? __builtin_bswap32(hs32[wi + 2]) : 0u;
+    uint32_t w0, w1, w2;
+    if (wi >= 0) {                // one 12-byte load (the lanes of a comparison sit 8 bytes apart: three dword loads look up every cache line three times)
+        struct __attribute__((packed, aligned(4))) W3 { uint32_t a, b, c; };
+        const W3 v = *(const W3 *) (hs32 + wi);
+        w0 = __builtin_bswap32(v.a), w1 = __builtin_bswap32(v.b), w2 = __builtin_bswap32(v.c);
+    } else {                      // (the first bases of a slab's first read, reverse strand: what lies in front is masked)
+        w0 = 0u;
+        w1 = wi + 1 >= 0? __builtin_bswap32(hs32[wi + 1]) : 0u;
+        w2 = wi + 2 >= 0? __builtin_bswap32(hs32[wi + 2]) : 0u;
+    }
     uint64_t hi = (uint64_t) w0 << 32 | w1;
     uint64_t V = sh? (hi << sh) | ((uint64_t) w2 >> (32u - sh)) : hi;
     if (rev) V = revcomp32(V);
@@ -177,19 +184,36 @@ __global__ __launch_bounds__(256) void verify_group_kernel(GroupArgs a, uint32_t
     const uint32_t *hs32 = (const uint32_t *) a.hoco_s;
     const int nw = (a.K + 31) / 32;
     uint32_t diff = 0;                                                    // bit r: this lane saw record r differ from its head
+    // A strip usually lies inside ONE group (a solid syncmer occurs once per read that covers it: tens of records at HiFi depth): then its
+    // records share their head, whose k-mer is fetched and realigned once instead of eight times.  Decided for the wave (both strips).
+    const uint32_t first_live = (uint32_t) __builtin_ctzll(live_mask);
+    const uint64_t lq0 = (uint64_t) __shfl((long long) my_lq, (int) (half0 + first_live));
+    const bool one_head = __ballot(my_live && my_lq != lq0) == 0;
     for (int w0 = 0; w0 < nw; w0 += 32) {                                 // (uniform trip count: every lane takes part in the shuffles, k < 225 idles lanes in the loads only)
         const int wd = w0 + (int) hl;
         const bool in = wd < nw;
         uint64_t p[OATK_VG_STRIP], q[OATK_VG_STRIP];
+        if (one_head) {
+            const uint64_t q0 = in? kmer_word_global(hs32 + (lq0 >> 32), (uint32_t) lq0 >> 1, (uint32_t) lq0 & 1u, a.K, wd) : 0;
 #pragma unroll
-        for (int r = 0; r < OATK_VG_STRIP; ++r) {                         // every load of the strip is issued before the first comparison
-            const uint64_t lp = (uint64_t) __shfl((long long) my_lp, (int) (half0 + r)), lq = (uint64_t) __shfl((long long) my_lq, (int) (half0 + r));
-            const bool live = in && ((live_mask >> r) & 1u);
-            p[r] = live? kmer_word_global(hs32 + (lp >> 32), (uint32_t) lp >> 1, (uint32_t) lp & 1u, a.K, wd) : 0;
-            q[r] = live? kmer_word_global(hs32 + (lq >> 32), (uint32_t) lq >> 1, (uint32_t) lq & 1u, a.K, wd) : 0;
+            for (int r = 0; r < OATK_VG_STRIP; ++r) {                     // every load of the strip is issued before the first comparison
+                const uint64_t lp = (uint64_t) __shfl((long long) my_lp, (int) (half0 + r));
+                const bool live = in && ((live_mask >> r) & 1u);
+                p[r] = live? kmer_word_global(hs32 + (lp >> 32), (uint32_t) lp >> 1, (uint32_t) lp & 1u, a.K, wd) : q0;
+            }
+#pragma unroll
+            for (int r = 0; r < OATK_VG_STRIP; ++r) diff |= (uint32_t) (p[r] != q0) << r;
+        } else {
+#pragma unroll
+            for (int r = 0; r < OATK_VG_STRIP; ++r) {
+                const uint64_t lp = (uint64_t) __shfl((long long) my_lp, (int) (half0 + r)), lq = (uint64_t) __shfl((long long) my_lq, (int) (half0 + r));
+                const bool live = in && ((live_mask >> r) & 1u);
+                p[r] = live? kmer_word_global(hs32 + (lp >> 32), (uint32_t) lp >> 1, (uint32_t) lp & 1u, a.K, wd) : 0;
+                q[r] = live? kmer_word_global(hs32 + (lq >> 32), (uint32_t) lq >> 1, (uint32_t) lq & 1u, a.K, wd) : 0;
+            }
+#pragma unroll
+            for (int r = 0; r < OATK_VG_STRIP; ++r) diff |= (uint32_t) (p[r] != q[r]) << r;
         }
-#pragma unroll
-        for (int r = 0; r < OATK_VG_STRIP; ++r) diff |= (uint32_t) (p[r] != q[r]) << r;
     }
 #pragma unroll
     for (int r = 0; r < OATK_VG_STRIP; ++r) {
