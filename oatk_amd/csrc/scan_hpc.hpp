@@ -408,7 +408,8 @@ __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
         const uint32_t done = nstart? (nstart - 1u) >> 6 : 0u;   // complete 64-groups among finished runs
         flush(flushed, done);
         flushed = done;
-        __syncthreads();
+        // (no barrier here: the next tile writes to the rings only behind ITS first barrier, which every wave reaches after this flush; what it
+        //  zeroes and what the next tile fills are different 64-groups, and the per-wave totals are not touched before that barrier either)
     }
     // the last run ends with the read
     if (tid == 0 && nstart) {
