@@ -26,6 +26,13 @@
  *
  * Results are bit-identical to one handle holding all the reads (tests/test_gpu_multi_c.py).  Every rank must make the same calls in the same
  * order; a call returns only when the rank's part is complete.
+ *
+ * STATUS OF THE RCCL BACKEND: validated against the real librccl with ONE rank (every collective call on the stream of a real communicator),
+ * with 2 - 8 ranks over the local group on one GPU, and with 2 - 4 ranks over a mock of the RCCL entry points whose ranks are threads
+ * (tests/mock_rccl_run.py) -- not yet on two physical GPUs: no multi-GPU node has been available to its builders.  Treat it as experimental
+ * until tests/test_gpu_multi_c.py has passed on such a node.  A communicator is bound to the device it was created for: a call with a handle of
+ * another device is refused (OATK_E_ARG), and a rank that fails between collectives aborts the communicator / poisons the group so that its
+ * peers return an error instead of waiting for it.
  */
 #ifndef OATK_HIP_MULTI_H
 #define OATK_HIP_MULTI_H
