@@ -601,22 +601,40 @@ struct EcRoute {
     uint32_t *list[4];
     unsigned long long *cnt[4];
 };
-__global__ void ec_route_kernel(const EcWork *work, uint64_t n_work, EcRoute rt)
+// (r03: one global atomic per WORKGROUP and tier.  With one per wave and tier -- ~250 k atomics on three addresses at config 3 -- the kernel took 1.4 ms for a
+//  pass over 7.9 M lengths; the lists are work queues, so their order is free.)
+#define ECW_ROUTE_ITEMS 8          // work items per thread
+__global__ __launch_bounds__(256) void ec_route_kernel(const EcWork *work, uint64_t n_work, EcRoute rt)
 {
-    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    int t = 0;
-    if (i < n_work) {
+    __shared__ uint32_t cnt[4], base_lo[4], base_hi[4];
+    __shared__ uint32_t stage[4][256 * ECW_ROUTE_ITEMS / 2];          // a workgroup routes at most half of its items through the staging area; the rest go one by one
+    constexpr uint32_t CAP = 256 * ECW_ROUTE_ITEMS / 2;
+    if (threadIdx.x < 4) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t i0 = (uint64_t) blockIdx.x * (256 * ECW_ROUTE_ITEMS);
+#pragma unroll
+    for (int k = 0; k < ECW_ROUTE_ITEMS; ++k) {
+        const uint64_t i = i0 + (uint64_t) k * 256 + threadIdx.x;
+        if (i >= n_work) continue;
         const int32_t l = work[i].l;
+        int t = 0;
         while (t < 3 && l > rt.cap[t]) ++t;
+        if (t == 0) continue;
+        const uint32_t at = atomicAdd(&cnt[t], 1u);
+        if (at < CAP) stage[t][at] = (uint32_t) i;
+        else rt.list[t][atomicAdd(rt.cnt[t], 1ULL)] = (uint32_t) i;   // (a workgroup full of long blocks: straight to the list)
     }
-    for (int k = 1; k <= 3; ++k) {
-        const uint64_t m = __ballot(t == k);
-        if (!m) continue;
-        const uint32_t lane = threadIdx.x & 63u;
-        unsigned long long base = 0;
-        if (lane == (uint32_t) __builtin_ctzll(m)) base = atomicAdd(rt.cnt[k], (unsigned long long) __builtin_popcountll(m));
-        base = (unsigned long long) __shfl((long long) base, __builtin_ctzll(m));
-        if (t == k) rt.list[k][base + (uint32_t) __builtin_popcountll(m & ((1ULL << lane) - 1ULL))] = (uint32_t) i;
+    __syncthreads();
+    if (threadIdx.x >= 1 && threadIdx.x <= 3) {
+        const uint32_t n = cnt[threadIdx.x] < CAP? cnt[threadIdx.x] : CAP;
+        const unsigned long long b = n? atomicAdd(rt.cnt[threadIdx.x], (unsigned long long) n) : 0ULL;
+        base_lo[threadIdx.x] = (uint32_t) b, base_hi[threadIdx.x] = (uint32_t) (b >> 32);
+    }
+    __syncthreads();
+    for (int t = 1; t <= 3; ++t) {
+        const uint32_t n = cnt[t] < CAP? cnt[t] : CAP;
+        const uint64_t b = (uint64_t) base_hi[t] << 32 | base_lo[t];
+        for (uint32_t j = threadIdx.x; j < n; j += 256) rt.list[t][b + j] = stage[t][j];
     }
 }
 
