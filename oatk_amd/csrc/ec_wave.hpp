@@ -564,7 +564,9 @@ __device__ bool ecw_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
 #ifndef ECW_WPB
 #define ECW_WPB 2                 // waves per workgroup of the LDS tiers (independent of each other: ecw_sync)
 #endif
-#define ECW_BATCH 8               // blocks taken from the queue per atomic
+#ifndef ECW_BATCH
+#define ECW_BATCH 16              // blocks taken from the queue per atomic (config 3: 8 -> 14.13 ms, 16 -> 13.83, 32 -> 13.86)
+#endif
 #define ECW_POOL_CHUNK 512        // path-pool entries taken per atomic
 
 struct EcwArgs {
