@@ -315,15 +315,17 @@ static int launch_scan_kernels(oatk_hip_ctx *ctx)
     t_begin(ctx, OATK_T_SYNCMER);
     if (fast_ring == 4096 && ctx->S == 31) {
         const dim3 g((unsigned) n), b(SYN_NT);
+        unsigned dyn = 0;                          // development aid: unused LDS on top of the kernel's own lowers its residency (3 workgroups per CU from 2600 bytes on, 2 from 16200)
+        { const char *ev = getenv("OATK_DEBUG_SYNCMER_LDS"); if (ev && atoi(ev) > 0) dyn = (unsigned) atoi(ev); }
         switch ((-(ctx->K - ctx->S)) & 7) {        // one instantiation per alignment of the window start against the chunks of 8
-            case 0: hipLaunchKernelGGL((syncmer_fast_kernel<4096, true, SYN_NT, 0>), g, b, 0, ctx->stream, s); break;
-            case 1: hipLaunchKernelGGL((syncmer_fast_kernel<4096, true, SYN_NT, 1>), g, b, 0, ctx->stream, s); break;
-            case 2: hipLaunchKernelGGL((syncmer_fast_kernel<4096, true, SYN_NT, 2>), g, b, 0, ctx->stream, s); break;
-            case 3: hipLaunchKernelGGL((syncmer_fast_kernel<4096, true, SYN_NT, 3>), g, b, 0, ctx->stream, s); break;
-            case 4: hipLaunchKernelGGL((syncmer_fast_kernel<4096, true, SYN_NT, 4>), g, b, 0, ctx->stream, s); break;
-            case 5: hipLaunchKernelGGL((syncmer_fast_kernel<4096, true, SYN_NT, 5>), g, b, 0, ctx->stream, s); break;
-            case 6: hipLaunchKernelGGL((syncmer_fast_kernel<4096, true, SYN_NT, 6>), g, b, 0, ctx->stream, s); break;
-            default: hipLaunchKernelGGL((syncmer_fast_kernel<4096, true, SYN_NT, 7>), g, b, 0, ctx->stream, s); break;
+            case 0: hipLaunchKernelGGL((syncmer_fast_kernel<4096, true, SYN_NT, 0>), g, b, dyn, ctx->stream, s); break;
+            case 1: hipLaunchKernelGGL((syncmer_fast_kernel<4096, true, SYN_NT, 1>), g, b, dyn, ctx->stream, s); break;
+            case 2: hipLaunchKernelGGL((syncmer_fast_kernel<4096, true, SYN_NT, 2>), g, b, dyn, ctx->stream, s); break;
+            case 3: hipLaunchKernelGGL((syncmer_fast_kernel<4096, true, SYN_NT, 3>), g, b, dyn, ctx->stream, s); break;
+            case 4: hipLaunchKernelGGL((syncmer_fast_kernel<4096, true, SYN_NT, 4>), g, b, dyn, ctx->stream, s); break;
+            case 5: hipLaunchKernelGGL((syncmer_fast_kernel<4096, true, SYN_NT, 5>), g, b, dyn, ctx->stream, s); break;
+            case 6: hipLaunchKernelGGL((syncmer_fast_kernel<4096, true, SYN_NT, 6>), g, b, dyn, ctx->stream, s); break;
+            default: hipLaunchKernelGGL((syncmer_fast_kernel<4096, true, SYN_NT, 7>), g, b, dyn, ctx->stream, s); break;
         }
     }
     else if (fast_ring == 4096) hipLaunchKernelGGL((syncmer_fast_kernel<4096, false>), dim3((unsigned) n), dim3(SYN_NT), 0, ctx->stream, s);

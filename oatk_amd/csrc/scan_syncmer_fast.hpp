@@ -86,21 +86,28 @@ __device__ __forceinline__ void wave_prefix_suffix_min_u32(uint32_t v, uint32_t 
     suf = sadd < s? sadd : s;
 }
 
+#define OATK_SYF_PADW(R) ((R) / 8)        // four pad words per 32 positions of the top-word ring
+#ifndef OATK_SYF_WAVES
+#define OATK_SYF_WAVES 6                  // waves per SIMD the register allocation aims at (six workgroups of four waves per CU)
+#endif
 // SH: (-(K - S)) & 7 when known at compile time (the offsets of the Open filter's eight reads become immediates), -1 otherwise
 template <int R, bool S31, int NT = SYN_NT, int SH = -1>
-__global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
+__global__ __launch_bounds__(NT, OATK_SYF_WAVES) void syncmer_fast_kernel(SynArgs a)
 {
     constexpr int C = SYF_C, T = NT * SYF_C, NCH = R / C, NWAVE = NT / OATK_WAVE;
     static_assert((R & (R - 1)) == 0, "power-of-two ring: index arithmetic is one AND (a 3200-slot ring raised occupancy from 3 to 4\n"
                   "workgroups per CU but its modulo arithmetic cost more issue slots than the occupancy returned)");
 
-    __shared__ uint64_t m_ring[R + R / 32];     // s-mer hashes by END position; one pad slot per 32 against bank conflicts
+    __shared__ uint32_t m_top[R + OATK_SYF_PADW(R)];   // TOP WORDS of the s-mer hashes by END position: all that the filter and the decision of a candidate
+                                                // look at; a position whose top word ties with its window's is re-hashed from the read's bases (r03h)
+    __shared__ uint64_t c_min[NCH];             // 64-bit minimum of every chunk: the whole chunks of a window when top words tie
     __shared__ uint32_t pre32[NCH], suf32[NCH]; // per-wave-block inclusive prefix / suffix minima of the chunk minima's top 32 bits
     __shared__ uint32_t w_cnt[2][NWAVE];         // syncmers per wave of a tile, double-buffered (two barriers per tile)
     __shared__ uint32_t sl_e[SYF_LIST];          // syncmers of the read so far, in position order: k-mer end | kind << 30 (1 Close, 2 Open);
                                                  // written out when the read is done (or the list is full)
-    // (LDS is what limits residency: 40.5 KB leave room for FOUR workgroups per CU.  The 64-bit chunk minima the tie path wants are
-    //  recomputed from the ring when a tie happens, the list is short, the kind rides in the top bits of the position.)
+    // (LDS and registers limit residency.  r03h: with whole 64-bit hashes in the ring a workgroup took 38.4 KB -- four per CU, and the kernel's time
+    //  still fell by 13 % from three to four (profiles/r03h_b_residency.txt).  Top words alone are 16 KB; the low words were only ever read when top
+    //  words tied, and those few positions are re-hashed from the packed bases instead.  24.6 KB: six workgroups per CU.)
     __shared__ uint32_t s_gb;                    // record slots of the list being written out
 
     const uint32_t r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -115,10 +122,12 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
     const int D = w / C - 1;                    // chunks that lie inside the window of EVERY position of a chunk
 
     auto rpos = [](int32_t i) -> uint32_t { return (uint32_t) i & (uint32_t) (R - 1); };
-    auto mi = [&](int32_t i) -> uint32_t { uint32_t p = rpos(i); return p + (p >> 5); };
+    // four pad words per 32 positions: a chunk stays 16-byte aligned, and lanes that read the same offset of consecutive chunks spread over the banks
+    // (r03h, 400 k reads: 11.1 ms without the pad words, 10.3 with them, both at four workgroups per CU)
+    auto mi = [&](int32_t i) -> uint32_t { const uint32_t p = rpos(i); return p + ((p >> 5) << 2); };
     auto rch = [](int32_t c) -> uint32_t { return (uint32_t) c & (uint32_t) (NCH - 1); };
-    for (uint32_t i = tid; i < R + R / 32; i += NT) m_ring[i] = UINT64_MAX;
-    for (uint32_t i = tid; i < NCH; i += NT) pre32[i] = suf32[i] = 0xFFFFFFFFu;
+    for (uint32_t i = tid; i < R + OATK_SYF_PADW(R); i += NT) m_top[i] = 0xFFFFFFFFu;
+    for (uint32_t i = tid; i < NCH; i += NT) pre32[i] = suf32[i] = 0xFFFFFFFFu, c_min[i] = UINT64_MAX;
     __syncthreads();
 
     // The bases a lane needs for a tile -- the 32 before its chunk (the s-mer that ends just in front of it) and the chunk's own 8 -- are
@@ -135,7 +144,6 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
         const int32_t wi0 = ((int32_t) (tid * C) - 32) >> 4;         // negative for the first four lanes: those bases lie before the read
         rw0 = ghs[wi0 < 0? 0 : wi0], rw1 = ghs[wi0 + 1 < 0? 0 : wi0 + 1], rw2 = ghs[wi0 + 2];       // (and no k-mer can end there: any value does)
     }
-    const uint32_t *m_hi = (const uint32_t *) m_ring;    // top word of entry e is m_hi[2e + 1]
 
     uint32_t ord0 = 0, par = 0;                 // syncmers already turned into records; parity of the count buffer
     uint32_t sl_n = 0;                          // syncmers in the list (the same value in every thread)
@@ -148,6 +156,14 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
         const uint64_t hi = (uint64_t) __builtin_bswap32(ghs[wi]) << 32 | __builtin_bswap32(ghs[wi + 1]);
         const uint32_t w2 = __builtin_bswap32(ghs[wi + 2]);            // the slab has slack behind the last read
         return sh? (hi << sh) | ((uint64_t) w2 >> (32u - sh)) : hi;
+    };
+    // the whole hash of the s-mer that ends at position q, as the hashing phase computed it (MAX where no s-mer ends): for the handful of
+    // positions whose top word ties with the value it is compared with
+    auto hash_at = [&](int32_t q) -> uint64_t {
+        if (q + 1 < S || (uint32_t) q >= hl) return UINT64_MAX;
+        const uint64_t X = get64g(q - S + 1) & (~0ULL << (64 - 2 * S));
+        const uint64_t fw = X >> (64 - 2 * S), rv = revcomp32(X) & mask;
+        return (S31 || fw != rv)? hash64(fw < rv? fw : rv, mask) : UINT64_MAX;
     };
     auto write_record = [&](int32_t E, uint32_t kind, uint32_t loc, uint32_t ordn) __attribute__((always_inline)) {
         const int32_t e = kind == 2u? E - w : E, j = E - K + 1;        // Open: first s-mer; Close: last s-mer
@@ -218,8 +234,8 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
     };
 
     // Ring addresses.  A tile advances every lane by T positions = HALF the ring (and half the chunk ring), so each address a lane
-    // uses alternates between two values: a chunk-ring byte offset flips one bit, a hash-ring index is mirrored in the sum of its two
-    // values (the pad slots make it more than a bit flip).  Twelve registers updated by one instruction each per tile instead of
+    // uses alternates between two values: a chunk-ring byte offset flips one bit, a top-word index is mirrored in the sum of its two
+    // values (the pad words make it more than a bit flip).  Twelve registers updated by one instruction each per tile instead of
     // ~40 instructions of shifts, masks and adds; which ranges hold a whole block in their middle does not change at all.
     static_assert(2 * T == R, "the address toggling below needs tile = half the ring");
     struct RangeAddr { uint32_t lo, hi, mid; bool whole; };
@@ -229,7 +245,7 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
     const int32_t ch_0 = (int32_t) tid, ca0_0 = ((int32_t) (tid * C) - w) >> 3;       // tile 0: the lane's chunk, the chunk of its first window start
     RangeAddr rB = range_addr(ch_0 - D, ch_0 - 1), rF0 = range_addr(ca0_0 + 1, ca0_0 + D), rF1 = range_addr(ca0_0 + 2, ca0_0 + 1 + D);
     uint32_t o_cs = rch(ch_0) * 4u;
-    uint32_t m_own = mi((int32_t) (tid * C)), m_fa = mi(ca0_0 * C), m_fb = mi((ca0_0 + 1) * C);
+    uint32_t m_own = mi((int32_t) (tid * C)), m_fa = mi(ca0_0 * C), m_fb = mi((ca0_0 + 1) * C);      // (indices of 8-aligned positions)
     const uint32_t m_own_sum = m_own + mi((int32_t) (tid * C) + T), m_fa_sum = m_fa + mi(ca0_0 * C + T), m_fb_sum = m_fb + mi((ca0_0 + 1) * C + T);
     auto next_tile_addr = [&]() __attribute__((always_inline)) {
         constexpr uint32_t FLIP = (uint32_t) (NCH / 2) * 4u;
@@ -243,7 +259,7 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
         // ---- P1: s-mer hashes of this lane's chunk, chunk minimum, wave prefix/suffix minima ----
         const int32_t i0 = (int32_t) (I0 + tid * C);
         const int32_t ch = i0 / C;                      // chunk index; ch % 64 == lane
-        uint64_t y[C];
+        uint32_t y[C];                                  // top words of the chunk's hashes
         {
             const uint32_t a_hi = __builtin_amdgcn_perm(rw0, rw1, bsel), a_lo = __builtin_amdgcn_perm(rw1, rw2, bsel);   // bases i0 - 32 .. i0 - 1
             const uint32_t vbh = __builtin_amdgcn_perm(rw2, 0u, bsel);  // the chunk's 8 bases sit in the top half
@@ -257,8 +273,7 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
             }
             const uint64_t X = ((uint64_t) a_hi << 32 | a_lo) << (2 * (32 - S));       // the S bases that end at i0 - 1, at the top
             uint64_t fw = X >> (64 - 2 * S), rv = revcomp32(X) & mask;
-            uint32_t cmin = 0xFFFFFFFFu;                // top word of the chunk minimum: all the filter looks at
-            const uint32_t mbase = m_own;               // = mi(i0); 8 consecutive positions never straddle a pad slot
+            uint64_t cm = UINT64_MAX;                   // the chunk minimum; the filter looks at its top word
             // (the test is made for the WAVE: a wave with one lane at either end of the read would otherwise run both branches, eight
             //  hashes each -- two waves per read, 5 % of the kernel)
             if (__ballot(!(i0 + 1 >= S && (uint32_t) (i0 + C) <= hl)) == 0) {
@@ -269,8 +284,8 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
                     rv = rv >> 2 | (3ULL ^ c) << (2 * S - 2);
                     // (S31: an odd-length s-mer is never its own reverse complement, so no fw != rv test)
                     uint64_t mv = (S31 || fw != rv)? hash64(fw < rv? fw : rv, mask) : UINT64_MAX;
-                    y[b] = mv;
-                    cmin = (uint32_t) (mv >> 32) < cmin? (uint32_t) (mv >> 32) : cmin;
+                    y[b] = (uint32_t) (mv >> 32);
+                    cm = mv < cm? mv : cm;
                 }
             } else {                                    // first / last chunk of the read
 #pragma unroll
@@ -281,10 +296,11 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
                     rv = rv >> 2 | (3ULL ^ c) << (2 * S - 2);
                     uint64_t mv = UINT64_MAX;
                     if (i + 1 >= S && (uint32_t) i < hl && fw != rv) mv = hash64(fw < rv? fw : rv, mask);
-                    y[b] = mv;
-                    cmin = (uint32_t) (mv >> 32) < cmin? (uint32_t) (mv >> 32) : cmin;
+                    y[b] = (uint32_t) (mv >> 32);
+                    cm = mv < cm? mv : cm;
                 }
             }
+            const uint32_t cmin = (uint32_t) (cm >> 32);
             uint32_t pre, suf;
 #ifdef OATK_SCAN_SHFL
             pre = suf = cmin;
@@ -299,8 +315,10 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
             // everything above lives in registers: a wave that is done with the previous tile hashes ahead while the others
             // still read that tile's windows from the ring.  Ring slots are only overwritten behind this barrier.
             __syncthreads();
-#pragma unroll
-            for (int b = 0; b < C; ++b) m_ring[mbase + b] = y[b];
+            static_assert(C == 8, "two 16-byte stores per lane");
+            *(uint4 *) (m_top + m_own) = make_uint4(y[0], y[1], y[2], y[3]);
+            *(uint4 *) (m_top + m_own + 4) = make_uint4(y[4], y[5], y[6], y[7]);
+            *(uint64_t *) ((char *) c_min + 2u * o_cs) = cm;
             *(uint32_t *) ((char *) pre32 + o_cs) = pre;
             *(uint32_t *) ((char *) suf32 + o_cs) = suf;
         }
@@ -327,14 +345,14 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
             const uint32_t fwd0 = range_min(rF0);            // Open bound, first s-mers ending in chunk ca0: chunks [ca0 + 1, ca0 + D]
             const uint32_t fwd1 = range_min(rF1);            // ... and in chunk ca0 + 1: chunks [ca0 + 2, ca0 + 1 + D]
             // the eight first s-mers sit in chunks ca0 (from offset sh) and ca0 + 1: two base addresses, constant offsets
-            const uint32_t bA = 2u * m_fa + 1u, bB = 2u * m_fb + 1u;
+            const uint32_t bA = m_fa, bB = m_fb;
             backF_keep = backF, fwd0_keep = fwd0, fwd1_keep = fwd1;
             uint32_t hit = 0;
 #pragma unroll
             for (int o = 0; o < C; ++o) {
                 const int q = o + sh;
-                const uint32_t fhi = q < C? m_hi[bA + 2u * (uint32_t) q] : m_hi[bB + 2u * (uint32_t) (q - C)];
-                const uint32_t yhi = (uint32_t) (y[o] >> 32);
+                const uint32_t fhi = q < C? m_top[bA + (uint32_t) q] : m_top[bB + (uint32_t) (q - C)];
+                const uint32_t yhi = y[o];
                 const uint32_t fb = o + sh < C? fwd0 : fwd1;
                 // (a MAX sentinel passes only when its whole window is MAX; the exact rule rejects it)
                 hit |= (uint32_t) ((yhi <= backF) | ((fhi <= fb) & (fhi <= yhi))) << o;
@@ -375,20 +393,20 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
                     mm &= mm - 1;
                     const int32_t E = ci0 + o, lo = E - w;
                     const int32_t ca = lo >> 3, n1 = (ca + 1) * C - lo - 1, tail0 = (ca + 1 + D) * C, n2 = E - tail0;
-                    const uint32_t yhi = m_hi[2u * mi(E) + 1u], fhi = m_hi[2u * mi(lo) + 1u];
+                    const uint32_t yhi = m_top[mi(E)], fhi = m_top[mi(lo)];
                     const uint32_t fb = o + sh < C? fwd0_keep : fwd1_keep;
                     bool cl = false, op = false, tie = false;
                     if (yhi <= backF_keep) {                                             // Close: head [lo, lo + HW - o) + tail [i0, E)
                         uint32_t cmin = 0xFFFFFFFFu;
-                        for (int32_t t = 0; t < HW - o; ++t) { const uint32_t u = m_hi[2u * mi(lo + t) + 1u]; cmin = u < cmin? u : cmin; }
-                        for (int32_t t = 0; t < o; ++t) { const uint32_t u = m_hi[2u * mi(ci0 + t) + 1u]; cmin = u < cmin? u : cmin; }
+                        for (int32_t t = 0; t < HW - o; ++t) { const uint32_t u = m_top[mi(lo + t)]; cmin = u < cmin? u : cmin; }
+                        for (int32_t t = 0; t < o; ++t) { const uint32_t u = m_top[mi(ci0 + t)]; cmin = u < cmin? u : cmin; }
                         const uint32_t bh = cmin < backF_keep? cmin : backF_keep;
                         cl = yhi < bh, tie = yhi == bh;
                     }
                     if (fhi <= fb && fhi <= yhi) {                                       // Open: rest of f's chunk + [tail0, E)
                         uint32_t omin = 0xFFFFFFFFu;
-                        for (int32_t t = 0; t < n1; ++t) { const uint32_t u = m_hi[2u * mi(lo + 1 + t) + 1u]; omin = u < omin? u : omin; }
-                        for (int32_t t = 0; t < n2; ++t) { const uint32_t u = m_hi[2u * mi(tail0 + t) + 1u]; omin = u < omin? u : omin; }
+                        for (int32_t t = 0; t < n1; ++t) { const uint32_t u = m_top[mi(lo + 1 + t)]; omin = u < omin? u : omin; }
+                        for (int32_t t = 0; t < n2; ++t) { const uint32_t u = m_top[mi(tail0 + t)]; omin = u < omin? u : omin; }
                         const uint32_t rh = omin < fb? omin : fb;
                         op = fhi < rh && fhi < yhi, tie |= fhi <= rh && !op;
                     }
@@ -416,7 +434,7 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
                     if (lane < 16) valid = t < HW, pos = t < HW - o? lo + t : ci0 + (t - (HW - o));          // Close: head [lo, lo + HW - o) + tail [i0, E)
                     else if (lane < 32) valid = t < n1 + n2, pos = t < n1? lo + 1 + t : tail0 + (t - n1);     // Open: rest of f's chunk + [tail0, E)
                     else if (lane == 33) pos = lo;
-                    const uint32_t u = m_hi[2u * mi(pos) + 1u];
+                    const uint32_t u = m_top[mi(pos)];
                     const uint32_t yhi = (uint32_t) __builtin_amdgcn_readlane((int) u, 32), fhi = (uint32_t) __builtin_amdgcn_readlane((int) u, 33);
                     uint32_t v = valid? u : 0xFFFFFFFFu, x;
                     x = dpp_u32<OATK_DPP_ROW_SHR(1)>(0xFFFFFFFFu, v); v = x < v? x : v;
@@ -442,37 +460,25 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
         }
         // Top words tied: ~2^-28 per candidate on random sequence, but the rule rather than the exception inside tandem repeats
         // (telomeres, microsatellites), where the window minimum comes back every period and every lane of the wave holds ties.
-        // Those are decided lane by lane on 64-bit hashes, and what makes that affordable is one 64-bit minimum per chunk: the wave
-        // computes them for the 192 chunks around its own when it meets its first tie (three per lane) and parks them in ring slots
-        // that nobody reads any more -- positions older than every window of this tile, which the next tile overwrites anyway.
-        // (Kept resident they would cost 4 KB of LDS and with it the fourth workgroup per CU.)
+        // Those are decided lane by lane on whole 64-bit hashes.  The ring holds top words only, so: a value whose top word differs from
+        // the one it is compared with is settled by the top words (its low word is taken as 0 -- no comparison below can tell); a value
+        // whose top word is EQUAL is hashed again from the read's packed bases (`hash_at`; in a repeat of period p that is one ragged
+        // position in p); and the whole chunks of a window come from the 64-bit chunk minima the hashing phase leaves in `c_min`.
         if (__ballot(tiemask != 0)) {
-            static_assert(R - T - 1040 >= NWAVE * 192, "room for the parked chunk minima behind the oldest window");
             const int sh = SH >= 0? SH : ((-w) & (C - 1));
-            const int32_t cw0 = (int32_t) (I0 >> 3) + (int32_t) __builtin_amdgcn_readfirstlane((int) wid) * OATK_WAVE;   // the wave's first chunk
-            const int32_t sp = (int32_t) I0 + T - R + (int32_t) __builtin_amdgcn_readfirstlane((int) wid) * 192;       // parked: chunk cw0 - 128 + j at position sp + j
-            {
-                uint64_t ma = UINT64_MAX, mb = UINT64_MAX, mc = UINT64_MAX;
-                const int32_t pa = (cw0 - 128 + (int32_t) lane) * C, pbb = (cw0 - 64 + (int32_t) lane) * C;
-#pragma unroll
-                for (int t = 0; t < C; ++t) {
-                    const uint64_t ua = m_ring[mi(pa + t)], ub = m_ring[mi(pbb + t)];
-                    ma = ua < ma? ua : ma, mb = ub < mb? ub : mb, mc = y[t] < mc? y[t] : mc;
-                }
-                m_ring[mi(sp + (int32_t) lane)] = ma, m_ring[mi(sp + 64 + (int32_t) lane)] = mb, m_ring[mi(sp + 128 + (int32_t) lane)] = mc;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
+            auto full = [&](int32_t q, uint32_t ref) -> uint64_t {
+                const uint32_t t = m_top[mi(q)];
+                return t == ref? hash_at(q) : (uint64_t) t << 32;
+            };
             // The whole chunks inside the windows of a lane's eight positions are only TWO ranges, [ca0 + 1, ca0 + D] and
             // [ca0 + 2, ca0 + 1 + D] (ca0: the chunk the first window starts in), and the Close range [ch - D, ch - 1] is one of them:
             // one walk over their common part serves every tie of the lane (in a repeat of period 2 that is four ties, eight ranges).
             uint64_t r0 = UINT64_MAX, r1 = UINT64_MAX;
             if (tiemask) {
-                const int32_t ca0 = (i0 - w) >> 3, pk = sp - (cw0 - 128);
+                const int32_t ca0 = (i0 - w) >> 3;
                 uint64_t mid = UINT64_MAX;
-                for (int32_t cc = ca0 + 2; cc <= ca0 + D; ++cc) { const uint64_t u = m_ring[mi(pk + cc)]; mid = u < mid? u : mid; }
-                const uint64_t e0 = m_ring[mi(pk + ca0 + 1)], e1 = m_ring[mi(pk + ca0 + 1 + D)];
+                for (int32_t cc = ca0 + 2; cc <= ca0 + D; ++cc) { const uint64_t u = c_min[rch(cc)]; mid = u < mid? u : mid; }
+                const uint64_t e0 = c_min[rch(ca0 + 1)], e1 = c_min[rch(ca0 + 1 + D)];
                 r0 = e0 < mid? e0 : mid, r1 = e1 < mid? e1 : mid;
             }
             const uint64_t r_close = (w & (C - 1))? r1 : r0;                // ch - D = ca0 + 2 unless w is a multiple of 8
@@ -481,22 +487,25 @@ __global__ __launch_bounds__(NT) void syncmer_fast_kernel(SynArgs a)
                 const int o = __builtin_ctz(tm);
                 tm &= tm - 1;
                 const int32_t E = i0 + o, lo = E - w;
-                const uint64_t yy = m_ring[mi(E)], f = m_ring[mi(lo)], x = m_ring[mi(lo - 1)];
-                const uint32_t yhi = (uint32_t) (yy >> 32), fhi = (uint32_t) (f >> 32);
+                const uint32_t yhi = m_top[mi(E)], fhi = m_top[mi(lo)];
+                const uint64_t yy = hash_at(E), f = hash_at(lo);
                 const uint32_t fb = o + sh < C? fwd0_keep : fwd1_keep;
                 bool cl = false, op = false;
                 if (yhi <= backF_keep) {                // Close: window = head [lo, lo + HW - o) + D chunks before `ch` + tail [i0, E)
                     uint64_t b = UINT64_MAX;
-                    for (int t = 0; t < HW - o; ++t) { const uint64_t u = m_ring[mi(lo + t)]; b = u < b? u : b; }
-                    for (int t = 0; t < o; ++t) { const uint64_t u = m_ring[mi(i0 + t)]; b = u < b? u : b; }
+                    for (int t = 0; t < HW - o; ++t) { const uint64_t u = t? full(lo + t, yhi) : f; b = u < b? u : b; }
+                    for (int t = 0; t < o; ++t) { const uint64_t u = full(i0 + t, yhi); b = u < b? u : b; }
                     if (yhi == backF_keep) b = r_close < b? r_close : b;
-                    cl = yy != UINT64_MAX && (yy < b || (yy == b && (x >= b || f == b)));
+                    if (yy != UINT64_MAX && yy <= b) {
+                        const uint64_t x = full(lo - 1, yhi);
+                        cl = yy < b || x >= b || f == b;
+                    }
                 }
                 if (fhi <= fb && fhi <= yhi) {          // Open: f must not exceed anything else in the window
                     const int32_t ca = lo >> 3, tail0 = (ca + 1 + D) * C;
                     uint64_t b = UINT64_MAX;
-                    for (int32_t q = lo + 1; q < (ca + 1) * C; ++q) { const uint64_t u = m_ring[mi(q)]; b = u < b? u : b; }
-                    for (int32_t q = tail0; q < E; ++q) { const uint64_t u = m_ring[mi(q)]; b = u < b? u : b; }
+                    for (int32_t q = lo + 1; q < (ca + 1) * C; ++q) { const uint64_t u = full(q, fhi); b = u < b? u : b; }
+                    for (int32_t q = tail0; q < E; ++q) { const uint64_t u = full(q, fhi); b = u < b? u : b; }
                     if (fhi == fb) { const uint64_t u = ca == ((i0 - w) >> 3)? r0 : r1; b = u < b? u : b; }
                     op = f != UINT64_MAX && f <= b && f <= yy;
                 }

@@ -155,3 +155,98 @@ def tandem_repeat_reads(K, n_reads=240, flank=20000, unit_len=47, mean_len=6000,
         r = bytes(r)
         out.append(revcomp(r) if i % 2 else r)
     return out
+
+
+# ---- s-mers whose hashes share their TOP WORD but not their low word (r03h) ----
+# The fast scan kernel keeps the top 32 bits of every s-mer hash and hashes a position again when top words tie.  On random sequence two
+# different s-mers tie with probability 2^-32, so such pairs are built: the mixing function (syncmer.c:116-126) is a bijection on 2S bits and
+# is inverted here step by step.
+
+def hash64_py(x, bits):
+    M = (1 << bits) - 1
+    x = (~x + (x << 21)) & M
+    x ^= x >> 24
+    x = (x + (x << 3) + (x << 8)) & M
+    x ^= x >> 14
+    x = (x + (x << 2) + (x << 4)) & M
+    x ^= x >> 28
+    x = (x + (x << 31)) & M
+    return x
+
+
+def _unxorshift(y, s, bits):
+    x = y
+    for _ in range(bits // s + 1):
+        x = y ^ (x >> s)
+    return x
+
+
+def hash64_inverse(h, bits):
+    N = 1 << bits
+    x = h * pow((1 << 31) + 1, -1, N) % N
+    x = _unxorshift(x, 28, bits)
+    x = x * pow(21, -1, N) % N
+    x = _unxorshift(x, 14, bits)
+    x = x * pow(265, -1, N) % N
+    x = _unxorshift(x, 24, bits)
+    return (x + 1) * pow((1 << 21) - 1, -1, N) % N      # (~x + (x << 21)) = x (2^21 - 1) - 1
+
+
+def _code_to_smer(code, S):
+    return bytes(b"ACGT"[(code >> (2 * (S - 1 - i))) & 3] for i in range(S))
+
+
+def _rc_code(code, S):
+    r = 0
+    for i in range(S):
+        r = r << 2 | (3 - ((code >> (2 * i)) & 3))
+    return r
+
+
+def smers_with_top_word(top, n, S=31, start_low=0):
+    """n s-mers (no two equal neighbours, forward strand canonical) whose hashes are top << 32 | low, lows ascending"""
+    out, low = [], start_low
+    while len(out) < n:
+        low += 1
+        code = hash64_inverse(top << 32 | low, 2 * S)
+        f = [(code >> (2 * i)) & 3 for i in range(S)]
+        if any(f[i] == f[i + 1] for i in range(S - 1)) or code >= _rc_code(code, S):
+            continue
+        assert hash64_py(code, 2 * S) == (top << 32 | low)
+        out.append((low, _code_to_smer(code, S)))
+    return out
+
+
+def _implant(rng, n, items):
+    """homopolymer-free random read of n bases with the given (position, string) pairs written in; neighbours fixed so no run forms"""
+    b = bytearray(rand_nohp(rng, n))
+    for pos, sm in items:
+        b[pos:pos + len(sm)] = sm
+    for pos, sm in items:
+        for j in (pos - 1, pos + len(sm)):
+            if 0 <= j < n:
+                taken = {b[j - 1] if j > 0 else 0, b[j + 1] if j + 1 < n else 0}
+                if b[j] in taken:
+                    b[j] = next(c for c in b"ACGT" if c not in taken)
+    for i in range(n - 1):
+        assert b[i] != b[i + 1]
+    return bytes(b)
+
+
+def top_word_tie_reads(K, S=31, seed=99):
+    """reads in which window minima tie on their top word only: the pair at every distance around the window length, in both orders, with an exact
+    duplicate between them, on either strand, and next to the start of the read"""
+    rng = np.random.default_rng(seed)
+    w = K - S
+    sm = smers_with_top_word(3, 4, S)                      # four s-mers, hashes 3 << 32 | low, lows ascending
+    a, b_, c, d = (s for _, s in sm)
+    reads = []
+    for dist in (1, 5, 8, 33, 400, w - 9, w - 8, w - 7, w - 1, w, w + 1, w + 7, w + 8, w + 9, 2 * w - 3):
+        for first, second in ((a, b_), (b_, a), (a, a), (c, revcomp(d)), (revcomp(d), c)):
+            for p0 in (2600, 2048 - 15):
+                reads.append(_implant(rng, 7000, [(p0, first), (p0 + dist + (S if dist < S else 0), second)]))
+    for p0 in (3000, 4090):                                 # three in a window: smaller, equal, larger lows in every order
+        for trio in ((a, b_, a), (b_, a, b_), (b_, c, a), (a, a, a), (d, c, b_)):
+            reads.append(_implant(rng, 9000, [(p0, trio[0]), (p0 + 300, trio[1]), (p0 + 300 + w - 4, trio[2])]))
+    reads.append(_implant(rng, 5000, [(0, b_), (w - 2, a), (2 * w, b_)]))
+    return reads

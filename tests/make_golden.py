@@ -213,6 +213,11 @@ def align_cases():
     align_case("diploid_k101", T.diploid_reads(101, 6000, 150, 500, 1200, 0.006), 101, 11, 4)
 
 
+def topties_cases():
+    for K in (1001, 991):                     # K - S = 970 (window start off the chunk grid) and 960 (on it)
+        scan_count_case("topties_k%d_s31" % K, A.top_word_tie_reads(K), K, 31, threads=2)
+
+
 def main():
     if not R.available():
         sys.exit("oracle/_ref/liboatk_ref.so missing: run `make -C oracle ref` (needs /root/reference)")
@@ -221,6 +226,8 @@ def main():
         return asmgraph_cases()
     if "--align-only" in sys.argv:
         return align_cases()
+    if "--topties-only" in sys.argv:         # r03h: s-mer pairs whose hashes tie on the top word only (adversarial.top_word_tie_reads)
+        return topties_cases()
     for (K, S) in [(101, 11), (61, 15), (33, 31), (25, 5), (64, 16)]:
         scan_count_case("adversarial_k%d_s%d" % (K, S), A.reads(K, S, scale=0.5), K, S)
     scan_count_case("adversarial_k1001_s31", A.reads(1001, 31, scale=0.5), 1001, 31)
@@ -233,6 +240,7 @@ def main():
     ec_case("ec_hifi_k1001", A.hifi_like(120, 30000, 9000, seed=1009, err=0.0008), 1001, 31, 6)
     asmgraph_cases()
     align_cases()
+    topties_cases()
 
 
 if __name__ == "__main__":

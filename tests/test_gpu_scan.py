@@ -179,3 +179,13 @@ def test_long_low_complexity_reads(hip, K, S):
     want = O.scan(reads, K, S, mode=0)
     compare_scan(got, want)
     assert int(got["n_scm"].sum()) > 1000
+
+
+@pytest.mark.parametrize("K", [1001, 991, 561])
+def test_top_words_tie_between_different_smers(hip, K):
+    """r03h: the fast kernel's ring holds top words only and re-hashes a position from the packed bases when top words tie.  Exact tandem repeats
+    tie on the whole hash; here DIFFERENT s-mers share a top word (built by inverting the mixing function), at every distance around the window
+    length, in both orders, with exact duplicates between them and on either strand (goldens of the compiled reference: topties_k*)"""
+    reads = A.top_word_tie_reads(K)
+    got, _ = run_hip(hip, reads, K, 31)
+    compare_scan(got, O.scan(reads, K, 31, mode=0))
