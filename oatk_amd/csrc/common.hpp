@@ -34,6 +34,28 @@ __device__ __forceinline__ uint64_t hash64(uint64_t x, uint64_t mask)
     return x;
 }
 
+// The same function for S = 31 (62 bits), written on 32-bit halves for gfx950: the low word's products as 32 x 32 -> 64, the high word's share
+// added in 32 bits, and NO mask between the steps -- what a product leaves above bit 61 never comes down again, because the right shifts
+// take the high word's bits through bit-field extracts (v_alignbit / v_bfe / v_bitop3).  23 instructions against 27 (r03h); equal to hash64 on
+// 2 x 10^8 random arguments and the corner values on the host, and through every scan test on the device.
+__device__ __forceinline__ uint64_t hash64_s31(uint64_t x)
+{
+    uint32_t lo = (uint32_t) x, hi = (uint32_t) (x >> 32);
+    uint64_t p;
+    p = (uint64_t) lo * 0x1FFFFFu + 0xFFFFFFFFFFFFFFFFull;              // ~x + (x << 21) = x (2^21 - 1) - 1
+    hi = (uint32_t) (p >> 32) + (hi << 21) - hi, lo = (uint32_t) p;
+    { const uint32_t t = __builtin_amdgcn_alignbit(hi, lo, 24), u = __builtin_amdgcn_ubfe(hi, 24, 6); lo ^= t, hi ^= u; }
+    p = (uint64_t) lo * 265u;
+    hi = hi * 265u + (uint32_t) (p >> 32), lo = (uint32_t) p;
+    { const uint32_t t = __builtin_amdgcn_alignbit(hi, lo, 14), u = __builtin_amdgcn_ubfe(hi, 14, 16); lo ^= t, hi ^= u; }
+    p = (uint64_t) lo * 21u;
+    hi = hi * 21u + (uint32_t) (p >> 32), lo = (uint32_t) p;
+    { const uint32_t t = __builtin_amdgcn_alignbit(hi, lo, 28), u = __builtin_amdgcn_ubfe(hi, 28, 2); lo ^= t, hi ^= u; }
+    p = (uint64_t) lo * 0x80000001u;
+    hi = (hi + (uint32_t) (p >> 32)) & 0x3FFFFFFFu, lo = (uint32_t) p;
+    return (uint64_t) hi << 32 | lo;
+}
+
 // Reverse the order of the 32 two-bit groups of x and complement each (3 ^ c).
 __device__ __forceinline__ uint64_t revcomp32(uint64_t x)
 {

@@ -87,6 +87,9 @@ __device__ __forceinline__ void wave_prefix_suffix_min_u32(uint32_t v, uint32_t 
 }
 
 #define OATK_SYF_PADW(R) ((R) / 8)        // four pad words per 32 positions of the top-word ring
+#ifndef OATK_SYF_EXP
+#define OATK_SYF_EXP 0                    // timing experiments (development aid; results are wrong with any of them)
+#endif
 #ifndef OATK_SYF_WAVES
 #define OATK_SYF_WAVES 6                  // waves per SIMD the register allocation aims at (six workgroups of four waves per CU)
 #endif
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(NT, OATK_SYF_WAVES) void syncmer_fast_kernel(SynArg
         if (q + 1 < S || (uint32_t) q >= hl) return UINT64_MAX;
         const uint64_t X = get64g(q - S + 1) & (~0ULL << (64 - 2 * S));
         const uint64_t fw = X >> (64 - 2 * S), rv = revcomp32(X) & mask;
-        return (S31 || fw != rv)? hash64(fw < rv? fw : rv, mask) : UINT64_MAX;
+        return S31? hash64_s31(fw < rv? fw : rv) : (fw != rv? hash64(fw < rv? fw : rv, mask) : UINT64_MAX);
     };
     auto write_record = [&](int32_t E, uint32_t kind, uint32_t loc, uint32_t ordn) __attribute__((always_inline)) {
         const int32_t e = kind == 2u? E - w : E, j = E - K + 1;        // Open: first s-mer; Close: last s-mer
@@ -283,7 +286,13 @@ __global__ __launch_bounds__(NT, OATK_SYF_WAVES) void syncmer_fast_kernel(SynArg
                     fw = (fw << 2 | c) & mask;
                     rv = rv >> 2 | (3ULL ^ c) << (2 * S - 2);
                     // (S31: an odd-length s-mer is never its own reverse complement, so no fw != rv test)
-                    uint64_t mv = (S31 || fw != rv)? hash64(fw < rv? fw : rv, mask) : UINT64_MAX;
+#if OATK_SYF_EXP == 3
+                    uint64_t mv = ((fw < rv? fw : rv) * 0x9E3779B1ull) & mask;      // (timing experiment: one multiplication instead of the hash)
+#elif OATK_SYF_EXP == 4
+                    uint64_t mv = hash64_s31(fw);                   // (timing experiment: no canonical choice)
+#else
+                    uint64_t mv = S31? hash64_s31(fw < rv? fw : rv) : (fw != rv? hash64(fw < rv? fw : rv, mask) : UINT64_MAX);
+#endif
                     y[b] = (uint32_t) (mv >> 32);
                     cm = mv < cm? mv : cm;
                 }
@@ -295,7 +304,7 @@ __global__ __launch_bounds__(NT, OATK_SYF_WAVES) void syncmer_fast_kernel(SynArg
                     fw = (fw << 2 | c) & mask;
                     rv = rv >> 2 | (3ULL ^ c) << (2 * S - 2);
                     uint64_t mv = UINT64_MAX;
-                    if (i + 1 >= S && (uint32_t) i < hl && fw != rv) mv = hash64(fw < rv? fw : rv, mask);
+                    if (i + 1 >= S && (uint32_t) i < hl && fw != rv) mv = S31? hash64_s31(fw < rv? fw : rv) : hash64(fw < rv? fw : rv, mask);
                     y[b] = (uint32_t) (mv >> 32);
                     cm = mv < cm? mv : cm;
                 }
@@ -351,7 +360,11 @@ __global__ __launch_bounds__(NT, OATK_SYF_WAVES) void syncmer_fast_kernel(SynArg
 #pragma unroll
             for (int o = 0; o < C; ++o) {
                 const int q = o + sh;
+#if OATK_SYF_EXP == 2
+                const uint32_t fhi = y[(o + 3) & 7] | 0x40000000u;     // (timing experiment: no LDS reads of the first s-mers)
+#else
                 const uint32_t fhi = q < C? m_top[bA + (uint32_t) q] : m_top[bB + (uint32_t) (q - C)];
+#endif
                 const uint32_t yhi = y[o];
                 const uint32_t fb = o + sh < C? fwd0 : fwd1;
                 // (a MAX sentinel passes only when its whole window is MAX; the exact rule rejects it)
@@ -371,6 +384,9 @@ __global__ __launch_bounds__(NT, OATK_SYF_WAVES) void syncmer_fast_kernel(SynArg
         //      bits), so only the HW ragged positions at the two ends of the window remain -- a dozen top words each for Close
         //      and Open.  Top words that TIE (~2^-28 per candidate on random sequence, common inside low-complexity repeats) send
         //      the position to the full 64-bit rule. ----
+#if OATK_SYF_EXP == 1
+        cmask &= (uint32_t) -a.want_n;                  // (timing experiment: no candidate survives the filter)
+#endif
         uint32_t kinds = 0;                             // 2 bits per position of the chunk: 0 none, 1 Close, 2 Open
         // The wave decides its candidates TOGETHER, one after the other (there is about one per wave and tile): lanes 0-15 fetch the
         // ragged positions of the Close window, lanes 16-31 those of the Open window, lanes 32 / 33 the two hashes in question -- one
@@ -516,6 +532,9 @@ __global__ __launch_bounds__(NT, OATK_SYF_WAVES) void syncmer_fast_kernel(SynArg
         //      the counts of the other waves (ordinals), exchanged through LDS across the NEXT tile's barrier, and the record
         //      slots, from a returning atomic (an HBM round trip) that the next tile's hashing covers.  So a tile's records
         //      are written one tile late (the packed-base ring still holds its bases then). ----
+#if OATK_SYF_EXP == 5
+        kinds &= (uint32_t) -a.want_n;                  // (timing experiment: candidates are decided, none becomes a syncmer)
+#endif
         const uint32_t ns = (uint32_t) __builtin_popcount((kinds | kinds >> 1) & 0x5555u);
         const uint32_t incl = wave_incl_sum_dpp(ns, lane);
         const uint32_t wtot = (uint32_t) __builtin_amdgcn_readlane((int) incl, 63);
