@@ -313,22 +313,20 @@ static int launch_scan_kernels(oatk_hip_ctx *ctx)
     const bool small = ctx->K + 8 * SYN_NT + 8 + 64 <= 4096;
     const int fast_ring = ctx->force_general? 0 : syncmer_fast_ring(ctx->K, ctx->S);
     t_begin(ctx, OATK_T_SYNCMER);
-    if (fast_ring == 4096 && ctx->S == 31) {
+    if (fast_ring == 4096) {
         const dim3 g((unsigned) n), b(SYN_NT);
-        unsigned dyn = 0;                          // development aid: unused LDS on top of the kernel's own lowers its residency (3 workgroups per CU from 2600 bytes on, 2 from 16200)
+        unsigned dyn = 0;                          // development aid: unused LDS on top of the kernel's own lowers its residency
         { const char *ev = getenv("OATK_DEBUG_SYNCMER_LDS"); if (ev && atoi(ev) > 0) dyn = (unsigned) atoi(ev); }
-        switch ((-(ctx->K - ctx->S)) & 7) {        // one instantiation per alignment of the window start against the chunks of 8
-            case 0: hipLaunchKernelGGL((syncmer_fast_kernel<4096, true, SYN_NT, 0>), g, b, dyn, ctx->stream, s); break;
-            case 1: hipLaunchKernelGGL((syncmer_fast_kernel<4096, true, SYN_NT, 1>), g, b, dyn, ctx->stream, s); break;
-            case 2: hipLaunchKernelGGL((syncmer_fast_kernel<4096, true, SYN_NT, 2>), g, b, dyn, ctx->stream, s); break;
-            case 3: hipLaunchKernelGGL((syncmer_fast_kernel<4096, true, SYN_NT, 3>), g, b, dyn, ctx->stream, s); break;
-            case 4: hipLaunchKernelGGL((syncmer_fast_kernel<4096, true, SYN_NT, 4>), g, b, dyn, ctx->stream, s); break;
-            case 5: hipLaunchKernelGGL((syncmer_fast_kernel<4096, true, SYN_NT, 5>), g, b, dyn, ctx->stream, s); break;
-            case 6: hipLaunchKernelGGL((syncmer_fast_kernel<4096, true, SYN_NT, 6>), g, b, dyn, ctx->stream, s); break;
-            default: hipLaunchKernelGGL((syncmer_fast_kernel<4096, true, SYN_NT, 7>), g, b, dyn, ctx->stream, s); break;
-        }
+        // one instantiation per alignment of the window start against the chunks of 8 (the offsets of the decision's ring reads are constants)
+#define OATK_SYF_LAUNCH(S31, SH) hipLaunchKernelGGL((syncmer_fast_kernel<4096, S31, SYN_NT, SH>), g, b, dyn, ctx->stream, s)
+#define OATK_SYF_SWITCH(S31) switch ((-(ctx->K - ctx->S)) & 7) { \
+            case 0: OATK_SYF_LAUNCH(S31, 0); break; case 1: OATK_SYF_LAUNCH(S31, 1); break; case 2: OATK_SYF_LAUNCH(S31, 2); break; \
+            case 3: OATK_SYF_LAUNCH(S31, 3); break; case 4: OATK_SYF_LAUNCH(S31, 4); break; case 5: OATK_SYF_LAUNCH(S31, 5); break; \
+            case 6: OATK_SYF_LAUNCH(S31, 6); break; default: OATK_SYF_LAUNCH(S31, 7); break; }
+        if (ctx->S == 31) OATK_SYF_SWITCH(true) else OATK_SYF_SWITCH(false)
+#undef OATK_SYF_SWITCH
+#undef OATK_SYF_LAUNCH
     }
-    else if (fast_ring == 4096) hipLaunchKernelGGL((syncmer_fast_kernel<4096, false>), dim3((unsigned) n), dim3(SYN_NT), 0, ctx->stream, s);
     else if (small) hipLaunchKernelGGL((syncmer_kernel<8, 4096, false>), dim3((unsigned) n), dim3(SYN_NT), 0, ctx->stream, s);
     else hipLaunchKernelGGL((syncmer_kernel<16, 8192, false>), dim3((unsigned) n), dim3(SYN_NT), 0, ctx->stream, s);
     t_end(ctx, OATK_T_SYNCMER);

@@ -94,7 +94,7 @@ __device__ __forceinline__ void wave_prefix_suffix_min_u32(uint32_t v, uint32_t 
 #define OATK_SYF_WAVES 6                  // waves per SIMD the register allocation aims at (six workgroups of four waves per CU)
 #endif
 // SH: (-(K - S)) & 7 when known at compile time (the offsets of the Open filter's eight reads become immediates), -1 otherwise
-template <int R, bool S31, int NT = SYN_NT, int SH = -1>
+template <int R, bool S31, int NT, int SH>
 __global__ __launch_bounds__(NT, OATK_SYF_WAVES) void syncmer_fast_kernel(SynArgs a)
 {
     constexpr int C = SYF_C, T = NT * SYF_C, NCH = R / C, NWAVE = NT / OATK_WAVE;
@@ -263,6 +263,7 @@ __global__ __launch_bounds__(NT, OATK_SYF_WAVES) void syncmer_fast_kernel(SynArg
         const int32_t i0 = (int32_t) (I0 + tid * C);
         const int32_t ch = i0 / C;                      // chunk index; ch % 64 == lane
         uint32_t y[C];                                  // top words of the chunk's hashes
+        uint32_t cmin_keep;                             // top word of the chunk's minimum
         {
             const uint32_t a_hi = __builtin_amdgcn_perm(rw0, rw1, bsel), a_lo = __builtin_amdgcn_perm(rw1, rw2, bsel);   // bases i0 - 32 .. i0 - 1
             const uint32_t vbh = __builtin_amdgcn_perm(rw2, 0u, bsel);  // the chunk's 8 bases sit in the top half
@@ -310,6 +311,7 @@ __global__ __launch_bounds__(NT, OATK_SYF_WAVES) void syncmer_fast_kernel(SynArg
                 }
             }
             const uint32_t cmin = (uint32_t) (cm >> 32);
+            cmin_keep = cmin;
             uint32_t pre, suf;
 #ifdef OATK_SCAN_SHFL
             pre = suf = cmin;
@@ -334,8 +336,24 @@ __global__ __launch_bounds__(NT, OATK_SYF_WAVES) void syncmer_fast_kernel(SynArg
         __syncthreads();
         flush();                                        // the previous tile's records
 
-        // ---- P3: filter on 32-bit keys (straight-line code: 64 <= D <= 127 means at most ONE whole block inside a range) ----
-        uint32_t cmask = 0, backF_keep = 0, fwd0_keep = 0, fwd1_keep = 0;
+        // ---- P3: filter on 32-bit keys (straight-line code: 64 <= D <= 127 means at most ONE whole block inside a range), and the decision.
+        //
+        // The window of the k-mer that ends at E = i0 + o starts at lo = E - w, and w = 8 (D + 1) + r.  Close compares M[E] with
+        //      [lo, E - 1]  =  the rest of lo's chunk from lo on  (+ one whole chunk when o < r)  +  D whole chunks  +  the lane's own [i0, E)
+        // and Open compares M[lo] with
+        //      (lo, E - 1]  =  the rest of lo's chunk behind lo  +  D whole chunks  (+ the chunk before the lane's own when o < r)  +  [i0, E).
+        // The D whole chunks are a range minimum over the prefix / suffix arrays, the lane's own positions are in registers, and the two chunks
+        // the eight windows start in are sixteen ring entries -- four 16-byte reads at offsets that are compile-time constants -- that serve all
+        // eight positions, for Close and for Open ("the rest of a chunk from lo on" is a minimum over registers with constant indices).  So every
+        // lane decides its own positions in straight-line code on top words; what is left for the tie path is a top word EQUAL to the minimum it
+        // is compared with.
+        // (Until r03h a filter picked ~1 candidate per wave and tile and the wave then decided its candidates one after the other, sixteen lanes
+        //  fetching the ragged ends of one window: 11.5 % of the kernel's time for two positions in a thousand, profiles/r03i_b_phase_experiments.txt.)
+        static_assert(SH >= 0 && SH < C, "the window's alignment against the chunks is a template argument");
+        constexpr int RR = (C - SH) & (C - 1);          // r = w mod 8
+        uint32_t backF_keep = 0, fwd0_keep = 0, fwd1_keep = 0;
+        uint32_t kinds = 0;                             // 2 bits per position of the chunk: 0 none, 1 Close, 2 Open
+        uint32_t tiemask = 0;
         {
             // minimum of the chunk minima over chunks [lo, hi], hi - lo = D - 1: suffix of lo's block, prefix of hi's block and,
             // when the two are not adjacent, the one whole block between them.  Chunks before the read map to ring slots that
@@ -347,131 +365,64 @@ __global__ __launch_bounds__(NT, OATK_SYF_WAVES) void syncmer_fast_kernel(SynArg
                 const uint32_t v = a0 < a1? a0 : a1;
                 return a2 < v? a2 : v;
             };
-            const int32_t a_first = i0 - w;             // first s-mer of the k-mer that ends at i0
-            const int32_t ca0 = a_first >> 3;
-            const int sh = SH >= 0? SH : ((-w) & (C - 1));   // = a_first & 7, the same for every lane
             const uint32_t backF = range_min(rB);            // Close bound: chunks [ch - D, ch - 1]
             const uint32_t fwd0 = range_min(rF0);            // Open bound, first s-mers ending in chunk ca0: chunks [ca0 + 1, ca0 + D]
             const uint32_t fwd1 = range_min(rF1);            // ... and in chunk ca0 + 1: chunks [ca0 + 2, ca0 + 1 + D]
-            // the eight first s-mers sit in chunks ca0 (from offset sh) and ca0 + 1: two base addresses, constant offsets
-            const uint32_t bA = m_fa, bB = m_fb;
             backF_keep = backF, fwd0_keep = fwd0, fwd1_keep = fwd1;
-            uint32_t hit = 0;
+            // W[j] = top word of position lo(o = 0) + j: chunk ca0 from offset SH on (j < BD), then chunk ca0 + 1
+            constexpr int BD = RR? RR : C;              // index of the first position of the second chunk
+            uint32_t W[2 * C];
+            {
+                const uint4 a0 = *(const uint4 *) (m_top + m_fa), a1 = *(const uint4 *) (m_top + m_fa + 4);
+                const uint4 b0 = *(const uint4 *) (m_top + m_fb), b1 = *(const uint4 *) (m_top + m_fb + 4);
+                const uint32_t all[2 * C] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int j = 0; j < 2 * C - SH; ++j) W[j] = all[SH + j];
+            }
+            // the minimum of the chunk before the lane's own (Open with o < r): the neighbour lane's, or for lane 0 the last chunk of the wave before
+            uint32_t cprev = 0xFFFFFFFFu;
+            if (RR > 0) {
+                const uint32_t nb = dpp_u32<0x138>(0xFFFFFFFFu, cmin_keep);                   // wave_shr:1
+                const uint32_t lb = ld32(suf32, (o_cs - 4u) & (uint32_t) (NCH * 4 - 1));         // (the suffix minimum of a block's last chunk is that chunk's own)
+                cprev = lane == 0? lb : nb;
+            }
+            // per position: a cheap necessary condition (three instructions, the result stays in a scalar register pair), and the rule itself
+            // only where some lane of the wave passes it -- about one position per wave and tile on random sequence
+            const bool edge = __ballot(!(i0 + 1 >= K && (uint32_t) (i0 + C) <= hl)) != 0;      // k-mers that do not fit the read: E + 1 < K, E >= hoco_l
 #pragma unroll
             for (int o = 0; o < C; ++o) {
-                const int q = o + sh;
-#if OATK_SYF_EXP == 2
-                const uint32_t fhi = y[(o + 3) & 7] | 0x40000000u;     // (timing experiment: no LDS reads of the first s-mers)
-#else
-                const uint32_t fhi = q < C? m_top[bA + (uint32_t) q] : m_top[bB + (uint32_t) (q - C)];
-#endif
-                const uint32_t yhi = y[o];
-                const uint32_t fb = o + sh < C? fwd0 : fwd1;
-                // (a MAX sentinel passes only when its whole window is MAX; the exact rule rejects it)
-                hit |= (uint32_t) ((yhi <= backF) | ((fhi <= fb) & (fhi <= yhi))) << o;
-            }
-            // k-mers that do not fit the read: E + 1 < K at the start, E >= hoco_l at the end
-            if (hit) {
-                if (i0 + 1 >= K && (uint32_t) (i0 + C) <= hl) cmask = hit;
-                else {
-#pragma unroll
-                    for (int o = 0; o < C; ++o)
-                        if ((uint32_t) (i0 + o) < hl && i0 + o + 1 >= K) cmask |= hit & (1u << o);
-                }
-            }
-        }
-        // ---- exact decision.  The filter already proved that the D whole chunks of the window hold nothing smaller (top 32
-        //      bits), so only the HW ragged positions at the two ends of the window remain -- a dozen top words each for Close
-        //      and Open.  Top words that TIE (~2^-28 per candidate on random sequence, common inside low-complexity repeats) send
-        //      the position to the full 64-bit rule. ----
+                const uint32_t yhi = y[o], fhi = W[o];
+                const uint32_t fb = o + SH < C? fwd0 : fwd1;
+                const uint32_t fy = fb < yhi? fb : yhi;
+                bool c = (yhi <= backF) | (fhi <= fy);
+                if (edge) c = c && (uint32_t) (i0 + o) < hl && i0 + o + 1 >= K;
 #if OATK_SYF_EXP == 1
-        cmask &= (uint32_t) -a.want_n;                  // (timing experiment: no candidate survives the filter)
+                c = c && a.want_n;                      // (timing experiment: nothing survives the filter)
 #endif
-        uint32_t kinds = 0;                             // 2 bits per position of the chunk: 0 none, 1 Close, 2 Open
-        // The wave decides its candidates TOGETHER, one after the other (there is about one per wave and tile): lanes 0-15 fetch the
-        // ragged positions of the Close window, lanes 16-31 those of the Open window, lanes 32 / 33 the two hashes in question -- one
-        // LDS read per lane, one row-wise DPP min, and the rest is scalar.  (A lone lane walking the same thirty positions cost the
-        // wave ~200 issue slots per candidate; this costs ~40.)
-        uint32_t tiemask = 0;
-        {
-            const int sh = SH >= 0? SH : ((-w) & (C - 1));
-            const uint32_t wbase = I0 + (uint32_t) __builtin_amdgcn_readfirstlane((int) wid) * (OATK_WAVE * C);
-            uint64_t cand = __ballot(cmask != 0);
-            if (__builtin_popcountll(cand) > 4) {
-                // Many lanes with candidates: not random sequence (there it is one lane per wave and tile) but a tandem repeat, where the
-                // window minimum returns every period.  Taking turns would cost the wave ~60 issue slots per candidate; here every lane
-                // walks the ragged ends of its own windows -- the same arithmetic, all lanes at once.
-                cand = 0;
-                uint32_t mm = cmask, res = 0, ties = 0;
-                const int32_t ci0 = i0;
-                while (mm) {
-                    const int o = __builtin_ctz(mm);
-                    mm &= mm - 1;
-                    const int32_t E = ci0 + o, lo = E - w;
-                    const int32_t ca = lo >> 3, n1 = (ca + 1) * C - lo - 1, tail0 = (ca + 1 + D) * C, n2 = E - tail0;
-                    const uint32_t yhi = m_top[mi(E)], fhi = m_top[mi(lo)];
-                    const uint32_t fb = o + sh < C? fwd0_keep : fwd1_keep;
-                    bool cl = false, op = false, tie = false;
-                    if (yhi <= backF_keep) {                                             // Close: head [lo, lo + HW - o) + tail [i0, E)
-                        uint32_t cmin = 0xFFFFFFFFu;
-                        for (int32_t t = 0; t < HW - o; ++t) { const uint32_t u = m_top[mi(lo + t)]; cmin = u < cmin? u : cmin; }
-                        for (int32_t t = 0; t < o; ++t) { const uint32_t u = m_top[mi(ci0 + t)]; cmin = u < cmin? u : cmin; }
-                        const uint32_t bh = cmin < backF_keep? cmin : backF_keep;
-                        cl = yhi < bh, tie = yhi == bh;
+                if (__ballot(c)) {
+                    uint32_t pmin = 0xFFFFFFFFu;        // the lane's own positions before E
+#pragma unroll
+                    for (int j = 0; j < o; ++j) pmin = y[j] < pmin? y[j] : pmin;
+                    const int cend = o < BD? BD - 1 : BD + C - 1;       // last position of lo's chunk
+                    uint32_t rest = 0xFFFFFFFFu;                        // lo's chunk behind lo
+#pragma unroll
+                    for (int j = o + 1; j <= cend; ++j) rest = W[j] < rest? W[j] : rest;
+                    // Close: M[E] against the window's minimum
+                    uint32_t head = fhi < rest? fhi : rest;             // lo's chunk from lo on ...
+                    if (o < RR) {                                       // ... and the whole chunk behind it
+#pragma unroll
+                        for (int j = RR; j < RR + C; ++j) head = W[j] < head? W[j] : head;
                     }
-                    if (fhi <= fb && fhi <= yhi) {                                       // Open: rest of f's chunk + [tail0, E)
-                        uint32_t omin = 0xFFFFFFFFu;
-                        for (int32_t t = 0; t < n1; ++t) { const uint32_t u = m_top[mi(lo + 1 + t)]; omin = u < omin? u : omin; }
-                        for (int32_t t = 0; t < n2; ++t) { const uint32_t u = m_top[mi(tail0 + t)]; omin = u < omin? u : omin; }
-                        const uint32_t rh = omin < fb? omin : fb;
-                        op = fhi < rh && fhi < yhi, tie |= fhi <= rh && !op;
-                    }
-                    ties |= (uint32_t) tie << o;
-                    res |= (tie? 0u : (cl && op? 0u : (cl? 1u : (op? 2u : 0u)))) << (2 * o);
+                    const uint32_t hb = head < backF? head : backF, bh = hb < pmin? hb : pmin;
+                    const bool cl = yhi < bh, tie_c = yhi == bh;
+                    // Open: M[lo] against everything else in the window and M[E]
+                    const uint32_t tailp = o < RR? (cprev < pmin? cprev : pmin) : pmin;
+                    const uint32_t rf = rest < fb? rest : fb, rh = rf < tailp? rf : tailp;
+                    const bool le = fhi <= rh && fhi <= yhi, op = fhi < rh && fhi < yhi;
+                    const bool tie = tie_c || (le && !op);
+                    const uint32_t k = tie? 0u : (cl && op? 0u : (cl? 1u : (op? 2u : 0u)));
+                    if (c) kinds |= k << (2 * o), tiemask |= (tie? 1u : 0u) << o;
                 }
-                kinds = res, tiemask = ties;
-            }
-            while (cand) {
-                const int L = __builtin_ctzll(cand);
-                cand &= cand - 1;
-                uint32_t mm = (uint32_t) __builtin_amdgcn_readlane((int) cmask, L);
-                const uint32_t cbackF = (uint32_t) __builtin_amdgcn_readlane((int) backF_keep, L);
-                const uint32_t cf0 = (uint32_t) __builtin_amdgcn_readlane((int) fwd0_keep, L), cf1 = (uint32_t) __builtin_amdgcn_readlane((int) fwd1_keep, L);
-                const int32_t ci0 = (int32_t) (wbase + (uint32_t) L * C);
-                uint32_t res = 0, ties = 0;
-                while (mm) {
-                    const int o = __builtin_ctz(mm);
-                    mm &= mm - 1;
-                    const int32_t E = ci0 + o, lo = E - w;
-                    const int32_t ca = lo >> 3, n1 = (ca + 1) * C - lo - 1, tail0 = (ca + 1 + D) * C, n2 = E - tail0;
-                    const int32_t t = (int32_t) (lane & 15u);
-                    int32_t pos = E;
-                    bool valid = false;
-                    if (lane < 16) valid = t < HW, pos = t < HW - o? lo + t : ci0 + (t - (HW - o));          // Close: head [lo, lo + HW - o) + tail [i0, E)
-                    else if (lane < 32) valid = t < n1 + n2, pos = t < n1? lo + 1 + t : tail0 + (t - n1);     // Open: rest of f's chunk + [tail0, E)
-                    else if (lane == 33) pos = lo;
-                    const uint32_t u = m_top[mi(pos)];
-                    const uint32_t yhi = (uint32_t) __builtin_amdgcn_readlane((int) u, 32), fhi = (uint32_t) __builtin_amdgcn_readlane((int) u, 33);
-                    uint32_t v = valid? u : 0xFFFFFFFFu, x;
-                    x = dpp_u32<OATK_DPP_ROW_SHR(1)>(0xFFFFFFFFu, v); v = x < v? x : v;
-                    x = dpp_u32<OATK_DPP_ROW_SHR(2)>(0xFFFFFFFFu, v); v = x < v? x : v;
-                    x = dpp_u32<OATK_DPP_ROW_SHR(4)>(0xFFFFFFFFu, v); v = x < v? x : v;
-                    x = dpp_u32<OATK_DPP_ROW_SHR(8)>(0xFFFFFFFFu, v); v = x < v? x : v;
-                    const uint32_t cmin = (uint32_t) __builtin_amdgcn_readlane((int) v, 15), omin = (uint32_t) __builtin_amdgcn_readlane((int) v, 31);
-                    const uint32_t fb = o + sh < C? cf0 : cf1;
-                    bool cl = false, op = false, tie = false;
-                    if (yhi <= cbackF) {
-                        const uint32_t bh = cmin < cbackF? cmin : cbackF;                // top word of the window minimum
-                        cl = yhi < bh, tie = yhi == bh;
-                    }
-                    if (fhi <= fb && fhi <= yhi) {
-                        const uint32_t rh = omin < fb? omin : fb;                        // top word of the minimum of everything in the window but f
-                        op = fhi < rh && fhi < yhi, tie |= fhi <= rh && !op;
-                    }
-                    ties |= (uint32_t) tie << o;
-                    res |= (tie? 0u : (cl && op? 0u : (cl? 1u : (op? 2u : 0u)))) << (2 * o);
-                }
-                if ((int) lane == L) kinds = res, tiemask = ties;
             }
         }
         // Top words tied: ~2^-28 per candidate on random sequence, but the rule rather than the exception inside tandem repeats
@@ -481,7 +432,7 @@ __global__ __launch_bounds__(NT, OATK_SYF_WAVES) void syncmer_fast_kernel(SynArg
         // whose top word is EQUAL is hashed again from the read's packed bases (`hash_at`; in a repeat of period p that is one ragged
         // position in p); and the whole chunks of a window come from the 64-bit chunk minima the hashing phase leaves in `c_min`.
         if (__ballot(tiemask != 0)) {
-            const int sh = SH >= 0? SH : ((-w) & (C - 1));
+            constexpr int sh = SH;
             auto full = [&](int32_t q, uint32_t ref) -> uint64_t {
                 const uint32_t t = m_top[mi(q)];
                 return t == ref? hash_at(q) : (uint64_t) t << 32;
