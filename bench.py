@@ -597,11 +597,11 @@ def main():
                     "share_of_step": round(phase_ms[dom] / (dt / args.steps * 1e3), 3),
                     "note": "kernel B reads 0.25 B and hashes one 31-mer per hoco position: it is integer-VALU issue bound, not HBM bound (DESIGN.md 5); "
                             "`valu` prices it against the bound that binds",
-                    # wave-instructions issued (PMC count per 64 positions, profiles/) against 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction
-                    "valu": {"achieved": round(valu_rate, 1), "peak": 614.4, "unit": "G wave-instr/s",
-                             "frac": round(valu_rate / 614.4, 3), "valu_per_64_positions": valu_per_64,
-                             # the same against the ceiling of THIS opcode mix: 1024 SIMDs x 2.4 GHz / (mix-weighted cycles per instruction)
-                             "cycles_per_instr_mix": cpi, "peak_mix": round(1024 * 2.4 / cpi, 1), "frac_mix": round(valu_rate * cpi / (1024 * 2.4), 3),
+                    # wave-instructions issued (PMC count per 64 positions, profiles/) against the issue ceiling of THIS opcode mix: 1024 SIMDs x 2.4 GHz /
+                    # (cycles per instruction weighted by the mix, per-opcode rates measured on the box).  (Up to r03g a second figure priced every
+                    # instruction at a flat four cycles; the kernel has since run at 1.12 of that "peak", which settles what it was worth.)
+                    "valu": {"achieved": round(valu_rate, 1), "peak": round(1024 * 2.4 / cpi, 1), "unit": "G wave-instr/s",
+                             "frac": round(valu_rate * cpi / (1024 * 2.4), 3), "valu_per_64_positions": valu_per_64, "cycles_per_instr_mix": cpi,
                              "mix_source": os.path.basename(mix_files[-1]) if mix_files else None},
                     "scan_bytes_per_base": round((alg_bytes["hpc"] + 28 * n_occ) / bases, 4),
                     # the scan of SURVEY.md 8(d) is kernel A + kernel B + the k-mer hash
@@ -639,8 +639,8 @@ def main():
         dist.destroy_process_group()
 
 
-# VALU wave-instructions kernel B issues per 64 hoco positions (profiles/r02l_pmc_scan.csv, the same in r02c: SQ_INSTS_VALU 545.07 M over 450 M positions; updated with every PMC pass)
-VALU_PER_64 = 77.5
+# VALU wave-instructions kernel B issues per 64 hoco positions (profiles/r03k_pmc_scan.csv: SQ_INSTS_VALU 543.13 M over 450 M positions; 545.07 M = 77.5 in r02l / r03e; updated with every PMC pass)
+VALU_PER_64 = 77.2
 
 if __name__ == "__main__":
     main()
