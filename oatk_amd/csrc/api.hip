@@ -301,7 +301,9 @@ static int launch_scan_kernels(oatk_hip_ctx *ctx)
                                                               // (config 3: 2048 workgroups 20.4 ms, 8192 17.0, 32768 16.5, one per read 17.4)
     { const char *ev = getenv("OATK_DEBUG_HPC_GRID"); if (ev && atoi(ev) > 0) hpc_grid = (uint64_t) atoi(ev); }
     if (hpc_grid > n) hpc_grid = n;
-    hipLaunchKernelGGL(hpc_pack_kernel, dim3((unsigned) (hpc_grid? hpc_grid : 1)), dim3(HPC_NT), 0, ctx->stream, h);
+    unsigned hpc_dyn = 0;                          // development aid: unused LDS on top of the kernel's own lowers its residency (8 workgroups per CU without)
+    { const char *ev = getenv("OATK_DEBUG_HPC_LDS"); if (ev && atoi(ev) > 0) hpc_dyn = (unsigned) atoi(ev); }
+    hipLaunchKernelGGL(hpc_pack_kernel, dim3((unsigned) (hpc_grid? hpc_grid : 1)), dim3(HPC_NT), hpc_dyn, ctx->stream, h);
     t_end(ctx, OATK_T_HPC);
 
     SynArgs s;

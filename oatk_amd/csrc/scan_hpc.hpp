@@ -32,6 +32,9 @@
 
 namespace oatk {
 
+#ifndef OATK_HPC_EXP
+#define OATK_HPC_EXP 0                    // timing experiments (development aid; results are wrong with any of them)
+#endif
 constexpr int HPC_NT = 256;
 constexpr int HPC_BPT = 16;
 constexpr int HPC_TILE = HPC_NT * HPC_BPT;
@@ -206,6 +209,14 @@ __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
         if (b0 + HPC_TILE < L) vnext = *(const uint4 *) (in + b0 + HPC_TILE);      // next tile's bytes, in flight while this one is processed
         if (lane == 0 && b0 + HPC_TILE <= L) upnext = in[b0 + HPC_TILE - 1];
         const int nvalid = b0 < L? (int) (L - b0 < (uint32_t) HPC_BPT? L - b0 : (uint32_t) HPC_BPT) : 0;
+#if OATK_HPC_EXP == 1
+        // (timing experiment: the kernel's HBM traffic and nothing else -- 16 bytes in, 12 bytes of "run lengths" and 3 of "codes" out per lane)
+        if (b0 < L) {
+            *(uint3 *) (out_rl + (size_t) (b0 / 16) * 12) = make_uint3(v.x, v.y, v.z);
+            if ((tid & 3) == 0) *(uint3 *) (out_hs + (size_t) (b0 / 64) * 12) = make_uint3(v.w, v.x, v.y);
+        }
+        continue;
+#endif
 
         uint32_t smask = 0;       // run starts among the lane's sixteen positions
         uint32_t pf = 0;          // sixteen 2-bit fields: the code of the byte BEFORE position b in field b
@@ -375,6 +386,9 @@ __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
                     const uint32_t l0 = (uint32_t) L0, l1 = (uint32_t) (L0 >> 32) | (uint32_t) L1, l2 = (uint32_t) (L1 >> 32);
                     const uint32_t g0 = (uint32_t) H0, g1 = (uint32_t) (H0 >> 32) | (uint32_t) H1, g2 = (uint32_t) (H1 >> 32);
                     const uint32_t ab = h0 & (uint32_t) (HPC_RING - 1) & ~3u;                              // byte address of the first word
+#if OATK_HPC_EXP == 2
+                    if (a.n_reads == 0xFFFFFFFFu)               // (timing experiment: no run lengths into the ring)
+#endif
                     if (ab <= (uint32_t) HPC_RING - 24u) {                                                 // (five words at most)
                         uint32_t *pl = (uint32_t *) ((char *) ring_rl4 + ab), *ph = (uint32_t *) ((char *) ring_rl4 + ab + q4);
                         atomicOr(pl, l0), atomicOr(pl + 1, l1), atomicOr(pl + 2, l2);
@@ -406,6 +420,9 @@ __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
         nstart += tot;
         last_start = tmax;
         const uint32_t done = nstart? (nstart - 1u) >> 6 : 0u;   // complete 64-groups among finished runs
+#if OATK_HPC_EXP == 3
+        if (a.n_reads == 0xFFFFFFFFu)                           // (timing experiment: nothing leaves the rings)
+#endif
         flush(flushed, done);
         flushed = done;
         // (no barrier here: the next tile writes to the rings only behind ITS first barrier, which every wave reaches after this flush; what it

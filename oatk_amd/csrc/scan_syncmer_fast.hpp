@@ -5,27 +5,28 @@
 // issuing ~1500 VALU wave-instructions per 2048-position tile per wave (486 of them in the unavoidable s-mer
 // hashing).  Here:
 //
-//  * the window decision sits behind a NECESSARY condition that costs two 32-bit compares per position:
-//      Close at k-mer end E needs  M[E]   <= every hash in [E-w, E-1]  -> in particular <= the D chunk minima before E's chunk
-//      Open  at k-mer end E needs  M[E-w] <= every hash in (E-w, E-1]  -> in particular <= the D chunk minima after (E-w)'s chunk
-//    (D = w/8 - 1 = 120 chunks of 8 at K=1001).  Only the top 32 bits of the hashes take part; the bounds come from
-//    one wave-level prefix-min and suffix-min over 32-bit keys done with DPP row shifts + v_readlane (VALU only, no
-//    LDS round trips).  About one position in 480 survives, and nearly every survivor IS a syncmer (closed syncmers have
-//    density 2/(w+1) = 1/486): the filter is almost the rule.
-//  * the exact rule for a survivor only needs the w - 8 D = 8..15 ragged positions at either end of its window (the filter has
-//    compared against the D whole chunks), and on top words alone unless they tie.  On random sequence there is about one survivor
-//    per wave and tile and the whole wave decides it: lanes 0-15 fetch the ragged positions of the Close window, lanes 16-31 those
-//    of the Open window, one row-wise DPP minimum, scalar logic.  Inside a tandem repeat nearly every lane holds survivors (the
-//    window minimum returns every period); then every lane walks the ragged ends of its own windows, all lanes at once.
-//  * top words that tie send a position to the rule on full 64-bit hashes, lane by lane.  The 64-bit minima of whole chunks it needs
-//    are not kept resident (4 KB of LDS that cost the fourth workgroup per CU): the wave computes them for the 192 chunks around
-//    its own when it meets its first tie and parks them in ring slots older than every window of the tile.
+//  * a window of w = K - S = 8 (D + 1) + r positions is D WHOLE chunks of 8 plus ragged ends.  The whole chunks are a range minimum over
+//    per-chunk minima (one wave-level prefix-min and suffix-min over 32-bit keys per tile, DPP row shifts + v_readlane, no LDS round trips;
+//    64 <= D <= 127 means at most one whole block of 64 chunks inside a range); the ragged ends are the lane's own positions (registers) and
+//    the two chunks the lane's eight windows start in -- sixteen ring entries, four 16-byte LDS reads at compile-time offsets.  Only the top 32
+//    bits of the hashes take part.
+//  * every lane decides its own eight positions in straight-line code: per position a three-instruction necessary condition
+//      Close at k-mer end E needs  M[E]   <= the D chunk minima before E's chunk
+//      Open  at k-mer end E needs  M[E-w] <= the D chunk minima after (E-w)'s chunk, and <= M[E]
+//    whose result stays in a scalar register pair, and the exact rule (~18 instructions: minima over registers with constant indices)
+//    only for the positions where some lane of the wave passes it -- about one per wave and tile on random sequence (closed syncmers have
+//    density 2/(w+1) = 1/486), every position inside a tandem repeat, at the same price per position.  (Until r03h the wave decided its
+//    candidates together, one after the other: 11.5 % of the kernel's time for two positions in a thousand.)
+//  * the ring holds TOP WORDS only (16 KB + pad words; whole hashes were 33 KB and four workgroups per CU).  Top words that tie send a
+//    position to the rule on full 64-bit hashes, lane by lane: a value whose top word equals the one it is compared with is hashed again from the
+//    read's packed bases, and the whole chunks of the window come from 64-bit chunk minima the hashing phase leaves in a 4 KB ring.
 //  * syncmers are appended to a per-read list in LDS at positions that follow from the waves' counts alone (no atomics, position
 //    order, index = ordinal) and become records when the read is done: one record-slot atomic per read.  A tile has two workgroup
 //    barriers, placed so that the s-mer hashing of the next tile (registers only) overlaps with the slower waves' decisions on this one.
-//  * what bounds it: integer VALU issue at four workgroups per CU (40.5 KB of LDS each); ~79 VALU wave-instructions per position, 41 of
-//    them the rolling canonical s-mer and hash64.  Ring addresses alternate between two values per lane (a tile is half the ring) and
-//    are toggled, not recomputed; end-of-read special cases are decided per wave, not per lane.  DESIGN.md 5 has the measurements.
+//  * what bounds it: 27.2 KB of LDS and 80 registers let six workgroups onto a CU; 77 VALU wave-instructions per position, 39 of them
+//    the rolling canonical s-mer and hash64, at 0.95 of the issue ceiling of that opcode mix.  Ring addresses alternate between two values per
+//    lane (a tile is half the ring) and are toggled, not recomputed; end-of-read special cases are decided per wave, not per lane.
+//    DESIGN.md 5 has the measurements.
 //  * selected syncmers leave as (sid|ordinal|rev, s-mer code, pos) records; their 251-byte k-mers are hashed
 //    afterwards by kmer_hash_kernel (one lane per syncmer) instead of by a lone lane inside this kernel.
 #pragma once
@@ -38,7 +39,6 @@ namespace oatk {
 constexpr int SYF_C = 8;                 // positions per lane per tile (one chunk)
 constexpr int SYF_T = SYN_NT * SYF_C;    // 2048 positions per tile
 constexpr int SYF_BLK = 64;              // chunks per wave = block of the prefix/suffix minima
-constexpr int SYF_SEG = 64;              // candidate slots per wave per round
 constexpr int SYF_LIST = 128;            // syncmers a read collects in LDS before they become records (a 15 kb read has ~25)
 
 // ring size (positions) the fast kernel needs for this K, or 0 if it does not apply

@@ -189,3 +189,19 @@ def test_top_words_tie_between_different_smers(hip, K):
     reads = A.top_word_tie_reads(K)
     got, _ = run_hip(hip, reads, K, 31)
     compare_scan(got, O.scan(reads, K, 31, mode=0))
+
+
+@pytest.mark.parametrize("K,S", [(1000, 30), (800, 20), (904, 27), (1024, 24), (601, 15), (1060, 31), (700, 17)])
+def test_fast_kernel_other_s_and_every_window_alignment(hip, K, S):
+    """r03j: the fast kernel's decision reads the ring at offsets fixed by (K - S) mod 8 -- one instantiation per alignment, for S = 31 and for any
+    other S (even S: s-mers that are their own reverse complement; S <= 16: hashes without a top word, where every comparison goes to the 64-bit rule)"""
+    rng = np.random.default_rng(K * 31 + S)
+    w = K - S
+    reads = A.hifi_like(12, 30000, 9000, seed=K + S) + A.reads(K, S, seed=5, scale=0.3)[:20]
+    for unit_len in (2, 7, S, w - 1, w + 1):
+        unit = A.rand_nohp(rng, unit_len)
+        reads.append(A.rand_nohp(rng, 1500) + (unit * (9000 // unit_len + 2))[:9000] + A.rand_nohp(rng, 1200))
+    pal = A.rand_nohp(rng, S // 2)
+    reads.append(A.rand_nohp(rng, 3000) + pal + A.revcomp(pal) + A.rand_nohp(rng, 3000))       # an even-length s-mer equal to its reverse complement
+    got, _ = run_hip(hip, reads, K, S)
+    compare_scan(got, O.scan(reads, K, S, mode=1))
