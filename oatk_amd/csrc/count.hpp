@@ -162,7 +162,10 @@ __global__ void regather_kernel(GroupArgs a)
 #ifndef OATK_VG_STRIP
 #define OATK_VG_STRIP 8
 #endif
-__global__ __launch_bounds__(256) void verify_group_kernel(GroupArgs a, uint32_t *bad_head)
+#ifndef OATK_VFY_WAVES
+#define OATK_VFY_WAVES 1
+#endif
+__global__ __launch_bounds__(256, OATK_VFY_WAVES) void verify_group_kernel(GroupArgs a, uint32_t *bad_head)
 {
     const uint32_t hl = threadIdx.x & 31, half0 = threadIdx.x & 32;       // lane in the half wave; first lane of the half wave within the wave
     const uint32_t i0 = (uint32_t) OATK_VG_STRIP * (blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5));

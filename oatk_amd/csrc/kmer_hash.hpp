@@ -37,7 +37,10 @@ __device__ __forceinline__ uint32_t kmh_rev_in_bytes(uint32_t x)
     return ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
 }
 
-__global__ __launch_bounds__(64) void kmer_hash_kernel(KmerHashArgs a)
+#ifndef OATK_KMH_WAVES
+#define OATK_KMH_WAVES 8                 // waves per SIMD the register allocation aims at: the kernel is a chain of dependent gathers, its rate is records in flight (r03m, 400 k reads: 0.94 ms at five waves, 0.60 at eight)
+#endif
+__global__ __launch_bounds__(64, OATK_KMH_WAVES) void kmer_hash_kernel(KmerHashArgs a)
 {
     extern __shared__ uint64_t kmix[];          // KMH_REC records x (NW + 1)
     const uint32_t lane = threadIdx.x, rr = lane >> 2, q = lane & 3u;
