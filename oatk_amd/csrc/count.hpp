@@ -129,6 +129,55 @@ __global__ void pack_slots_kernel(GroupArgs a)
     a.slot_rec[2 * (size_t) p + 1] = make_uint4((uint32_t) loc, (uint32_t) (loc >> 32), 0u, 0u);
 }
 
+// The sort of the k-mer hashes looks at their top 40 bits only (five radix passes instead of eight: 42 M records at config 3, 0.36 ms per pass).
+// Two DIFFERENT hashes share 40 bits about n_distinct^2 / 2^41 times per batch -- a handful of runs -- and then their records sit interleaved,
+// in slot order.  These two kernels finish the order there: every position where the hash changes inside a run of equal top bits reports to
+// the run's start, and the smallest such position of a run sorts it (stable insertion sort of keys and permutation; runs are a few coverages
+// long).  A run longer than OATK_SORT_REPAIR_MAX sets flags[3] and the host sorts again on all 64 bits.
+#define OATK_SORT_LOW_BITS 24
+#define OATK_SORT_REPAIR_MAX 4096u
+__device__ __forceinline__ bool sort_repair_boundary(const uint64_t *key, uint32_t n, uint32_t i, uint32_t &start, uint32_t *flags)
+{
+    if (i == 0 || i >= n) return false;
+    const uint64_t k = key[i], kp = key[i - 1];
+    if ((k >> OATK_SORT_LOW_BITS) != (kp >> OATK_SORT_LOW_BITS) || k == kp) return false;
+    uint32_t s = i - 1;
+    while (s > 0 && (key[s - 1] >> OATK_SORT_LOW_BITS) == (k >> OATK_SORT_LOW_BITS)) {
+        --s;
+        if (i - s > OATK_SORT_REPAIR_MAX) { flags[3] = 1u; return false; }
+    }
+    start = s;
+    return true;
+}
+__global__ void sort_repair_find_kernel(const uint64_t *key, uint32_t n, uint32_t *owner, uint32_t *flags)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t s;
+    if (sort_repair_boundary(key, n, i, s, flags)) atomicMin(&owner[s], i);       // owner[] starts as all ones
+    // (nothing is taken on trust: rocPRIM's small-size paths were seen to leave the top bits of a bit-range sort out of order -- tools/ubench/sort_repair_test.hip,
+    //  2000 - 100 000 keys -- and any inversion sends the count to the sort on all 64 bits)
+    if (i > 0 && i < n && (key[i] >> OATK_SORT_LOW_BITS) < (key[i - 1] >> OATK_SORT_LOW_BITS)) flags[3] = 1u;
+}
+__global__ void sort_repair_kernel(uint64_t *key, uint32_t *perm, uint32_t n, uint32_t *owner, uint32_t *flags)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t s;
+    if (!sort_repair_boundary(key, n, i, s, flags) || owner[s] != i) return;     // (only a run's owner writes, and nobody reads what it writes: the others leave at once)
+    const uint64_t top = key[i] >> OATK_SORT_LOW_BITS;
+    uint32_t e = i + 1;
+    while (e < n && (key[e] >> OATK_SORT_LOW_BITS) == top) {
+        ++e;
+        if (e - s > OATK_SORT_REPAIR_MAX) { flags[3] = 1u; return; }
+    }
+    for (uint32_t a = i; a < e; ++a) {                    // [s, i) holds one hash: sorted already
+        const uint64_t kk = key[a];
+        const uint32_t pp = perm[a];
+        uint32_t b = a;
+        while (b > s && key[b - 1] > kk) { key[b] = key[b - 1], perm[b] = perm[b - 1]; --b; }
+        key[b] = kk, perm[b] = pp;
+    }
+}
+
 __global__ void mark_heads_kernel(GroupArgs a)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -260,3 +260,31 @@ def test_full_size_graph_tables_and_alignment_properties(hip, batch):
     assert np.array_equal(uid, want_uid)
     per_aln = np.diff(aoff).astype(np.int64)
     assert np.all(per_aln >= np.ceil(0.9 * n_scm[sid.astype(np.int64)] - 1e-9))         # min_a_frac
+
+
+@pytest.mark.parametrize("mask", [0xFFFFFFFFFFFFFFFF, 0xFFFC000000FFFFFF, 0xFFFFC00000000FFF, 0x0000000000FFFFFF])
+def test_sort_on_top_bits_with_repair_equals_the_sort_on_all_bits(hip, mask, monkeypatch):
+    """r03o: batches of 4 M records and more are sorted on the top 40 bits of their k-mer hashes (five radix passes), and the runs in which different hashes
+    share those bits are repaired (count.hpp: sort_repair_kernel).  220 k reads of config 2 (4.6 M records): untouched hashes (a handful of such runs at most), hashes masked
+    to 14 + 24 bits (every run holds several hashes, interleaved in slot order), to 18 + 12 bits (mixed runs WITH true collisions inside them) and to the low 24 bits
+    alone (ONE run of everything: too long for the repair, the count sorts again on all 64 bits) must
+    give the table, the ids and the occurrence lists of the eight-pass sort, array for array."""
+    cfg = dict(CONFIGS["config2"])
+    cfg["n_reads"] = 220_000                    # (config 2 itself is 4.18 M records, just under the 2^22 from which the sort looks at the top bits only)
+    rs = ReadSet(**cfg)
+    seq, off, lens = rs.slice(0, cfg["n_reads"])
+    res = {}
+    hip.debug_hash_mask(mask)
+    try:
+        for mode in ("top", "full"):
+            if mode == "full":
+                monkeypatch.setenv("OATK_DEBUG_FULL_SORT", "1")
+            hip.scan_host(seq, off, lens, K, S)
+            hip.count()
+            assert hip.info()["n_occ"] >= 1 << 22
+            res[mode] = {b: crc(hip.fetch(b)) for b in COUNT_BUFS} | {"collisions": hip.info()["collisions"], "n_scm": hip.info()["n_scm"]}
+    finally:
+        hip.debug_hash_mask(0xFFFFFFFFFFFFFFFF)
+    assert res["top"] == res["full"]
+    if mask == 0xFFFFC00000000FFF:
+        assert res["top"]["collisions"] == 1

@@ -69,19 +69,24 @@ def test_scan_hifi_like_k1001(hip):
     assert int(got["n_scm"].sum()) > 0
 
 
-def test_forced_hash_collisions(hip):
+@pytest.mark.parametrize("mask,collide,full", [(0xFF, 1, False), (0xFF, 1, True),
+                                               (0xFFC0000000FFFFFF, 0, False), (0xFFC0000000FFFFFF, 0, True), (0xFF00000000000FFF, None, False)])
+def test_forced_hash_collisions(hip, mask, collide, full, monkeypatch):
     """AND the hashes down to a few bits so unrelated k-mers share a 'hash': exercises the sequence comparison
-    and first-seen split of process_kmer_cluster (syncmer.c:1293-1335)."""
+    and first-seen split of process_kmer_cluster (syncmer.c:1293-1335).  (Batches this small are sorted on all 64 bits whatever the switch says; the sort on
+    the top 40 bits with its repair pass is compared with it at 4.6 M records in tests/test_gpu_fullsize.py, with the same kinds of masks.)"""
     K, S = 101, 11
-    reads = A.hifi_like(80, 5000, 1500, seed=5)
+    reads = A.hifi_like(200 if mask == 0xFF else 80, 5000, 1500, seed=5)       # (0xFF: one run of ~6600 records, beyond OATK_SORT_REPAIR_MAX)
     seq, off, lens = pack_reads(reads)
-    mask = 0xFF
+    if full:
+        monkeypatch.setenv("OATK_DEBUG_FULL_SORT", "1")
     hip.debug_hash_mask(mask)
     try:
         hip.scan_host(seq, off, lens, K, S)
         hip.count()
         c = hip.fetch_count()
-        assert hip.info()["collisions"] == 1
+        if collide is not None:
+            assert hip.info()["collisions"] == collide
     finally:
         hip.debug_hash_mask(0xFFFFFFFFFFFFFFFF)
     # oracle with the same masked hashes
