@@ -639,8 +639,9 @@ def main():
         dist.destroy_process_group()
 
 
-# VALU wave-instructions kernel B issues per 64 hoco positions (profiles/r03k_pmc_scan.csv: SQ_INSTS_VALU 543.13 M over 450 M positions; 545.07 M = 77.5 in r02l / r03e; updated with every PMC pass)
-VALU_PER_64 = 77.2
+# VALU wave-instructions kernel B issues per 64 hoco positions (profiles/r03p_pmc_scan.csv: SQ_INSTS_VALU 506.69 M over 450 M positions; 543.13 M = 77.2 with tiles of 2048 positions in r03k,
+# 545.07 M = 77.5 in r02l / r03e; updated with every PMC pass)
+VALU_PER_64 = 72.1
 
 if __name__ == "__main__":
     main()

@@ -23,7 +23,9 @@
 //  * syncmers are appended to a per-read list in LDS at positions that follow from the waves' counts alone (no atomics, position
 //    order, index = ordinal) and become records when the read is done: one record-slot atomic per read.  A tile has two workgroup
 //    barriers, placed so that the s-mer hashing of the next tile (registers only) overlaps with the slower waves' decisions on this one.
-//  * what bounds it: 27.2 KB of LDS and 80 registers let six workgroups onto a CU; 77 VALU wave-instructions per position, 39 of them
+//  * two forms: two waves per workgroup on a 2048-slot ring (tiles of 1024 positions; K - S <= 1023) and four waves on 4096 slots.  A read's last tile
+//    costs a tile's time however little of it lies inside the read, and two waves meet at a barrier sooner than four (r03p).
+//  * what bounds it: 13.6 KB of LDS and 80 registers let eleven two-wave workgroups onto a CU; 72 VALU wave-instructions per position, 39 of them
 //    the rolling canonical s-mer and hash64, at 0.95 of the issue ceiling of that opcode mix.  Ring addresses alternate between two values per
 //    lane (a tile is half the ring) and are toggled, not recomputed; end-of-read special cases are decided per wave, not per lane.
 //    DESIGN.md 5 has the measurements.

@@ -210,3 +210,17 @@ def test_fast_kernel_other_s_and_every_window_alignment(hip, K, S):
     reads.append(A.rand_nohp(rng, 3000) + pal + A.revcomp(pal) + A.rand_nohp(rng, 3000))       # an even-length s-mer equal to its reverse complement
     got, _ = run_hip(hip, reads, K, S)
     compare_scan(got, O.scan(reads, K, S, mode=1))
+
+
+@pytest.mark.parametrize("K", [1001, 991, 1060])
+def test_fast_kernel_four_wave_form(hip, K, monkeypatch):
+    """r03p: the fast kernel runs as two waves per workgroup on a 2048-slot ring wherever K - S <= 1023 and as four waves on 4096 slots beyond
+    (K = 1060 here); OATK_DEBUG_SYNCMER_NT256 takes the four-wave form for every K, on tandem repeats, top-word ties and ordinary reads"""
+    monkeypatch.setenv("OATK_DEBUG_SYNCMER_NT256", "1")
+    rng = np.random.default_rng(K)
+    reads = A.hifi_like(10, 30000, 9000, seed=K) + A.top_word_tie_reads(K)[:40]
+    for unit_len in (2, 7, 64, K - 32):
+        unit = A.rand_nohp(rng, unit_len)
+        reads.append(A.rand_nohp(rng, 2500) + (unit * (12000 // unit_len + 2))[:12000] + A.rand_nohp(rng, 1800))
+    got, _ = run_hip(hip, reads, K, 31)
+    compare_scan(got, O.scan(reads, K, 31, mode=0))

@@ -5,7 +5,7 @@ the VERDICT of round 2 asked for roofline.valu from Sigma n_i c_i instead of a f
 import collections, json, os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "syncmer_fast_kernelILi4096ELb1ELi256ELi6E"
+KERNEL = "syncmer_fast_kernelILi2048ELb1ELi128ELi6E"
 # cycles per wave64 instruction per SIMD, event-derived at 2.4 GHz (profiles/r02c_valu_rates.txt); classes not measured there take the flat 4.0
 RATES = [(r"^v_(xor|and|or|not|add|sub|subrev|mov|cndmask|lshlrev|lshrrev|ashrrev|bfe|bfi|perm|min|max|min3|max3|and_or|or3|xad|lshl_add|add_lshl|lshl_or|add3|xor3)_[a-z]?(b|u|i)?(16|32)?(_e32|_e64|_dpp|_sdwa)?$", 2.9, "32-bit simple"),
          (r"^v_alignbit_b32", 5.15, "v_alignbit_b32"), (r"^v_mul_u32_u24|^v_mad_u32_u24", 4.76, "24-bit multiply"), (r"^v_mul_lo_u32", 5.49, "v_mul_lo_u32"),
