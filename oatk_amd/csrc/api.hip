@@ -297,7 +297,7 @@ static int launch_scan_kernels(oatk_hip_ctx *ctx)
     h.nn_cap = ctx->nn_cap, h.lrl_cap = ctx->lrl_cap, h.counters = ctx->counters.as<uint32_t>();
     t_begin(ctx, OATK_T_HPC);
     h.n_reads = (uint32_t) n;
-    uint64_t hpc_grid = (uint64_t) ctx->n_cu * 8 * 16;        // workgroups stride over the reads: eight resident per CU, sixteen rounds of them to even out read lengths
+    uint64_t hpc_grid = (uint64_t) ctx->n_cu * 8 * 16;        // workgroups stride over the reads: eight to fourteen resident per CU, ten to sixteen rounds of them to even out read lengths
                                                               // (config 3: 2048 workgroups 20.4 ms, 8192 17.0, 32768 16.5, one per read 17.4)
     { const char *ev = getenv("OATK_DEBUG_HPC_GRID"); if (ev && atoi(ev) > 0) hpc_grid = (uint64_t) atoi(ev); }
     if (hpc_grid > n) hpc_grid = n;

@@ -7,7 +7,7 @@
 // coordinate goes to n_nucl (:316-321).
 //
 // MI355X mapping: the HBM-streaming kernel of the scan (1 B read + 1.25*rho B written per raw base).
-// One 256-thread workgroup per read walks 4 KiB tiles; each lane owns one aligned 16-byte vector (reads
+// One 128-thread workgroup per read walks 2 KiB tiles; each lane owns one aligned 16-byte vector (reads
 // start on 64-byte boundaries of the packed stream) and the next tile's vector is requested before the
 // current one is processed.  Bytes are classified through a 256-entry LDS table (the reference's own
 // table semantics, syncmer.c:47-64); a workgroup scan of (run-start count, last run-start position) --
@@ -35,10 +35,16 @@ namespace oatk {
 #ifndef OATK_HPC_EXP
 #define OATK_HPC_EXP 0                    // timing experiments (development aid; results are wrong with any of them)
 #endif
-constexpr int HPC_NT = 256;
+// r03p: 128 threads.  A read's last tile takes a tile's time however little of it lies inside the read (a 15 kb read is 3.7 tiles of 4 KiB: an eighth of the
+// kernel), two waves meet at the tile's two barriers sooner than four, and the rings shrink with the tile (11.3 KB with the tables: 14 workgroups = 28 waves per CU,
+// where the kernel is saturated): 3.50 -> 3.15 ms at 400 k reads; one wave per workgroup: 3.7 ms (18 waves per CU: the tables are 6.3 KB per workgroup).
+#ifndef OATK_HPC_NT
+#define OATK_HPC_NT 128
+#endif
+constexpr int HPC_NT = OATK_HPC_NT;
 constexpr int HPC_BPT = 16;
 constexpr int HPC_TILE = HPC_NT * HPC_BPT;
-constexpr int HPC_RING = 8192;   // staged hoco positions; > one tile + one unflushed 64-group
+constexpr int HPC_RING = 2 * HPC_TILE;   // staged hoco positions; > one tile + one unflushed 64-group
 
 // squeeze table: index = keep << 8 | four 2-bit codes (position i in bits 2i+1:2i); value = the kept codes in position
 // order, the first in bits 7:6
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
     __shared__ uint4 ring_rl4[HPC_RING / 16];      // run lengths, one byte per staged hoco position
     __shared__ uint4 ring_hs4[HPC_RING / 64];      // 2-bit codes, 16 per word, MSB-first words (byte-swapped on the way out)
     __shared__ uint8_t lut[256];
-    __shared__ uint4 sq4[HPC_NT];                   // the squeeze table, 4 KiB
+    __shared__ uint4 sq4[256];                      // the squeeze table, 4 KiB
     __shared__ uint64_t gap8[256];                  // the gap table, 2 KiB
     __shared__ uint32_t w_cnt[HPC_NT / OATK_WAVE];
     __shared__ int32_t w_max[HPC_NT / OATK_WAVE];
@@ -140,9 +146,11 @@ __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
     uint32_t *ring_hs = (uint32_t *) ring_hs4;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    lut[tid] = (uint8_t) nt4_code(tid);
-    sq4[tid] = ((const uint4 *) hpc_squeeze_tab.v)[tid];
-    gap8[tid] = hpc_gap_tab.v[tid];
+    for (uint32_t i = tid; i < 256; i += HPC_NT) {
+        lut[i] = (uint8_t) nt4_code(i);
+        sq4[i] = ((const uint4 *) hpc_squeeze_tab.v)[i];
+        gap8[i] = hpc_gap_tab.v[i];
+    }
     const uint8_t *sq = (const uint8_t *) sq4;
     for (uint32_t i = tid; i < HPC_RING / 16; i += HPC_NT) ring_hs[i] = 0;
     for (uint32_t i = tid; i < HPC_RING / 16; i += HPC_NT) ring_rl4[i] = make_uint4(0, 0, 0, 0);      // runs of one base (most) never write their 0
