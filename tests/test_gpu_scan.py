@@ -160,14 +160,14 @@ def test_fast_kernel_record_list_overflows(hip, cap):
         hip.debug_list_cap(129)
 
 
-@pytest.mark.parametrize("K,S", [(550, 31), (1500, 21), (1976, 31), (1977, 31)])
+@pytest.mark.parametrize("K,S", [(550, 31), (1500, 21), (1976, 31), (1977, 31), (1054, 31), (1055, 31), (551, 31), (552, 31)])
 def test_fast_kernel_k_range(hip, K, S):
     reads = A.hifi_like(30, 30000, 9000, seed=K) + A.reads(K, S, seed=3, scale=0.3)[:30]
     got, _ = run_hip(hip, reads, K, S)
     compare_scan(got, O.scan(reads, K, S, mode=1))
 
 
-@pytest.mark.parametrize("K,S", [(1001, 31), (561, 31), (1060, 31)])
+@pytest.mark.parametrize("K,S", [(1001, 31), (561, 31), (1060, 31), (1054, 31), (551, 31)])
 def test_long_low_complexity_reads(hip, K, S):
     """many tiles of tandem repeats inside long reads: equal s-mer hashes everywhere, so the top-word filter of the fast kernel
     ties constantly and the exact 64-bit rule (chunk minima included) decides -- at the edges of the fast kernel's K - S range too"""
