@@ -393,4 +393,16 @@ __global__ __launch_bounds__(64) void egr_mode_big_kernel(const uint32_t *counts
     }
 }
 
+// the pairs a light graph keeps, in their order: one exclusive scan of the keep flags places keys and distances together (r03q; two
+// rocprim::select calls over 42 M pairs, one per array and each with its own wait on the host, were 1.6 ms at config 3)
+__global__ void egr_compact_pairs_kernel(uint64_t n, const uint8_t *keep, const uint32_t *pos, const uint64_t *keys, const uint32_t *dist,
+                                         uint64_t *lkeys, uint32_t *ldist, uint64_t *n_out)
+{
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t k = keep[i], p = pos[i];
+    if (k) lkeys[p] = keys[i], ldist[p] = dist[i];
+    if (i == n - 1) *n_out = (uint64_t) p + k;
+}
+
 }  // namespace oatk
