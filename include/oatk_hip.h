@@ -130,6 +130,11 @@ int oatk_hip_h2d_async(oatk_hip_ctx *ctx, void *d_dst, const void *h_src, uint64
 /* Page-locked host memory owned by the context (one block, regrown on demand, freed with the context; NULL on failure): oatk_hip_d2h into it
  * runs at PCIe speed, into pageable memory at a fraction of it -- callers that move gigabytes of results stage them through it in pieces. */
 void *oatk_hip_staging(oatk_hip_ctx *ctx, uint64_t bytes);
+/* The caller's OWN host memory page-locked for a while, so that it can be the destination (or source) of asynchronous copies as it lies -- the reads'
+ * arenas of liboatk_host.so are filled that way, without a staging copy (host/srdb.c).  Registering memory that has been touched and sits on
+ * transparent huge pages costs ~3 ms per GB on the bench box; hipHostMalloc'ed memory 170 ms per GB (tools/ubench/pin_rates.hip). */
+int oatk_hip_host_register(oatk_hip_ctx *ctx, void *p, uint64_t bytes);
+int oatk_hip_host_unregister(oatk_hip_ctx *ctx, void *p);
 
 /* ---- measurement: HIP-event timing of the phases, recorded on the handle's stream ---- */
 enum {

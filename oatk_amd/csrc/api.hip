@@ -9,7 +9,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/oatk_hip.h"
@@ -67,6 +69,8 @@ struct oatk_hip_ctx {
     bool force_general = false;   // test hook: run the general syncmer kernel even where the fast one applies
     void *staging = nullptr;      // page-locked host memory lent to callers (oatk_hip_staging)
     uint64_t staging_cap = 0;
+    void *staging_raw = nullptr;  // the anonymous mapping `staging` lies in (nullptr: it came from hipHostMalloc)
+    uint64_t staging_raw_size = 0;
     bool ra_two_pass = false;     // test hook: the read alignment counts, scans and runs again instead of writing into its pool
     int list_cap = 0;             // test hook: syncmers the fast kernel collects per read before writing records (0 = default)
     uint64_t import_reserve = 1u << 20;  // bytes kept free behind the hoco strings for k-mers imported from other shards (api_ec.inc)
@@ -167,6 +171,14 @@ static void t_collect(oatk_hip_ctx *ctx, int first, int last)
 #include "api_multi.inc"
 #include "api_multi_tail.inc"
 
+static void staging_free(oatk_hip_ctx *ctx)
+{
+    if (!ctx->staging) return;
+    if (ctx->staging_raw) { (void) hipHostUnregister(ctx->staging); munmap(ctx->staging_raw, ctx->staging_raw_size); }
+    else (void) hipHostFree(ctx->staging);
+    ctx->staging = ctx->staging_raw = nullptr, ctx->staging_cap = ctx->staging_raw_size = 0;
+}
+
 extern "C" {
 
 int oatk_hip_abi_version(void) { return OATK_HIP_ABI_VERSION; }
@@ -223,7 +235,7 @@ void oatk_hip_destroy(oatk_hip_ctx *ctx)
         (void) hipEventDestroy(ctx->ev[i][0]);
         (void) hipEventDestroy(ctx->ev[i][1]);
     }
-    if (ctx->staging) (void) hipHostFree(ctx->staging);
+    staging_free(ctx);
     (void) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -811,10 +823,46 @@ void *oatk_hip_staging(oatk_hip_ctx *ctx, uint64_t bytes)
 {
     if (!ctx || hipSetDevice(ctx->device) != hipSuccess) return nullptr;
     if (bytes <= ctx->staging_cap) return ctx->staging;
-    if (ctx->staging) { (void) hipHostFree(ctx->staging); ctx->staging = nullptr; ctx->staging_cap = 0; }
+    staging_free(ctx);
+    // A fresh anonymous mapping on transparent huge pages, touched by a few threads and then page-locked: 8 GB in 0.05 s on the bench box, where
+    // hipHostMalloc takes 1.5 s (tools/ubench/pin_rates.hip, profiles/r04a_pin_rates.txt).  hipHostMalloc remains the fallback.
+    const uint64_t HP = 2ull << 20, want = (bytes + HP - 1) & ~(HP - 1);
+    void *raw = mmap(nullptr, want + HP, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (raw != MAP_FAILED) {
+        uint8_t *base = (uint8_t *) (((uintptr_t) raw + HP - 1) & ~(uintptr_t) (HP - 1));
+        (void) madvise(base, want, MADV_HUGEPAGE);
+        const int nt = want >= (256ull << 20)? 8 : 1;
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back([=] { for (uint64_t o = want / nt * t; o < (t + 1 == nt? want : want / nt * (t + 1)); o += 4096) *(volatile uint8_t *) (base + o) = 0; });
+        for (uint64_t o = 0; o < want / nt; o += 4096) *(volatile uint8_t *) (base + o) = 0;
+        for (auto &x : th) x.join();
+        if (hipHostRegister(base, want, hipHostRegisterDefault) == hipSuccess) {
+            ctx->staging = base, ctx->staging_cap = want, ctx->staging_raw = raw, ctx->staging_raw_size = want + HP;
+            return ctx->staging;
+        }
+        (void) hipGetLastError();
+        munmap(raw, want + HP);
+    }
     if (hipHostMalloc(&ctx->staging, bytes, hipHostMallocDefault) != hipSuccess) { ctx->staging = nullptr; ctx->err = "hipHostMalloc failed (staging)"; return nullptr; }
     ctx->staging_cap = bytes;
     return ctx->staging;
+}
+
+int oatk_hip_host_register(oatk_hip_ctx *ctx, void *p, uint64_t bytes)
+{
+    if (!ctx) return OATK_E_NODEV;
+    if (!p || bytes == 0) return OATK_E_ARG;
+    CK(hipSetDevice(ctx->device));
+    CK(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return OATK_OK;
+}
+
+int oatk_hip_host_unregister(oatk_hip_ctx *ctx, void *p)
+{
+    if (!ctx) return OATK_E_NODEV;
+    CK(hipSetDevice(ctx->device));
+    CK(hipHostUnregister(p));
+    return OATK_OK;
 }
 
 int oatk_hip_d2h(oatk_hip_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes)

@@ -302,6 +302,7 @@ struct WaveKh {
 };
 
 #define EGR_SMALL_RUN 48
+#define EGR_HUGE_SCRATCH (256ull << 20)     // working memory of egr_mode_huge_kernel (tables of the runs with more than 48 distinct distances)
 
 // overlap of the arc a run of equal keys stands for: K minus the most frequent distance (calc_syncmer_overlap,
 // syncasm.c:477-582, and the arc.ls assignment :793-812).  One lane per short run; long runs go on a list and are then
@@ -316,7 +317,7 @@ __device__ __forceinline__ uint32_t egr_to_ls(int64_t l, int K)   // scg_syncmer
 }
 
 __global__ __launch_bounds__(64) void egr_mode_kernel(uint64_t n_runs, const uint64_t *ukeys, const uint32_t *counts, const uint64_t *run_off,
-                                                      const uint32_t *sdist, int K, uint32_t *run_ls, uint32_t *flags, uint32_t *big_list,
+                                                      const uint32_t *sdist, int K, uint32_t *run_ls, uint32_t *flags, uint32_t *big_list, uint32_t *huge_list,
                                                       const uint32_t *swgt = nullptr, uint32_t *run_cov = nullptr)
 {
     const int lane = threadIdx.x;
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(64) void egr_mode_kernel(uint64_t n_runs, const uin
         } else {
             for (uint32_t t = 0; t < c; ++t) h.add1((int32_t) sdist[o + t]);
         }
-        if (h.overflow) flags[1] = 1u;
+        if (h.overflow) huge_list[atomicAdd(&flags[5], 1u)] = (uint32_t) i;       // (48 weighted segments and a call behind the last insert)
         else run_ls[i] = egr_to_ls(h.mode(), K);
     }
     const bool is_big = valid && c > EGR_SMALL_RUN;
@@ -349,7 +350,8 @@ __global__ __launch_bounds__(64) void egr_mode_kernel(uint64_t n_runs, const uin
 
 // the long runs, one per wave (flags[4] = how many; the grid is fixed and strides over the list)
 __global__ __launch_bounds__(64) void egr_mode_big_kernel(const uint32_t *counts, const uint64_t *run_off, const uint32_t *sdist, int K, uint32_t *run_ls,
-                                                          uint32_t *flags, const uint32_t *big_list, const uint32_t *swgt = nullptr, uint32_t *run_cov = nullptr)
+                                                          uint32_t *flags, const uint32_t *big_list, uint32_t *huge_list, const uint32_t *swgt = nullptr,
+                                                          uint32_t *run_cov = nullptr)
 {
     __shared__ int32_t tk[64], tv[64];
     const int lane = threadIdx.x;
@@ -385,11 +387,117 @@ __global__ __launch_bounds__(64) void egr_mode_big_kernel(const uint32_t *counts
         }
         if (!h.overflow && h.due() && !tail_new) h.resize(h.nb() + 1U);       // khashl grows at the call AFTER the insert that filled it
         if (lane == 0) {
-            if (swgt) run_cov[i] = tot;
-            if (h.overflow) flags[1] = 1u;
+            if (swgt && !h.overflow) run_cov[i] = tot;
+            if (h.overflow) huge_list[atomicAdd(&flags[5], 1u)] = i;        // more than 48 distinct distances: egr_mode_huge_kernel
             else run_ls[i] = egr_to_ls(h.mode(), K);
         }
         __syncthreads();                               // the table in LDS is reused
+    }
+}
+
+// ---- the same table without a size limit, in global memory: runs with more than 48 distinct distances (arcs across a tandem array read at
+// thousand-fold coverage; none on random sequence).  One lane replays the run call by call.  Until round 4 such an arc was OATK_E_SPLIT. ----
+struct BigKh {
+    int32_t *keys, *vals;
+    uint8_t *used, *nused;
+    uint32_t cap, bits, count;
+    bool overflow;
+
+    __device__ uint32_t nb() const { return bits? 1U << bits : 0U; }
+    __device__ void resize(uint32_t want)                                  // khashl.h:150-192, growing only
+    {
+        uint32_t j = 0, x = want;
+        while ((x >>= 1) != 0) ++j;
+        if (want & (want - 1)) ++j;
+        const uint32_t nbits = j > 2? j : 2;
+        if (nbits > 30 || (1U << nbits) > cap) { overflow = true; return; }
+        const uint32_t n_old = nb(), n_new = 1U << nbits;
+        for (j = 0; j != n_new; ++j) nused[j] = 0;
+        for (j = 0; j != n_old; ++j) {
+            if (!used[j]) continue;
+            int32_t key = keys[j], val = vals[j];
+            used[j] = 0;
+            for (;;) {
+                uint32_t i = MiniKh::h2b((uint32_t) key, nbits);
+                while (nused[i]) i = (i + 1) & (n_new - 1);
+                nused[i] = 1;
+                if (i < n_old && used[i]) {
+                    const int32_t tk = keys[i], tv = vals[i];
+                    keys[i] = key, vals[i] = val, key = tk, val = tv;
+                    used[i] = 0;
+                } else {
+                    keys[i] = key, vals[i] = val;
+                    break;
+                }
+            }
+        }
+        uint8_t *t = used; used = nused, nused = t;
+        bits = nbits;
+    }
+    __device__ void add1(int32_t key)                                      // add_ovl_count, syncasm.c:465-474
+    {
+        uint32_t n = nb();
+        if (count >= (n >> 1) + (n >> 2)) { resize(n + 1U); if (overflow) return; n = nb(); }
+        uint32_t i = MiniKh::h2b((uint32_t) key, bits);
+        const uint32_t last = i;
+        while (used[i] && keys[i] != key) { i = (i + 1U) & (n - 1); if (i == last) break; }
+        if (!used[i]) keys[i] = key, vals[i] = 1, used[i] = 1, ++count;
+        else ++vals[i];
+    }
+    __device__ void addw(int32_t key, uint32_t w)                          // w consecutive calls for one distance
+    {
+        add1(key);
+        if (w < 2 || overflow) return;
+        add1(key);
+        if (w < 3 || overflow) return;
+        const uint32_t n = nb();
+        uint32_t i = MiniKh::h2b((uint32_t) key, bits);
+        while (keys[i] != key || !used[i]) i = (i + 1U) & (n - 1);
+        vals[i] += (int32_t) (w - 2);
+    }
+    __device__ int32_t mode() const
+    {
+        int32_t movl = 0, mcnt = 0;
+        for (uint32_t k = 0; k < nb(); ++k) if (used[k] && vals[k] > mcnt) mcnt = vals[k], movl = keys[k];
+        return movl;
+    }
+};
+
+// buckets a run of c calls can need: the table doubles at three quarters full, and once more when a call follows the insert that filled it
+__device__ __forceinline__ uint32_t egr_huge_cap(uint32_t c)
+{
+    uint32_t n = 4;
+    while ((uint64_t) n * 3 < (uint64_t) c * 4 + 4 && n < (1U << 30)) n <<= 1;
+    return n < (1U << 30)? n << 1 : n;
+}
+
+// flags[5] runs on huge_list; scratch: `scratch_bytes` of working memory handed out with flags[6] as the bump pointer (in units of 16 bytes);
+// a run that does not get its table sets flags[1] (the caller answers OATK_E_SPLIT)
+__global__ __launch_bounds__(64) void egr_mode_huge_kernel(const uint32_t *counts, const uint64_t *run_off, const uint32_t *sdist, int K, uint32_t *run_ls,
+                                                           uint32_t *flags, const uint32_t *huge_list, uint8_t *scratch, uint64_t scratch_bytes,
+                                                           const uint32_t *swgt = nullptr, uint32_t *run_cov = nullptr)
+{
+    if (threadIdx.x != 0) return;
+    const uint32_t n_huge = flags[5];
+    for (uint32_t b = blockIdx.x; b < n_huge; b += gridDim.x) {
+        const uint32_t i = huge_list[b], cc = counts[i];
+        const uint64_t oo = run_off[i];
+        const uint32_t cap = egr_huge_cap(cc);
+        const uint64_t need = ((uint64_t) cap * 10 + 15) >> 4;             // keys + vals + two flag arrays, in 16-byte units
+        const uint64_t at = (uint64_t) atomicAdd(&flags[6], (uint32_t) need);
+        if (need >= (1ULL << 31) || (at + need) * 16 > scratch_bytes) { flags[1] = 1u; continue; }
+        BigKh h;
+        uint8_t *base = scratch + at * 16;
+        h.keys = (int32_t *) base, h.vals = h.keys + cap, h.used = (uint8_t *) (h.vals + cap), h.nused = h.used + cap;
+        h.cap = cap, h.bits = 0, h.count = 0, h.overflow = false;
+        uint32_t tot = 0;
+        for (uint32_t t = 0; t < cc && !h.overflow; ++t) {
+            if (swgt) h.addw((int32_t) sdist[oo + t], swgt[oo + t]), tot += swgt[oo + t];
+            else h.add1((int32_t) sdist[oo + t]);
+        }
+        if (swgt) run_cov[i] = tot;
+        if (h.overflow) flags[1] = 1u;
+        else run_ls[i] = egr_to_ls(h.mode(), K);
     }
 }
 

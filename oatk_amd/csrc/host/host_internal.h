@@ -29,4 +29,19 @@ int oatk_host_read_alignment_n(oatk_hip_ctx **ctx, const uint64_t *first, int n,
 /* sr_read (syncmer.c:487) for files with the reads spread over n handles by position in the input: first[0 .. n] receives the read ranges */
 int oatk_host_sr_read_files_n(oatk_hip_ctx **ctx, int n, oatk_sr_db_t *sr_db, char **files, int n_files, uint64_t *first, uint64_t m_data);
 
+
+typedef struct { uint8_t *p, *end; } oatk_name_bump_t;
+char *oatk_host_name_dup(const uint8_t *src, size_t len, oatk_name_bump_t *b, const void *owner);
+int oatk_host_threads_granted(void);
+void oatk_host_set_threads_internal(int n);
+
+/* a gzip'ed file (one member, several, BGZF) as a stream of inflated bytes (gzsrc.c) */
+typedef struct oatk_gzsrc oatk_gzsrc_t;
+oatk_gzsrc_t *oatk_gzsrc_open(const char *path, int n_threads, int *rc);
+int64_t oatk_gzsrc_read(oatk_gzsrc_t *g, uint8_t *dst, uint64_t cap);
+uint64_t oatk_gzsrc_tell_in(const oatk_gzsrc_t *g);
+uint64_t oatk_gzsrc_size_in(const oatk_gzsrc_t *g);
+int oatk_gzsrc_kind(const oatk_gzsrc_t *g);          /* 1 plain member(s), 2 BGZF, 3 not a regular file (zlib's gzread) */
+void oatk_gzsrc_close(oatk_gzsrc_t *g);
+
 #endif

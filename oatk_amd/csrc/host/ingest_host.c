@@ -3,7 +3,9 @@
  * (sstream.c:70-103): several files are read one after the other as one stream of records; plain or gzip'ed (zlib inflates, exactly as the
  * reference's gzdopen does, sstream.c:50).  The host only moves bytes, and moves them once: a plain file goes from the page cache straight
  * into page-locked memory (pread by the host threads, piece by piece) and from there over PCIe while the next piece is being read; a
- * gzip'ed one is inflated first (serial per stream on any hardware) and then takes the same road.  The records are found on the device.
+ * gzip'ed one is inflated AS A STREAM (gzsrc.c: BGZF members in parallel, plain members one after the other) straight into the page-locked
+ * window it is uploaded from, while the windows before it are parsed and scanned on the device (round 4; until then it was inflated whole,
+ * in front of everything).  The records are found on the device.
  */
 #define _GNU_SOURCE
 #include <stdio.h>
@@ -34,6 +36,8 @@ typedef struct {
     uint8_t *map;                  /* lazily mapped (no populate) for the header lines only */
     int borrowed;                  /* mem belongs to the caller */
     int pinned;                    /* ... and is page-locked: it goes over PCIe as it lies */
+    oatk_gzsrc_t *gz;              /* a gzip'ed file read as a stream (sr_read path): size and base are unknown */
+    uint64_t fsize;                /* bytes of the file itself */
 } seg_t;
 
 static void seg_close(seg_t *s, int n)
@@ -42,6 +46,7 @@ static void seg_close(seg_t *s, int n)
     for (i = 0; i < n; ++i) {
         if (s[i].map) munmap(s[i].map, (size_t) s[i].size);
         if (s[i].fd >= 0) close(s[i].fd);
+        if (s[i].gz) oatk_gzsrc_close(s[i].gz);
         if (!s[i].borrowed) free(s[i].mem);
     }
     free(s);
@@ -75,7 +80,7 @@ static int inflate_file(const char *path, seg_t *s)
     return OATK_OK;
 }
 
-static seg_t *open_segments(char **files, int n_files, uint64_t *total, int *rc)
+static seg_t *open_segments(char **files, int n_files, uint64_t *total, int *rc, int stream_gz, int *any_gz)
 {
     seg_t *s = (seg_t *) calloc((size_t) n_files, sizeof(seg_t));
     uint64_t base = 0;
@@ -93,11 +98,16 @@ static seg_t *open_segments(char **files, int n_files, uint64_t *total, int *rc)
             break;
         }
         const ssize_t nm = pread(fd, mg, 2, 0);
-        if (nm == 2 && mg[0] == 0x1f && mg[1] == 0x8b) {          /* gzip magic: inflate; anything else is read as it lies (gzread would do the same) */
+        s[i].fsize = S_ISREG(sb.st_mode)? (uint64_t) sb.st_size : 0;
+        if ((nm == 2 && mg[0] == 0x1f && mg[1] == 0x8b) || !S_ISREG(sb.st_mode)) {
+            /* gzip magic: inflate; anything else is read as it lies (gzread would do the same).  A pipe or device: no pread; zlib's transparent mode streams it */
             close(fd);
-            if ((*rc = inflate_file(files[i], &s[i])) != OATK_OK) break;
-        } else if (!S_ISREG(sb.st_mode)) {                         /* a pipe or device: no pread; let zlib's transparent mode stream it */
-            close(fd);
+            if (any_gz) *any_gz = 1;
+            if (stream_gz) {
+                s[i].gz = oatk_gzsrc_open(files[i], oatk_host_threads_granted(), rc);
+                if (!s[i].gz) { fprintf(stderr, "[E::%s] fail to open file \"%s\"\n", __func__, files[i]); break; }
+                continue;                                          /* size, last byte and base are known when the stream has been read */
+            }
             if ((*rc = inflate_file(files[i], &s[i])) != OATK_OK) break;
         } else {
             s[i].fd = fd, s[i].size = (uint64_t) sb.st_size;
@@ -190,7 +200,7 @@ static int ingest_files(oatk_hip_ctx *ctx, char **files, int n_files, uint64_t *
 {
     uint64_t total = 0, used = 0;
     int rc = OATK_OK;
-    seg_t *seg = open_segments(files, n_files, &total, &rc);
+    seg_t *seg = open_segments(files, n_files, &total, &rc, 0, 0);
     if (!seg) return rc;
     uint8_t *d_text = 0;
     struct timespec t0, t1, t2;
@@ -216,26 +226,48 @@ int oatk_ingest_files(oatk_hip_ctx *ctx, char **files, int n_files, uint64_t *n_
 }
 
 /* ---- read names (kseq's name: the header up to the first white space), cut out of the text on the host threads ---- */
-typedef struct { seg_t *seg; int n_seg; const uint64_t *hdr; uint64_t hdr_base, n; char **names; } name_job_t;
+typedef struct { seg_t *seg; int n_seg; const uint64_t *hdr; uint64_t hdr_base, n; char **names; const void *owner; } name_job_t;
 
+/* (Until round 4 the files were mapped and the header lines read through the mapping: a minor page fault per read, 1.2 s of the 2 M-read CLI run.  A
+ * 128-byte pread from the page cache costs a quarter of that and needs no mapping.) */
 static void name_worker(void *arg, int tid, int n_threads)
 {
     name_job_t *j = (name_job_t *) arg;
     const uint64_t a = j->n * (uint64_t) tid / (uint64_t) n_threads, b = j->n * (uint64_t) (tid + 1) / (uint64_t) n_threads;
+    oatk_name_bump_t bump = {0, 0};
+    uint8_t small[128], *big = 0;
+    size_t big_cap = 0;
     uint64_t i;
     int si = 0;
     for (i = a; i < b; ++i) {
         const uint64_t g = j->hdr_base + j->hdr[i] + 1;            /* behind '>' / '@'; headers ascend, so the segment index only moves forward */
         while (si + 1 < j->n_seg && g >= j->seg[si + 1].base) ++si;
         const seg_t *s = &j->seg[si];
-        const uint8_t *t = s->fd >= 0? s->map : s->mem;
         const uint64_t p = g - s->base;
-        uint64_t e = p;
-        while (e < s->size && t[e] != ' ' && t[e] != '\t' && t[e] != '\n' && t[e] != '\r') ++e;
-        char *nm = (char *) malloc(e - p + 1);
-        if (nm) { memcpy(nm, t + p, e - p); nm[e - p] = 0; }
-        j->names[i] = nm;
+        const uint8_t *t;
+        uint64_t avail, e = 0;
+        if (s->fd >= 0) {                                           /* the line's first bytes from the page cache; a longer name is read again, whole */
+            size_t want = sizeof(small);
+            uint8_t *buf = small;
+            for (;;) {
+                const uint64_t left = s->size - p;
+                const size_t n = left < want? (size_t) left : want;
+                size_t done = 0;
+                while (done < n) { const ssize_t got = pread(s->fd, buf + done, n - done, (off_t) (p + done)); if (got <= 0) break; done += (size_t) got; }
+                for (e = 0; e < done && buf[e] != ' ' && buf[e] != '\t' && buf[e] != '\n' && buf[e] != '\r'; ++e) {}
+                if (e < done || done < want || done == left) break;
+                want *= 8;
+                if (want > big_cap) { free(big); big = (uint8_t *) malloc(want); big_cap = big? want : 0; if (!big) { e = 0; break; } }
+                buf = big;
+            }
+            t = buf;
+        } else {
+            t = s->mem + p, avail = s->size - p;
+            while (e < avail && t[e] != ' ' && t[e] != '\t' && t[e] != '\n' && t[e] != '\r') ++e;
+        }
+        j->names[i] = oatk_host_name_dup(t, (size_t) e, &bump, j->owner);
     }
+    free(big);
 }
 
 /* ---- sr_read (syncmer.c:487) for files, streamed ----
@@ -259,6 +291,7 @@ typedef struct {
     oatk_hip_ctx *piece[2];        /* record scan + syncmer scan of one window */
     uint8_t *d_win[2];             /* where a slot's window goes on the device */
     uint8_t *stage;                /* the uploader's page-locked pieces */
+    uint8_t *h_win[2];             /* streamed input: a slot's window on the host (page-locked; the names are cut out of it), CARRY_CAP bytes of room in front */
 } stream_dev_t;
 
 typedef struct {
@@ -274,13 +307,18 @@ typedef struct {
     const seg_t *seg;
     int n_seg, n_up;
     uint64_t total, win;
+    /* where a window lies in the FILES' bytes (their sizes summed: known in advance, unlike the length of a gzip'ed file's text): decides the handle its
+     * reads go to and how much room to reserve.  For plain files it is the text's own offset. */
+    uint64_t f0[2], f1[2], ftotal;
+    int streamed;                  /* the input is pulled through sources (a gzip'ed file among them), window by window; the last window says so */
+    int final[2];
 } stream_t;
 
 /* the handle a window's reads go to: by where the window starts in the input, so the ranks hold contiguous ranges of reads of about equal text */
-static int rank_of_window(const stream_t *st, uint64_t g0)
+static int rank_of_window(const stream_t *st, uint64_t f0)
 {
-    if (st->n_rank <= 1 || st->total == 0) return 0;
-    const uint64_t r = (uint64_t) (((unsigned __int128) g0 * (uint64_t) st->n_rank) / st->total);
+    if (st->n_rank <= 1 || st->ftotal == 0) return 0;
+    const uint64_t r = (uint64_t) (((unsigned __int128) f0 * (uint64_t) st->n_rank) / st->ftotal);
     return r >= (uint64_t) st->n_rank? st->n_rank - 1 : (int) r;
 }
 
@@ -308,7 +346,7 @@ static void *uploader(void *arg)
             if (!rc) rc = oatk_hip_sync(D->up);
             pthread_mutex_lock(&st->mu);
             if (rc) st->failed = rc;
-            else st->state[s] = 1, st->g0[s] = g0, st->g1[s] = g1;
+            else st->state[s] = 1, st->g0[s] = st->f0[s] = g0, st->g1[s] = st->f1[s] = g1, st->final[s] = g1 == st->total;
             pthread_cond_broadcast(&st->cv);
             pthread_mutex_unlock(&st->mu);
             g0 = g1;
@@ -332,7 +370,7 @@ static void *uploader(void *arg)
         if (job.failed) rc = OATK_E_ARG;
         pthread_mutex_lock(&st->mu);
         if (rc) st->failed = rc;
-        else st->state[s] = 1, st->g0[s] = g0, st->g1[s] = g1;
+        else st->state[s] = 1, st->g0[s] = st->f0[s] = g0, st->g1[s] = st->f1[s] = g1, st->final[s] = g1 == st->total;
         pthread_cond_broadcast(&st->cv);
         pthread_mutex_unlock(&st->mu);
         g0 = g1;
@@ -344,6 +382,121 @@ static void *uploader(void *arg)
         pthread_mutex_unlock(&st->mu);
     }
     return 0;
+}
+
+
+/* ---- streamed input: the files pulled through sources, one after the other ---- */
+typedef struct {
+    const seg_t *seg; int n_seg, cur;
+    uint64_t in_seg;               /* plain file: bytes delivered of the current one */
+    uint64_t out_seg;              /* text delivered of the current file */
+    uint8_t last;
+    uint64_t f_before;             /* bytes of the files before the current one */
+} src_t;
+
+static uint64_t src_fpos(const src_t *q)
+{
+    if (q->cur >= q->n_seg) return q->f_before;
+    const seg_t *s = &q->seg[q->cur];
+    return q->f_before + (s->gz? oatk_gzsrc_tell_in(s->gz) : q->in_seg);
+}
+
+/* the next bytes of the input (at most cap, at least one unless the input is spent: 0), < 0 on a damaged file */
+static int64_t src_read(src_t *q, uint8_t *dst, uint64_t cap)
+{
+    while (q->cur < q->n_seg) {
+        const seg_t *s = &q->seg[q->cur];
+        int64_t n = 0;
+        if (s->gz) {
+            n = oatk_gzsrc_read(s->gz, dst, cap);
+            if (n < 0) { fprintf(stderr, "[E::%s] input file %d is damaged (gzip stream)\n", __func__, q->cur + 1); return -1; }
+        } else if (s->fd >= 0) {
+            const uint64_t left = s->size - q->in_seg, want = left < cap? left : cap;
+            uint64_t done = 0;
+            while (done < want) {
+                const ssize_t got = pread(s->fd, dst + done, (size_t) (want - done), (off_t) (q->in_seg + done));
+                if (got <= 0) return -1;
+                done += (uint64_t) got;
+            }
+            n = (int64_t) want, q->in_seg += want;
+        } else {
+            const uint64_t left = s->size - q->in_seg, want = left < cap? left : cap;
+            memcpy(dst, s->mem + q->in_seg, (size_t) want);
+            n = (int64_t) want, q->in_seg += want;
+        }
+        if (n > 0) { q->last = dst[n - 1], q->out_seg += (uint64_t) n; return n; }
+        /* the file is spent: a fresh kseq starts every file at a header line (sstream.c:91-97), so a last line without a newline gets one */
+        const int add = q->out_seg && q->last != '\n';
+        q->f_before += s->fsize, q->in_seg = q->out_seg = 0, ++q->cur;
+        if (add) { dst[0] = '\n'; q->last = '\n'; return 1; }
+    }
+    return 0;
+}
+
+static void *uploader_src(void *arg)
+{
+    stream_t *st = (stream_t *) arg;
+    const uint64_t chunk = st->win < ((uint64_t) 32 << 20)? st->win : (uint64_t) 32 << 20;
+    src_t q;
+    uint64_t g0 = 0, w;
+    int rc = OATK_OK, final = 0;
+    memset(&q, 0, sizeof(q));
+    q.seg = st->seg, q.n_seg = st->n_seg, q.last = '\n';
+    for (w = 0; !rc && !final; ++w) {
+        const int s = (int) (w & 1);
+        const uint64_t f0 = src_fpos(&q);
+        stream_dev_t *D = &st->res[st->res_of_rank[rank_of_window(st, f0)]];
+        if (!D->stage) {
+            D->stage = (uint8_t *) oatk_hip_staging(D->up, 2 * (CARRY_CAP + st->win));
+            if (!D->stage) { rc = OATK_E_NOMEM; break; }
+            D->h_win[0] = D->stage + CARRY_CAP, D->h_win[1] = D->stage + CARRY_CAP + st->win + CARRY_CAP;
+        }
+        pthread_mutex_lock(&st->mu);
+        while (st->state[s] != 0 && !st->stop) pthread_cond_wait(&st->cv, &st->mu);
+        const int stop = st->stop;
+        pthread_mutex_unlock(&st->mu);
+        if (stop) break;
+        uint64_t filled = 0;
+        while (!rc && filled < st->win) {                            /* a piece is on the bus while the next one is inflated / read */
+            const uint64_t want = st->win - filled < chunk? st->win - filled : chunk;
+            const int64_t n = src_read(&q, D->h_win[s] + filled, want);
+            if (n < 0) { rc = OATK_E_ARG; break; }
+            if (n == 0) { final = 1; break; }
+            rc = oatk_hip_h2d_async(D->up, D->d_win[s] + filled, D->h_win[s] + filled, (uint64_t) n);
+            filled += (uint64_t) n;
+        }
+        if (!rc) rc = oatk_hip_sync(D->up);
+        pthread_mutex_lock(&st->mu);
+        if (rc) st->failed = rc;
+        else st->state[s] = 1, st->g0[s] = g0, st->g1[s] = g0 + filled, st->f0[s] = f0, st->f1[s] = src_fpos(&q), st->final[s] = final;
+        pthread_cond_broadcast(&st->cv);
+        pthread_mutex_unlock(&st->mu);
+        g0 += filled;
+    }
+    if (rc) {
+        pthread_mutex_lock(&st->mu);
+        st->failed = rc;
+        pthread_cond_broadcast(&st->cv);
+        pthread_mutex_unlock(&st->mu);
+    }
+    return 0;
+}
+
+/* read names out of a window that lies in host memory (streamed input) */
+typedef struct { const uint8_t *text; uint64_t len; const uint64_t *hdr; uint64_t n; char **names; const void *owner; } hname_job_t;
+
+static void hname_worker(void *arg, int tid, int n_threads)
+{
+    hname_job_t *j = (hname_job_t *) arg;
+    const uint64_t a = j->n * (uint64_t) tid / (uint64_t) n_threads, b = j->n * (uint64_t) (tid + 1) / (uint64_t) n_threads;
+    oatk_name_bump_t bump = {0, 0};
+    uint64_t i;
+    for (i = a; i < b; ++i) {
+        const uint64_t p = j->hdr[i] + 1;                           /* behind '>' / '@' */
+        uint64_t e = p;
+        while (e < j->len && j->text[e] != ' ' && j->text[e] != '\t' && j->text[e] != '\n' && j->text[e] != '\r') ++e;
+        j->names[i] = oatk_host_name_dup(j->text + p, (size_t) (e - p), &bump, j->owner);
+    }
 }
 
 /* the first character of the text that is not white space decides the format, as kseq and oatk_hip_ingest(AUTO) decide it */
@@ -368,7 +521,7 @@ static double now_s(void)
  * (rank_of_window) and first[0 .. n_ctx] their ranges; sid0 of handle r = first[r] */
 /* m_data: sr_read's data cap (syncmer.c:537-541; 0 = none): the read that takes the total of raw bases to the cap is the last one taken */
 static int sr_read_stream(oatk_hip_ctx **ctxs, int n_ctx, uint64_t *first, oatk_sr_db_t *sr_db, int K, int S, seg_t *seg, int n_files, uint64_t total, uint64_t win,
-                          uint64_t m_data)
+                          uint64_t m_data, int streamed)
 {
     const char *lg = getenv("OATK_DROPIN_LOG");
     const int log = lg && lg[0] && lg[0] != '0';
@@ -383,16 +536,22 @@ static int sr_read_stream(oatk_hip_ctx **ctxs, int n_ctx, uint64_t *first, oatk_
     uint64_t n_done = 0, carry = 0, w, text_done = 0;
     uint64_t *off = 0, *hdr = 0;
     uint8_t *hop = 0;                                               /* a carried record tail on its way from one device to the next */
-    char **names = 0;
+    uint8_t *h_carry = 0;                                           /* streamed input: the same tail on the host (the names are cut out of the host's copy of the text) */
+    char **names = 0, **early_names = 0;
+    uint64_t ftotal = 0;
+    int all_done = 0;
     memset(&st, 0, sizeof(st));
     memset(res, 0, sizeof(res));
     if (n_ctx < 1 || n_ctx > 64) return OATK_E_ARG;
     pthread_mutex_init(&st.mu, 0);
     pthread_cond_init(&st.cv, 0);
     st.seg = seg, st.n_seg = n_files, st.total = total, st.win = win, st.res = res, st.res_of_rank = res_of_rank, st.n_rank = n_ctx;
+    st.streamed = streamed;
+    if (streamed) { for (i = 0; i < n_files; ++i) ftotal += seg[i].fsize; } else ftotal = total;
+    st.ftotal = ftotal;
     st.n_up = threads > 1? threads : 1;            /* readers of the file beside the threads that fill the structs: with the reads in arenas the file is what sr_read waits for */
     { const char *e = getenv("OATK_HOST_UP_THREADS"); if (e && atoi(e) > 0) st.n_up = atoi(e); }
-    int fmt = sniff_format(seg, n_files, total);
+    int fmt = streamed? -1 : sniff_format(seg, n_files, total);     /* (streamed: from the first window, below) */
     uint64_t n_bases = 0;                                           /* raw bases taken so far */
     int capped = 0;
     for (r = 0; r < n_ctx; ++r) {                                   /* one set of working handles per device */
@@ -409,28 +568,29 @@ static int sr_read_stream(oatk_hip_ctx **ctxs, int n_ctx, uint64_t *first, oatk_
             uint8_t *d = 0;
             res[r].piece[i] = oatk_hip_create(res[r].dev);
             if (!res[r].piece[i] || !res[r].up) { rc = OATK_E_NODEV; break; }
-            if (i == 1 && total <= win) break;                        /* one window: one slot */
-            rc = oatk_hip_ingest_text_buffer(res[r].piece[i], CARRY_CAP + (win < total? win : total) + 64, &d);
+            if (i == 1 && !streamed && total <= win) break;           /* one window: one slot */
+            rc = oatk_hip_ingest_text_buffer(res[r].piece[i], CARRY_CAP + (streamed || win < total? win : total) + 64, &d);
             res[r].d_win[i] = d + CARRY_CAP;
         }
     }
     if (rc) goto done;
-    oatk_host_set_threads(threads > 1? threads / 2 : 1);           /* the other half reads the file */
-    if (pthread_create(&th, 0, uploader, &st) != 0) { rc = OATK_E_NOMEM; goto done; }
+    oatk_host_set_threads_internal(threads > 1? threads / 2 : 1);  /* the other half reads the file */
+    if (streamed && !(h_carry = (uint8_t *) malloc(CARRY_CAP))) { rc = OATK_E_NOMEM; goto done; }
+    if (pthread_create(&th, 0, streamed? uploader_src : uploader, &st) != 0) { rc = OATK_E_NOMEM; goto done; }
     started = 1;
 
-    for (w = 0; text_done < total; ++w) {
+    for (w = 0; !all_done; ++w) {
         const int s = (int) (w & 1);
         double t0 = now_s();
         pthread_mutex_lock(&st.mu);
         while (st.state[s] != 1 && !st.failed) pthread_cond_wait(&st.cv, &st.mu);
         rc = st.failed;
-        const uint64_t g0 = st.g0[s], g1 = st.g1[s];
+        const uint64_t g0 = st.g0[s], g1 = st.g1[s], wf0 = st.f0[s], wf1 = st.f1[s];
+        const int final = st.final[s];
         pthread_mutex_unlock(&st.mu);
         if (rc) break;
         t_wait += now_s() - t0, t0 = now_s();
-        const int final = g1 == total;
-        const int rank = rank_of_window(&st, g0), ri = res_of_rank[rank];
+        const int rank = rank_of_window(&st, wf0), ri = res_of_rank[rank];
         stream_dev_t *D = &res[ri];
         while (cur < rank) {                                         /* the reads from here on belong to the next handle(s) */
             ++cur;
@@ -451,6 +611,24 @@ static int sr_read_stream(oatk_hip_ctx **ctxs, int n_ctx, uint64_t *first, oatk_
         uint8_t *d_text = D->d_win[s] - carry;
         const uint64_t len = carry + (g1 - g0);
         uint64_t n = 0, used = 0, b = 0;
+        const uint8_t *h_text = 0;
+        if (streamed) {                                              /* the host's copy of the same text: the carried tail in front of the window */
+            if (carry) memcpy(D->h_win[s] - carry, h_carry, carry);
+            h_text = D->h_win[s] - carry;
+            if (fmt < 0) {
+                uint64_t i2;
+                for (i2 = 0; i2 < len && (h_text[i2] == '\n' || h_text[i2] == '\r' || h_text[i2] == ' ' || h_text[i2] == '\t'); ++i2) {}
+                if (i2 < len || final) fmt = i2 < len && h_text[i2] == '@'? OATK_FMT_FASTQ : OATK_FMT_FASTA;
+            }
+            if (len == 0 || fmt < 0) {                               /* an empty last window, or nothing but white space so far (dropped, as kseq skips it) */
+                pthread_mutex_lock(&st.mu);
+                st.state[s] = 0;
+                pthread_cond_broadcast(&st.cv);
+                pthread_mutex_unlock(&st.mu);
+                carry = 0, text_done = g1, prev_res = ri, prev_slot = s, all_done = final;
+                continue;
+            }
+        }
         rc = oatk_hip_ingest(D->piece[s], d_text, len, fmt, final, &n, &used);
         if (rc == OATK_E_SPLIT && fmt != OATK_FMT_KSEQ) {
             /* not what the two device-only formats take (wrapped FASTQ; FASTQ records among FASTA ones): kseq's own reading from here on, line by line */
@@ -479,12 +657,27 @@ static int sr_read_stream(oatk_hip_ctx **ctxs, int n_ctx, uint64_t *first, oatk_
             rc = oatk_hip_d2d(D->piece[s], D->d_win[s ^ 1] - next_carry, d_text + used, next_carry);      /* (moved on above if the next window lands on another device) */
             if (rc) break;
         }
+        if (streamed) {                                             /* before the slot goes back: the names and the carried tail, from the host's copy */
+            if (sr_db && n) {
+                const void *dh = 0;
+                uint64_t bb = 0;
+                hdr = (uint64_t *) malloc(8 * n), early_names = (char **) calloc(n, sizeof(char *));
+                if (!hdr || !early_names) { rc = OATK_E_NOMEM; break; }
+                rc = oatk_hip_buffer(D->piece[s], OATK_BUF_INGEST_HDR, &dh, &bb);
+                if (!rc) rc = oatk_hip_d2h(D->piece[s], hdr, dh, 8 * n);
+                if (rc) break;
+                hname_job_t hj = {h_text, len, hdr, n, early_names, sr_db};
+                oatk_par_run(hname_worker, &hj);
+                free(hdr), hdr = 0;
+            }
+            if (!final && !capped && next_carry) memcpy(h_carry, h_text + used, next_carry);
+        }
         pthread_mutex_lock(&st.mu);                                 /* the window's text is spent: the uploader may have the slot back */
         st.state[s] = 0;
         pthread_cond_broadcast(&st.cv);
         pthread_mutex_unlock(&st.mu);
         const uint64_t text0 = g0 - carry;                          /* where this piece's text starts in the whole text */
-        carry = next_carry, text_done = capped? total : g1, prev_res = ri, prev_slot = s;
+        carry = next_carry, text_done = g1, prev_res = ri, prev_slot = s, all_done = final || capped;
         if (n == 0) continue;
         oatk_hip_ctx *ctx = ctxs[cur];
         rc = oatk_hip_scan_ingested(D->piece[s], n_done, K, S);
@@ -493,7 +686,7 @@ static int sr_read_stream(oatk_hip_ctx **ctxs, int n_ctx, uint64_t *first, oatk_
         /* room for the reads: from the first piece's density, generously; grown when a later piece needs more */
         if (sr_db && sr_db->m < n_done + n) {
             uint64_t m = n_done + n;
-            if (!final && !capped && used) m = n_done + (uint64_t) ((double) n * ((double) (total - text0) / (double) used) * 1.05) + 1024;
+            if (!final && !capped && used && wf1 > wf0) m = n_done + (uint64_t) ((double) n * ((double) (ftotal > wf0? ftotal - wf0 : wf1 - wf0) / (double) (wf1 - wf0)) * 1.05) + 1024;
             oatk_sr_t *na = (oatk_sr_t *) realloc(sr_db->a, sizeof(oatk_sr_t) * m);
             if (!na) { rc = OATK_E_NOMEM; break; }
             memset(na + sr_db->m, 0, sizeof(oatk_sr_t) * (m - sr_db->m));
@@ -502,11 +695,11 @@ static int sr_read_stream(oatk_hip_ctx **ctxs, int n_ctx, uint64_t *first, oatk_
         {   /* ... and for the batch assembled in this handle, at its first piece */
             oatk_hip_info_t have;
             oatk_hip_info(ctx, &have);
-            if (have.n_reads == 0 && !final && !capped && used) {
+            if (have.n_reads == 0 && !final && !capped && used && wf1 > wf0) {
                 oatk_hip_info_t inf;
                 oatk_hip_info(D->piece[s], &inf);
-                const double share = (double) total / (double) n_ctx, left = (double) (total - text0);
-                const double scale = (share < left? share : left) / (double) used * 1.03 + (n_ctx > 1? 1.0 : 0.0);       /* (a handle's part ends on a window boundary) */
+                const double share = (double) ftotal / (double) n_ctx, left = ftotal > wf0? (double) (ftotal - wf0) : (double) (wf1 - wf0);
+                const double scale = (share < left? share : left) / (double) (wf1 - wf0) * 1.03 + (n_ctx > 1? 1.0 : 0.0);       /* (a handle's part ends on a window boundary) */
                 rc = oatk_hip_scan_reserve(ctx, (uint64_t) ((double) inf.seq_bytes * scale) + (1 << 20), (uint64_t) ((double) n * scale) + 1024,
                                            (uint64_t) ((double) inf.n_occ * scale * 1.1) + 4096);
                 if (rc) break;
@@ -520,15 +713,21 @@ static int sr_read_stream(oatk_hip_ctx **ctxs, int n_ctx, uint64_t *first, oatk_
             continue;
         }
         const void *d = 0;
-        off = (uint64_t *) malloc(8 * n), hdr = (uint64_t *) malloc(8 * n), names = (char **) calloc(n, sizeof(char *));
-        if (!off || !hdr || !names) { rc = OATK_E_NOMEM; break; }
+        off = (uint64_t *) malloc(8 * n);
+        if (streamed) names = early_names, early_names = 0;           /* (cut out of the host's window above) */
+        else hdr = (uint64_t *) malloc(8 * n), names = (char **) calloc(n, sizeof(char *));
+        if (!off || (!streamed && !hdr) || !names) { rc = OATK_E_NOMEM; break; }
         rc = oatk_hip_buffer(D->piece[s], OATK_BUF_INGEST_OFF, &d, &b);
         if (!rc) rc = oatk_hip_d2h(D->piece[s], off, d, 8 * n);
-        if (!rc) rc = oatk_hip_buffer(D->piece[s], OATK_BUF_INGEST_HDR, &d, &b);
-        if (!rc) rc = oatk_hip_d2h(D->piece[s], hdr, d, 8 * n);
+        if (!rc && !streamed) {
+            rc = oatk_hip_buffer(D->piece[s], OATK_BUF_INGEST_HDR, &d, &b);
+            if (!rc) rc = oatk_hip_d2h(D->piece[s], hdr, d, 8 * n);
+        }
         if (rc) break;
-        name_job_t nj = {seg, n_files, hdr, text0, n, names};
-        oatk_par_run(name_worker, &nj);
+        if (!streamed) {
+            name_job_t nj = {seg, n_files, hdr, text0, n, names, sr_db};
+            oatk_par_run(name_worker, &nj);
+        }
         rc = oatk_sr_db_fill_range(D->piece[s], sr_db, n_done, off, n, names);
         free(off); free(hdr); free(names);
         off = hdr = 0, names = 0;
@@ -554,8 +753,9 @@ done:
         pthread_mutex_unlock(&st.mu);
         pthread_join(th, 0);
     }
-    oatk_host_set_threads(threads);
-    free(off); free(hdr); free(names); free(hop);
+    oatk_host_set_threads_internal(threads);
+    free(off); free(hdr); free(names); free(hop); free(h_carry);
+    free(early_names);
     for (r = 0; r < st.n_res; ++r) {
         for (i = 0; i < 2; ++i) if (res[r].piece[i]) oatk_hip_destroy(res[r].piece[i]);
         if (res[r].up) oatk_hip_destroy(res[r].up);
@@ -567,7 +767,7 @@ done:
         if (na) sr_db->a = na, sr_db->m = sr_db->n;
     }
     if (log) fprintf(stderr, "[M::oatk_sr_read_files] %.2f GB of text in %lu windows, %lu reads into %d handle(s): %.3f s (waiting for the uploader %.3f, record + syncmer scan %.3f, "
-                             "structs %.3f, append %.3f)\n", (double) total / 1e9, (unsigned long) w, (unsigned long) n_done, n_ctx, now_s() - t_begin, t_wait, t_dev, t_fill, t_app);
+                             "structs %.3f, append %.3f)\n", (double) text_done / 1e9, (unsigned long) w, (unsigned long) n_done, n_ctx, now_s() - t_begin, t_wait, t_dev, t_fill, t_app);
     return rc;
 }
 
@@ -584,29 +784,44 @@ int oatk_sr_read_files_capped(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, char **fil
 int oatk_host_sr_read_files_n(oatk_hip_ctx **ctxs, int n_ctx, oatk_sr_db_t *sr_db, char **files, int n_files, uint64_t *first, uint64_t m_data)
 {
     uint64_t total = 0;
-    int i, rc = OATK_OK;
-    seg_t *seg = open_segments(files, n_files, &total, &rc);
+    int i, rc = OATK_OK, any_gz = 0;
+    seg_t *seg = open_segments(files, n_files, &total, &rc, 1, &any_gz);
     if (!seg) return rc;
-    for (i = 0; !rc && i < n_files; ++i)                           /* the header lines are read where the file lies in the page cache */
-        if (seg[i].fd >= 0 && seg[i].size) {
-            seg[i].map = (uint8_t *) mmap(0, (size_t) seg[i].size, PROT_READ, MAP_PRIVATE, seg[i].fd, 0);
-            if (seg[i].map == MAP_FAILED) { seg[i].map = 0; rc = OATK_E_NOMEM; }
+    const char *ew = getenv("OATK_DEBUG_WINDOW");                  /* test hook, like oatk_host_debug_window */
+    const uint64_t forced = g_window? g_window : (ew && atoll(ew) > 0? (uint64_t) atoll(ew) : 0);
+    if (any_gz) {
+        /* A gzip'ed file among the inputs: everything is pulled through sources, window by window (uploader_src).  The windows are smaller than for
+         * plain files -- the device waits for the inflating host anyway, and two of them lie page-locked on the host. */
+        uint64_t win = forced? forced : (uint64_t) 256 << 20;
+        int attempt;
+        if (win < 4096) win = 4096;
+        for (attempt = 0;; ++attempt) {
+            rc = sr_read_stream(ctxs, n_ctx, first, sr_db, sr_db->k, sr_db->s, seg, n_files, 0, win, m_data, 1);
+            if (rc != OATK_E_NOMEM || attempt == 2) break;
+            /* a record longer than a window: the stream cannot be rewound, so the files are opened again and read with windows eight times the size */
+            seg_close(seg, n_files);
+            oatk_sr_db_clean(sr_db);
+            win *= 8;
+            seg = open_segments(files, n_files, &total, &rc, 1, &any_gz);
+            if (!seg) return rc;
         }
+        seg_close(seg, n_files);
+        return rc;
+    }
     if (!rc && total == 0) {
         for (i = 0; !rc && i < n_ctx; ++i) rc = oatk_hip_scan_begin(ctxs[i], 0, sr_db->k, sr_db->s);
         for (i = 0; first && i <= n_ctx; ++i) first[i] = 0;
     } else if (!rc) {
-        const char *ew = getenv("OATK_DEBUG_WINDOW");              /* test hook, like oatk_host_debug_window */
-        uint64_t win = g_window? g_window : (ew && atoll(ew) > 0? (uint64_t) atoll(ew) : WIN_DEFAULT);
-        if (n_ctx > 1 && !g_window && !(ew && atoll(ew) > 0)) {     /* several handles: at least four windows each, so the parts come out even */
+        uint64_t win = forced? forced : WIN_DEFAULT;
+        if (n_ctx > 1 && !forced) {                                 /* several handles: at least four windows each, so the parts come out even */
             const uint64_t even = total / (4 * (uint64_t) n_ctx);
             if (even < win) win = even > ((uint64_t) 64 << 20)? even : (uint64_t) 64 << 20;
         }
         if (win < 4096) win = 4096;
-        rc = sr_read_stream(ctxs, n_ctx, first, sr_db, sr_db->k, sr_db->s, seg, n_files, total, win, m_data);
+        rc = sr_read_stream(ctxs, n_ctx, first, sr_db, sr_db->k, sr_db->s, seg, n_files, total, win, m_data, 0);
         if (rc == OATK_E_NOMEM && win < total) {                    /* a record longer than a window: once more, in one piece */
             oatk_sr_db_clean(sr_db);
-            rc = sr_read_stream(ctxs, n_ctx, first, sr_db, sr_db->k, sr_db->s, seg, n_files, total, total, m_data);
+            rc = sr_read_stream(ctxs, n_ctx, first, sr_db, sr_db->k, sr_db->s, seg, n_files, total, total, m_data, 0);
         }
     }
     seg_close(seg, n_files);
@@ -629,8 +844,8 @@ int oatk_scan_text(oatk_hip_ctx *ctx, const uint8_t *text, uint64_t n_bytes, int
     else {
         uint64_t win = window? window : WIN_DEFAULT;
         if (win < 4096) win = 4096;
-        rc = sr_read_stream(&ctx, 1, 0, 0, k, s, &seg, 1, total, win, 0);
-        if (rc == OATK_E_NOMEM && win < total) rc = sr_read_stream(&ctx, 1, 0, 0, k, s, &seg, 1, total, total, 0);
+        rc = sr_read_stream(&ctx, 1, 0, 0, k, s, &seg, 1, total, win, 0, 0);
+        if (rc == OATK_E_NOMEM && win < total) rc = sr_read_stream(&ctx, 1, 0, 0, k, s, &seg, 1, total, total, 0, 0);
     }
     if (!rc && n_reads) { oatk_hip_info_t inf; oatk_hip_info(ctx, &inf); *n_reads = inf.n_reads; }
     return rc;

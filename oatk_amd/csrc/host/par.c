@@ -9,11 +9,22 @@
 
 #include "oatk_syncasm.h"
 
-static int g_threads = 0;
+static int g_threads = 0, g_threads_raw = 0;
 
 /* more than 16 threads only get in each other's way here (measured on a 2 x 64-core host: page-cache reads and first-touch page faults stop
  * scaling, and a thread is started per piece), whatever the caller grants */
-void oatk_host_set_threads(int n) { g_threads = n > 0? (n > 16? 16 : n) : 0; }
+void oatk_host_set_threads(int n) { g_threads = n > 0? (n > 16? 16 : n) : 0; g_threads_raw = n > 0? n : 0; }
+
+/* the adaptors' own adjustments (half the threads fill structs while the other half reads the file): what the caller granted is kept */
+void oatk_host_set_threads_internal(int n) { g_threads = n > 0? (n > 16? 16 : n) : 0; }
+
+/* what the caller granted, uncapped (at most 64): inflating BGZF members scales with the cores, unlike the struct filling above */
+int oatk_host_threads_granted(void)
+{
+    if (g_threads_raw > 0) return g_threads_raw > 64? 64 : g_threads_raw;
+    long n = sysconf(_SC_NPROCESSORS_ONLN);
+    return n < 1? 1 : (n > 64? 64 : (int) n);
+}
 
 int oatk_host_threads(void)
 {

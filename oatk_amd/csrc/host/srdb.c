@@ -105,7 +105,7 @@ static int heap_tune_wanted(void)
  * does, include/oatk_dropin.h -- can ask for ARENAS instead: one block per piece of reads (tens of MB: an anonymous mapping, fresh zero pages
  * that the copying threads touch first, in parallel), the member pointers carved from it; a registry of the blocks tells arena memory from
  * malloc'ed memory wherever a member is freed or replaced. */
-typedef struct { uint8_t *base; size_t size; const void *owner; } host_arena_t;
+typedef struct { uint8_t *base; size_t size; const void *owner; uint8_t *raw; size_t raw_size; } host_arena_t;      /* raw != NULL: an anonymous mapping (munmap), else malloc'ed */
 static host_arena_t *g_ar = 0;
 static size_t g_nar = 0, g_mar = 0;
 static int g_use_arena = 0;
@@ -125,11 +125,11 @@ static long arena_of(const void *p, long *hint)
     if (lo < g_nar && q >= g_ar[lo].base) { if (hint) *hint = (long) lo; return (long) lo; }
     return -1;
 }
-static void arena_register(uint8_t *b, size_t size, const void *owner);
+static void arena_register(uint8_t *b, size_t size, const void *owner, uint8_t *raw, size_t raw_size);
 static uint8_t *arena_new(size_t size, const void *owner)
 {
     uint8_t *b = (uint8_t *) xmalloc(size? size : 1);
-    arena_register(b, size, owner);
+    arena_register(b, size, owner, 0, 0);
     static int thp = -1;
     if (thp < 0) { const char *e = getenv("OATK_HOST_THP"); thp = !(e && e[0] == '0'); }
     if (thp && size >= ((size_t) 4 << 20)) {        /* huge pages for the bulk of it: 512 times fewer first-touch faults */
@@ -138,24 +138,24 @@ static uint8_t *arena_new(size_t size, const void *owner)
     }
     return b;
 }
-static void arena_register(uint8_t *b, size_t size, const void *owner)
+static void arena_register(uint8_t *b, size_t size, const void *owner, uint8_t *raw, size_t raw_size)
 {
     pthread_mutex_lock(&g_ar_mu);
     if (g_nar == g_mar) { g_mar = g_mar? 2 * g_mar : 256; g_ar = (host_arena_t *) realloc(g_ar, g_mar * sizeof(host_arena_t)); if (!g_ar) abort(); }
     size_t at = g_nar;
     while (at && g_ar[at - 1].base > b) { g_ar[at] = g_ar[at - 1]; --at; }
-    g_ar[at].base = b, g_ar[at].size = size? size : 1, g_ar[at].owner = owner;
+    g_ar[at].base = b, g_ar[at].size = size? size : 1, g_ar[at].owner = owner, g_ar[at].raw = raw, g_ar[at].raw_size = raw_size;
     ++g_nar;
     pthread_mutex_unlock(&g_ar_mu);
 }
 /* a malloc'ed block the caller already holds (an array fetched from the device) becomes an arena: its parts are handed out as they lie */
-void oatk_host_arena_adopt(void *block, size_t bytes, const void *owner) { if (block) arena_register((uint8_t *) block, bytes + 1, owner); }      /* (+ 1: a pointer one past the end belongs to it too) */
+void oatk_host_arena_adopt(void *block, size_t bytes, const void *owner) { if (block) arena_register((uint8_t *) block, bytes + 1, owner, 0, 0); }      /* (+ 1: a pointer one past the end belongs to it too) */
 static void arena_release(const void *owner)
 {
     pthread_mutex_lock(&g_ar_mu);
     size_t i, k = 0;
     for (i = 0; i < g_nar; ++i) {
-        if (g_ar[i].owner == owner) free(g_ar[i].base);
+        if (g_ar[i].owner == owner) { if (g_ar[i].raw) munmap(g_ar[i].raw, g_ar[i].raw_size); else free(g_ar[i].base); }
         else g_ar[k++] = g_ar[i];
     }
     g_nar = k;
@@ -164,6 +164,26 @@ static void arena_release(const void *owner)
 /* free() for a member array that may live in an arena (then it goes with its arena) */
 void oatk_sr_member_free(void *p) { if (p && arena_of(p, 0) < 0) free(p); }
 void *oatk_host_arena_alloc(size_t bytes, const void *owner) { return arena_new(bytes, owner); }
+
+/* A read's name (sr_t.sname): a block of its own that sr_destroy may free() -- or, with arenas, a piece of a 1 MiB block that goes with the reads
+ * (2 M mallocs and as many frees less at 2 M reads).  `b`: the calling thread's current block. */
+char *oatk_host_name_dup(const uint8_t *src, size_t len, oatk_name_bump_t *b, const void *owner)
+{
+    char *nm;
+    if (!g_use_arena || !b) {
+        nm = (char *) malloc(len + 1);
+        if (!nm) return 0;
+    } else {
+        if (!b->p || (size_t) (b->end - b->p) < len + 1) {
+            const size_t sz = len + 1 > ((size_t) 1 << 20)? len + 1 : (size_t) 1 << 20;
+            b->p = arena_new(sz, owner), b->end = b->p + sz;
+        }
+        nm = (char *) b->p, b->p += len + 1;
+    }
+    memcpy(nm, src, len);
+    nm[len] = 0;
+    return nm;
+}
 
 /* the occurrence list of every syncmer as a block of its own again: what update_syncmer_db frees and mallocs (syncerr.c:789-790) */
 void oatk_syncmer_db_own_mpos(oatk_syncmer_db_t *db)
@@ -319,6 +339,161 @@ static void fill_worker(void *arg, int tid, int n_threads)
     }
 }
 
+
+/* ---- arenas, filled WITHOUT a host copy (round 4) ------------------------------------------------------------------------------------------
+ * Until round 3 a piece's arrays came over PCIe into a page-locked staging buffer and were then copied into the arena by the host threads: every
+ * byte of the reads' structs (29 GB at 2 M reads) crossed the host's memory twice, 2.3 of the CLI's 8.7 s.  Member pointers into an arena may point
+ * anywhere, so the arena of a piece is now laid out exactly as the piece lies on the DEVICE -- the run-length slab with the reads at their 64-byte
+ * aligned offsets, the packed-base slab at a quarter of them, the three per-syncmer arrays back to back -- and is itself the destination of the
+ * copies: a fresh anonymous mapping on transparent huge pages, touched by the host threads while the piece before is on the bus (294 GB/s with 32
+ * threads on the bench box, tools/ubench/pin_rates.hip), page-locked for the duration of the copy (hipHostRegister of touched huge pages: 0.02 s per
+ * 8 GB; hipHostMalloc would be 5.8 GB/s) and unlocked when it has landed.  What the host still does per read is set eight pointers. */
+#define ZC_RL_BYTES ((uint64_t) 256 << 20)            /* run-length slab bytes per piece */
+
+typedef struct {
+    uint8_t *raw; size_t raw_size;                    /* the mapping */
+    uint8_t *base; size_t size;                       /* 2 MiB aligned part that is used */
+    uint8_t *rl, *hs; uint64_t *s_mer, *k_hash; uint32_t *m_pos, *lrl, *nn;
+    uint64_t i0, i1, rl_bytes, ns;
+} zc_piece_t;
+
+typedef struct {
+    oatk_sr_db_t *sr_db;
+    uint64_t first;
+    const uint64_t *off, *scm_off;
+    const uint32_t *hoco_l, *n_nn, *n_lrl, *lrl_val;
+    const uint64_t *nn_key, *o_nn, *o_lrl;
+    char **names;
+    const zc_piece_t *cur;                            /* structs of this piece are set ... */
+    const zc_piece_t *next;                           /* ... while this one's pages are touched */
+} zc_job_t;
+
+static int zc_wanted(void)
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("OATK_HOST_ZERO_COPY"); v = !(e && e[0] == '0'); }
+    return v;
+}
+
+static int zc_map(zc_piece_t *pc, const zc_job_t *j, uint64_t i0, uint64_t i1)
+{
+#define A64(x) (((size_t) (x) + 63) & ~(size_t) 63)
+    const uint64_t last = i1 - 1;
+    pc->i0 = i0, pc->i1 = i1;
+    pc->rl_bytes = j->off[last] + j->hoco_l[last] - j->off[i0];
+    pc->ns = j->scm_off[i1] - j->scm_off[i0];
+    const size_t n_lrl = (size_t) (j->o_lrl[i1] - j->o_lrl[i0]), n_nn = (size_t) (j->o_nn[i1] - j->o_nn[i0]);
+    const size_t o_rl = 0, o_hs = A64(pc->rl_bytes + 64), o_sm = o_hs + A64(pc->rl_bytes / 4 + 128), o_kh = o_sm + A64(8 * pc->ns), o_mp = o_kh + A64(8 * pc->ns),
+                 o_lrl = o_mp + A64(4 * pc->ns), o_nn = o_lrl + A64(4 * n_lrl), tot = o_nn + A64(4 * n_nn) + 64;
+    const size_t HP = (size_t) 2 << 20;
+    pc->raw_size = ((tot + HP - 1) & ~(HP - 1)) + HP;
+    pc->raw = (uint8_t *) mmap(0, pc->raw_size, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (pc->raw == MAP_FAILED) { pc->raw = 0; return OATK_E_NOMEM; }
+    pc->base = (uint8_t *) (((uintptr_t) pc->raw + HP - 1) & ~(uintptr_t) (HP - 1));
+    pc->size = (tot + HP - 1) & ~(HP - 1);
+    {
+        static int thp = -1;
+        if (thp < 0) { const char *e = getenv("OATK_HOST_THP"); thp = !(e && e[0] == '0'); }
+        if (thp) (void) madvise(pc->base, pc->size, MADV_HUGEPAGE);
+    }
+    pc->rl = pc->base + o_rl, pc->hs = pc->base + o_hs, pc->s_mer = (uint64_t *) (pc->base + o_sm), pc->k_hash = (uint64_t *) (pc->base + o_kh);
+    pc->m_pos = (uint32_t *) (pc->base + o_mp), pc->lrl = (uint32_t *) (pc->base + o_lrl), pc->nn = (uint32_t *) (pc->base + o_nn);
+    arena_register(pc->base, pc->size, j->sr_db, pc->raw, pc->raw_size);
+    return OATK_OK;
+#undef A64
+}
+
+static void zc_worker(void *arg, int tid, int n_threads)
+{
+    const zc_job_t *j = (const zc_job_t *) arg;
+    if (j->next && j->next->base) {                    /* first touch of the next piece's pages: a huge page per 2 MiB where the kernel grants them */
+        const size_t pages = j->next->size >> 12, a = pages * (size_t) tid / (size_t) n_threads, b = pages * (size_t) (tid + 1) / (size_t) n_threads;
+        size_t p;
+        for (p = a; p < b; ++p) *(volatile uint8_t *) (j->next->base + (p << 12)) = 0;
+    }
+    if (j->cur) {
+        const zc_piece_t *pc = j->cur;
+        const uint64_t n = pc->i1 - pc->i0, a = pc->i0 + n * (uint64_t) tid / (uint64_t) n_threads, b = pc->i0 + n * (uint64_t) (tid + 1) / (uint64_t) n_threads;
+        const uint64_t rl0 = j->off[pc->i0], scm0 = j->scm_off[pc->i0], lrl0 = j->o_lrl[pc->i0], nn0 = j->o_nn[pc->i0];
+        uint64_t i;
+        for (i = a; i < b; ++i) {
+            oatk_sr_t *r = &j->sr_db->a[j->first + i];
+            const uint32_t hl = j->hoco_l[i];
+            const uint64_t ns = j->scm_off[i + 1] - j->scm_off[i], os = j->scm_off[i] - scm0;
+            r->sid = j->first + i;                         /* reads are numbered in input order, syncmer.c:525 */
+            r->sname = j->names? j->names[i] : 0;
+            r->hoco_l = hl;
+            /* empty arrays are NULL in the reference (kvec never allocated), syncmer.c:396-412 */
+            r->hoco_s = hl? pc->hs + (j->off[i] - rl0) / 4 : 0;
+            r->ho_rl = hl? pc->rl + (j->off[i] - rl0) : 0;
+            r->n = (uint32_t) ns;
+            r->m_pos = ns? pc->m_pos + os : 0;
+            r->s_mer = ns? pc->s_mer + os : 0;
+            r->k_mer = ns? pc->k_hash + os : 0;
+            r->ho_l_rl = 0, r->n_nucl = 0;
+            if (j->n_lrl[i]) {
+                r->ho_l_rl = pc->lrl + (j->o_lrl[i] - lrl0);
+                memcpy(r->ho_l_rl, j->lrl_val + j->o_lrl[i], 4 * (size_t) j->n_lrl[i]);
+            }
+            if (j->n_nn[i]) {
+                uint32_t t;
+                r->n_nucl = pc->nn + (j->o_nn[i] - nn0);
+                for (t = 0; t < j->n_nn[i]; ++t) r->n_nucl[t] = (uint32_t) j->nn_key[j->o_nn[i] + t];     /* low word = raw coordinate */
+            }
+        }
+    }
+}
+
+static int fill_range_zero_copy(oatk_hip_ctx *ctx, zc_job_t *j, uint64_t n_reads, const void *d_rl, const void *d_hs, const void *d_mp, const void *d_sm, const void *d_kh,
+                                double *t_prep, double *t_wait)
+{
+    zc_piece_t pc[2];
+    int rc = OATK_OK, cur = 0, have_next;
+    uint64_t p0 = 0, p1;
+    memset(pc, 0, sizeof(pc));
+    /* piece limits as in the copying form; a single read larger than the default makes its own piece */
+#define NEXT_END(a, e) do { e = (a) + 1; while (e < n_reads && j->off[e] + j->hoco_l[e] - j->off[a] <= ZC_RL_BYTES) ++e; } while (0)
+    NEXT_END(p0, p1);
+    double t0 = host_now();
+    rc = zc_map(&pc[0], j, p0, p1);
+    if (rc) return rc;
+    j->cur = 0, j->next = &pc[0];
+    oatk_par_run(zc_worker, j);
+    *t_prep += host_now() - t0;
+    for (;;) {
+        zc_piece_t *P = &pc[cur];
+        t0 = host_now();
+        const int locked = oatk_hip_host_register(ctx, P->base, P->size) == OATK_OK;      /* (not page-locked the copies still arrive, staged by the runtime) */
+        rc = oatk_hip_d2h_async(ctx, P->rl, (const uint8_t *) d_rl + j->off[P->i0], P->rl_bytes);
+        if (!rc) rc = oatk_hip_d2h_async(ctx, P->hs, (const uint8_t *) d_hs + j->off[P->i0] / 4, (P->rl_bytes + 3) / 4 + 1);
+        if (!rc) rc = oatk_hip_d2h_async(ctx, P->m_pos, (const uint32_t *) d_mp + j->scm_off[P->i0], P->ns * 4);
+        if (!rc) rc = oatk_hip_d2h_async(ctx, P->s_mer, (const uint64_t *) d_sm + j->scm_off[P->i0], P->ns * 8);
+        if (!rc) rc = oatk_hip_d2h_async(ctx, P->k_hash, (const uint64_t *) d_kh + j->scm_off[P->i0], P->ns * 8);
+        /* while it is on the bus: the next piece's mapping is made and touched, this piece's structs are set */
+        p0 = P->i1, have_next = 0;
+        if (!rc && p0 < n_reads) {
+            NEXT_END(p0, p1);
+            rc = zc_map(&pc[cur ^ 1], j, p0, p1);
+            have_next = !rc;
+        }
+        j->cur = P, j->next = have_next? &pc[cur ^ 1] : 0;
+        if (!rc) oatk_par_run(zc_worker, j);
+        *t_prep += host_now() - t0, t0 = host_now();
+        {
+            const int rs = oatk_hip_sync(ctx);                 /* the piece has landed */
+            if (!rc) rc = rs;
+        }
+        if (locked) (void) oatk_hip_host_unregister(ctx, P->base);
+        *t_wait += host_now() - t0;
+        if (rc) return rc;
+        j->sr_db->n = j->first + P->i1;
+        if (!have_next) break;
+        cur ^= 1;
+    }
+#undef NEXT_END
+    return OATK_OK;
+}
+
 int oatk_sr_db_fill_resident(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, const uint64_t *off, uint64_t n_reads, char **names)
 {
     if (n_reads == 0) return OATK_OK;
@@ -363,6 +538,17 @@ int oatk_sr_db_fill_range(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, uint64_t first
     rc = oatk_hip_buffer(ctx, OATK_BUF_POS_SMER, &d_sm, &b); if (rc) goto done;
     rc = oatk_hip_buffer(ctx, OATK_BUF_POS_HASH, &d_kh, &b); if (rc) goto done;
 
+    if (g_use_arena && zc_wanted()) {
+        zc_job_t zj;
+        double t_prep = 0;
+        memset(&zj, 0, sizeof(zj));
+        zj.sr_db = sr_db, zj.first = first, zj.off = off, zj.scm_off = scm_off, zj.hoco_l = hoco_l, zj.n_nn = n_nn, zj.n_lrl = n_lrl, zj.lrl_val = lrl_val;
+        zj.nn_key = nn_key, zj.o_nn = o_nn, zj.o_lrl = o_lrl, zj.names = names;
+        t_setup = host_now() - t_begin;
+        rc = fill_range_zero_copy(ctx, &zj, n_reads, d_rl, d_hs, d_mp, d_sm, d_kh, &t_prep, &t_wait);
+        t_copy = t_prep;
+        goto done;
+    }
     /* piece limits: a single read larger than the defaults makes its own (larger) piece */
     uint64_t cap_rl = off[n_reads - 1] + (((uint64_t) hoco_l[n_reads - 1] + 63) & ~63ULL) + 64, cap_scm = scm_off[n_reads] + 1;      /* small inputs: one piece */
     if (cap_rl > FILL_RL_BYTES) cap_rl = FILL_RL_BYTES;
@@ -429,8 +615,9 @@ int oatk_sr_db_fill_range(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, uint64_t first
 done:
     free(hoco_l); free(n_nn); free(n_lrl); free(nn_key); free(lrl_val); free(scm_off); free(o_nn); free(o_lrl);
     if (heap_tune) { (void) mallopt(M_TOP_PAD, 128 * 1024); (void) mallopt(M_TRIM_THRESHOLD, 128 * 1024); }      /* glibc's defaults back: the host program's heap is its own again */
-    if (host_log()) fprintf(stderr, "[M::%s] %lu reads into sr_db_t: %.3f s on %d host threads (setup %.3f, block allocation %.3f beside copying %.3f, waiting for PCIe %.3f)\n",
-                            __func__, (unsigned long) n_reads, host_now() - t_begin, oatk_host_threads(), t_setup, job.t_alloc, t_copy, t_wait);
+    if (host_log()) fprintf(stderr, "[M::%s] %lu reads into sr_db_t: %.3f s on %d host threads (setup %.3f, %s %.3f beside %s %.3f, waiting for PCIe %.3f)\n",
+                            __func__, (unsigned long) n_reads, host_now() - t_begin, oatk_host_threads(), t_setup, g_use_arena && zc_wanted()? "no host copy: block allocation" : "block allocation", job.t_alloc,
+                            g_use_arena && zc_wanted()? "mapping + first touch + page-locking + pointers" : "copying", t_copy, t_wait);
     return rc;
 }
 

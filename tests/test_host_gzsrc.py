@@ -1,0 +1,111 @@
+"""CPU: host/gzsrc.c -- a gzip'ed file as a stream of inflated bytes (what the reader of host/ingest_host.c pulls its windows from): the three forms
+host/fasta_out.c writes (one member, BGZF, several members), odd buffer sizes, an empty file, bytes behind the last member (ignored like gzread
+ignores them), and damage (a flipped byte, a cut file) reported instead of passed on."""
+import ctypes as C
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from oatk_amd import _lib, synth
+
+
+@pytest.fixture(scope="module")
+def H():
+    L = C.CDLL(_lib.HOST_LIB_PATH)
+    L.oatk_gzsrc_open.restype = C.c_void_p
+    L.oatk_gzsrc_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int)]
+    L.oatk_gzsrc_read.restype = C.c_int64
+    L.oatk_gzsrc_read.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.oatk_gzsrc_close.argtypes = [C.c_void_p]
+    L.oatk_gzsrc_kind.argtypes = [C.c_void_p]
+    L.oatk_gzsrc_tell_in.restype = C.c_uint64
+    L.oatk_gzsrc_tell_in.argtypes = [C.c_void_p]
+    return L
+
+
+def slurp(H, path, cap, threads=4):
+    rc = C.c_int(0)
+    g = H.oatk_gzsrc_open(path.encode(), threads, C.byref(rc))
+    assert g, rc.value
+    kind = H.oatk_gzsrc_kind(g)
+    buf = np.empty(cap, np.uint8)
+    out, status = [], 0
+    while True:
+        n = H.oatk_gzsrc_read(g, buf.ctypes.data, cap)
+        if n < 0:
+            status = -1
+            break
+        if n == 0:
+            break
+        out.append(buf[:n].tobytes())
+    consumed = H.oatk_gzsrc_tell_in(g)
+    H.oatk_gzsrc_close(g)
+    return b"".join(out), status, kind, consumed
+
+
+@pytest.fixture(scope="module")
+def files(tmp_path_factory):
+    d = tmp_path_factory.mktemp("gz")
+    cfg = dict(synth.CONFIG1S)
+    cfg.update(n_reads=300, nuclear_len=2_000_000)
+    rs = synth.MixReadSet(**cfg)
+    seq, off, lens = rs.slice(0, 300)
+    paths = {}
+    for name, mode in (("plain", synth.FA_PLAIN), ("one", synth.FA_GZ), ("bgzf", synth.FA_BGZF), ("members", synth.FA_GZ_MEMBERS)):
+        paths[name] = str(d / (name + (".fa" if mode == 0 else ".fa.gz")))
+        synth.write_fasta(paths[name], seq, off, lens, mode=mode, member_bytes=700_000, threads=4)
+    return paths, open(paths["plain"], "rb").read(), d
+
+
+@pytest.mark.parametrize("cap", [1 << 16, 100_003, 1 << 20, 1 << 24])
+def test_every_form_inflates_to_the_text(H, files, cap):
+    paths, text, _ = files
+    for name, kind in (("one", 1), ("bgzf", 2), ("members", 1)):
+        assert gzip.open(paths[name]).read() == text                 # the writer, against Python's zlib
+        got, status, k, consumed = slurp(H, paths[name], cap)
+        assert status == 0 and got == text, name
+        assert k == kind and consumed == os.path.getsize(paths[name])
+
+
+def test_small_buffers_cut_bgzf_members(H, files):
+    paths, text, _ = files
+    got, status, _, _ = slurp(H, paths["bgzf"], 5000)             # smaller than a BGZF member: the serial form, piece by piece
+    assert status == 0 and got == text
+
+
+def test_empty_and_trailing_bytes(H, files, tmp_path):
+    paths, text, _ = files
+    e = str(tmp_path / "empty.gz")
+    with gzip.open(e, "wb"):
+        pass
+    assert slurp(H, e, 1 << 16)[:2] == (b"", 0)
+    z = str(tmp_path / "zero.gz")
+    open(z, "wb").close()
+    assert slurp(H, z, 1 << 16)[:2] == (b"", 0)
+    t = str(tmp_path / "trail.fa.gz")
+    with open(t, "wb") as f:
+        f.write(open(paths["one"], "rb").read() + b"\0" * 512)       # padding behind the member (tar, some archivers): gzread ignores it
+    got, status, _, _ = slurp(H, t, 1 << 20)
+    assert status == 0 and got == text and gzip.open(paths["one"]).read() == text
+    m = str(tmp_path / "mixed.fa.gz")
+    with open(m, "wb") as f:                                         # a plain member in front of BGZF members and another plain one behind
+        f.write(gzip.compress(b">x\nACGT\n") + open(paths["bgzf"], "rb").read() + gzip.compress(b">y\nTTTT\n"))
+    got, status, _, _ = slurp(H, m, 1 << 20)
+    assert status == 0 and got == b">x\nACGT\n" + text + b">y\nTTTT\n"
+
+
+def test_damage_is_reported(H, files, tmp_path):
+    paths, text, _ = files
+    for name in ("one", "bgzf", "members"):
+        raw = bytearray(open(paths[name], "rb").read())
+        raw[len(raw) // 2] ^= 0x55
+        p = str(tmp_path / (name + ".bad.gz"))
+        open(p, "wb").write(bytes(raw))
+        got, status, _, _ = slurp(H, p, 1 << 20)
+        assert status == -1, name
+        cut = str(tmp_path / (name + ".cut.gz"))
+        open(cut, "wb").write(open(paths[name], "rb").read()[:-100])
+        got, status, _, _ = slurp(H, cut, 1 << 20)
+        assert status == -1 or (name == "bgzf" and got != text), name       # (a BGZF file cut at a member boundary simply ends early: bgzip's end marker is what tells)

@@ -19,13 +19,16 @@
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
 
 enum { XOR, ADD, MIN, ALIGNBIT, PERM, CNDMASK, MUL24, MULLO, MULHI, MAD64, SHL64, SHR64, LSHLADD64, ADDC, CMP64SEL, CMP32SEL, DPPMIN, ANDOR, ADD3, XAD, LSHLOR,
-       MAD64_XOR, MAD64_2XOR, CMP64_XOR, NOPS };
+       MAD64_XOR, MAD64_2XOR, CMP64_XOR,
+       AND, OR, SHL32, SHR32, SUB, MOV, NOT, BFE, CNDS, CMP32, CMPEQ32, CMP64, MAX, MIN3, XOR64E, ADD64E, BITOP3, BFI, LSHLADD, ADDC1, ADDCO, FMA, FMAC, MULF, PKFMA, MOVDPP, XOR_MIN, XOR3_MAD, NOPS };
 
 static const char *NAMES[] = {"v_xor_b32", "v_add_u32", "v_min_u32", "v_alignbit_b32", "v_perm_b32", "v_cndmask_b32 (vcc)", "v_mul_u32_u24", "v_mul_lo_u32", "v_mul_hi_u32",
                               "v_mad_u64_u32", "v_lshlrev_b64", "v_lshrrev_b64", "v_lshl_add_u64", "v_add_co+v_addc (2)", "v_cmp_lt_u64+2 cndmask (3)", "v_cmp_lt_u32+cndmask (2)",
                               "v_min_u32 dpp row_shr:1", "v_and_or_b32", "v_add3_u32", "v_xad_u32", "v_lshl_or_b32",
-                              "v_mad_u64_u32 + v_xor (2)", "v_mad_u64_u32 + 2 v_xor (3)", "v_cmp_lt_u64 + v_xor (2)"};
-static const int PER[] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 3, 2, 1, 1, 1, 1, 1, 2, 3, 2};
+                              "v_mad_u64_u32 + v_xor (2)", "v_mad_u64_u32 + 2 v_xor (3)", "v_cmp_lt_u64 + v_xor (2)",
+                              "v_and_b32", "v_or_b32", "v_lshlrev_b32", "v_lshrrev_b32", "v_sub_u32", "v_mov_b32", "v_not_b32", "v_bfe_u32", "v_cndmask_b32 (sgpr pair)", "v_cmp_lt_u32 (vcc)", "v_cmp_eq_u32 (vcc)", "v_cmp_lt_u64 (vcc)", "v_max_u32", "v_min3_u32", "v_xor_b32_e64", "v_add_u32_e64", "v_bitop3_b32", "v_bfi_b32", "v_lshl_add_u32", "v_addc_co_u32 (vcc in, vcc out)", "v_add_co_u32 (vcc out)", "v_fma_f32", "v_fmac_f32", "v_mul_f32", "v_pk_fma_f32", "v_mov_b32 dpp row_shr:1", "v_xor + v_min_u32 (2)", "3 v_xor + v_mad_u64_u32 (4)"};
+static const int PER[] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 3, 2, 1, 1, 1, 1, 1, 2, 3, 2,
+                          1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 4};
 
 template <int OP, int CH>
 __device__ __forceinline__ void step(uint64_t &v, uint32_t &x, uint32_t b, uint64_t other)
@@ -56,6 +59,34 @@ __device__ __forceinline__ void step(uint64_t &v, uint32_t &x, uint32_t b, uint6
     else if (OP == LSHLOR) asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(x) : "v"(b));
     else if (OP == MAD64_XOR) { asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(v) : "v"(b), "v"(b) : "vcc"); asm volatile("v_xor_b32 %0, %0, %1" : "+v"(x) : "v"(b)); }
     else if (OP == MAD64_2XOR) { asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(v) : "v"(b), "v"(b) : "vcc"); asm volatile("v_xor_b32 %0, %0, %1\n v_xor_b32 %0, %0, %1" : "+v"(x) : "v"(b)); }
+    else if (OP == AND) asm volatile("v_and_b32 %0, %0, %1" : "+v"(x) : "v"(b));
+    else if (OP == OR) asm volatile("v_or_b32 %0, %0, %1" : "+v"(x) : "v"(b));
+    else if (OP == SHL32) asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(x));
+    else if (OP == SHR32) asm volatile("v_lshrrev_b32 %0, 3, %0" : "+v"(x));
+    else if (OP == SUB) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(x) : "v"(b));
+    else if (OP == MOV) asm volatile("v_mov_b32 %0, %1" : "+v"(x) : "v"(b));
+    else if (OP == NOT) asm volatile("v_not_b32 %0, %0" : "+v"(x));
+    else if (OP == BFE) asm volatile("v_bfe_u32 %0, %0, 3, 29" : "+v"(x));
+    else if (OP == CNDS) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "s"(other));
+    else if (OP == CMP32) asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(x), "v"(b) : "vcc");
+    else if (OP == CMPEQ32) asm volatile("v_cmp_eq_u32 vcc, %0, %1" : : "v"(x), "v"(b) : "vcc");
+    else if (OP == CMP64) asm volatile("v_cmp_lt_u64 vcc, %0, %1" : : "v"(v), "v"(other) : "vcc");
+    else if (OP == MAX) asm volatile("v_max_u32 %0, %0, %1" : "+v"(x) : "v"(b));
+    else if (OP == MIN3) asm volatile("v_min3_u32 %0, %0, %1, %1" : "+v"(x) : "v"(b));
+    else if (OP == XOR64E) asm volatile("v_xor_b32_e64 %0, %0, %1" : "+v"(x) : "v"(b));
+    else if (OP == ADD64E) asm volatile("v_add_u32_e64 %0, %0, %1" : "+v"(x) : "v"(b));
+    else if (OP == BITOP3) asm volatile("v_bitop3_b32 %0, %0, %1, %1 bitop3:0x96" : "+v"(x) : "v"(b));
+    else if (OP == BFI) asm volatile("v_bfi_b32 %0, %0, %1, %1" : "+v"(x) : "v"(b));
+    else if (OP == LSHLADD) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(x) : "v"(b));
+    else if (OP == ADDC1) asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(x) : "v"(b) : "vcc");
+    else if (OP == ADDCO) asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(x) : "v"(b) : "vcc");
+    else if (OP == FMA) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x) : "v"(b));
+    else if (OP == FMAC) asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(x) : "v"(b));
+    else if (OP == MULF) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x) : "v"(b));
+    else if (OP == PKFMA) asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(v));
+    else if (OP == MOVDPP) { if (CH == 1) asm volatile("s_nop 1\n v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(x)); else asm volatile("v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(x)); }
+    else if (OP == XOR_MIN) { asm volatile("v_xor_b32 %0, %0, %1" : "+v"(x) : "v"(b)); uint32_t lo = (uint32_t) v; asm volatile("v_min_u32 %0, %0, %1" : "+v"(lo) : "v"(b)); v = lo; }
+    else if (OP == XOR3_MAD) { asm volatile("v_xor_b32 %0, %0, %1\n v_xor_b32 %0, %0, %1\n v_xor_b32 %0, %0, %1" : "+v"(x) : "v"(b)); asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(v) : "v"(b), "v"(b) : "vcc"); }
     else if (OP == CMP64_XOR) { asm volatile("v_cmp_lt_u64 vcc, %0, %1" : : "v"(v), "v"(other) : "vcc"); asm volatile("v_xor_b32 %0, %0, %1" : "+v"(x) : "v"(b)); }
 }
 
@@ -127,6 +158,10 @@ int main(int argc, char **argv)
 {
     FILE *fo = stdout;
     CHECK(hipMalloc(&d_out, ((1 << 20) + 8) * 8));
+    if (argc > 1 && !strcmp(argv[1], "more")) {       // the wider census (round 4): which opcodes issue at the 2-cycle rate at all?
+        run<AND>(fo); run<OR>(fo); run<SHL32>(fo); run<SHR32>(fo); run<SUB>(fo); run<MOV>(fo); run<NOT>(fo); run<BFE>(fo); run<CNDS>(fo); run<CMP32>(fo); run<CMPEQ32>(fo); run<CMP64>(fo); run<MAX>(fo); run<MIN3>(fo); run<XOR64E>(fo); run<ADD64E>(fo); run<BITOP3>(fo); run<BFI>(fo); run<LSHLADD>(fo); run<ADDC1>(fo); run<ADDCO>(fo); run<FMA>(fo); run<FMAC>(fo); run<MULF>(fo); run<PKFMA>(fo); run<MOVDPP>(fo); run<XOR_MIN>(fo); run<XOR3_MAD>(fo);
+        return 0;
+    }
     run<XOR>(fo); run<ADD>(fo); run<MIN>(fo); run<ALIGNBIT>(fo); run<PERM>(fo); run<CNDMASK>(fo); run<ANDOR>(fo); run<ADD3>(fo); run<XAD>(fo); run<LSHLOR>(fo);
     run<MUL24>(fo); run<MULLO>(fo); run<MULHI>(fo); run<MAD64>(fo);
     run<SHL64>(fo); run<SHR64>(fo); run<LSHLADD64>(fo); run<ADDC>(fo); run<CMP64SEL>(fo); run<CMP32SEL>(fo); run<DPPMIN>(fo);
