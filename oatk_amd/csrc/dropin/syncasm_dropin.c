@@ -166,11 +166,20 @@ void sr_db_clean(oatk_sr_db_t *sr_db) { oatk_sr_db_clean(sr_db); }
 void sr_db_destroy(oatk_sr_db_t *sr_db)
 {
     if (!sr_db) return;
+    const double t0 = now();
+    const size_t n = sr_db->n;
     oatk_sr_db_clean(sr_db);
     free(sr_db);
+    if (D.init && D.log && n) fprintf(stderr, "[M::oatk_dropin] +%.3f s sr_db_destroy: %lu reads, %.3f s\n", t0 - D.t_start, (unsigned long) n, now() - t0);
 }
 void syncmer_db_clean(oatk_syncmer_db_t *scm_db) { oatk_syncmer_db_clean(scm_db); }          /* syncmer.c:1094-1110 */
-void syncmer_db_destroy(oatk_syncmer_db_t *scm_db) { oatk_syncmer_db_destroy(scm_db); }
+void syncmer_db_destroy(oatk_syncmer_db_t *scm_db)
+{
+    const double t0 = now();
+    const size_t n = scm_db? scm_db->n : 0;
+    oatk_syncmer_db_destroy(scm_db);
+    if (D.init && D.log && n) fprintf(stderr, "[M::oatk_dropin] +%.3f s syncmer_db_destroy: %lu syncmers, %.3f s\n", t0 - D.t_start, (unsigned long) n, now() - t0);
+}
 
 /* ---------------------------------------------------------------- sr_read ---------------------------------------------------------------- */
 

@@ -132,7 +132,13 @@ __global__ void egr_expand_kernel(uint64_t n_keys, const uint64_t *ukeys, const 
     if (i >= n_keys) return;
     const uint64_t k = ukeys[i];
     if (k == EGR_INVALID) return;
-    const uint64_t v0 = k >> 32, v1 = k & 0xFFFFFFFFULL, o = out_off[i], c = (uint64_t) run_ls[i] << 44 | (uint64_t) counts[i] << 1;
+    const uint64_t v0 = k >> 32, v1 = k & 0xFFFFFFFFULL, o = out_off[i];
+    // An arc that is its own complement (v -> v^1: a syncmer next to its reverse complement on a read) never gets an overlap in the reference:
+    // asmg_arc_fix_symm looks up "the complement", finds the arc itself and sets its comp flag (graph.c:221), and scg_consensus skips arcs with
+    // that flag (syncasm.c:779), so ls keeps its initial 0.  (Found by the config-1 surrogate in round 4: 16 such arcs among 4.5 M; the earlier
+    // read sets had none.)
+    const uint64_t ls = (v1 ^ 1ULL) == v0? 0ULL : (uint64_t) run_ls[i];
+    const uint64_t c = ls << 44 | (uint64_t) counts[i] << 1;
     akey[o] = k, aval[o] = c;                                             // comp = 0
     if ((v1 ^ 1ULL) != v0) akey[o + 1] = (v1 ^ 1ULL) << 32 | (v0 ^ 1ULL), aval[o + 1] = c | 1ULL;
 }

@@ -146,3 +146,62 @@ def test_config1s_cli_on_the_gzipped_file_in_three_forms(tmp_path, config1s):
         assert {f: v[2] for f, v in tab.items() if v[2] > 0} == {}, "%s: calls served by their original bodies" % name
         print("config1s CLI, %s: reference %.1f s, drop-in %.1f s" % (name, t_ref, t_dev))
     assert os.path.getsize(os.path.join(d, "ref.utg.final.gfa")) > 100_000
+
+
+def test_an_arc_that_is_its_own_complement_gets_no_overlap(hip):
+    """fold-back reads (A followed by its reverse complement: a syncmer next to its own reverse complement) make arcs v -> v^1; asmg_arc_fix_symm finds such
+    an arc as its own complement and flags it (graph.c:221), and scg_consensus never gives a flagged arc an overlap (syncasm.c:779): ls stays 0.  The device
+    assigned K - distance until round 4 (16 of the 4.5 M arcs of the config-1 surrogate)."""
+    import oracle_lib as O
+    rng = np.random.default_rng(11)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    genome = bytes(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 40000)].tolist())
+    reads = [genome[a:a + 12000] for a in rng.integers(0, 28000, 40)]
+    for a in rng.integers(0, 30000, 12):
+        half = genome[a:a + 7000]
+        reads.append(half + half.translate(comp)[::-1])
+    from oatk_amd import pack_reads
+    seq, off, lens = pack_reads(reads)
+    hip.scan_host(seq, off, lens, K, S)
+    got = hip.fetch_scan(off)
+    hip.count()
+    cnt = hip.fetch_count()
+    hip.ec_graph()
+    og = E.oracle_ecgraph(got["n_scm"], cnt["k_id"], got["m_pos"], cnt["occ_off"], cnt["occ"], K)
+    v, w = hip.fetch("EG_ARC_V").astype(np.uint64), hip.fetch("EG_ARC_W").astype(np.uint64)
+    own = (w ^ np.uint64(1)) == v
+    assert int(own.sum()) >= 5, "fold-back reads make self-complementary arcs"
+    for name, key in (("EG_ARC_V", "arc_v"), ("EG_ARC_W", "arc_w"), ("EG_ARC_COV", "arc_cov"), ("EG_ARC_LS", "arc_ls"), ("EG_ARC_COMP", "arc_comp")):
+        assert np.array_equal(hip.fetch(name).astype(np.uint64), og[key].astype(np.uint64)), key
+    assert not hip.fetch("EG_ARC_LS")[own].any() and hip.fetch("EG_ARC_COMP")[own].all()
+
+
+def many_distance_reads(n=90):
+    """two unique flanks around an (AC)n array whose length differs from read to read: the array itself yields no syncmers (period 2 divides K - S: the first
+    and the last s-mer of every window tie, Open and Close cancel, syncmer.c:337,393), so the last syncmer before it and the first one behind it are adjacent
+    on every read -- at a different distance on each"""
+    rng = np.random.default_rng(3)
+    nt = np.frombuffer(b"ACGT", np.uint8)
+    fa, fb = (bytes(nt[rng.integers(0, 4, 4000)].tolist()) for _ in range(2))
+    return [fa + b"AC" * (700 + 3 * i) + fb for i in range(n)] + [fa + b"AC" * 800 + fb] * 7
+
+
+def test_an_arc_with_more_distinct_distances_than_the_lds_tables_hold(hip):
+    """> 48 (EC graph) / > 64 (pair tables) distinct distances for one arc: OATK_E_SPLIT until round 4, now the khashl replay continues in global memory"""
+    import oracle_lib as O
+    import test_gpu_overlap as TO
+    from oatk_amd import pack_reads
+    reads = many_distance_reads()
+    seq, off, lens = pack_reads(reads)
+    hip.scan_host(seq, off, lens, K, S)
+    got = hip.fetch_scan(off)
+    hip.count()
+    cnt = hip.fetch_count()
+    hip.ec_graph()
+    og = E.oracle_ecgraph(got["n_scm"], cnt["k_id"], got["m_pos"], cnt["occ_off"], cnt["occ"], K)
+    # the shape the case is meant to have: some pair of syncmers adjacent at > 64 different distances
+    tabs = TO.tables_from_chains(got["n_scm"], cnt["k_id"], got["m_pos"])
+    assert max(len(t[0]) for t in tabs.values()) > 64
+    for name, key in (("EG_ARC_V", "arc_v"), ("EG_ARC_W", "arc_w"), ("EG_ARC_COV", "arc_cov"), ("EG_ARC_LS", "arc_ls"), ("EG_ARC_COMP", "arc_comp")):
+        assert np.array_equal(hip.fetch(name).astype(np.uint64), og[key].astype(np.uint64)), key
+    assert TO.check_tables(hip, got["n_scm"], cnt["k_id"], got["m_pos"]) > 5
