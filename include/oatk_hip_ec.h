@@ -70,7 +70,11 @@ enum {
     OATK_BUF_EC_N_SCM = 100, OATK_BUF_EC_SCM_OFF, OATK_BUF_EC_KMER, OATK_BUF_EC_MPOS, OATK_BUF_EC_SMER,
     OATK_BUF_EC_SCM_COV, OATK_BUF_EC_SCM_DEL, OATK_BUF_EC_SCM_OCC_OFF, OATK_BUF_EC_SCM_OCC, OATK_BUF_EC_ERR_DEL,
     OATK_BUF_EC_SCM_FWD,        /* u32[n_scm]  forward-strand occurrences per syncmer after correction (del = !fwd, syncerr.c:803-812) */
-    OATK_BUF_EC_VTX_SRC         /* u64[n_scm]  after oatk_hip_ec_mark: byte offset of the hoco string holding the vertex's k-mer, ~0 = none here */
+    OATK_BUF_EC_VTX_SRC,        /* u64[n_scm]  after oatk_hip_ec_mark: byte offset of the hoco string holding the vertex's k-mer, ~0 = none here */
+    /* what the search cost, block by block (measurement aid; the layout may change): 12 u32 per error block -- beg_utg lo/hi, end_utg lo/hi, read,
+     * beg_pos, length l, r, then 4 words of launch data -- and 10 u32 per block -- status, path entries, path offset lo/hi, flags, short, arcs tried
+     * (DFS steps), dead ends counted (n_path, syncerr.c:147), wavefront steps, diagonals covered / 64 */
+    OATK_BUF_EC_BLOCK_WORK, OATK_BUF_EC_BLOCK_OUT
 };
 
 /* oatk_hip_ec in two steps, for callers that need to act in between (sharded reads, below):

@@ -20,7 +20,7 @@ BUF = {name: i for i, name in enumerate([
 # include/oatk_hip_ec.h
 BUF.update({name: 100 + i for i, name in enumerate([
     "EC_N_SCM", "EC_SCM_OFF", "EC_KMER", "EC_MPOS", "EC_SMER", "EC_SCM_COV", "EC_SCM_DEL", "EC_SCM_OCC_OFF", "EC_SCM_OCC", "EC_ERR_DEL",
-    "EC_SCM_FWD", "EC_VTX_SRC"])})
+    "EC_SCM_FWD", "EC_VTX_SRC", "EC_BLOCK_WORK", "EC_BLOCK_OUT"])})
 # include/oatk_hip_ingest.h
 BUF.update({name: 160 + i for i, name in enumerate(["INGEST_SEQ", "INGEST_OFF", "INGEST_LEN", "INGEST_HDR"])})
 FMT_AUTO, FMT_FASTA, FMT_FASTQ = 0, 1, 2

@@ -170,6 +170,8 @@ struct EcBlockOut {
     uint64_t path_off;            // into the path pool
     uint32_t flags;               // 1 = did not fit the scratch slab (must be re-run with a large one)
     uint32_t short_block;         // 1 = l < EC_MIN_ERR_SEQ_LEN (stats[10])
+    uint32_t tried, n_path;       // the search's effort: arcs followed (DFS steps), dead ends counted (syncerr.c:147) -- OATK_BUF_EC_BLOCK_OUT
+    uint32_t wf_steps, wf_diag;   // ... wavefront steps taken, and the diagonals they covered in all (>> 6: units of 64)
 };
 
 // The arcs the search may follow: the graph's arc array with the deleted arcs squeezed out (same order), each carrying

@@ -160,6 +160,55 @@ __device__ int ecw_step(const uint32_t *ts, int32_t tl, const uint32_t *qs, int3
     if (n <= 32) lg = n <= 1? 6 : __builtin_clz((uint32_t) (n - 1)) - 26;      // 64 / next_pow2(n)
     const int G = 1 << lg, c = lane & (G - 1), gbase = lane & ~(G - 1);
     const uint64_t gmask = G == 64? ~0ULL : (1ULL << G) - 1ULL;
+    // More than 64 diagonals (a long block late in a failing path: up to 2 bw + 1 = several hundred): one lane per diagonal, and FOUR rounds of 64 diagonals
+    // side by side -- the rounds are independent chains of LDS round trips (wavefront entry, two windows of each string, the comparison), and one after the
+    // other they left the wave waiting for LDS most of the time: a long block of the config-1 surrogate took 2.5 s, forty times a CPU core (r04g).  What
+    // the step returns depends on the LOWEST diagonal that reaches an end and on the diagonals below it alone, so the rounds are finished in order.
+    if (n > 64) {
+        for (int32_t base = 0; base < n; base += 256) {
+            int32_t kk[4], dd[4], lim[4];
+            bool a0[4], act[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int32_t j = base + 64 * u + lane;
+                const bool valid = j < n;
+                kk[u] = valid? k[j] : 0, dd[u] = valid? d0 + j : 0;
+                a0[u] = valid && !(kk[u] >= tl || kk[u] + dd[u] >= ql);
+                act[u] = a0[u];
+                lim[u] = (ql - dd[u] < tl? ql - dd[u] : tl) - 1;
+            }
+            ECW_D(1);
+            while (__ballot(act[0] | act[1] | act[2] | act[3])) {
+                ECW_D(2);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int32_t r = lim[u] - kk[u];
+                    const uint32_t x = ecw_win16(ts, kk[u] + 1) ^ ecw_win16(qs, kk[u] + dd[u] + 1);
+                    int32_t m = x? __builtin_ctz(x) >> 1 : 16;
+                    m = m < r? m : r;
+                    m = act[u] && r > 0? m : 0;
+                    kk[u] += m;
+                    act[u] = act[u] && m == 16;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int32_t j = base + 64 * u + lane;
+                const bool reached = a0[u] && (kk[u] + dd[u] == ql - 1 || kk[u] == tl - 1);
+                const uint64_t rmask = __ballot(reached);
+                if (rmask) {
+                    const int fl = __builtin_ctzll(rmask);
+                    if (a0[u] && lane < fl) k[j] = kk[u];
+                    t_end = (int32_t) ecw_lane((uint32_t) kk[u], fl);
+                    q_end = t_end + d0 + base + 64 * u + fl;
+                    ECW_D(3);
+                    ecw_sync();
+                    return 1;
+                }
+                if (a0[u]) k[j] = kk[u];
+            }
+        }
+    } else
     for (int32_t base = 0; base < n; base += 64) {
         const int32_t j = base + (lane >> lg);
         ECW_D(1);
@@ -206,8 +255,9 @@ __device__ int ecw_step(const uint32_t *ts, int32_t tl, const uint32_t *qs, int3
     }
     ecw_sync();
     // next wavefront: diagonals d0 - 1 .. d0 + n (levdist.c:183-205)
-    int32_t *nk = wv.spare;
+    int32_t *__restrict__ nk = wv.spare;
     ECW_D(4);
+#pragma unroll 4
     for (int32_t ib = 0; ib < n + 2; ib += 64) {      // (a uniform trip count -- one turn up to 62 diagonals -- and no branches inside: reads with clamped indices, selects)
         const int32_t i = ib + lane, jj = i - 1;
         const int32_t ja = jj - 1 < 0? 0 : (jj - 1 < n? jj - 1 : n - 1), jb = jj < 0? 0 : (jj < n? jj : n - 1), jc = jj + 1 < n? jj + 1 : n - 1;
@@ -339,7 +389,7 @@ __device__ __forceinline__ EcwArcRegs ecw_arc_load(const EcLiveArc *arc, uint32_
 
 // Solve one block with the whole wave.  Returns false when the scratch is too small (the block is then re-run by a larger tier).
 __device__ bool ecw_solve_block(const EcLive &lv, const EcReads &rd, const EcWork &wk, const EcwScratch &s, double max_edist,
-                                uint32_t &status_out, uint32_t &np_out)
+                                uint32_t &status_out, uint32_t &np_out, uint32_t &tried_out, uint32_t &n_path_out, uint32_t &wf_steps_out, uint32_t &wf_diag_out)
 {
     const int lane = threadIdx.x & 63;
     const int K = rd.K;
@@ -385,6 +435,8 @@ __device__ bool ecw_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
     ECW_T(0);                                          // 0: target gather
     int32_t status = EC_FAILURE, n_path = 0, edist = INT32_MAX, s_edist = INT32_MAX;
     int32_t c_len = 0, o_len = 0, np = 0;
+    uint32_t tried = 0, wf_steps = 0;
+    uint64_t wf_diag = 0;
     int32_t score = 0, t_end = 0, q_end = 0;
     EcwWave wv;
     wv.k = s.ka, wv.spare = s.kb, wv.n = 1, wv.d0 = 0;
@@ -443,6 +495,7 @@ __device__ bool ecw_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
             for (int32_t j = lane; j < wv.n; j += 64) s.ka[j] = sv[j];
         }
         ECW_C(8, 1);                                   // 8: arcs tried
+        ++tried;
         if (ECW_RARE(pre_idx != a)) pre = ecw_arc_load(lv.arc, a);
         const uint64_t w = ecw_uniu(pre.a.x);
         const int32_t ls = (int32_t) ecw_uniu(pre.a.y), ext = K - ls;
@@ -493,6 +546,7 @@ __device__ bool ecw_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
         }
         // wf_ed_core (levdist.c:265-310)
         for (;;) {
+            ++wf_steps, wf_diag += (uint64_t) wv.n;
             if (ecw_step(s.ts, tl, s.cs, c_len, bw, wv, s.ka, s.kb, t_end, q_end)) break;
             ++score;
             ECW_C(9, 1);                               // 9: wavefront steps beyond the first
@@ -557,7 +611,7 @@ __device__ bool ecw_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
         ECW_T(6);                                      // 6: result handling + push
     }
     ecw_sync();
-    status_out = (uint32_t) status, np_out = (uint32_t) np;
+    status_out = (uint32_t) status, np_out = (uint32_t) np, tried_out = tried, n_path_out = (uint32_t) n_path, wf_steps_out = wf_steps, wf_diag_out = (uint32_t) (wf_diag >> 6);
     return true;
 }
 
@@ -590,6 +644,7 @@ struct EcwArgs {
     uint32_t *todo_out;           // blocks that did not fit this tier's carve-up: the next tier's list, appended by the waves themselves
     unsigned long long *todo_cnt;
     int32_t skip_l;               // blocks longer than this were routed to a larger tier before the launch (ec_route_kernel): not this launch's business
+    int32_t batch;                // blocks taken from the queue per atomic: ECW_BATCH where the blocks are millions and small, 1 where they are few and long
 #ifdef ECW_PROF
     unsigned long long *prof;
 #endif
@@ -641,6 +696,12 @@ __global__ __launch_bounds__(256) void ec_route_kernel(const EcWork *work, uint6
 }
 
 __host__ __device__ inline uint32_t ecw_words(int32_t bases) { return (uint32_t) ((bases + 15) / 16 + 2); }
+// MODE 2 of ec_wave_kernel: what stays in LDS (ts, cs, two wavefronts) and what goes to the wave's HBM slab (two paths, frames)
+__host__ __device__ inline uint32_t ecw_lds_words_hybrid(int32_t cap_t, int32_t cap_c, int32_t cap_w)
+{
+    return (ecw_words(cap_t) + ecw_words(cap_c) + 2u * (uint32_t) (cap_w + 2) + 1u) & ~1u;
+}
+__host__ __device__ inline uint64_t ecw_slab_bytes_hybrid(int32_t cap_path, int32_t cap_f) { return ((uint64_t) 16 * (uint64_t) cap_path + (uint64_t) cap_f + 63) & ~63ULL; }
 // 32-bit words of one wave's carve-up: ts, cs, os, two wavefronts, two paths, frames
 // (os_too: the optimum consensus as well -- the HBM slabs of the last tier; the LDS tiers keep theirs in a slab of its own, EcwArgs::os_slabs)
 __host__ __device__ inline uint32_t ecw_scratch_words(int32_t cap_t, int32_t cap_c, int32_t cap_w, int32_t cap_path, int32_t cap_f, bool os_too = true)
@@ -648,16 +709,22 @@ __host__ __device__ inline uint32_t ecw_scratch_words(int32_t cap_t, int32_t cap
     return ((ecw_words(cap_t) + (os_too? 2u : 1u) * ecw_words(cap_c) + 2u * (uint32_t) (cap_w + 2) + 1u) & ~1u) + 4u * (uint32_t) cap_path + (uint32_t) cap_f / 4u;
 }
 
-template <bool BIG, int WPB = 1>
+// MODE 0: every array in LDS.  MODE 1 (BIG): every array in an HBM slab.  MODE 2 (round 4): the strings and the wavefronts -- what the alignment
+// reads in every step, 89 % of a long search's cycles -- in LDS, the paths and the DFS frames -- touched once per arc -- in an HBM slab.  A search
+// through a tandem array is hundreds of levels deep with a frame at every level: it outgrew every LDS carve-up and ran in the slabs at a tenth of
+// the speed, eight seconds for 40 k reads of the config-1 surrogate (profiles/r04e_solver_config1s.txt).
+template <int MODE, int WPB = 1>
 __global__ __launch_bounds__(64 * WPB) void ec_wave_kernel(EcwArgs a)
 {
+    constexpr bool BIG = MODE == 1;
     extern __shared__ uint32_t ecw_lds[];
     const int lane = threadIdx.x & 63;
     const uint32_t wave = blockIdx.x * (uint32_t) WPB + ecw_uniu(threadIdx.x >> 6);      // the waves of a workgroup share nothing but the launch
     EcwScratch s;
     s.cap_t = a.cap_t, s.cap_c = a.cap_c, s.cap_w = a.cap_w, s.cap_path = a.cap_path, s.cap_f = a.cap_f;
     uint32_t *const p0 = BIG? (uint32_t *) (a.slabs + (uint64_t) wave * a.slab_bytes)
-                            : ecw_lds + (WPB > 1? ecw_uniu(threadIdx.x >> 6) * ecw_scratch_words(a.cap_t, a.cap_c, a.cap_w, a.cap_path, a.cap_f, false) : 0u);
+                            : ecw_lds + (WPB > 1? ecw_uniu(threadIdx.x >> 6) * (MODE == 2? ecw_lds_words_hybrid(a.cap_t, a.cap_c, a.cap_w)
+                                                                                                      : ecw_scratch_words(a.cap_t, a.cap_c, a.cap_w, a.cap_path, a.cap_f, false)) : 0u);
     uint32_t *p = p0;
     s.ts = p, p += ecw_words(a.cap_t);
     s.cs = p, p += ecw_words(a.cap_c);
@@ -668,6 +735,7 @@ __global__ __launch_bounds__(64 * WPB) void ec_wave_kernel(EcwArgs a)
     s.ka = (int32_t *) p, p += a.cap_w + 2;
     s.kb = (int32_t *) p, p += a.cap_w + 2;
     p += (p - p0) & 1;                 // (the base is 8-byte aligned; no detour through an integer, which would turn every access behind it into a flat one)
+    if (MODE == 2) p = (uint32_t *) (a.slabs + (uint64_t) wave * a.slab_bytes);
     s.c_path = (uint64_t *) p, p += 2 * a.cap_path;
     s.o_path = (uint64_t *) p, p += 2 * a.cap_path;
     s.frames = (uint8_t *) p;
@@ -687,7 +755,7 @@ __global__ __launch_bounds__(64 * WPB) void ec_wave_kernel(EcwArgs a)
     for (;;) {
         ECW_T(7);                                      // 7: queue + output
         unsigned long long t0 = 0;
-        if (lane == 0) t0 = atomicAdd(a.next, (unsigned long long) ECW_BATCH);
+        if (lane == 0) t0 = atomicAdd(a.next, (unsigned long long) a.batch);
         t0 = ecw_uni64(t0);
         if (t0 >= total) break;
 #ifdef ECW_CENSUS
@@ -698,7 +766,7 @@ __global__ __launch_bounds__(64 * WPB) void ec_wave_kernel(EcwArgs a)
         if (first_batch) { ECW_D(12); first_batch = false; }
         ECW_D(14);
 #endif
-        const int cnt = total - t0 < ECW_BATCH? (int) (total - t0) : ECW_BATCH;
+        const int cnt = total - t0 < (uint64_t) a.batch? (int) (total - t0) : a.batch;
         // lane i holds block i of the batch
         uint64_t my_wi = 0;
         uint4 m0 = make_uint4(0, 0, 0, 0), m1 = m0, m2 = m0;
@@ -717,12 +785,12 @@ __global__ __launch_bounds__(64 * WPB) void ec_wave_kernel(EcwArgs a)
             wk.hs16 = ecw_lane(m2.x, i), wk.lp = ecw_lane(m2.y, i), wk.ln = ecw_lane(m2.z, i), wk.pad = 0;
             if (ECW_RARE(wk.l > a.skip_l)) continue;
             EcBlockOut o;
-            o.status = EC_FAILURE, o.np = 0, o.path_off = 0, o.flags = 0, o.short_block = 0;
+            o.status = EC_FAILURE, o.np = 0, o.path_off = 0, o.flags = 0, o.short_block = 0, o.tried = 0, o.n_path = 0, o.wf_steps = 0, o.wf_diag = 0;
             if (ECW_RARE(wk.l < EC_MIN_ERR_SEQ_LEN)) {
                 o.short_block = 1;                     // syncerr.c:502-504
             } else {
                 uint32_t st = 0, np = 0;
-                if (ECW_RARE(!ecw_solve_block(a.lv, a.rd, wk, s, a.max_edist, st, np))) {
+                if (ECW_RARE(!ecw_solve_block(a.lv, a.rd, wk, s, a.max_edist, st, np, o.tried, o.n_path, o.wf_steps, o.wf_diag))) {
                     o.flags = 1;
                     if (lane == 0) a.todo_out[atomicAdd(a.todo_cnt, 1ULL)] = (uint32_t) wi;
                 } else {

@@ -38,6 +38,7 @@ typedef struct {
     int pinned;                    /* ... and is page-locked: it goes over PCIe as it lies */
     oatk_gzsrc_t *gz;              /* a gzip'ed file read as a stream (sr_read path): size and base are unknown */
     uint64_t fsize;                /* bytes of the file itself */
+    int no_map;                    /* its pages could not be page-locked where they lie: windows of it are staged */
 } seg_t;
 
 static void seg_close(seg_t *s, int n)
@@ -322,20 +323,60 @@ static int rank_of_window(const stream_t *st, uint64_t f0)
     return r >= (uint64_t) st->n_rank? st->n_rank - 1 : (int) r;
 }
 
+static int map_upload_wanted(void)
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("OATK_HOST_MAP_UPLOAD"); v = !(e && e[0] == '0'); }
+    return v;
+}
+
+typedef struct { const uint8_t *p; uint64_t n; } touch_job_t;
+static void touch_worker(void *arg, int tid, int n_threads)
+{
+    const touch_job_t *j = (const touch_job_t *) arg;
+    const uint64_t pages = (j->n + 4095) >> 12, a = pages * (uint64_t) tid / (uint64_t) n_threads, b = pages * (uint64_t) (tid + 1) / (uint64_t) n_threads;
+    uint64_t i;
+    unsigned acc = 0;
+    for (i = a; i < b; ++i) acc += *(volatile const uint8_t *) (j->p + (i << 12));
+    (void) acc;
+}
+
+/* text [g0, g1) of ONE plain file from its mapping to the device; anything else than OATK_OK: the caller stages the window instead (nothing has been sent) */
+static int upload_mapped(stream_t *st, stream_dev_t *D, int slot, uint64_t g0, uint64_t g1)
+{
+    int i;
+    seg_t *sg = 0;
+    for (i = 0; i < st->n_seg; ++i) {
+        seg_t *c = (seg_t *) &st->seg[i];
+        if (g0 >= c->base && g1 <= c->base + c->size && c->fd >= 0) { sg = c; break; }
+    }
+    if (!sg || sg->no_map) return OATK_E_ARG;
+    if (!sg->map) {
+        sg->map = (uint8_t *) mmap(0, (size_t) sg->size, PROT_READ, MAP_SHARED, sg->fd, 0);
+        if (sg->map == MAP_FAILED) { sg->map = 0, sg->no_map = 1; return OATK_E_ARG; }
+    }
+    const uint64_t a = (g0 - sg->base) & ~(uint64_t) 4095, b = g1 - sg->base;           /* the mapping covers whole pages */
+    const uint64_t blen = ((b - a) + 4095) & ~(uint64_t) 4095;
+    touch_job_t tj = {sg->map + a, b - a};
+    oatk_par_run_n(touch_worker, &tj, st->n_up);
+    if (oatk_hip_host_register(D->up, sg->map + a, blen) != OATK_OK) { sg->no_map = 1; return OATK_E_ARG; }
+    int rc = oatk_hip_h2d_async(D->up, D->d_win[slot], sg->map + (g0 - sg->base), g1 - g0);
+    if (!rc) rc = oatk_hip_sync(D->up);
+    (void) oatk_hip_host_unregister(D->up, sg->map + a);
+    if (rc) sg->no_map = 1;
+    return rc;
+}
+
 static void *uploader(void *arg)
 {
     stream_t *st = (stream_t *) arg;
     const uint64_t chunk = st->win < UP_CHUNK? ((st->win + 63) & ~63ULL) : UP_CHUNK;
-    const int direct = st->n_seg == 1 && st->seg[0].pinned;
     uint64_t g0, w;
     int rc = OATK_OK;
     for (w = 0, g0 = 0; !rc && g0 < st->total; ++w) {
         const int s = (int) (w & 1);
         const uint64_t g1 = g0 + st->win < st->total? g0 + st->win : st->total;
         stream_dev_t *D = &st->res[st->res_of_rank[rank_of_window(st, g0)]];
-        if (!direct && !D->stage) D->stage = (uint8_t *) oatk_hip_staging(D->up, 2 * chunk);
-        uint8_t *stage = D->stage;
-        if (!direct && !stage) { rc = OATK_E_NOMEM; break; }
         pthread_mutex_lock(&st->mu);
         while (st->state[s] != 0 && !st->stop) pthread_cond_wait(&st->cv, &st->mu);
         const int stop = st->stop;
@@ -352,7 +393,26 @@ static void *uploader(void *arg)
             g0 = g1;
             continue;
         }
+        if (map_upload_wanted()) {
+            /* The window as it lies in the PAGE CACHE (round 4): the file is mapped, the window's pages are touched by the host threads (minor faults: the
+             * page-cache pages enter this process's page table), the range is page-locked and goes over PCIe from where it lies -- no copy on the host.
+             * Registering a populated file mapping runs at hundreds of GB/s on the bench box and the upload from it at the bus's 57 GB/s, where the
+             * pread into page-locked staging below managed ~15 GB/s (tools/ubench/file_pin.hip, profiles/r04a_file_pin.txt).  A window that spans two
+             * files, or a file system whose pages cannot be locked, takes the staging road. */
+            const int rm = upload_mapped(st, D, s, g0, g1);
+            if (rm == OATK_OK) {
+                pthread_mutex_lock(&st->mu);
+                st->state[s] = 1, st->g0[s] = st->f0[s] = g0, st->g1[s] = st->f1[s] = g1, st->final[s] = g1 == st->total;
+                pthread_cond_broadcast(&st->cv);
+                pthread_mutex_unlock(&st->mu);
+                g0 = g1;
+                continue;
+            }
+        }
         /* the window in pieces: read piece p + 1 while piece p is on the bus */
+        if (!D->stage) D->stage = (uint8_t *) oatk_hip_staging(D->up, 2 * chunk);
+        uint8_t *stage = D->stage;
+        if (!stage) { rc = OATK_E_NOMEM; break; }
         up_job_t job = {st->seg, st->n_seg, stage, g0, g0 + chunk < g1? g0 + chunk : g1, 0};
         oatk_par_run_n(up_worker, &job, st->n_up);
         uint64_t p0 = g0;

@@ -17,7 +17,7 @@ _DTYPES = {
     "SCM_COV": np.uint32, "SCM_OCC_OFF": np.uint64, "SCM_OCC": np.uint64,
     "EC_N_SCM": np.uint32, "EC_SCM_OFF": np.uint64, "EC_KMER": np.uint64, "EC_MPOS": np.uint32, "EC_SMER": np.uint64,
     "EC_SCM_COV": np.uint32, "EC_SCM_DEL": np.uint8, "EC_SCM_OCC_OFF": np.uint64, "EC_SCM_OCC": np.uint64, "EC_ERR_DEL": np.uint8,
-    "EC_SCM_FWD": np.uint32, "EC_VTX_SRC": np.uint64,
+    "EC_SCM_FWD": np.uint32, "EC_VTX_SRC": np.uint64, "EC_BLOCK_WORK": np.uint32, "EC_BLOCK_OUT": np.uint32,
     "INGEST_SEQ": np.uint8, "INGEST_OFF": np.uint64, "INGEST_LEN": np.uint32, "INGEST_HDR": np.uint64,
     "CONS_SEL": np.uint32, "CONS_SLOT": np.uint32, "CONS_RL": np.uint32, "CONS_MSEQ": np.uint32, "CONS_FIRST": np.uint64, "CONS_TOT": np.uint64,
     "EG_IDX_P": np.uint64, "EG_IDX_N": np.uint32, "EG_ARC_V": np.uint64, "EG_ARC_W": np.uint64, "EG_ARC_LS": np.uint32,

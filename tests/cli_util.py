@@ -48,11 +48,8 @@ def time_cli(readset, first, n_reads, k, s, c, threads, workdir=None, strict=Tru
     d = tempfile.mkdtemp(prefix="oatk_cli_", dir=workdir or os.environ.get("TMPDIR", "/tmp"))
     fa = os.path.join(d, "reads.fa")
     try:
-        with open(fa, "wb") as f:
-            for i in range(n_reads):
-                f.write(b">r%d\n" % i)
-                f.write(seq[int(off[i]):int(off[i]) + int(lens[i])].tobytes())
-                f.write(b"\n")
+        from oatk_amd import synth
+        synth.write_fasta(fa, seq, off, lens, mode=synth.FA_PLAIN)          # (host/fasta_out.c: 30 GB at 2 M reads, on every host thread)
         del seq
         t_ref, _ = run_cli(CLI_REF, fa, os.path.join(d, "ref"), k, c, threads)
         t_dev, err = run_cli(CLI_DROPIN, fa, os.path.join(d, "dev"), k, c, threads, {"OATK_DROPIN_LOG": "1"})
@@ -83,6 +80,41 @@ def time_cli(readset, first, n_reads, k, s, c, threads, workdir=None, strict=Tru
                 "served": {f: {"device_calls": v[0], "device_s": v[1], "original_calls": v[2], "original_s": v[3]} for f, v in tab.items()},
                 "workload": "syncasm -k %d -c %d -t %d on a FASTA file of %d reads: process start to exit, parse and both GFA files included; "
                             "the drop-in binary's wall clock includes creating the HIP context" % (k, c, threads, n_reads)}
+    finally:
+        for fn in os.listdir(d):
+            os.unlink(os.path.join(d, fn))
+        os.rmdir(d)
+
+
+def time_cli_gz(seq, off, lens, n_reads, k, c, threads, workdir=None, forms=("one", "bgzf")):
+    """the same comparison on a gzip'ed file (BASELINE.json configs[0] is a .fa.gz): the reference binary on the single-member file, the drop-in binary on
+    every form asked for; zcat's time beside it (what the reference's reader waits for); GFA files compared, original bodies counted"""
+    if not available():
+        return {"skipped": "the CLI binaries are built only where the reference's sources are (make ref ref_dropin)"}
+    from oatk_amd import synth
+    modes = {"one": synth.FA_GZ, "bgzf": synth.FA_BGZF, "members": synth.FA_GZ_MEMBERS}
+    bases = int(lens[:n_reads].sum())
+    d = tempfile.mkdtemp(prefix="oatk_cligz_", dir=workdir or os.environ.get("TMPDIR", "/tmp"))
+    out = {"reads": n_reads, "gbases": round(bases / 1e9, 3), "threads": threads}
+    try:
+        for f in forms:
+            synth.write_fasta(os.path.join(d, f + ".fa.gz"), seq, off[:n_reads], lens[:n_reads], mode=modes[f], member_bytes=200_000_000)
+        t0 = time.perf_counter()
+        subprocess.run("zcat %s > /dev/null" % os.path.join(d, forms[0] + ".fa.gz"), shell=True)
+        out["zcat_s"] = round(time.perf_counter() - t0, 2)
+        out["file_MB"] = os.path.getsize(os.path.join(d, forms[0] + ".fa.gz")) >> 20
+        t_ref, _ = run_cli(CLI_REF, os.path.join(d, forms[0] + ".fa.gz"), os.path.join(d, "ref"), k, c, threads)
+        out["reference_s"] = round(t_ref, 2)
+        for f in forms:
+            t_dev, err = run_cli(CLI_DROPIN, os.path.join(d, f + ".fa.gz"), os.path.join(d, f), k, c, threads, {"OATK_DROPIN_LOG": "1"})
+            same = all(filecmp.cmp(os.path.join(d, "ref" + x), os.path.join(d, f + x), shallow=False) for x in (".utg.gfa", ".utg.final.gfa"))
+            tab = served_table(err)
+            m = re.search(r"oatk_sr_read_files\] .*?: ([\d.]+) s \(waiting for the uploader ([\d.]+)", err)
+            out[f] = {"dropin_s": round(t_dev, 2), "speedup": round(t_ref / t_dev, 2), "gfa_identical": bool(same),
+                      "sr_read_s": float(m.group(1)) if m else None, "waiting_for_the_inflater_s": float(m.group(2)) if m else None,
+                      "original_calls": {fn: v[2] for fn, v in tab.items() if v[2] > 0},
+                      "device_s": {fn: v[1] for fn, v in tab.items() if v[0] > 0 and v[1] >= 0.01}}
+        return out
     finally:
         for fn in os.listdir(d):
             os.unlink(os.path.join(d, fn))

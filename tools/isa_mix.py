@@ -1,24 +1,30 @@
 #!/usr/bin/env python3
-"""Opcode mix of kernel B's tile loop, priced with the per-opcode issue rates measured on the box (profiles/r02c_valu_rates.txt, tools/ubench/valu_rates.hip):
+"""Opcode mix of kernel B's tile loop, priced with the per-opcode issue rates measured on the box (profiles/r04a_valu_rates.txt, tools/ubench/valu_rates.hip):
 the VERDICT of round 2 asked for roofline.valu from Sigma n_i c_i instead of a flat 4 cycles per wave64 instruction.  CPU only (hipcc -S).
     python tools/isa_mix.py profiles/r03c_isa_mix_syncmer_fast.json"""
 import collections, json, os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL = "syncmer_fast_kernelILi2048ELb1ELi128ELi6E"
-# cycles per wave64 instruction per SIMD, event-derived at 2.4 GHz (profiles/r02c_valu_rates.txt); classes not measured there take the flat 4.0
-RATES = [(r"^v_(xor|and|or|not|add|sub|subrev|mov|cndmask|lshlrev|lshrrev|ashrrev|bfe|bfi|perm|min|max|min3|max3|and_or|or3|xad|lshl_add|add_lshl|lshl_or|add3|xor3)_[a-z]?(b|u|i)?(16|32)?(_e32|_e64|_dpp|_sdwa)?$", 2.9, "32-bit simple"),
-         (r"^v_alignbit_b32", 5.15, "v_alignbit_b32"), (r"^v_mul_u32_u24|^v_mad_u32_u24", 4.76, "24-bit multiply"), (r"^v_mul_lo_u32", 5.49, "v_mul_lo_u32"),
-         (r"^v_mul_hi_u32", 5.17, "v_mul_hi_u32"), (r"^v_mad_u64_u32", 5.20, "v_mad_u64_u32"), (r"^v_lsh[lr]rev_b64|^v_ashrrev_i64", 4.47, "64-bit shift"),
-         (r"^v_lshl_add_u64", 4.82, "v_lshl_add_u64"), (r"^v_add_co|^v_addc|^v_sub_co|^v_subb", 4.72, "carry add"), (r"^v_cmp_.*_[ui]64", 4.68, "64-bit compare"),
-         (r"^v_cmp_", 2.9, "32-bit compare"), (r"^v_mov_b64|^v_pk_", 4.0, "64-bit move")]
+# cycles per wave64 instruction per SIMD, event-derived at 2.4 GHz (profiles/r04a_valu_rates.txt); classes not measured there take the flat 4.0
+# cycles per wave64 instruction per SIMD with >= 2 waves resident, event-derived at the MEASURED clock (round 4: profiles/r04a_valu_rates.txt and
+# r04a_valu_rates_more.txt, kernels of >= 25 ms; the round-3 table came from 0.2 ms kernels priced at an assumed 2.4 GHz).  Two classes: ~2.3 for the plain
+# two-operand forms of xor / and / or / not / add / sub / mov / lshrrev_b32 (and v_mul_f32), ~4.1 - 4.3 for everything else measured -- min / max,
+# lshlrev_b32 (!), every three-operand form, every 64-bit operation incl. v_mad_u64_u32 and v_lshl_add_u64, compares, v_cndmask, DPP.
+FAST = r"^v_(xor|and|or|not|add|sub|subrev|mov|lshrrev)_(b|u|i)32(_e32|_e64)?$"
+RATES = [(FAST, 2.3, "full rate (2.3)"), (r"^v_bitop3_b32|^v_fma", 3.7, "v_bitop3 / fma (3.7)"), (r"^v_mad_u64_u32|^v_add_co|^v_addc|^v_sub_co|^v_subb", 4.3, "v_mad_u64_u32 / carry (4.3)"),
+         (r"^v_", 4.15, "half rate (4.15)")]
 
 
 def main():
     d = tempfile.mkdtemp()
-    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", os.path.join(ROOT, "oatk_amd/csrc/api.hip"), "--save-temps", "-o", "x.o"], cwd=d, check=True,
+    # (the kernel alone: the header with the one instantiation bench.py's workload runs -- seconds instead of the minutes api.hip takes)
+    with open(os.path.join(d, "kb.hip"), "w") as f:
+        f.write('#include <hip/hip_runtime.h>\n#include "%s"\ntemplate __global__ void oatk::syncmer_fast_kernel<2048, true, 128, 6>(oatk::SynArgs);\n'
+                % os.path.join(ROOT, "oatk_amd/csrc/scan_syncmer_fast.hpp"))
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", "kb.s", "kb.hip"], cwd=d, check=True,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    asm = open(os.path.join(d, "api-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
+    asm = open(os.path.join(d, "kb.s")).read()
     m = re.search(r"^(_ZN4oatk\d+" + KERNEL + r"[A-Za-z0-9_]*):(.*?)\.Lfunc_end", asm, re.S | re.M)
     lines = [ln.strip() for ln in m.group(2).splitlines()]
     ins, labels = [], {}
@@ -58,7 +64,7 @@ def main():
             cyc += 4.0
     out = {"kernel": m.group(1), "loop_instructions": len(body), "loop_valu": n_valu, "by_class": dict(by.most_common()), "top_opcodes": dict(ops.most_common(20)),
            "cycles_per_valu_instruction_mix": round(cyc / max(n_valu, 1), 3),
-           "note": "static count over the tile loop of the instantiation bench.py runs (rare paths inside it included); cycles per class from profiles/r02c_valu_rates.txt"}
+           "note": "static count over the tile loop of the instantiation bench.py runs (rare paths inside it included); cycles per class from profiles/r04a_valu_rates.txt"}
     json.dump(out, open(sys.argv[1], "w"), indent=1)
     print(json.dumps(out, indent=1))
 

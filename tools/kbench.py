@@ -32,6 +32,7 @@ for it in range(a.steps + 1):
         for k, v in hip.timing().items():
             acc[k] = acc.get(k, 0) + v / a.steps
 bases = int(lens.sum())
+print("hoco positions per dispatch %d" % int(hip.fetch("HOCO_L").astype(np.uint64).sum()))
 print("reads %d bases %.3f G  " % (a.reads, bases / 1e9) + "  ".join("%s %.3f" % kv for kv in acc.items()))
 tot = sum(v for k, v in acc.items() if k not in ("scan_post",))
 print("device ms/step %.3f -> %.1f Gbases/s ; hpc %.1f GB/s" % (tot, bases / tot / 1e6, (bases * 1.9375) / acc["hpc"] / 1e6))

@@ -13,8 +13,10 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python - <<PY
 import csv, collections
+import re
+pos = int(re.search(r"hoco positions per dispatch (\d+)", open("$O/a.log").read()).group(1))
 out = open("$O/${TAG}_pmc_scan.csv", "w")
-out.write('kernel,counter,"sum_over_dispatches (tools/pmc_r02.sh: tools/kbench.py --reads 20000 --steps 1 = 2 dispatches per kernel; rocprofv3 --kernel-trace --pmc, two passes)"\n')
+out.write('kernel,counter,"sum_over_dispatches (tools/pmc_r02.sh: tools/kbench.py --reads 20000 --steps 1 = 2 dispatches per kernel, positions=%d hoco positions in all; rocprofv3 --kernel-trace --pmc, two passes)"\n' % (2 * pos))
 for d in "ab":
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     for r in csv.DictReader(open("$O/%s/p_counter_collection.csv" % d)):
