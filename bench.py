@@ -475,10 +475,35 @@ def main():
                 return hip.ec_sharded(comm1, 0.02, c, 0.35)[0]
             step_sharded()
             dss, st_s = timed(step_sharded, args.steps)
-            hip.L.oatk_comm_destroy(comm1)
+            traffic = (C.c_uint64 * 8)()
+            hip.L.oatk_comm_traffic(comm1, traffic, 1)
+            step_sharded()
+            hip.L.oatk_comm_traffic(comm1, traffic, 1)
+            tr_full = [int(x) for x in traffic]
             extras["sharded_path_world_of_one"] = {"value": round(total_bases / dss / 1e9, 3), "unit": "Gbases/s", "ms_per_step": round(dss * 1e3, 3),
                                                    "same_statistics": bool(st is not None and list(st_s[:11]) == list(st[:11])),
                                                    "workload": "the headline step through oatk_hip_merge_counts + oatk_hip_ec_sharded over an RCCL communicator of one rank"}
+            # ---- a prediction to hold the first measured N = 2 / 4 / 8 runs against (strong scaling: the workload's reads divided over the GPUs).  Measured
+            #      here: the sharded step of ONE rank at the workload's reads and at an eighth of them (time and what it puts into the collectives, both
+            #      taken as a + b x reads); assumed: the link figures below.  Not a measurement of any link. ----
+            try:
+                n8 = max(per_gpu // 8, 1)
+                nb8 = int(off[n8]) if n8 < per_gpu else seq_bytes
+
+                def step_eighth():
+                    scan_count(d_seq, d_off, d_len, n8, nb8, first)
+                    hip.merge_counts(comm1)
+                    return hip.ec_sharded(comm1, 0.02, c, 0.35)[0]
+                step_eighth()
+                d8, _ = timed(step_eighth, args.steps)
+                hip.L.oatk_comm_traffic(comm1, traffic, 1)
+                step_eighth()
+                hip.L.oatk_comm_traffic(comm1, traffic, 1)
+                tr_8 = [int(x) for x in traffic]
+                extras["scale_model"] = scale_model(per_gpu, dss * 1e3, tr_full, n8, d8 * 1e3, tr_8, total_bases, dt / args.steps * 1e3)
+            except Exception as ex:         # noqa: BLE001
+                extras["scale_model"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+            hip.L.oatk_comm_destroy(comm1)
         except Exception as ex:             # noqa: BLE001
             extras["sharded_path_world_of_one"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
 
@@ -530,7 +555,10 @@ def main():
                     return hip.ec(0.02, cc1, 0.35)
                 full1()
                 d1s, s1 = timed(full1, 2)
+                hip.set_timing(True)                    # (one more step with the phase timers on: they synchronise, so the step above ran without them)
+                full1()
                 ph1 = {k_: round(v, 3) for k_, v in hip.timing().items() if v > 0.0005}
+                hip.set_timing(False)
                 inf1 = hip.info()
                 extras["config1s"] = {"workload": "config-1 surrogate: %d reads (%.2f Gbases) -- a 154 kb + a 368 kb genome at >= 1000x in a 256 Mb background at ~7x, tandem arrays, "
                                                   "homopolymers > 256, N, 1 %% reads < K; -c %d; resident in HBM" % (n1, b1 / 1e9, cc1),
@@ -684,6 +712,42 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def scale_model(n1, ms1, tr1, n8, ms8, tr8, bases1, ms_headline):
+    """Predicted strong-scaling steps at N = 2, 4, 8 from two one-rank measurements of the sharded step (n reads -> ms, traffic as oatk_comm_traffic
+    counts it).  Per rank at N GPUs: compute(reads / N) from the line through the two measured points; every collective pays a latency; an exchange's
+    bytes leave over N - 1 links at once, 1 / N of them staying home; an all-gather's bytes arrive from N - 1 peers over N - 1 links; an all-reduce
+    moves 2 (N - 1) / N of its bytes round a ring.  xGMI: seven links per GPU, 153.6 GB/s each both directions together (the task's figure) = 76.8 GB/s
+    one way, taken at 60 %; 40 us per collective (launch + the host's wait for it: comm_wait polls the stream)."""
+    link_GBs, eff, lat_ms = 76.8, 0.6, 0.040
+    bw = link_GBs * eff * 1e6                   # bytes per ms per link
+    slope = (ms1 - ms8) / max(n1 - n8, 1)
+    fixed = ms8 - slope * n8
+
+    def lin(a1, a8, n):                         # a + b n through the two points
+        b = (a1 - a8) / max(n1 - n8, 1)
+        return max(a8 - b * n8 + b * n, 0.0)
+    calls = tr1[0] + tr1[2] + tr1[4] + tr1[6]
+    out = {"measured": {"reads": [n1, n8], "ms": [round(ms1, 3), round(ms8, 3)], "ms_headline_step_n1": round(ms_headline, 3),
+                        "collectives_per_step": calls,
+                        "bytes_put_in_per_step": {"small_allgather": [tr1[1], tr8[1]], "allgather": [tr1[3], tr8[3]], "allreduce": [tr1[5], tr8[5]], "exchange": [tr1[7], tr8[7]]}},
+           "assumed": {"link_GBs_one_way": link_GBs, "efficiency": eff, "ms_per_collective": lat_ms, "compute_ms": "%.3f + %.6f x reads" % (fixed, slope)},
+           "predicted": {}}
+    for n in (2, 4, 8):
+        r = n1 / n
+        comp = fixed + slope * r
+        ex, ag, ar = lin(tr1[7], tr8[7], r), lin(tr1[3], tr8[3], r), lin(tr1[5], tr8[5], r)
+        # all-reduced arrays are global quantities (they do not shrink with the shard): the measured full-size figure
+        ar = max(ar, float(tr1[5]))
+        t_ex = (ex / n) / bw                    # per link: a rank's bytes for ONE peer
+        t_ag = ag / bw                          # per link: one peer's whole contribution comes in
+        t_ar = 2.0 * (n - 1) / n * ar / bw
+        t = comp + calls * lat_ms + t_ex + t_ag + t_ar
+        out["predicted"][str(n)] = {"ms_per_step": round(t, 2), "Gbases_per_s": round(bases1 / t / 1e6, 1), "speedup_over_1": round(ms_headline / t, 2),
+                                    "efficiency": round(ms_headline / t / n, 3),
+                                    "parts_ms": {"compute": round(comp, 2), "latencies": round(calls * lat_ms, 2), "exchange": round(t_ex, 3), "allgather": round(t_ag, 3), "allreduce": round(t_ar, 3)}}
+    return out
 
 
 def pmc_valu_per_64():

@@ -57,6 +57,11 @@ void oatk_comm_destroy(oatk_comm *c);
 int oatk_comm_rank(const oatk_comm *c);
 int oatk_comm_size(const oatk_comm *c);
 const char *oatk_comm_backend(const oatk_comm *c);          /* "rccl" or "local" */
+/* What this rank has put into the collectives since the communicator was made (or since the last call with reset != 0): out[0] small all-gathers
+ * (counts, verdicts), out[2] all-gathers of arrays, out[4] all-reduces, out[6] personalised exchanges -- calls; out[1], out[3], out[5], out[7] the
+ * bytes of this rank's contribution to them (an exchange counts what goes to every rank, its own share included).  What a scaling estimate needs:
+ * the number of latencies and the bytes per link (bench.py: scale_model). */
+void oatk_comm_traffic(oatk_comm *c, uint64_t out[8], int reset);
 
 /* after oatk_hip_count on every rank.  Resident afterwards (oatk_hip_buffer): this rank's RANGE of the global table -- MG_H u64[n_owned] hashes
  * ascending, MG_S u64[n_owned] s-mers, MG_COV u32[n_owned] coverage over all shards (global ids first_id .. first_id + n_owned, oatk_hip_multi_range;

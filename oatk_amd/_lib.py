@@ -43,7 +43,7 @@ EXPORTS = [
     "oatk_hip_abi_version", "oatk_hip_device_count", "oatk_hip_create", "oatk_hip_destroy", "oatk_hip_last_error",
     "oatk_hip_stream", "oatk_hip_sync", "oatk_hip_max_k", "oatk_hip_scan", "oatk_hip_scan_host", "oatk_hip_count",
     "oatk_comm_unique_id", "oatk_comm_create", "oatk_comm_group_create", "oatk_comm_group_rank", "oatk_comm_group_destroy", "oatk_comm_destroy",
-    "oatk_comm_rank", "oatk_comm_size", "oatk_comm_backend", "oatk_hip_merge_counts", "oatk_hip_multi_range", "oatk_hip_ec_sharded",
+    "oatk_comm_rank", "oatk_comm_size", "oatk_comm_backend", "oatk_comm_traffic", "oatk_hip_merge_counts", "oatk_hip_multi_range", "oatk_hip_ec_sharded",
     "oatk_hip_gather_table", "oatk_hip_asm_graph_sharded", "oatk_hip_consensus_sharded", "oatk_hip_overlap_hist_sharded", "oatk_hip_stat_sharded",
     "oatk_hip_scan_begin", "oatk_hip_scan_reserve", "oatk_hip_scan_append", "oatk_hip_device", "oatk_hip_d2d",
     "oatk_hip_info", "oatk_hip_buffer", "oatk_hip_d2h", "oatk_hip_d2h_async", "oatk_hip_h2d_async", "oatk_hip_staging", "oatk_hip_ingest_text_buffer", "oatk_hip_set_timing", "oatk_hip_get_timing",
@@ -124,6 +124,8 @@ def load():
     L.oatk_comm_size.argtypes = [vp]
     L.oatk_comm_backend.restype = C.c_char_p
     L.oatk_comm_backend.argtypes = [vp]
+    L.oatk_comm_traffic.restype = None
+    L.oatk_comm_traffic.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
     L.oatk_hip_merge_counts.argtypes = [vp, vp, C.POINTER(C.c_uint64)]
     L.oatk_hip_multi_range.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.oatk_hip_ec_sharded.argtypes = [vp, vp, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, vp, C.POINTER(C.c_uint64)]

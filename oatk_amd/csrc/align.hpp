@@ -7,15 +7,37 @@
 // results depend on it: the sort of the hits, the order fragments are pushed in, the STABLE sort of the fragments (glibc's qsort is a
 // merge sort here), the chaining loop's early exit, the order predecessors are recorded and walked in.
 #pragma once
+#include <type_traits>
 #include "common.hpp"
 #include "scan_hpc.hpp"
 
 namespace oatk {
 
-constexpr int RA_MAXS = 160;      // syncmer hits per read
-constexpr int RA_MAXF = 128;      // fragments per read
-constexpr int RA_PREV = 6;        // recorded predecessors per fragment
-constexpr int RA_DEPTH = 48;      // fragments per alignment
+// Two sizes of the per-read working arrays.  RaSmall is what almost every read needs (a read is a few dozen syncmers, each on one or two unitigs) and what
+// the layout is tuned for: 10 KB per lane, the walk's stack in LDS.  RaBig takes the reads RaSmall reports as over its limits -- reads through tandem
+// arrays and other repeats, whose syncmers sit on hundreds of unitig positions (round 4: the config-1 surrogate sent every call of scg_read_alignment
+// back to the original routine because of a few hundred such reads) -- one lane each again, with everything in HBM.  What is over RaBig's limits is
+// still reported, not aligned.
+struct RaSmall {
+    static constexpr int MAXS = 160;      // syncmer hits per read
+    static constexpr int MAXF = 128;      // fragments per read
+    static constexpr int PREV = 6;        // recorded predecessors per fragment
+    static constexpr int DEPTH = 48;      // fragments per alignment
+    static constexpr int FBITS = 8;       // stack entry: the fragment in the low FBITS bits, the next predecessor to visit above them
+    static constexpr bool LDS_STACK = true;
+    static constexpr int THREADS = 256;
+    typedef uint16_t st_t;
+};
+struct RaBig {
+    static constexpr int MAXS = 8192;
+    static constexpr int MAXF = 4096;
+    static constexpr int PREV = 64;
+    static constexpr int DEPTH = 2048;
+    static constexpr int FBITS = 16;
+    static constexpr bool LDS_STACK = false;
+    static constexpr int THREADS = 64;
+    typedef uint32_t st_t;
+};
 constexpr uint64_t RA_NONE = 0xFFFFFFFFFFFFFFFEULL;
 
 // A lane's working arrays, element i of every lane next to each other: lanes that walk their arrays in step touch consecutive words
@@ -31,7 +53,7 @@ struct RaFrgs {
     RaCol<uint64_t> uid;
     RaCol<uint32_t> u_beg, u_end, s_beg, s_end, s_cnt;
     RaCol<int32_t> score0, score;
-    RaCol<uint16_t> prev_n, prev;         // prev[i * RA_PREV + k]
+    RaCol<uint16_t> prev_n, prev;         // prev[i * L::PREV + k]
     __device__ void copy(uint32_t dst, const RaFrgs &o, uint32_t src) const
     {
         uid[dst] = o.uid[src], u_beg[dst] = o.u_beg[src], u_end[dst] = o.u_end[src], s_beg[dst] = o.s_beg[src], s_end[dst] = o.s_end[src];
@@ -52,6 +74,8 @@ struct RaArgs {
     uint32_t *cnt_aln, *cnt_frg;              // [n_reads] pass 1
     uint8_t *skipped;                         // [n_reads]
     const uint64_t *aln_off, *frg_off;        // [n_reads + 1] pass 2
+    const uint32_t *list;                     // RaBig: the reads to take, n_list of them
+    uint64_t n_list;
     unsigned long long *pool_used;            // [0] alignments, [1] fragments taken from the pool, [2] it ran short
     uint64_t pool_cap_a, pool_cap_f;
     uint64_t *pool_a, *pool_f;                // [n_reads] where a read's block starts in the pool
@@ -62,13 +86,19 @@ struct RaArgs {
     uint32_t *o_ubeg, *o_uend, *o_sbeg, *o_send;
 };
 
-// bytes of working arrays per lane: hits, fragments as collected, fragments in sorted order, the sorted order itself
-constexpr uint64_t RA_LANE_BYTES = (uint64_t) RA_MAXS * 24 + 2 * ((uint64_t) RA_MAXF * (8 + 5 * 4 + 2 * 4 + 2 + 2 * RA_PREV)) + (uint64_t) RA_MAXF * 2;
-static inline uint64_t ra_slab_bytes(uint64_t lanes) { return lanes * RA_LANE_BYTES + 256; }
+// bytes of working arrays per lane: hits, fragments as collected, fragments in sorted order, the sorted order itself (and RaBig's stack)
+template <class L>
+static inline uint64_t ra_slab_bytes(uint64_t lanes)
+{
+    const uint64_t lane_bytes = (uint64_t) L::MAXS * 24 + 2 * ((uint64_t) L::MAXF * (8 + 5 * 4 + 2 * 4 + 2 + 2 * L::PREV)) + (uint64_t) L::MAXF * 2 + (L::LDS_STACK? 0 : (uint64_t) L::DEPTH * 4);
+    return lanes * lane_bytes + 256;
+}
 
-struct RaWork { RaHits S; RaFrgs F, G; RaCol<uint16_t> P; };
+struct RaWork { RaHits S; RaFrgs F, G; RaCol<uint16_t> P; RaCol<uint32_t> stack; };
+template <class L>
 __device__ inline RaWork ra_work(uint8_t *slab, uint64_t tid, uint64_t nthr)
 {
+    constexpr int RA_MAXS = L::MAXS, RA_MAXF = L::MAXF, RA_PREV = L::PREV;
     RaWork w;
     uint8_t *q = slab;
     auto col64 = [&](uint64_t n) { RaCol<uint64_t> c = {(uint64_t *) q + tid, nthr}; q += n * nthr * 8; return c; };
@@ -84,6 +114,8 @@ __device__ inline RaWork ra_work(uint8_t *slab, uint64_t tid, uint64_t nthr)
     }
     for (RaFrgs *f : {&w.F, &w.G}) f->prev_n = col16(RA_MAXF), f->prev = col16((uint64_t) RA_MAXF * RA_PREV);
     w.P = col16(RA_MAXF);
+    if (!L::LDS_STACK) { q = (uint8_t *) (((uintptr_t) q + 3) & ~(uintptr_t) 3); w.stack = col32(L::DEPTH); }
+    else w.stack = RaCol<uint32_t>{nullptr, 0};
     return w;
 }
 
@@ -98,33 +130,34 @@ __device__ inline int64_t ra_arc_ln(const RaArgs &a, uint64_t v, uint64_t w)
 // Depth-first walk over the recorded predecessors from every fragment of maximal score; a chain's fragments come out earliest first.
 // WR: write alignments from slot wa / fragments from slot wf on (offsets stored relative to f_base); otherwise only count.  Returns true
 // when a chain is longer than the stack.
-template <bool WR>
-__device__ inline bool ra_backtrace(const RaArgs &a, uint16_t *st_mem, const RaFrgs &G, uint32_t nf, int64_t max_score, uint64_t n, uint64_t r,
+template <bool WR, class L, class Stack>
+__device__ inline bool ra_backtrace(const RaArgs &a, const Stack &st, const RaFrgs &G, uint32_t nf, int64_t max_score, uint64_t n, uint64_t r,
                                     uint32_t tot_a, uint64_t wa, uint64_t wf, uint64_t f_base, uint32_t &n_a, uint32_t &n_fr)
 {
+    constexpr int RA_DEPTH = L::DEPTH, RA_PREV = L::PREV;
+    constexpr uint32_t FMASK = (1u << L::FBITS) - 1u, CHILD1 = 1u << L::FBITS;
+    typedef typename L::st_t st_t;
     // the walk's stack lives in LDS (st_mem, RA_DEPTH * 256 entries per workgroup), one column per lane: an array in registers indexed by a per-lane depth turns every access into a
     // loop over all its elements (measured: the walk took three times as long as everything before it).  An entry is the fragment
     // (< RA_MAXF = 128) in its low byte and the next predecessor to visit (<= RA_PREV) above it: 24 KB per workgroup, so that registers, not
     // LDS, decide how many of the 782 workgroups of 200 k reads are resident at once (all of them at four waves per SIMD).
-    static_assert(RA_MAXF <= 256 && RA_PREV < 256, "stack entry: fragment in the low byte, child counter in the high byte");
-    struct Col { uint16_t *p; __device__ uint16_t &operator[](int i) const { return p[i * 256]; } };
-    const Col st = {st_mem + threadIdx.x};
+    static_assert(L::MAXF <= (1 << L::FBITS) && (uint64_t) (L::PREV + 1) << L::FBITS <= (1ull << (8 * sizeof(st_t))), "stack entry: the fragment in the low bits, the child counter above them");
     n_a = 0, n_fr = 0;
     for (uint32_t j = 0; j < nf; ++j) {
         if (G.score[j] < max_score) continue;
         int d = 0;
-        st[0] = (uint16_t) j;
+        st[0] = (st_t) j;
         while (d >= 0) {
-            const uint32_t e = st[d], f = e & 0xFFu, child = e >> 8;
+            const uint32_t e = st[d], f = e & FMASK, child = e >> L::FBITS;
             const uint32_t pn = G.prev_n[f];
             if (pn == 0) {                                                         // a chain is complete: its fragments are st[d .. 0]
                 uint64_t s = 0;
-                for (int t = d; t >= 0; --t) s += G.s_cnt[st[t] & 0xFFu];
+                for (int t = d; t >= 0; --t) s += G.s_cnt[st[t] & FMASK];
                 if (!((double) s / (double) n < 0.9)) {                            // min_a_frac (:161, :547)
                     if (WR) {
                         a.o_sid[wa] = (uint32_t) r, a.o_off[wa] = wf - f_base, a.o_s[wa] = 1.0 / (double) tot_a + (double) max_score;
                         for (int t = d; t >= 0; --t, ++wf) {
-                            const uint32_t q = st[t] & 0xFFu;
+                            const uint32_t q = st[t] & FMASK;
                             a.o_uid[wf] = G.uid[q], a.o_ubeg[wf] = G.u_beg[q], a.o_uend[wf] = G.u_end[q], a.o_sbeg[wf] = G.s_beg[q], a.o_send[wf] = G.s_end[q];
                         }
                         ++wa;
@@ -135,9 +168,9 @@ __device__ inline bool ra_backtrace(const RaArgs &a, uint16_t *st_mem, const RaF
             } else if (child < pn) {
                 if (d + 1 == RA_DEPTH) return true;
                 const uint16_t c = G.prev[f * RA_PREV + child];
-                st[d] = (uint16_t) (e + 0x100u);
+                st[d] = (st_t) (e + CHILD1);
                 ++d;
-                st[d] = c;
+                st[d] = (st_t) c;
             } else --d;
         }
     }
@@ -145,10 +178,11 @@ __device__ inline bool ra_backtrace(const RaArgs &a, uint16_t *st_mem, const RaF
 }
 
 // Everything of scg_ra_analysis_thread up to the chained fragments for read r.  Returns 0: nothing to report, 1: the fragments G[0 .. nf) in
-// sorted order with their best scores and predecessors are ready and max_score passes the read's threshold, 2: the read is over the limits.
-template <int MODE>
+// sorted order with their best scores and predecessors are ready and max_score passes the read's threshold, 2: the read is over the limits (skipped[r] says which).
+template <int MODE, class L>
 __device__ inline int ra_prepare(const RaArgs &a, uint64_t r, const RaWork &w, uint32_t &nf, int64_t &max_score, uint64_t &n)
 {
+    constexpr int RA_MAXS = L::MAXS, RA_MAXF = L::MAXF, RA_PREV = L::PREV;
     const RaHits &S = w.S;
     const RaFrgs &F = w.F, &G = w.G;
     const RaCol<uint16_t> &P = w.P;
@@ -159,13 +193,14 @@ __device__ inline int ra_prepare(const RaArgs &a, uint64_t r, const RaWork &w, u
     if (n == 0) return 0;
     if (MODE == 1 && (a.skipped[r] || a.cnt_aln[r] == 0)) return 0;
     bool over = false;
+    // (which limit a read is over goes straight into skipped[r]: 1 hits, 2 fragments, 3 predecessors; the caller adds 4, the depth of the walk)
     // ---- every position of every syncmer of the read on the unitigs (alignment.c:233-251), kept sorted by unitig, read position, unitig
     //      position as they arrive (sr_scm_cmpfunc :93-107; the order is total, so inserting in place equals sorting afterwards) ----
     uint32_t ns = 0;
     for (uint64_t j = 0; j < n && !over; ++j) {
         const uint64_t s = a.k_mer[co + j] >> 1;
         for (uint64_t k = a.su_off[s]; k < a.su_off[s + 1]; ++k) {
-            if (ns == RA_MAXS) { over = true; break; }
+            if (ns == RA_MAXS) { over = true; if (MODE != 1) a.skipped[r] = 1; break; }
             const uint64_t x = a.su_uid[k], u = x >> 1, t = (x & 1ULL) ^ (a.m_pos[co + j] & 1u);
             const uint32_t p = a.su_pos[k];
             const uint64_t xu = u << 1 | t;
@@ -230,7 +265,7 @@ __device__ inline int ra_prepare(const RaArgs &a, uint64_t r, const RaWork &w, u
             if (u_gap < 0) u_gap = 0;
             const int64_t score = (int64_t) s_cnt - u_gap;                     // match_score = gap_penalty = 1 (:159-160)
             if (score >= 0) {
-                if (nf == RA_MAXF) { over = true; break; }
+                if (nf == RA_MAXF) { over = true; if (MODE != 1) a.skipped[r] = 2; break; }
                 F.uid[nf] = u, F.s_beg[nf] = s_beg, F.s_end[nf] = S.s_pos[s], F.s_cnt[nf] = s_cnt, F.u_beg[nf] = u_beg, F.u_end[nf] = S.u_pos[s];
                 F.score0[nf] = F.score[nf] = (int32_t) score, F.prev_n[nf] = 0;
                 ++nf;
@@ -238,7 +273,7 @@ __device__ inline int ra_prepare(const RaArgs &a, uint64_t r, const RaWork &w, u
         }
         for (uint32_t k = j; k < p && !over; ++k) {                            // :329-336
             if (S.next[k] != RA_NONE) continue;
-            if (nf == RA_MAXF) { over = true; break; }
+            if (nf == RA_MAXF) { over = true; if (MODE != 1) a.skipped[r] = 2; break; }
             const uint32_t sp = S.s_pos[k], up = S.u_pos[k];
             F.uid[nf] = u, F.s_beg[nf] = F.s_end[nf] = sp, F.s_cnt[nf] = 1, F.u_beg[nf] = F.u_end[nf] = up, F.score0[nf] = F.score[nf] = 1, F.prev_n[nf] = 0;
             ++nf;
@@ -277,7 +312,7 @@ __device__ inline int ra_prepare(const RaArgs &a, uint64_t r, const RaWork &w, u
             uint32_t pn = G.prev_n[k];
             if (score1 <= score || score1 < sk || (score1 == sk && pn == 0)) continue;
             if (score1 > sk) G.score[k] = (int32_t) score1, pn = 0;
-            if (pn == RA_PREV) { over = true; break; }
+            if (pn == RA_PREV) { over = true; if (MODE != 1) a.skipped[r] = 3; break; }
             G.prev[k * RA_PREV + pn] = (uint16_t) j;
             G.prev_n[k] = (uint16_t) (pn + 1);
         }
@@ -293,27 +328,39 @@ __device__ inline int ra_prepare(const RaArgs &a, uint64_t r, const RaWork &w, u
 //      2: count, take room in a pool and write there (the normal path; 0 + 1 is the fallback when the pool is short).  The pool is
 //      handed out per WAVE -- the lanes' needs are summed with DPP and one lane asks -- because 200 k lanes asking one by one serialise
 //      on the two counters (measured: as long as the whole routine again).
-template <int MODE>
-__global__ __launch_bounds__(256, 4) void ra_kernel(RaArgs a)
+// L = RaSmall: every read, round-robin.  L = RaBig: the reads of a.list (those RaSmall reported), whose `skipped` mark is replaced by the new verdict.
+template <class L> struct RaStackLds { typename L::st_t *p; __device__ typename L::st_t &operator[](int i) const { return p[i * L::THREADS]; } };
+template <bool WR, class L>
+__device__ __forceinline__ bool ra_walk(const RaArgs &a, const RaStackLds<L> &st_lds, const RaWork &w, uint32_t nf, int64_t max_score, uint64_t n, uint64_t r,
+                                        uint32_t tot_a, uint64_t wa, uint64_t wf, uint64_t f_base, uint32_t &n_a, uint32_t &n_fr)
+{
+    if (L::LDS_STACK) return ra_backtrace<WR, L>(a, st_lds, w.G, nf, max_score, n, r, tot_a, wa, wf, f_base, n_a, n_fr);
+    return ra_backtrace<WR, L>(a, w.stack, w.G, nf, max_score, n, r, tot_a, wa, wf, f_base, n_a, n_fr);
+}
+template <int MODE, class L>
+__global__ __launch_bounds__(L::THREADS, L::LDS_STACK? 4 : 1) void ra_kernel(RaArgs a)
 {
     const uint64_t tid = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x, nthr = (uint64_t) gridDim.x * blockDim.x;
     const uint32_t lane = threadIdx.x & 63u;
-    __shared__ uint16_t st_mem[RA_DEPTH * 256];
-    const RaWork w = ra_work(a.slab, tid, nthr);
-    for (uint64_t base = tid - lane; base < a.n_reads; base += nthr) {                 // the same trip count in every lane of a wave
-        const uint64_t r = base + lane;
+    __shared__ typename L::st_t st_mem[L::LDS_STACK? L::DEPTH * L::THREADS : 1];
+    const RaWork w = ra_work<L>(a.slab, tid, nthr);
+    const RaStackLds<L> st_lds = {st_mem + threadIdx.x};
+    const uint64_t n_items = L::LDS_STACK? a.n_reads : a.n_list;
+    for (uint64_t base = tid - lane; base < n_items; base += nthr) {                   // the same trip count in every lane of a wave
+        const bool have = base + lane < n_items;
+        const uint64_t r = L::LDS_STACK? base + lane : (have? (uint64_t) a.list[base + lane] : 0);
         uint32_t nf = 0, n_a = 0, n_fr = 0;
         int64_t max_score = 0;
         uint64_t n = 0;
         int st = 0;
-        if (r < a.n_reads) {
+        if (have) {
             if (MODE != 1) a.cnt_aln[r] = 0, a.cnt_frg[r] = 0, a.skipped[r] = 0;
-            st = ra_prepare<MODE>(a, r, w, nf, max_score, n);
+            st = ra_prepare<MODE, L>(a, r, w, nf, max_score, n);
             if (MODE == 1) {
-                if (st == 1) ra_backtrace<true>(a, st_mem, w.G, nf, max_score, n, r, a.cnt_aln[r], a.aln_off[r], a.frg_off[r], 0, n_a, n_fr);
+                if (st == 1) ra_walk<true, L>(a, st_lds, w, nf, max_score, n, r, a.cnt_aln[r], a.aln_off[r], a.frg_off[r], 0, n_a, n_fr);
             } else {
-                if (st == 1 && ra_backtrace<false>(a, st_mem, w.G, nf, max_score, n, r, 0, 0, 0, 0, n_a, n_fr)) st = 2;
-                if (st == 2) a.skipped[r] = 1, n_a = n_fr = 0;
+                if (st == 1 && ra_walk<false, L>(a, st_lds, w, nf, max_score, n, r, 0, 0, 0, 0, n_a, n_fr)) st = 2, a.skipped[r] = 4;
+                if (st == 2) n_a = n_fr = 0;
                 else a.cnt_aln[r] = n_a, a.cnt_frg[r] = n_fr;
             }
         }
@@ -330,7 +377,7 @@ __global__ __launch_bounds__(256, 4) void ra_kernel(RaArgs a)
                     const uint64_t pa = wa + ia - n_a, pf = wf + ifr - n_fr;
                     uint32_t x, y;
                     a.pool_a[r] = pa, a.pool_f[r] = pf;
-                    ra_backtrace<true>(a, st_mem, w.G, nf, max_score, n, r, n_a, pa, pf, pf, x, y);
+                    ra_walk<true, L>(a, st_lds, w, nf, max_score, n, r, n_a, pa, pf, pf, x, y);
                 }
             }
         }

@@ -702,19 +702,54 @@ sort_again:
     ENSURE(slot_rec, n * 32);
     g.slot_rec = ctx->slot_rec.as<uint4>();
     hipLaunchKernelGGL(pack_slots_kernel, dim3(nb), dim3(256), 0, ctx->stream, g);
-    hipLaunchKernelGGL(mark_heads_kernel, dim3(nb), dim3(256), 0, ctx->stream, g);
+    hipLaunchKernelGGL(pair_sum_kernel, dim3(2048), dim3(256), 0, ctx->stream, ctx->key_hash.as<uint64_t>(), (const uint32_t *) nullptr, (uint32_t) n, ctx->flags.as<uint32_t>(), 8);
+    hipLaunchKernelGGL(pair_sum_kernel, dim3(2048), dim3(256), 0, ctx->stream, ctx->key_sorted.as<uint64_t>(), ctx->perm.as<uint32_t>(), (uint32_t) n, ctx->flags.as<uint32_t>(), 12);
+    // Optimistic order (round 4): heads -> ids -> ONE pass through the permutation (the verification's gathers + the table's and the reads' ids) -> verification.
+    // A hash group with two k-mers (never seen outside the forced-collision tests) takes the pessimistic order afterwards: split, gather again, ids again, write again.
+    hipLaunchKernelGGL(heads_only_kernel, dim3(nb), dim3(256), 0, ctx->stream, g);
     {   // head_idx := index of the latest head at or before i
         size_t tb = 0;
         CK(rocprim::inclusive_scan(nullptr, tb, ctx->head_idx.as<uint32_t>(), ctx->head_idx.as<uint32_t>(), n, rocprim::maximum<uint32_t>(), ctx->stream));
         ENSURE(tmp, tb);
         CK(rocprim::inclusive_scan(ctx->tmp.p, tb, ctx->head_idx.as<uint32_t>(), ctx->head_idx.as<uint32_t>(), n, rocprim::maximum<uint32_t>(), ctx->stream));
     }
+    uint32_t n_scm = 0;
+    FinishArgs f;
+    auto ids = [&]() -> int {               // clus_id := number of heads at or before i (= id + 1); n_scm; room for the table
+        size_t tb = 0;
+        CK(rocprim::inclusive_scan(nullptr, tb, ctx->newclus.as<uint32_t>(), ctx->clus_id.as<uint32_t>(), n, rocprim::plus<uint32_t>(), ctx->stream));
+        ENSURE(tmp, tb);
+        CK(rocprim::inclusive_scan(ctx->tmp.p, tb, ctx->newclus.as<uint32_t>(), ctx->clus_id.as<uint32_t>(), n, rocprim::plus<uint32_t>(), ctx->stream));
+        uint32_t last_id = 0;
+        CK(hipMemcpyAsync(&last_id, ctx->clus_id.as<uint32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+        CK(hipStreamSynchronize(ctx->stream));
+        n_scm = last_id;                    // inclusive scan: last value = number of clusters
+        ENSURE(scm_h, (size_t) n_scm * 8); ENSURE(scm_s, (size_t) n_scm * 8); ENSURE(scm_cov, (size_t) n_scm * 4); ENSURE(scm_loc, (size_t) n_scm * 8);
+        ENSURE(scm_occ_off, ((size_t) n_scm + 1) * 8);
+        f.perm = ctx->perm.as<uint32_t>(), f.newclus = ctx->newclus.as<uint32_t>(), f.clus_id = ctx->clus_id.as<uint32_t>(), f.n_rec = (uint32_t) n;
+        f.sorted_key = ctx->key_sorted.as<uint64_t>(), f.smer_sorted = ctx->smer_sorted.as<uint64_t>();
+        f.loc = ctx->kloc.as<uint64_t>(), f.scm_loc = ctx->scm_loc.as<uint64_t>();
+        f.scm_h = ctx->scm_h.as<uint64_t>(), f.scm_s = ctx->scm_s.as<uint64_t>(), f.scm_occ_off = ctx->scm_occ_off.as<uint64_t>();
+        f.scm_occ = ctx->scm_occ.as<uint64_t>(), f.pos_kid = ctx->pos_kid.as<uint64_t>(), f.flags = ctx->flags.as<uint32_t>();
+        return OATK_OK;
+    };
+    { int rc = ids(); if (rc) return rc; }
+    hipLaunchKernelGGL(gather_finish_kernel, dim3(nb), dim3(256), 0, ctx->stream, g, f, ctx->clus_id.as<uint32_t>(), n_scm);
     CK(hipMemsetAsync(ctx->bad_head.p, 0, n * 4, ctx->stream));
     hipLaunchKernelGGL(verify_group_kernel, dim3((unsigned) ((n + 8 * OATK_VG_STRIP - 1) / (8 * OATK_VG_STRIP))), dim3(256), 0, ctx->stream, g, ctx->bad_head.as<uint32_t>());
-    uint32_t fl[4];
+    // clus_id holds id + 1: shift in place (check_smer_kernel and the collision path read ids)
+    CK(rocprim::transform(ctx->clus_id.as<uint32_t>(), ctx->clus_id.as<uint32_t>(), n, [] __device__(uint32_t v) { return v - 1u; }, ctx->stream));
+    uint32_t fl[16];
     CK(hipMemcpyAsync(fl, ctx->flags.p, sizeof(fl), hipMemcpyDeviceToHost, ctx->stream));
     CK(hipStreamSynchronize(ctx->stream));
-    if (fl[3] && !full_sort) {                  // a run of equal top bits too long for the repair: everything from the sort on again, on all 64 bits
+    // the sort's output is the sort's input, permuted and in order (count.hpp: pair_sum_kernel)?  The sort on a bit range gets a second chance on all 64 bits
+    const bool sort_bad = fl[4] != 0 || memcmp(fl + 8, fl + 12, 16) != 0 || (!full_sort && getenv("OATK_DEBUG_SORT_DISTRUST") != nullptr);
+    if (sort_bad && full_sort) {
+        t_end(ctx, OATK_T_COUNT_GROUP);
+        ctx->err = "the device sort returned something that is not its input in order (rocPRIM radix_sort_pairs): refusing to build the syncmer table from it";
+        return OATK_E_NODEV;
+    }
+    if ((fl[3] || sort_bad) && !full_sort) {                  // a run of equal top bits too long for the repair: everything from the sort on again, on all 64 bits
         t_end(ctx, OATK_T_COUNT_GROUP);
         CK(hipMemsetAsync(ctx->flags.p, 0, 64, ctx->stream));
         full_sort = true;
@@ -725,28 +760,10 @@ sort_again:
         hipLaunchKernelGGL(split_collisions_kernel, dim3(nb), dim3(256), 0, ctx->stream, g, ctx->bad_head.as<uint32_t>(), ctx->perm.as<uint32_t>(),
                            ctx->tag.as<uint32_t>(), ctx->tmp_perm.as<uint32_t>());
         hipLaunchKernelGGL(regather_kernel, dim3(nb), dim3(256), 0, ctx->stream, g);
+        { int rc = ids(); if (rc) return rc; }
+        CK(rocprim::transform(ctx->clus_id.as<uint32_t>(), ctx->clus_id.as<uint32_t>(), n, [] __device__(uint32_t v) { return v - 1u; }, ctx->stream));
+        hipLaunchKernelGGL(finish_heads_kernel, dim3(nb), dim3(256), 0, ctx->stream, f, n_scm);
     }
-    {   // ids
-        size_t tb = 0;
-        CK(rocprim::inclusive_scan(nullptr, tb, ctx->newclus.as<uint32_t>(), ctx->clus_id.as<uint32_t>(), n, rocprim::plus<uint32_t>(), ctx->stream));
-        ENSURE(tmp, tb);
-        CK(rocprim::inclusive_scan(ctx->tmp.p, tb, ctx->newclus.as<uint32_t>(), ctx->clus_id.as<uint32_t>(), n, rocprim::plus<uint32_t>(), ctx->stream));
-    }
-    uint32_t last_id = 0;
-    CK(hipMemcpyAsync(&last_id, ctx->clus_id.as<uint32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
-    CK(hipStreamSynchronize(ctx->stream));
-    const uint32_t n_scm = last_id;       // inclusive scan: last value = number of clusters
-    ENSURE(scm_h, (size_t) n_scm * 8); ENSURE(scm_s, (size_t) n_scm * 8); ENSURE(scm_cov, (size_t) n_scm * 4); ENSURE(scm_loc, (size_t) n_scm * 8);
-    ENSURE(scm_occ_off, ((size_t) n_scm + 1) * 8);
-    // clus_id currently holds id+1; shift in place with a tiny transform
-    CK(rocprim::transform(ctx->clus_id.as<uint32_t>(), ctx->clus_id.as<uint32_t>(), n, [] __device__(uint32_t v) { return v - 1u; }, ctx->stream));
-    FinishArgs f;
-    f.perm = ctx->perm.as<uint32_t>(), f.newclus = ctx->newclus.as<uint32_t>(), f.clus_id = ctx->clus_id.as<uint32_t>(), f.n_rec = (uint32_t) n;
-    f.sorted_key = ctx->key_sorted.as<uint64_t>(), f.smer_sorted = ctx->smer_sorted.as<uint64_t>();
-    f.loc = ctx->kloc.as<uint64_t>(), f.scm_loc = ctx->scm_loc.as<uint64_t>();
-    f.scm_h = ctx->scm_h.as<uint64_t>(), f.scm_s = ctx->scm_s.as<uint64_t>(), f.scm_occ_off = ctx->scm_occ_off.as<uint64_t>();
-    f.scm_occ = ctx->scm_occ.as<uint64_t>(), f.pos_kid = ctx->pos_kid.as<uint64_t>(), f.flags = ctx->flags.as<uint32_t>();
-    hipLaunchKernelGGL(finish_heads_kernel, dim3(nb), dim3(256), 0, ctx->stream, f, n_scm);
     hipLaunchKernelGGL(check_smer_kernel, dim3(nb), dim3(256), 0, ctx->stream, f);
     hipLaunchKernelGGL(cov_kernel, dim3((n_scm + 255) / 256), dim3(256), 0, ctx->stream, ctx->scm_occ_off.as<uint64_t>(), ctx->scm_cov.as<uint32_t>(), n_scm);
     t_end(ctx, OATK_T_COUNT_GROUP);

@@ -48,8 +48,13 @@ __device__ __forceinline__ uint64_t hash64_s31(uint64_t x)
     p = (uint64_t) lo * 265u;
     hi = hi * 265u + (uint32_t) (p >> 32), lo = (uint32_t) p;
     { const uint32_t t = __builtin_amdgcn_alignbit(hi, lo, 14), u = __builtin_amdgcn_ubfe(hi, 14, 16); lo ^= t, hi ^= u; }
-    p = (uint64_t) lo * 21u;
-    hi = hi * 21u + (uint32_t) (p >> 32), lo = (uint32_t) p;
+    p = (uint64_t) hi << 32 | lo;                                       // x 21 = 16 x + (4 x + x): two v_lshl_add_u64 (r04; a 32 x 32 -> 64 product, a move and a second
+    {                                                                   // product before -- every one of these instructions issues at the same 4-cycle rate;
+        uint64_t p5;                                                    // written as shifts and adds the compiler turns it back into the products)
+        asm("v_lshl_add_u64 %0, %1, 2, %1" : "=v"(p5) : "v"(p));
+        asm("v_lshl_add_u64 %0, %1, 4, %2" : "=v"(p) : "v"(p), "v"(p5));
+    }
+    hi = (uint32_t) (p >> 32), lo = (uint32_t) p;
     { const uint32_t t = __builtin_amdgcn_alignbit(hi, lo, 28), u = __builtin_amdgcn_ubfe(hi, 28, 2); lo ^= t, hi ^= u; }
     p = (uint64_t) lo * 0x80000001u;
     hi = (hi + (uint32_t) (p >> 32)) & 0x3FFFFFFFu, lo = (uint32_t) p;

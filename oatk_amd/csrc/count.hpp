@@ -178,6 +178,56 @@ __global__ void sort_repair_kernel(uint64_t *key, uint32_t *perm, uint32_t n, ui
     }
 }
 
+// The sort is a library call whose paths differ by size and version: what comes back is CHECKED to be the input, permuted and in order.  Two independent
+// 64-bit sums over a mix of every (hash, slot) pair are taken of the sort's input and of its output (after the repair); equal sums = the same multiset of
+// pairs (up to 2^-128), so perm is a permutation and every hash sits beside its own slot; the order is compared directly.
+// flags[8..11] hold the input's sums, flags[12..15] the output's, flags[4] an inversion.  Grid-stride with a fixed grid and one pair of atomics per
+// workgroup: a first version with a pair per WAVE of a one-thread-per-record kernel cost 16 ms at config 3 -- 1.3 M atomics on two addresses.
+__device__ __forceinline__ void pair_sums(uint64_t key, uint32_t slot, uint64_t &s0, uint64_t &s1)
+{
+    uint64_t x = key ^ ((uint64_t) slot * 0x9E3779B97F4A7C15ULL);
+    x ^= x >> 32; x *= 0xD6E8FEB86659FD93ULL; x ^= x >> 32;
+    s0 = x;
+    x *= 0xD6E8FEB86659FD93ULL; x ^= x >> 29; x += key;
+    s1 = x;
+}
+// perm == nullptr: the pairs are (key[i], i) -- the sort's input; otherwise (key[i], perm[i]) and the keys are checked to ascend
+__global__ __launch_bounds__(256) void pair_sum_kernel(const uint64_t *key, const uint32_t *perm, uint32_t n, uint32_t *flags, int at)
+{
+    __shared__ uint64_t part[2][4];
+    uint64_t s0 = 0, s1 = 0;
+    bool inv = false;
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+        const uint64_t k = key[i];
+        uint64_t a, b;
+        pair_sums(k, perm? perm[i] : (uint32_t) i, a, b);
+        s0 += a, s1 += b;
+        if (perm && i && k < key[i - 1]) inv = true;
+    }
+    #pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s0 += __shfl_xor(s0, d), s1 += __shfl_xor(s1, d);
+    if ((threadIdx.x & 63u) == 0) part[0][threadIdx.x >> 6] = s0, part[1][threadIdx.x >> 6] = s1;
+    if (inv) flags[4] = 1u;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd((unsigned long long *) (flags + at), (unsigned long long) (part[0][0] + part[0][1] + part[0][2] + part[0][3]));
+        atomicAdd((unsigned long long *) (flags + at + 2), (unsigned long long) (part[1][0] + part[1][1] + part[1][2] + part[1][3]));
+    }
+}
+
+// round 4: the heads alone (sorted keys only).  With the ids known from a scan of these flags BEFORE the verification -- on the assumption, checked
+// afterwards, that no hash group holds two k-mers -- one pass through the permutation both gathers what verify_group needs and writes what
+// finish_heads_kernel wrote in a second pass (gather_finish_kernel); a collision falls back to the two passes below.
+__global__ void heads_only_kernel(GroupArgs a)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_rec) return;
+    const uint32_t h = i == 0 || a.sorted_key[i] != a.sorted_key[i - 1];
+    a.head[i] = h;
+    a.newclus[i] = h;
+    a.head_idx[i] = h? i : 0u;
+}
+
 __global__ void mark_heads_kernel(GroupArgs a)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -346,6 +396,26 @@ __global__ void finish_heads_kernel(FinishArgs a, uint32_t n_scm)
         a.scm_s[id] = a.smer_sorted[i];
         a.scm_occ_off[id] = i;
         a.scm_loc[id] = a.loc[i];
+    }
+    if (i == a.n_rec - 1) a.scm_occ_off[n_scm] = a.n_rec;
+}
+
+// mark_heads_kernel's gathers and finish_heads_kernel's writes in one pass (clus_id1 = id + 1, straight from the inclusive scan of the head flags)
+__global__ void gather_finish_kernel(GroupArgs g, FinishArgs a, const uint32_t *clus_id1, uint32_t n_scm)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_rec) return;
+    const uint32_t p = g.perm[i], id = clus_id1[i] - 1u;
+    const uint4 r0 = g.slot_rec[2 * (size_t) p], r1 = g.slot_rec[2 * (size_t) p + 1];
+    const uint64_t loc = (uint64_t) r1.y << 32 | r1.x, smer = (uint64_t) r0.w << 32 | r0.z;
+    g.loc[i] = loc;
+    g.occ_sorted[i] = (uint64_t) r0.y << 32 | r0.x, g.smer_sorted[i] = smer;
+    a.pos_kid[p] = (uint64_t) id << 1;
+    if (g.newclus[i]) {
+        a.scm_h[id] = a.sorted_key[i];
+        a.scm_s[id] = smer;
+        a.scm_occ_off[id] = i;
+        a.scm_loc[id] = loc;
     }
     if (i == a.n_rec - 1) a.scm_occ_off[n_scm] = a.n_rec;
 }

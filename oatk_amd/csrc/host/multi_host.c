@@ -48,12 +48,18 @@ static void *xmalloc(size_t n)
 
 /* ---- one host thread per handle ---- */
 typedef int (*rank_fn)(oatk_multi *m, int rank, void *arg);
-typedef struct { oatk_multi *m; int rank; rank_fn fn; void *arg; int rc; } rank_job_t;
+typedef struct { pthread_mutex_t mu; pthread_cond_t cv; int open, go; } rank_gate_t;
+typedef struct { oatk_multi *m; int rank; rank_fn fn; void *arg; int rc; rank_gate_t *gate; } rank_job_t;
 
 static void *rank_entry(void *p)
 {
     rank_job_t *j = (rank_job_t *) p;
-    j->rc = j->fn(j->m, j->rank, j->arg);
+    /* nobody enters a collective before every rank has a thread to enter it on */
+    pthread_mutex_lock(&j->gate->mu);
+    while (!j->gate->open) pthread_cond_wait(&j->gate->cv, &j->gate->mu);
+    const int go = j->gate->go;
+    pthread_mutex_unlock(&j->gate->mu);
+    j->rc = go? j->fn(j->m, j->rank, j->arg) : OATK_E_STATE;
     return 0;
 }
 
@@ -63,15 +69,27 @@ static int run_ranks(oatk_multi *m, rank_fn fn, void *arg)
 {
     pthread_t th[64];
     rank_job_t job[64];
-    int r, rc = OATK_OK, started[64];
+    rank_gate_t gate;
+    int r, rc = OATK_OK, started[64], all = 1;
+    pthread_mutex_init(&gate.mu, 0), pthread_cond_init(&gate.cv, 0), gate.open = 0, gate.go = 0;
     for (r = 0; r < m->n; ++r) {
-        job[r].m = m, job[r].rank = r, job[r].fn = fn, job[r].arg = arg, job[r].rc = OATK_OK;
+        job[r].m = m, job[r].rank = r, job[r].fn = fn, job[r].arg = arg, job[r].rc = OATK_OK, job[r].gate = &gate;
         started[r] = r > 0 && pthread_create(&th[r], 0, rank_entry, &job[r]) == 0;
+        if (r > 0 && !started[r]) all = 0;
     }
-    /* (a thread that could not be started would leave the others waiting in the collective: run it here, after rank 0 -- it only happens when the
-     * process is out of threads, and then nothing below would work either) */
+    /* (a rank without a thread cannot be run after the others: they would wait for it inside the collective.  The threads that did start are
+     * sent home and the call fails as a whole) */
+    pthread_mutex_lock(&gate.mu);
+    gate.open = 1, gate.go = all;
+    pthread_cond_broadcast(&gate.cv);
+    pthread_mutex_unlock(&gate.mu);
     rank_entry(&job[0]);
-    for (r = 1; r < m->n; ++r) { if (started[r]) pthread_join(th[r], 0); else rank_entry(&job[r]); }
+    for (r = 1; r < m->n; ++r) if (started[r]) pthread_join(th[r], 0);
+    pthread_mutex_destroy(&gate.mu), pthread_cond_destroy(&gate.cv);
+    if (!all) {
+        snprintf(m->err, sizeof(m->err), "could not start one host thread per handle (%d handles)", m->n);
+        return OATK_E_STATE;
+    }
     for (r = 0; r < m->n; ++r)
         if (job[r].rc != OATK_OK && (rc == OATK_OK || (rc == OATK_E_STATE && job[r].rc != OATK_E_STATE))) {
             rc = job[r].rc;                              /* prefer the cause over the peers' "somebody failed" */

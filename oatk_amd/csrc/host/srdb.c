@@ -53,9 +53,117 @@ static void *fetch(oatk_hip_ctx *ctx, int which, uint64_t *bytes, int *rc)
     return h;
 }
 
+/* Reads already in memory, in pieces (round 4): piece p + 1 goes up and is scanned on a handle of its own while piece p's arrays come down into the reads'
+ * structs and piece p - 1 has been moved behind the batch assembled in ctx (oatk_hip_scan_append) -- the bus carries text one way and results the other
+ * at the same time, where one H2D - scan - D2H pass used it one direction after the other. */
+#define PACKED_PIECE ((uint64_t) 256 << 20)
+
+typedef struct {
+    oatk_hip_ctx *piece[2];
+    const uint8_t *seq; const uint64_t *off; const uint32_t *len;
+    uint64_t n_reads, seq_bytes;
+    int k, s;
+    pthread_mutex_t mu; pthread_cond_t cv;
+    int state[2];                  /* 0 free, 1 scanned */
+    uint64_t i0[2], i1[2];
+    uint64_t *rel[2];              /* the piece's offsets, relative to its first read */
+    int failed, stop;
+} packed_t;
+
+static uint64_t packed_end(const packed_t *P, uint64_t i0)
+{
+    uint64_t i1 = i0 + 1;
+    while (i1 < P->n_reads && P->off[i1] - P->off[i0] < PACKED_PIECE) ++i1;
+    return i1;
+}
+
+static void *packed_producer(void *arg)
+{
+    packed_t *P = (packed_t *) arg;
+    uint64_t i0 = 0, w;
+    for (w = 0; i0 < P->n_reads; ++w) {
+        const int sl = (int) (w & 1);
+        const uint64_t i1 = packed_end(P, i0), n = i1 - i0, bytes = (i1 < P->n_reads? P->off[i1] : P->seq_bytes) - P->off[i0];
+        uint64_t i;
+        pthread_mutex_lock(&P->mu);
+        while (P->state[sl] != 0 && !P->stop) pthread_cond_wait(&P->cv, &P->mu);
+        const int stop = P->stop;
+        pthread_mutex_unlock(&P->mu);
+        if (stop) break;
+        uint64_t *rel = (uint64_t *) realloc(P->rel[sl], 8 * n);
+        int rc = rel? OATK_OK : OATK_E_NOMEM;
+        if (rel) {
+            P->rel[sl] = rel;
+            for (i = 0; i < n; ++i) rel[i] = P->off[i0 + i] - P->off[i0];
+            rc = oatk_hip_scan_host(P->piece[sl], P->seq + P->off[i0], rel, P->len + i0, n, bytes, i0, P->k, P->s);
+        }
+        pthread_mutex_lock(&P->mu);
+        if (rc) P->failed = rc;
+        else P->state[sl] = 1, P->i0[sl] = i0, P->i1[sl] = i1;
+        pthread_cond_broadcast(&P->cv);
+        pthread_mutex_unlock(&P->mu);
+        if (rc) break;
+        i0 = i1;
+    }
+    return 0;
+}
+
+static int sr_read_packed_pipelined(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, const uint8_t *seq, const uint64_t *off, const uint32_t *len,
+                                    uint64_t n_reads, uint64_t seq_bytes, char **names)
+{
+    packed_t P;
+    pthread_t th;
+    int rc, started = 0;
+    uint64_t done = 0, w;
+    memset(&P, 0, sizeof(P));
+    P.seq = seq, P.off = off, P.len = len, P.n_reads = n_reads, P.seq_bytes = seq_bytes, P.k = sr_db->k, P.s = sr_db->s;
+    pthread_mutex_init(&P.mu, 0);
+    pthread_cond_init(&P.cv, 0);
+    sr_db->a = (oatk_sr_t *) calloc(n_reads, sizeof(oatk_sr_t));
+    if (!sr_db->a) return OATK_E_NOMEM;
+    sr_db->n = 0, sr_db->m = n_reads;
+    rc = oatk_hip_scan_begin(ctx, 0, sr_db->k, sr_db->s);
+    if (!rc) rc = oatk_hip_scan_reserve(ctx, seq_bytes + (1 << 20), n_reads + 1024, seq_bytes / 500 + 4096);
+    P.piece[0] = oatk_hip_create(oatk_hip_device(ctx)), P.piece[1] = oatk_hip_create(oatk_hip_device(ctx));
+    if (!rc && (!P.piece[0] || !P.piece[1])) rc = OATK_E_NODEV;
+    if (!rc && pthread_create(&th, 0, packed_producer, &P) != 0) rc = OATK_E_NOMEM;
+    else if (!rc) started = 1;
+    for (w = 0; !rc && done < n_reads; ++w) {
+        const int sl = (int) (w & 1);
+        pthread_mutex_lock(&P.mu);
+        while (P.state[sl] != 1 && !P.failed) pthread_cond_wait(&P.cv, &P.mu);
+        rc = P.failed;
+        const uint64_t i0 = P.i0[sl], i1 = P.i1[sl];
+        pthread_mutex_unlock(&P.mu);
+        if (rc) break;
+        rc = oatk_sr_db_fill_range(P.piece[sl], sr_db, i0, P.rel[sl], i1 - i0, names? names + i0 : 0);
+        if (!rc) rc = oatk_hip_scan_append(ctx, P.piece[sl]);
+        pthread_mutex_lock(&P.mu);
+        P.state[sl] = 0;
+        pthread_cond_broadcast(&P.cv);
+        pthread_mutex_unlock(&P.mu);
+        done = i1;
+    }
+    if (started) {
+        pthread_mutex_lock(&P.mu);
+        P.stop = 1;
+        pthread_cond_broadcast(&P.cv);
+        pthread_mutex_unlock(&P.mu);
+        pthread_join(th, 0);
+    }
+    if (P.piece[0]) oatk_hip_destroy(P.piece[0]);
+    if (P.piece[1]) oatk_hip_destroy(P.piece[1]);
+    free(P.rel[0]); free(P.rel[1]);
+    pthread_mutex_destroy(&P.mu);
+    pthread_cond_destroy(&P.cv);
+    return rc;
+}
+
 int oatk_sr_read_packed(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, const uint8_t *seq, const uint64_t *off, const uint32_t *len,
                         uint64_t n_reads, uint64_t seq_bytes, char **names)
 {
+    const char *e = getenv("OATK_HOST_PACKED_PIECES");
+    if (seq_bytes > 2 * PACKED_PIECE && n_reads > 1 && !(e && e[0] == '0')) return sr_read_packed_pipelined(ctx, sr_db, seq, off, len, n_reads, seq_bytes, names);
     int rc = oatk_hip_scan_host(ctx, seq, off, len, n_reads, seq_bytes, 0, sr_db->k, sr_db->s);
     if (rc) return rc;
     return oatk_sr_db_fill_resident(ctx, sr_db, off, n_reads, names);

@@ -32,6 +32,7 @@
 //  * selected syncmers leave as (sid|ordinal|rev, s-mer code, pos) records; their 251-byte k-mers are hashed
 //    afterwards by kmer_hash_kernel (one lane per syncmer) instead of by a lone lane inside this kernel.
 #pragma once
+#include <type_traits>
 #include "common.hpp"
 #include "scan_syncmer.hpp"
 #include "scan_hpc.hpp"
@@ -64,28 +65,25 @@ __device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t src)
     return (uint32_t) __builtin_amdgcn_update_dpp((int) old, (int) src, CTRL, ROW_MASK, 0xf, false);
 }
 
-// inclusive prefix-min and suffix-min over the 64 lanes of a wave (lanes without a source keep their value)
-__device__ __forceinline__ void wave_prefix_suffix_min_u32(uint32_t v, uint32_t lane, uint32_t &pre, uint32_t &suf)
+// inclusive prefix-min over the 64 lanes of a wave: four shifts inside the rows of sixteen, then lane 15 of rows 0 and 2 into rows 1 and 3 and lane 31 into
+// rows 2 and 3 (row_bcast, row masks 0xa and 0xc) -- six v_min_u32_dpp.  (Until r04 the row totals went through v_readlane and came back through a v_mov and a
+// v_cndmask each: fourteen instructions per direction.)
+__device__ __forceinline__ uint32_t wave_prefix_min_u32(uint32_t v)
 {
-    uint32_t p = v, s = v, t;         // (old = the identity of min: the compiler folds shift and minimum into one v_min_u32_dpp)
+    uint32_t p = v, t;                // (old = the identity of min: the compiler folds shift and minimum into one v_min_u32_dpp)
     t = dpp_u32<OATK_DPP_ROW_SHR(1)>(0xFFFFFFFFu, p); p = t < p? t : p;
     t = dpp_u32<OATK_DPP_ROW_SHR(2)>(0xFFFFFFFFu, p); p = t < p? t : p;
     t = dpp_u32<OATK_DPP_ROW_SHR(4)>(0xFFFFFFFFu, p); p = t < p? t : p;
     t = dpp_u32<OATK_DPP_ROW_SHR(8)>(0xFFFFFFFFu, p); p = t < p? t : p;
-    t = dpp_u32<OATK_DPP_ROW_SHL(1)>(0xFFFFFFFFu, s); s = t < s? t : s;
-    t = dpp_u32<OATK_DPP_ROW_SHL(2)>(0xFFFFFFFFu, s); s = t < s? t : s;
-    t = dpp_u32<OATK_DPP_ROW_SHL(4)>(0xFFFFFFFFu, s); s = t < s? t : s;
-    t = dpp_u32<OATK_DPP_ROW_SHL(8)>(0xFFFFFFFFu, s); s = t < s? t : s;
-    // row totals: prefix totals sit in lanes 15/31/47, suffix totals in lanes 16/32/48
-    const uint32_t r15 = __builtin_amdgcn_readlane(p, 15), r31 = __builtin_amdgcn_readlane(p, 31), r47 = __builtin_amdgcn_readlane(p, 47);
-    const uint32_t p2 = r31 < r15? r31 : r15, p3 = r47 < p2? r47 : p2;
-    const uint32_t s48 = __builtin_amdgcn_readlane(s, 48), s32 = __builtin_amdgcn_readlane(s, 32), s16 = __builtin_amdgcn_readlane(s, 16);
-    const uint32_t q2 = s32 < s48? s32 : s48, q1 = s16 < q2? s16 : q2;
-    const uint32_t row = lane >> 4;
-    const uint32_t padd = row == 1? r15 : (row == 2? p2 : (row == 3? p3 : 0xFFFFFFFFu));
-    const uint32_t sadd = row == 0? q1 : (row == 1? q2 : (row == 2? s48 : 0xFFFFFFFFu));
-    pre = padd < p? padd : p;
-    suf = sadd < s? sadd : s;
+    t = dpp_u32<OATK_DPP_ROW_BCAST15, 0xa>(0xFFFFFFFFu, p); p = t < p? t : p;
+    t = dpp_u32<OATK_DPP_ROW_BCAST31, 0xc>(0xFFFFFFFFu, p); p = t < p? t : p;
+    return p;
+}
+// ... and the inclusive suffix-min, MIRRORED: lane l returns the suffix minimum of lane 63 - l (there is no row_bcast towards lower lanes: the values are turned
+// round by one ds_bpermute_b32 and scanned the same way; the caller stores the result at the mirrored address)
+__device__ __forceinline__ uint32_t wave_suffix_min_mirrored_u32(uint32_t v, uint32_t lane)
+{
+    return wave_prefix_min_u32((uint32_t) __builtin_amdgcn_ds_bpermute((int) ((63u - lane) << 2), (int) v));
 }
 
 #define OATK_SYF_PADW(R) ((R) / 8)        // four pad words per 32 positions of the top-word ring
@@ -105,7 +103,10 @@ __global__ __launch_bounds__(NT, OATK_SYF_WAVES) void syncmer_fast_kernel(SynArg
 
     __shared__ uint32_t m_top[R + OATK_SYF_PADW(R)];   // TOP WORDS of the s-mer hashes by END position: all that the filter and the decision of a candidate
                                                 // look at; a position whose top word ties with its window's is re-hashed from the read's bases (r03h)
-    __shared__ uint64_t c_min[NCH];             // 64-bit minimum of every chunk: the whole chunks of a window when top words tie
+    __shared__ uint64_t c_min[NCH];             // 64-bit minimum of every chunk: the whole chunks of a window when top words tie.  Kept up to date by the
+                                                // hashing phase only while the read is inside a stretch that ties ("repeat mode", below); otherwise the
+                                                // waves that meet a tie fill in what their windows need themselves
+    __shared__ uint32_t s_tie[2];               // some wave met a tie in the tile of this parity
     __shared__ uint32_t pre32[NCH], suf32[NCH]; // per-wave-block inclusive prefix / suffix minima of the chunk minima's top 32 bits
     __shared__ uint32_t w_cnt[2][NWAVE];         // syncmers per wave of a tile, double-buffered (two barriers per tile)
     __shared__ uint32_t sl_e[SYF_LIST];          // syncmers of the read so far, in position order: k-mer end | kind << 30 (1 Close, 2 Open);
@@ -133,6 +134,7 @@ __global__ __launch_bounds__(NT, OATK_SYF_WAVES) void syncmer_fast_kernel(SynArg
     auto rch = [](int32_t c) -> uint32_t { return (uint32_t) c & (uint32_t) (NCH - 1); };
     for (uint32_t i = tid; i < R + OATK_SYF_PADW(R); i += NT) m_top[i] = 0xFFFFFFFFu;
     for (uint32_t i = tid; i < NCH; i += NT) pre32[i] = suf32[i] = 0xFFFFFFFFu, c_min[i] = UINT64_MAX;
+    if (tid < 2) s_tie[tid] = 0;
     __syncthreads();
 
     // The bases a lane needs for a tile -- the 32 before its chunk (the s-mer that ends just in front of it) and the chunk's own 8 -- are
@@ -260,9 +262,20 @@ __global__ __launch_bounds__(NT, OATK_SYF_WAVES) void syncmer_fast_kernel(SynArg
     };
     auto ld32 = [](const uint32_t *base, uint32_t byte_off) -> uint32_t { return *(const uint32_t *) ((const char *) base + byte_off); };
 
-    for (uint32_t I0 = 0; I0 < hl; I0 += T, next_tile_addr()) {
+    // Repeat mode.  The 64-bit chunk minima are only ever read when top words tie -- 2^-28 of the candidates on ordinary sequence, every position
+    // inside a tandem repeat.  Keeping them (a 64-bit compare and two selects per position: the slowest pair of the loop, 5 % of the kernel) is
+    // therefore switched on by the ties themselves: a wave that meets a tie says so in LDS; one barrier later every thread knows and the hashing
+    // of the tile after keeps the minima -- until two tiles have passed without a tie.  What a tying wave needs from tiles hashed without them
+    // (the first two tiles of a repeat, and one window's reach behind) it computes itself from the packed bases, wave-wide (fill_c_min below).
+    bool rep_mode = false, rep_next = false;
+    int32_t rep_start = 0x7FFFFFFF;             // first chunk hashed in repeat mode (valid while rep_mode)
+    uint32_t quiet = 0, tpar = 0;
+    const int32_t wave_first = __builtin_amdgcn_readfirstlane((int) (wid * OATK_WAVE * C));
+    for (uint32_t I0 = 0; I0 < hl; I0 += T, next_tile_addr(), tpar ^= 1u) {
+        if (rep_next != rep_mode) { rep_mode = rep_next; rep_start = rep_mode? (int32_t) (I0 / C) : 0x7FFFFFFF; }
         // ---- P1: s-mer hashes of this lane's chunk, chunk minimum, wave prefix/suffix minima ----
         const int32_t i0 = (int32_t) (I0 + tid * C);
+        const int32_t wb = (int32_t) I0 + wave_first;   // the wave's first position, in a scalar register: what is decided for the wave is decided there
         const int32_t ch = i0 / C;                      // chunk index; ch % 64 == lane
         uint32_t y[C];                                  // top words of the chunk's hashes
         uint32_t cmin_keep;                             // top word of the chunk's minimum
@@ -277,29 +290,55 @@ __global__ __launch_bounds__(NT, OATK_SYF_WAVES) void syncmer_fast_kernel(SynArg
                 const Words3 nx = *(const Words3 *) (ghs + (wn < last_w? wn : last_w));
                 rw0 = nx.a, rw1 = nx.b, rw2 = nx.c;
             }
-            const uint64_t X = ((uint64_t) a_hi << 32 | a_lo) << (2 * (32 - S));       // the S bases that end at i0 - 1, at the top
-            uint64_t fw = X >> (64 - 2 * S), rv = revcomp32(X) & mask;
-            uint64_t cm = UINT64_MAX;                   // the chunk minimum; the filter looks at its top word
+            uint64_t cm = UINT64_MAX;                   // the chunk minimum in full (repeat mode only)
+            uint32_t cmin = 0xFFFFFFFFu;                // its top word: what the filter looks at
             // (the test is made for the WAVE: a wave with one lane at either end of the read would otherwise run both branches, eight
             //  hashes each -- two waves per read, 5 % of the kernel)
-            if (__ballot(!(i0 + 1 >= S && (uint32_t) (i0 + C) <= hl)) == 0) {
+            if (wb + 1 >= S && (uint32_t) (wb + OATK_WAVE * C) <= hl) {
+                if (S31) {
+                    // The s-mer that ends at position i0 + b is a FIXED bit field of the 96-bit window [a_hi : a_lo : vbh] (bases i0 - 32 .. i0 + 15): bits
+                    // [91 - 2b : 30 - 2b]; its reverse complement is the field [65 + 2b : 4 + 2b] of the window's reverse complement [r2 : r1 : r0].  Two
+                    // v_alignbit_b32 per strand and position, against the six + four instructions of rolling both 62-bit values along (r04: both forms
+                    // cost the same per instruction class, profiles/r04a_valu_rates.txt, so the count decides).
+                    auto rc16 = [](uint32_t x) -> uint32_t {
+                        const uint32_t r = __builtin_bitreverse32(x);
+                        return ~(((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1));
+                    };
+                    const uint32_t r0 = rc16(a_hi), r1 = rc16(a_lo), r2 = rc16(vbh);
+                    auto hash_chunk = [&](auto keep) __attribute__((always_inline)) {
 #pragma unroll
-                for (int b = 0; b < C; ++b) {
-                    const uint64_t c = (vbh >> (30 - 2 * b)) & 3u;
-                    fw = (fw << 2 | c) & mask;
-                    rv = rv >> 2 | (3ULL ^ c) << (2 * S - 2);
-                    // (S31: an odd-length s-mer is never its own reverse complement, so no fw != rv test)
-#if OATK_SYF_EXP == 3
-                    uint64_t mv = ((fw < rv? fw : rv) * 0x9E3779B1ull) & mask;      // (timing experiment: one multiplication instead of the hash)
-#elif OATK_SYF_EXP == 4
-                    uint64_t mv = hash64_s31(fw);                   // (timing experiment: no canonical choice)
-#else
-                    uint64_t mv = S31? hash64_s31(fw < rv? fw : rv) : (fw != rv? hash64(fw < rv? fw : rv, mask) : UINT64_MAX);
-#endif
-                    y[b] = (uint32_t) (mv >> 32);
-                    cm = mv < cm? mv : cm;
+                        for (int b = 0; b < C; ++b) {
+                            // both strands LEFT-aligned in 64 bits, two bits of the neighbouring base below them: they never decide the comparison (an odd-length
+                            // s-mer is never its own reverse complement, so the 62 bits above differ), and no mask is needed to form the operands
+                            uint64_t fw = (uint64_t) __builtin_amdgcn_alignbit(a_hi, a_lo, 28 - 2 * b) << 32 | __builtin_amdgcn_alignbit(a_lo, vbh, 28 - 2 * b);
+                            uint64_t rv = (uint64_t) __builtin_amdgcn_alignbit(r2, r1, 2 + 2 * b) << 32 | __builtin_amdgcn_alignbit(r1, r0, 2 + 2 * b);
+                            asm("" : "+v"(fw), "+v"(rv));        // (the halves are read back out of the register pairs: without this the compiler keeps each half twice, a v_mov per word)
+                            const uint64_t cn = fw < rv? fw : rv;
+                            const uint64_t mv = hash64_s31(cn >> 2);
+                            y[b] = (uint32_t) (mv >> 32);
+                            cmin = y[b] < cmin? y[b] : cmin;
+                            if (decltype(keep)::value) cm = mv < cm? mv : cm;
+                        }
+                    };
+                    // (two copies of the loop, chosen by a scalar branch: as one loop with a per-position select the compiler keeps the 64-bit chain for every position)
+                    if (__builtin_amdgcn_readfirstlane((int) rep_mode)) hash_chunk(std::true_type()); else hash_chunk(std::false_type());
+                } else {
+                    const uint64_t X = ((uint64_t) a_hi << 32 | a_lo) << (2 * (32 - S));       // the S bases that end at i0 - 1, at the top
+                    uint64_t fw = X >> (64 - 2 * S), rv = revcomp32(X) & mask;
+#pragma unroll
+                    for (int b = 0; b < C; ++b) {
+                        const uint64_t c = (vbh >> (30 - 2 * b)) & 3u;
+                        fw = (fw << 2 | c) & mask;
+                        rv = rv >> 2 | (3ULL ^ c) << (2 * S - 2);
+                        const uint64_t mv = fw != rv? hash64(fw < rv? fw : rv, mask) : UINT64_MAX;
+                        y[b] = (uint32_t) (mv >> 32);
+                        cmin = y[b] < cmin? y[b] : cmin;
+                        cm = mv < cm? mv : cm;      // (S != 31: the chain is always kept; this form of the kernel is not the one the headline workload runs)
+                    }
                 }
             } else {                                    // first / last chunk of the read
+                const uint64_t X = ((uint64_t) a_hi << 32 | a_lo) << (2 * (32 - S));       // the S bases that end at i0 - 1, at the top
+                uint64_t fw = X >> (64 - 2 * S), rv = revcomp32(X) & mask;
 #pragma unroll
                 for (int b = 0; b < C; ++b) {
                     const int32_t i = i0 + b;
@@ -309,10 +348,10 @@ __global__ __launch_bounds__(NT, OATK_SYF_WAVES) void syncmer_fast_kernel(SynArg
                     uint64_t mv = UINT64_MAX;
                     if (i + 1 >= S && (uint32_t) i < hl && fw != rv) mv = S31? hash64_s31(fw < rv? fw : rv) : hash64(fw < rv? fw : rv, mask);
                     y[b] = (uint32_t) (mv >> 32);
-                    cm = mv < cm? mv : cm;
+                    cmin = y[b] < cmin? y[b] : cmin;
+                    if (rep_mode) cm = mv < cm? mv : cm;
                 }
             }
-            const uint32_t cmin = (uint32_t) (cm >> 32);
             cmin_keep = cmin;
             uint32_t pre, suf;
 #ifdef OATK_SCAN_SHFL
@@ -323,7 +362,8 @@ __global__ __launch_bounds__(NT, OATK_SYF_WAVES) void syncmer_fast_kernel(SynArg
                 if ((int) lane + d < OATK_WAVE) suf = dn < suf? dn : suf;
             }
 #else
-            wave_prefix_suffix_min_u32(cmin, lane, pre, suf);
+            pre = wave_prefix_min_u32(cmin);
+            suf = wave_suffix_min_mirrored_u32(cmin, lane);
 #endif
             // everything above lives in registers: a wave that is done with the previous tile hashes ahead while the others
             // still read that tile's windows from the ring.  Ring slots are only overwritten behind this barrier.
@@ -331,11 +371,21 @@ __global__ __launch_bounds__(NT, OATK_SYF_WAVES) void syncmer_fast_kernel(SynArg
             static_assert(C == 8, "two 16-byte stores per lane");
             *(uint4 *) (m_top + m_own) = make_uint4(y[0], y[1], y[2], y[3]);
             *(uint4 *) (m_top + m_own + 4) = make_uint4(y[4], y[5], y[6], y[7]);
-            *(uint64_t *) ((char *) c_min + 2u * o_cs) = cm;
+            if (rep_mode) *(uint64_t *) ((char *) c_min + 2u * o_cs) = cm;
+            {   // what the tile before saw (its flags are behind a barrier now) decides how the tile AFTER this one is hashed
+                const uint32_t seen = s_tie[tpar ^ 1u];
+                quiet = seen? 0u : quiet + 1u;
+                rep_next = seen != 0u || (rep_mode && quiet < 2u);
+            }
             *(uint32_t *) ((char *) pre32 + o_cs) = pre;
+#ifdef OATK_SCAN_SHFL
             *(uint32_t *) ((char *) suf32 + o_cs) = suf;
+#else
+            *(uint32_t *) ((char *) suf32 + (o_cs ^ 252u)) = suf;        // lane l holds the suffix minimum of the chunk of lane 63 - l
+#endif
         }
         __syncthreads();
+        if (tid == 0) s_tie[tpar ^ 1u] = 0;             // (read above by everybody, written next by the tile after this one, two barriers on)
         flush();                                        // the previous tile's records
 
         // ---- P3: filter on 32-bit keys (straight-line code: 64 <= D <= 127 means at most ONE whole block inside a range), and the decision.
@@ -388,44 +438,56 @@ __global__ __launch_bounds__(NT, OATK_SYF_WAVES) void syncmer_fast_kernel(SynArg
                 const uint32_t lb = ld32(suf32, (o_cs - 4u) & (uint32_t) (NCH * 4 - 1));         // (the suffix minimum of a block's last chunk is that chunk's own)
                 cprev = lane == 0? lb : nb;
             }
-            // per position: a cheap necessary condition (three instructions, the result stays in a scalar register pair), and the rule itself
-            // only where some lane of the wave passes it -- about one position per wave and tile on random sequence
-            const bool edge = __ballot(!(i0 + 1 >= K && (uint32_t) (i0 + C) <= hl)) != 0;      // k-mers that do not fit the read: E + 1 < K, E >= hoco_l
+            // per position: a cheap necessary condition -- a minimum and two compares whose results are LANE MASKS in scalar registers, or'ed and tested there --
+            // and the rule itself only where some lane of the wave passes it: about one position per wave and tile on random sequence.
+            // (r04: written on the masks themselves.  As `bool c = ...; if (__ballot(c))` the compiler rebuilt c as a vector 0/1 and compared that again, and
+            //  carried the end-of-read test of the two edge waves of a read through every wave under a saved exec mask: eleven VALU per position, not three.)
+            const bool edge = !(wb + 1 >= K && (uint32_t) (wb + OATK_WAVE * C) <= hl);         // k-mers that do not fit the read: E + 1 < K, E >= hoco_l
+            auto decide = [&](auto at_edge) __attribute__((always_inline)) {
 #pragma unroll
-            for (int o = 0; o < C; ++o) {
-                const uint32_t yhi = y[o], fhi = W[o];
-                const uint32_t fb = o + SH < C? fwd0 : fwd1;
-                const uint32_t fy = fb < yhi? fb : yhi;
-                bool c = (yhi <= backF) | (fhi <= fy);
-                if (edge) c = c && (uint32_t) (i0 + o) < hl && i0 + o + 1 >= K;
-#if OATK_SYF_EXP == 1
-                c = c && a.want_n;                      // (timing experiment: nothing survives the filter)
-#endif
-                if (__ballot(c)) {
-                    uint32_t pmin = 0xFFFFFFFFu;        // the lane's own positions before E
-#pragma unroll
-                    for (int j = 0; j < o; ++j) pmin = y[j] < pmin? y[j] : pmin;
-                    const int cend = o < BD? BD - 1 : BD + C - 1;       // last position of lo's chunk
-                    uint32_t rest = 0xFFFFFFFFu;                        // lo's chunk behind lo
-#pragma unroll
-                    for (int j = o + 1; j <= cend; ++j) rest = W[j] < rest? W[j] : rest;
-                    // Close: M[E] against the window's minimum
-                    uint32_t head = fhi < rest? fhi : rest;             // lo's chunk from lo on ...
-                    if (o < RR) {                                       // ... and the whole chunk behind it
-#pragma unroll
-                        for (int j = RR; j < RR + C; ++j) head = W[j] < head? W[j] : head;
+                for (int o = 0; o < C; ++o) {
+                    const uint32_t yhi = y[o], fhi = W[o];
+                    const uint32_t fb = o + SH < C? fwd0 : fwd1;
+                    const uint32_t fy = fb < yhi? fb : yhi;
+                    const bool c1 = yhi <= backF, c2 = fhi <= fy;
+                    uint64_t cand = __ballot(c1) | __ballot(c2);
+                    bool fits = true;
+                    if (decltype(at_edge)::value) {
+                        fits = (uint32_t) (i0 + o) < hl && i0 + o + 1 >= K;
+                        cand &= __ballot(fits);
                     }
-                    const uint32_t hb = head < backF? head : backF, bh = hb < pmin? hb : pmin;
-                    const bool cl = yhi < bh, tie_c = yhi == bh;
-                    // Open: M[lo] against everything else in the window and M[E]
-                    const uint32_t tailp = o < RR? (cprev < pmin? cprev : pmin) : pmin;
-                    const uint32_t rf = rest < fb? rest : fb, rh = rf < tailp? rf : tailp;
-                    const bool le = fhi <= rh && fhi <= yhi, op = fhi < rh && fhi < yhi;
-                    const bool tie = tie_c || (le && !op);
-                    const uint32_t k = tie? 0u : (cl && op? 0u : (cl? 1u : (op? 2u : 0u)));
-                    if (c) kinds |= k << (2 * o), tiemask |= (tie? 1u : 0u) << o;
+#if OATK_SYF_EXP == 1
+                    if (!a.want_n) cand = 0;                // (timing experiment: nothing survives the filter)
+#endif
+                    if (cand) {
+                        const bool c = (c1 | c2) && fits;
+                        uint32_t pmin = 0xFFFFFFFFu;        // the lane's own positions before E
+#pragma unroll
+                        for (int j = 0; j < o; ++j) pmin = y[j] < pmin? y[j] : pmin;
+                        const int cend = o < BD? BD - 1 : BD + C - 1;       // last position of lo's chunk
+                        uint32_t rest = 0xFFFFFFFFu;                        // lo's chunk behind lo
+#pragma unroll
+                        for (int j = o + 1; j <= cend; ++j) rest = W[j] < rest? W[j] : rest;
+                        // Close: M[E] against the window's minimum
+                        uint32_t head = fhi < rest? fhi : rest;             // lo's chunk from lo on ...
+                        if (o < RR) {                                       // ... and the whole chunk behind it
+#pragma unroll
+                            for (int j = RR; j < RR + C; ++j) head = W[j] < head? W[j] : head;
+                        }
+                        const uint32_t hb = head < backF? head : backF, bh = hb < pmin? hb : pmin;
+                        const bool cl = yhi < bh, tie_c = yhi == bh;
+                        // Open: M[lo] against everything else in the window and M[E]
+                        const uint32_t tailp = o < RR? (cprev < pmin? cprev : pmin) : pmin;
+                        const uint32_t rf = rest < fb? rest : fb, rh = rf < tailp? rf : tailp;
+                        const bool le = fhi <= rh && fhi <= yhi, op = fhi < rh && fhi < yhi;
+                        const bool tie = tie_c || (le && !op);
+                        const uint32_t k = tie? 0u : (cl && op? 0u : (cl? 1u : (op? 2u : 0u)));
+                        if (c) kinds |= k << (2 * o), tiemask |= (tie? 1u : 0u) << o;
+                    }
                 }
-            }
+            };
+            // (two copies, chosen by a scalar branch: the ordinary one knows nothing of read ends)
+            if (edge) decide(std::true_type()); else decide(std::false_type());
         }
         // Top words tied: ~2^-28 per candidate on random sequence, but the rule rather than the exception inside tandem repeats
         // (telomeres, microsatellites), where the window minimum comes back every period and every lane of the wave holds ties.
@@ -435,6 +497,22 @@ __global__ __launch_bounds__(NT, OATK_SYF_WAVES) void syncmer_fast_kernel(SynArg
         // position in p); and the whole chunks of a window come from the 64-bit chunk minima the hashing phase leaves in `c_min`.
         if (__ballot(tiemask != 0)) {
             constexpr int sh = SH;
+            {   // the 64-bit minima of the chunks this wave's windows cover, where the hashing phase did not keep them (see "repeat mode" above): the wave
+                // computes them from the packed bases, a chunk per lane and turn, and leaves them in the ring (another wave with ties may write the same
+                // values to the same slots).  The windows of the wave's 64 chunks reach from chunk ca0(lane 0) + 1 to ca0(lane 63) + 1 + D: fewer than the ring holds.
+                if (lane == 0) s_tie[tpar] = 1u;
+                const int32_t ca0_l = (i0 - w) >> 3;
+                const int32_t c_lo = __builtin_amdgcn_readlane(ca0_l, 0) + 1, c_hi_all = __builtin_amdgcn_readlane(ca0_l, 63) + 1 + D;
+                const int32_t c_hi = rep_mode && rep_start - 1 < c_hi_all? rep_start - 1 : c_hi_all;
+                for (int32_t cc = c_lo + (int32_t) lane; cc <= c_hi; cc += 64) {
+                    uint64_t u = UINT64_MAX;
+                    for (int b = 0; b < C; ++b) { const uint64_t h = hash_at(cc * C + b); u = h < u? h : u; }
+                    c_min[rch(cc)] = u;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
             auto full = [&](int32_t q, uint32_t ref) -> uint64_t {
                 const uint32_t t = m_top[mi(q)];
                 return t == ref? hash_at(q) : (uint64_t) t << 32;

@@ -26,15 +26,24 @@ namespace {
 struct Op { int kind; const void *send; void *recv; size_t bytes; int peer; int dtype, red; size_t count; };      // kind: 0 send, 1 recv, 2 bcast, 3 allgather, 4 allreduce
 struct Group {
     int n = 0, joined = 0, arrived = 0, phase = 0;
+    bool aborted = false;                   // ncclCommAbort on any rank's communicator: everybody waiting returns an error, nobody waits again
     std::mutex mu;
     std::condition_variable cv;
     std::vector<std::vector<Op>> ops;       // per rank, the operations of the group being executed
-    void barrier()
+    bool barrier()                          // false: the group was aborted
     {
         std::unique_lock<std::mutex> lk(mu);
+        if (aborted) return false;
         const int ph = phase;
         if (++arrived == n) { arrived = 0, ++phase; cv.notify_all(); }
-        else cv.wait(lk, [&] { return phase != ph; });
+        else cv.wait(lk, [&] { return phase != ph || aborted; });
+        return !aborted;
+    }
+    void abort()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        aborted = true;
+        cv.notify_all();
     }
 };
 struct Comm { Group *g; int rank; };
@@ -55,7 +64,7 @@ ncclResult_t run(Comm *c, hipStream_t st, std::vector<Op> &mine)
     if (st && hipStreamSynchronize(st) != hipSuccess) return ncclUnhandledCudaError;      // what the others are about to read is complete
     if (!st && hipDeviceSynchronize() != hipSuccess) return ncclUnhandledCudaError;
     g->ops[c->rank] = mine;
-    g->barrier();
+    if (!g->barrier()) return ncclSystemError;
     ncclResult_t rc = ncclSuccess;
     std::vector<size_t> recv_seen(g->n, 0);
     for (size_t e = 0; e < mine.size() && rc == ncclSuccess; ++e) {
@@ -91,11 +100,11 @@ ncclResult_t run(Comm *c, hipStream_t st, std::vector<Op> &mine)
                     for (size_t i = 0; i < o.count; ++i) a[i] = o.red == ncclMin? (b[i] < a[i]? b[i] : a[i]) : a[i] + b[i];
                 }
             }
-            g->barrier();                    // in place: nobody's input changes before everybody has read it
+            if (!g->barrier()) return ncclSystemError;      // in place: nobody's input changes before everybody has read it
             if (rc == ncclSuccess && o.bytes && hipMemcpy(o.recv, acc.data(), o.bytes, hipMemcpyHostToDevice) != hipSuccess) rc = ncclUnhandledCudaError;
         }
     }
-    g->barrier();                            // nobody's buffers go away before everybody has read them
+    if (!g->barrier()) return ncclSystemError;       // nobody's buffers go away before everybody has read them
     return rc;
 }
 
@@ -137,10 +146,14 @@ ncclResult_t ncclCommInitRank(Comm **out, int n, ncclUniqueId id, int rank)
     if (g->n != n || rank < 0 || rank >= n) return ncclInvalidArgument;
     *out = new Comm{g, rank};
     t_mine = *out;
-    g->barrier();                            // ncclCommInitRank returns when every rank has joined
+    if (!g->barrier()) return ncclSystemError;       // ncclCommInitRank returns when every rank has joined
     return ncclSuccess;
 }
 ncclResult_t ncclCommDestroy(Comm *c) { delete c; return ncclSuccess; }
+// (real RCCL: the aborting rank's peers find out through ncclCommGetAsyncError or a time-out -- oatk's comm_wait polls both; here the ranks are
+//  threads at a barrier, so the abort wakes them directly)
+ncclResult_t ncclCommAbort(Comm *c) { c->g->abort(); delete c; return ncclSuccess; }
+ncclResult_t ncclCommGetAsyncError(Comm *c, ncclResult_t *e) { *e = c->g->aborted? ncclSystemError : ncclSuccess; return ncclSuccess; }
 ncclResult_t ncclGroupStart() { ++t_depth; return ncclSuccess; }
 ncclResult_t ncclGroupEnd()
 {

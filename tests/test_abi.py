@@ -56,3 +56,22 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".c", ".h", ".hip", ".hpp", ".inc", ".sh")):
                 txt = open(os.path.join(base, f), errors="ignore").read()
                 assert "oracle_lib" not in txt and "ref_lib" not in txt and "liboatk_oracle" not in txt and "oracle/" not in txt, f
+
+
+def test_the_scale_model_of_bench_is_plain_arithmetic_on_its_inputs():
+    """bench.py `scale_model`: the predicted strong-scaling step is compute(reads / N) + latencies + bytes over links -- more GPUs
+    never predict a slower compute part, what is predicted is printed with its parts, and the parts add up."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    tr1, tr8 = [40, 3000, 6, 5 * 10**8, 8, 4 * 10**8, 6, 12 * 10**8], [40, 3000, 6, 7 * 10**7, 8, 39 * 10**7, 6, 15 * 10**7]
+    m = b.scale_model(2_000_000, 95.0, tr1, 250_000, 14.0, tr8, 30 * 10**9, 90.0)
+    assert m["measured"]["collectives_per_step"] == 60
+    prev = None
+    for n in ("2", "4", "8"):
+        p = m["predicted"][n]
+        assert abs(sum(p["parts_ms"].values()) - p["ms_per_step"]) < 0.02
+        assert prev is None or p["parts_ms"]["compute"] < prev
+        prev = p["parts_ms"]["compute"]
+        assert abs(p["speedup_over_1"] - 90.0 / p["ms_per_step"]) < 0.01

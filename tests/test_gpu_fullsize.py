@@ -288,3 +288,22 @@ def test_sort_on_top_bits_with_repair_equals_the_sort_on_all_bits(hip, mask, mon
     assert res["top"] == res["full"]
     if mask == 0xFFFFC00000000FFF:
         assert res["top"]["collisions"] == 1
+
+
+def test_a_sort_whose_output_is_not_trusted_is_done_again_on_all_bits(hip, monkeypatch):
+    """round 4: what the library sort hands back is checked to be its input, permuted and in order -- two 64-bit sums over a mix of every
+    (hash, slot) pair before and after, and the order directly (count.hpp: pair_sum_kernel).  OATK_DEBUG_SORT_DISTRUST makes the check
+    of the sort on the top bits fail: the count must come back with the table of the sort on all 64 bits, not with an error and not with something else."""
+    cfg = dict(CONFIGS["config2"])
+    cfg["n_reads"] = 220_000
+    rs = ReadSet(**cfg)
+    seq, off, lens = rs.slice(0, cfg["n_reads"])
+    res = {}
+    for mode in ("distrust", "full"):
+        monkeypatch.delenv("OATK_DEBUG_SORT_DISTRUST", raising=False)
+        monkeypatch.setenv("OATK_DEBUG_SORT_DISTRUST" if mode == "distrust" else "OATK_DEBUG_FULL_SORT", "1")
+        hip.scan_host(seq, off, lens, K, S)
+        hip.count()
+        assert hip.info()["n_occ"] >= 1 << 22
+        res[mode] = {b: crc(hip.fetch(b)) for b in COUNT_BUFS} | {"n_scm": hip.info()["n_scm"]}
+    assert res["distrust"] == res["full"]

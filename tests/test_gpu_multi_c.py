@@ -40,12 +40,12 @@ def single(hip, reads, K, S, c):
     return cnt, st, want
 
 
-def run_ranks(world, make_comm, reads, bounds, K, S, c, mask=None):
+def run_ranks(world, make_comm, reads, bounds, K, S, c, mask=None, devices=None):
     out, errs = [None] * world, []
 
     def work(rank):
         try:
-            h = HipSyncasm(0)
+            h = HipSyncasm(devices[rank] if devices else 0)      # (real RCCL: a device per rank, tests/test_gpu_real_rccl.py)
             if mask is not None:
                 h.debug_hash_mask(mask)
             comm = make_comm(rank)
@@ -305,3 +305,19 @@ def test_rccl_branch_with_several_ranks_over_a_mock_library(tmp_path):
     env = dict(os.environ, OATK_RCCL_LIB=lib)
     p = subprocess.run([sys.executable, os.path.join(here, "mock_rccl_run.py")], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert p.returncode == 0 and p.stdout.strip().endswith(b"ok 8"), (p.returncode, p.stdout[-300:], p.stderr.decode(errors="replace")[-1500:])
+
+
+def test_a_rank_that_fails_mid_way_releases_its_peers(tmp_path):
+    """include/oatk_hip_multi.h promises that a rank-local failure between two collectives does not leave the peers waiting.  Over the mock library (ranks are
+    threads) rank 1 fails on request in the middle of the table merge; its comm_finish aborts the communicator, which releases the others with an error
+    (tests/mock_rccl_abort.py).  Against real RCCL a peer's abort is not visible to the others at once: there oatk's wait polls ncclCommGetAsyncError and gives
+    up after OATK_COMM_TIMEOUT_S (api_multi.inc: comm_wait) -- that form needs two GPUs (test_real_rccl_*)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    lib = str(tmp_path / "libmock_rccl.so")
+    subprocess.run(["hipcc", "-shared", "-fPIC", "-O2", "-o", lib, os.path.join(here, "c", "mock_rccl.cpp")], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    env = dict(os.environ, OATK_RCCL_LIB=lib, OATK_DEBUG_FAIL_RANK="1,5")
+    p = subprocess.run([sys.executable, os.path.join(here, "mock_rccl_abort.py")], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0 and p.stdout.strip().startswith(b"ok"), (p.returncode, p.stdout[-300:], p.stderr.decode(errors="replace")[-1500:])

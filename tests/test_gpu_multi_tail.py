@@ -63,14 +63,14 @@ def single(hip, reads, K, S, c, a):
     return out
 
 
-def run_ranks(world, grp, reads, bounds, K, S, c, a, root=0, make_comm=None):
+def run_ranks(world, grp, reads, bounds, K, S, c, a, root=0, make_comm=None, devices=None):
     """make_comm(rank): another communicator factory than the in-process group (tests/mock_rccl_run.py: the RCCL branch over a mock library)"""
     L = _lib.load()
     out, errs = [None] * world, []
 
     def work(rank):
         try:
-            h = HipSyncasm(0)
+            h = HipSyncasm(devices[rank] if devices else 0)      # (real RCCL: a device per rank, tests/test_gpu_real_rccl.py)
             comm = make_comm(rank) if make_comm else L.oatk_comm_group_rank(grp, rank)
             lo, hi = bounds[rank], bounds[rank + 1]
             seq, off, lens = pack_reads(reads[lo:hi])

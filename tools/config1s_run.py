@@ -20,6 +20,7 @@ ap.add_argument("--cli", type=int, default=0, help="reads of the CLI runs (0: no
 ap.add_argument("--ref", action="store_true", help="also the reference binary")
 ap.add_argument("--threads", type=int, default=32)
 ap.add_argument("--steps", type=int, default=3)
+ap.add_argument("--forms", default="plain,one,bgzf,members", help="which file forms the CLI runs on")
 args = ap.parse_args()
 K, S = 1001, 31
 cfg = dict(synth.CONFIG1S)
@@ -55,6 +56,8 @@ if args.cli:
     n = args.cli
     res = {}
     for name, mode, mb in (("plain", synth.FA_PLAIN, 0), ("one", synth.FA_GZ, 0), ("bgzf", synth.FA_BGZF, 0), ("members", synth.FA_GZ_MEMBERS, 200_000_000)):
+        if name not in args.forms.split(","):
+            continue
         p = os.path.join(d, "c1s_%s.fa%s" % (name, "" if mode == 0 else ".gz"))
         t0 = time.perf_counter()
         synth.write_fasta(p, seq, off[:n], lens[:n], mode=mode, member_bytes=mb)
@@ -66,11 +69,11 @@ if args.cli:
         t, err = CU.run_cli(CU.CLI_DROPIN, p, os.path.join(d, "c1s_dev_" + name), K, c, args.threads, {"OATK_DROPIN_LOG": "1"})
         res[name] = {"file_MB": os.path.getsize(p) >> 20, "write_s": round(tw, 2), "zcat_s": round(tz, 2), "dropin_s": round(t, 2)}
         print("== %s: %s" % (name, res[name]))
-        print("\n".join(l for l in err.splitlines() if "oatk_" in l and "fill_range" not in l)[-3500:], flush=True)
+        print("\n".join(l for l in err.splitlines() if ("oatk_" in l or "oatk::" in l) and "fill_range" not in l)[-4500:], flush=True)
     if args.ref:
         t, _ = CU.run_cli(CU.CLI_REF, os.path.join(d, "c1s_one.fa.gz"), os.path.join(d, "c1s_ref"), K, c, args.threads)
         res["reference_s"] = round(t, 2)
         import filecmp
         res["gfa_identical"] = {nm: all(filecmp.cmp(os.path.join(d, "c1s_ref" + x), os.path.join(d, "c1s_dev_%s%s" % (nm, x)), shallow=False) for x in (".utg.gfa", ".utg.final.gfa"))
-                                for nm in ("plain", "one", "bgzf", "members")}
+                                for nm in args.forms.split(",")}
     print(json.dumps(res))
