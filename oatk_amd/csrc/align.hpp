@@ -13,11 +13,9 @@
 
 namespace oatk {
 
-// Two sizes of the per-read working arrays.  RaSmall is what almost every read needs (a read is a few dozen syncmers, each on one or two unitigs) and what
-// the layout is tuned for: 10 KB per lane, the walk's stack in LDS.  RaBig takes the reads RaSmall reports as over its limits -- reads through tandem
-// arrays and other repeats, whose syncmers sit on hundreds of unitig positions (round 4: the config-1 surrogate sent every call of scg_read_alignment
-// back to the original routine because of a few hundred such reads) -- one lane each again, with everything in HBM.  What is over RaBig's limits is
-// still reported, not aligned.
+// The per-read working arrays of the lane-per-read routine: what almost every read needs (a read is a few dozen syncmers, each on one or two unitigs) and
+// what the layout is tuned for -- 10 KB per lane, the walk's stack in LDS.  Reads over these limits (reads through tandem arrays, whose syncmers sit on
+// hundreds of positions of one unitig: tens of thousands of hits) go through align_big.hpp, data-parallel inside the read.
 struct RaSmall {
     static constexpr int MAXS = 160;      // syncmer hits per read
     static constexpr int MAXF = 128;      // fragments per read
@@ -27,16 +25,6 @@ struct RaSmall {
     static constexpr bool LDS_STACK = true;
     static constexpr int THREADS = 256;
     typedef uint16_t st_t;
-};
-struct RaBig {
-    static constexpr int MAXS = 8192;
-    static constexpr int MAXF = 4096;
-    static constexpr int PREV = 64;
-    static constexpr int DEPTH = 2048;
-    static constexpr int FBITS = 16;
-    static constexpr bool LDS_STACK = false;
-    static constexpr int THREADS = 64;
-    typedef uint32_t st_t;
 };
 constexpr uint64_t RA_NONE = 0xFFFFFFFFFFFFFFFEULL;
 
@@ -74,7 +62,7 @@ struct RaArgs {
     uint32_t *cnt_aln, *cnt_frg;              // [n_reads] pass 1
     uint8_t *skipped;                         // [n_reads]
     const uint64_t *aln_off, *frg_off;        // [n_reads + 1] pass 2
-    const uint32_t *list;                     // RaBig: the reads to take, n_list of them
+    const uint32_t *list;                     // align_big.hpp: the reads to take, n_list of them
     uint64_t n_list;
     unsigned long long *pool_used;            // [0] alignments, [1] fragments taken from the pool, [2] it ran short
     uint64_t pool_cap_a, pool_cap_f;
@@ -328,7 +316,6 @@ __device__ inline int ra_prepare(const RaArgs &a, uint64_t r, const RaWork &w, u
 //      2: count, take room in a pool and write there (the normal path; 0 + 1 is the fallback when the pool is short).  The pool is
 //      handed out per WAVE -- the lanes' needs are summed with DPP and one lane asks -- because 200 k lanes asking one by one serialise
 //      on the two counters (measured: as long as the whole routine again).
-// L = RaSmall: every read, round-robin.  L = RaBig: the reads of a.list (those RaSmall reported), whose `skipped` mark is replaced by the new verdict.
 template <class L> struct RaStackLds { typename L::st_t *p; __device__ typename L::st_t &operator[](int i) const { return p[i * L::THREADS]; } };
 template <bool WR, class L>
 __device__ __forceinline__ bool ra_walk(const RaArgs &a, const RaStackLds<L> &st_lds, const RaWork &w, uint32_t nf, int64_t max_score, uint64_t n, uint64_t r,

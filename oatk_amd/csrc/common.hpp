@@ -61,6 +61,33 @@ __device__ __forceinline__ uint64_t hash64_s31(uint64_t x)
     return (uint64_t) hi << 32 | lo;
 }
 
+// ... and with the 62-bit key LEFT-aligned: the argument is key << 2 (its two low bits may hold anything: kernel B passes the base that follows the s-mer),
+// the result hash64 << 2.  Arithmetic modulo 2^62 on the key is arithmetic modulo 2^64 on four times the key, so no product needs a mask; a right shift takes
+// two bits of the key's low end along, which an AND removes.  The last step, x += x << 31, adds nothing to the low word (bit 0 of it is zero) and
+// (hi : lo) >> 1 to the high word.  Saves the 64-bit shift that right-aligns the key and two of the last step's three instructions (r04; checked on the host
+// against hash64 on 2 x 10^8 random keys and the corner values with every pair of junk bits: tools/ubench/hash_left_check.cpp).
+__device__ __forceinline__ uint64_t hash64_s31_left(uint64_t x4)
+{
+    uint32_t lo = (uint32_t) x4 & ~3u, hi = (uint32_t) (x4 >> 32);
+    uint64_t p;
+    p = (uint64_t) lo * 0x1FFFFFu + 0xFFFFFFFFFFFFFFFCull;              // 4 (~x + (x << 21)) = 4 x (2^21 - 1) - 4
+    hi = (uint32_t) (p >> 32) + (hi << 21) - hi, lo = (uint32_t) p;
+    { const uint32_t t = __builtin_amdgcn_alignbit(hi, lo, 24) & ~3u, u = hi >> 24; lo ^= t, hi ^= u; }
+    p = (uint64_t) lo * 265u;
+    hi = hi * 265u + (uint32_t) (p >> 32), lo = (uint32_t) p;
+    { const uint32_t t = __builtin_amdgcn_alignbit(hi, lo, 14) & ~3u, u = hi >> 14; lo ^= t, hi ^= u; }
+    p = (uint64_t) hi << 32 | lo;
+    {
+        uint64_t p5;
+        asm("v_lshl_add_u64 %0, %1, 2, %1" : "=v"(p5) : "v"(p));
+        asm("v_lshl_add_u64 %0, %1, 4, %2" : "=v"(p) : "v"(p), "v"(p5));
+    }
+    hi = (uint32_t) (p >> 32), lo = (uint32_t) p;
+    { const uint32_t t = __builtin_amdgcn_alignbit(hi, lo, 28) & ~3u, u = hi >> 28; lo ^= t, hi ^= u; }
+    hi += __builtin_amdgcn_alignbit(hi, lo, 1);
+    return (uint64_t) hi << 32 | lo;
+}
+
 // Reverse the order of the 32 two-bit groups of x and complement each (3 ^ c).
 __device__ __forceinline__ uint64_t revcomp32(uint64_t x)
 {

@@ -106,29 +106,30 @@ __device__ __forceinline__ uint32_t hpc_dpp(uint32_t old, uint32_t src)
     return (uint32_t) __builtin_amdgcn_update_dpp((int) old, (int) src, CTRL, ROW_MASK, 0xf, false);
 }
 
-// inclusive wave scans with DPP row shifts (row = 16 lanes) + v_readlane across rows: VALU only
+// inclusive wave scans with DPP: four shifts inside the rows of sixteen lanes, then lane 15 of rows 0 and 2 into rows 1 and 3 (row_bcast:15, row mask 0xa)
+// and lane 31 into rows 2 and 3 (row_bcast:31, row mask 0xc) -- six instructions (r04; the row totals went through v_readlane and a chain of selects before)
 __device__ __forceinline__ uint32_t wave_incl_sum_dpp(uint32_t v, uint32_t lane)
 {
+    (void) lane;
     v += hpc_dpp<0x111>(0u, v);
     v += hpc_dpp<0x112>(0u, v);
     v += hpc_dpp<0x114>(0u, v);
     v += hpc_dpp<0x118>(0u, v);
-    const uint32_t r15 = __builtin_amdgcn_readlane(v, 15), r31 = __builtin_amdgcn_readlane(v, 31), r47 = __builtin_amdgcn_readlane(v, 47);
-    const uint32_t row = lane >> 4;
-    return v + (row == 0? 0u : (row == 1? r15 : (row == 2? r15 + r31 : r15 + r31 + r47)));
+    v += hpc_dpp<0x142, 0xa>(0u, v);
+    v += hpc_dpp<0x143, 0xc>(0u, v);
+    return v;
 }
 __device__ __forceinline__ int32_t wave_incl_max_dpp(int32_t v, uint32_t lane)
 {
+    (void) lane;
     int32_t t;
     t = (int32_t) hpc_dpp<0x111>((uint32_t) v, (uint32_t) v); v = t > v? t : v;
     t = (int32_t) hpc_dpp<0x112>((uint32_t) v, (uint32_t) v); v = t > v? t : v;
     t = (int32_t) hpc_dpp<0x114>((uint32_t) v, (uint32_t) v); v = t > v? t : v;
     t = (int32_t) hpc_dpp<0x118>((uint32_t) v, (uint32_t) v); v = t > v? t : v;
-    const int32_t r15 = __builtin_amdgcn_readlane(v, 15), r31 = __builtin_amdgcn_readlane(v, 31), r47 = __builtin_amdgcn_readlane(v, 47);
-    const int32_t p2 = r31 > r15? r31 : r15, p3 = r47 > p2? r47 : p2;
-    const uint32_t row = lane >> 4;
-    const int32_t add = row == 1? r15 : (row == 2? p2 : (row == 3? p3 : -1));
-    return add > v? add : v;
+    t = (int32_t) hpc_dpp<0x142, 0xa>((uint32_t) v, (uint32_t) v); v = t > v? t : v;
+    t = (int32_t) hpc_dpp<0x143, 0xc>((uint32_t) v, (uint32_t) v); v = t > v? t : v;
+    return v;
 }
 
 __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)

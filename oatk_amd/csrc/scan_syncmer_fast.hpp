@@ -314,11 +314,12 @@ __global__ __launch_bounds__(NT, OATK_SYF_WAVES) void syncmer_fast_kernel(SynArg
                             uint64_t rv = (uint64_t) __builtin_amdgcn_alignbit(r2, r1, 2 + 2 * b) << 32 | __builtin_amdgcn_alignbit(r1, r0, 2 + 2 * b);
                             asm("" : "+v"(fw), "+v"(rv));        // (the halves are read back out of the register pairs: without this the compiler keeps each half twice, a v_mov per word)
                             const uint64_t cn = fw < rv? fw : rv;
-                            const uint64_t mv = hash64_s31(cn >> 2);
-                            y[b] = (uint32_t) (mv >> 32);
+                            const uint64_t mv4 = hash64_s31_left(cn);   // four times the hash: the order is the hash's, the top word a shift away
+                            y[b] = (uint32_t) (mv4 >> 34);
                             cmin = y[b] < cmin? y[b] : cmin;
-                            if (decltype(keep)::value) cm = mv < cm? mv : cm;
+                            if (decltype(keep)::value) cm = mv4 < cm? mv4 : cm;
                         }
+                        if (decltype(keep)::value) cm >>= 2;
                     };
                     // (two copies of the loop, chosen by a scalar branch: as one loop with a per-position select the compiler keeps the 64-bit chain for every position)
                     if (__builtin_amdgcn_readfirstlane((int) rep_mode)) hash_chunk(std::true_type()); else hash_chunk(std::false_type());

@@ -177,12 +177,12 @@ def test_read_alignment_matches_oracle_at_scale_and_reports_reads_over_the_limit
     want = AU.oracle_align(*chains, graph)
     AU.assert_same(got, want)
     assert got["skipped"] == 0 and len(got["sid"]) > 0.9 * n and (got["n_mapped"], got["n_unique"]) == (want["n_mapped"], want["n_unique"])
-    # one popular syncmer on 200 extra single-syncmer unitigs: reads that carry it are over the first tier's limits (160 hits) and are aligned by the
-    # second (align.hpp: RaBig, round 4); on 9000 extra unitigs they are over the second tier's too and are reported, not aligned
+    # one popular syncmer on 200 (then 3000) extra single-syncmer unitigs: reads that carry it are over the lane-per-read limits (160 hits) and go through
+    # the data-parallel routine (align_big.hpp, round 4); with that switched off they are reported, not aligned, and everybody else's alignments are the same
     pop = int(ag["vtx_scm"][0])
     carriers = np.unique(np.repeat(np.arange(n), chains[0])[(chains[1] >> np.uint64(1)) == pop])
     assert len(carriers) > 0
-    for extra, aligned in ((200, True), (9000, False)):
+    for extra in (200, 3000):
         su_uid = np.concatenate([graph["su_uid"][:1], (np.arange(nv, nv + extra, dtype=np.uint64) << np.uint64(1)), graph["su_uid"][1:]])
         su_off2 = su_off.copy()
         su_off2[pop + 1:] += np.uint64(extra)
@@ -190,20 +190,18 @@ def test_read_alignment_matches_oracle_at_scale_and_reports_reads_over_the_limit
                   idx_p=np.concatenate([graph["idx_p"], np.zeros(2 * extra, np.uint64)]), idx_n=np.concatenate([graph["idx_n"], np.zeros(2 * extra, np.uint64)]))
         got2 = AU.device_align(hip, g2)
         want2 = AU.oracle_align(*chains, g2)
-        if aligned:
-            assert got2["skipped"] == 0
-            AU.assert_same(got2, want2)
-            os.environ["OATK_DEBUG_RA_NO_BIG"] = "1"            # ... and the first tier alone reports them
+        assert got2["skipped"] == 0
+        AU.assert_same(got2, want2, extra)
+        if extra == 200:
+            os.environ["OATK_DEBUG_RA_NO_BIG"] = "1"
             try:
                 got3 = AU.device_align(hip, g2)
             finally:
                 del os.environ["OATK_DEBUG_RA_NO_BIG"]
             assert got3["skipped"] == len(carriers)
-        else:
-            assert got2["skipped"] == len(carriers)
             assert np.array_equal(np.sort(hip.fetch("RA_SKIPPED")), carriers.astype(np.uint32))
             keep = ~np.isin(want2["sid"], carriers)
-            assert np.array_equal(got2["sid"], want2["sid"][keep]) and np.array_equal(got2["s"], want2["s"][keep])
+            assert np.array_equal(got3["sid"], want2["sid"][keep]) and np.array_equal(got3["s"], want2["s"][keep])
 
 
 @pytest.mark.parametrize("seed", range(6))
