@@ -52,13 +52,6 @@ int oatk_hip_debug_ec_tiers(oatk_hip_ctx *ctx, int cap_t0, int cap_t1);
 int oatk_hip_debug_wf_ed(oatk_hip_ctx *ctx, uint64_t n_jobs, const uint8_t *t_codes, const uint64_t *t_off, const uint8_t *q_codes, const uint64_t *q_off,
                          const int32_t *bw, const int32_t *step_ql, const uint64_t *step_off, int32_t *out3);
 
-/* The A/B SURVEY.md 7-5 asks for ("benchmark both"): the same jobs -- whole query, no resumption -- through the wavefront routine above (myers = 0) or
- * through Myers' bit-vector algorithm with one lane per pair and the bit-vectors over the target (myers = 1; north_star's "bit-parallel (Myers) kernel
- * batching reads per wavefront").  out3 holds one (score, t_end, q_end) per JOB -- both give wf_ed's values --, *kernel_ms the duration of the kernel.
- * The correction uses the wavefront routine: its search resumes, saves and restores alignments. */
-int oatk_hip_debug_ed_ab(oatk_hip_ctx *ctx, int myers, uint64_t n_jobs, const uint8_t *t_codes, const uint64_t *t_off, const uint8_t *q_codes, const uint64_t *q_off,
-                         const int32_t *bw, int32_t *out3, float *kernel_ms);
-
 /* Resident results of oatk_hip_ec (ids for oatk_hip_buffer):
  *   EC_N_SCM   u32[n_reads]      sr_t.n after correction
  *   EC_SCM_OFF u64[n_reads+1]    slots of the corrected chains

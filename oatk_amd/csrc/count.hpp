@@ -197,12 +197,25 @@ __global__ __launch_bounds__(256) void pair_sum_kernel(const uint64_t *key, cons
     __shared__ uint64_t part[2][4];
     uint64_t s0 = 0, s1 = 0;
     bool inv = false;
-    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
-        const uint64_t k = key[i];
-        uint64_t a, b;
-        pair_sums(k, perm? perm[i] : (uint32_t) i, a, b);
-        s0 += a, s1 += b;
-        if (perm && i && k < key[i - 1]) inv = true;
+    // (four independent elements per turn: the loads of a turn are in flight together)
+    const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
+    for (uint64_t i0 = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 4 * stride) {
+        uint64_t k[4], kp[4];
+        uint32_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint64_t i = i0 + u * stride;
+            const bool in = i < n;
+            k[u] = in? key[i] : 0, v[u] = in? (perm? perm[i] : (uint32_t) i) : 0, kp[u] = in && perm && i? key[i - 1] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u * stride >= n) continue;
+            uint64_t a, b;
+            pair_sums(k[u], v[u], a, b);
+            s0 += a, s1 += b;
+            if (k[u] < kp[u]) inv = true;
+        }
     }
     #pragma unroll
     for (int d = 32; d > 0; d >>= 1) s0 += __shfl_xor(s0, d), s1 += __shfl_xor(s1, d);

@@ -311,6 +311,7 @@ __global__ __launch_bounds__(64) void ecw_wf_ed_kernel(const uint32_t *tw, const
     }
 }
 
+#ifdef OATK_EXPERIMENTS            // (tools/experiments/: built into a library of its own, not into liboatk_hip.so)
 // ---- Myers' bit-vector edit distance (north_star names it; SURVEY.md 7-5: "benchmark both") ----
 // Measured beside the wavefront routine, not used by the correction (the search RESUMES an alignment after every appended k-mer, saves
 // it at a branch and restores it, and its results are defined on wavefronts; a column-wise bit-vector DP can do neither cheaply).  One LANE per pair --
@@ -372,6 +373,8 @@ __global__ __launch_bounds__(64) void myers_ed_kernel(uint64_t n_jobs, const uin
     if (band >= 0 && best > band) best = band + 1, bi = 0, bj = 0;
     out3[3 * j] = best, out3[3 * j + 1] = bi, out3[3 * j + 2] = bj;
 }
+#endif
+
 
 // a live-arc record in flight: issued as two loads, made uniform only where it is used
 struct EcwArcRegs {

@@ -108,6 +108,34 @@ static void *packed_producer(void *arg)
     return 0;
 }
 
+/* the two piece handles outlive the call (their buffers are a gigabyte each, and allocating them is most of what a call of this size takes): kept per device,
+ * handed to the next call on that device */
+static pthread_mutex_t g_pp_mu = PTHREAD_MUTEX_INITIALIZER;
+static int g_pp_dev = -1;
+static oatk_hip_ctx *g_pp[2];
+
+static void packed_pieces_take(int dev, oatk_hip_ctx *piece[2])
+{
+    pthread_mutex_lock(&g_pp_mu);
+    if (g_pp[0] && g_pp_dev == dev) piece[0] = g_pp[0], piece[1] = g_pp[1], g_pp[0] = g_pp[1] = 0;
+    else piece[0] = piece[1] = 0;
+    pthread_mutex_unlock(&g_pp_mu);
+    if (!piece[0]) piece[0] = oatk_hip_create(dev), piece[1] = oatk_hip_create(dev);
+}
+
+static void packed_pieces_give(int dev, oatk_hip_ctx *piece[2], int failed)
+{
+    oatk_hip_ctx *old[2] = {0, 0};
+    if (!failed && piece[0] && piece[1]) {
+        pthread_mutex_lock(&g_pp_mu);
+        old[0] = g_pp[0], old[1] = g_pp[1];
+        g_pp[0] = piece[0], g_pp[1] = piece[1], g_pp_dev = dev;
+        pthread_mutex_unlock(&g_pp_mu);
+    } else old[0] = piece[0], old[1] = piece[1];
+    if (old[0]) oatk_hip_destroy(old[0]);
+    if (old[1]) oatk_hip_destroy(old[1]);
+}
+
 static int sr_read_packed_pipelined(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, const uint8_t *seq, const uint64_t *off, const uint32_t *len,
                                     uint64_t n_reads, uint64_t seq_bytes, char **names)
 {
@@ -124,7 +152,7 @@ static int sr_read_packed_pipelined(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, cons
     sr_db->n = 0, sr_db->m = n_reads;
     rc = oatk_hip_scan_begin(ctx, 0, sr_db->k, sr_db->s);
     if (!rc) rc = oatk_hip_scan_reserve(ctx, seq_bytes + (1 << 20), n_reads + 1024, seq_bytes / 500 + 4096);
-    P.piece[0] = oatk_hip_create(oatk_hip_device(ctx)), P.piece[1] = oatk_hip_create(oatk_hip_device(ctx));
+    packed_pieces_take(oatk_hip_device(ctx), P.piece);
     if (!rc && (!P.piece[0] || !P.piece[1])) rc = OATK_E_NODEV;
     if (!rc && pthread_create(&th, 0, packed_producer, &P) != 0) rc = OATK_E_NOMEM;
     else if (!rc) started = 1;
@@ -151,8 +179,7 @@ static int sr_read_packed_pipelined(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, cons
         pthread_mutex_unlock(&P.mu);
         pthread_join(th, 0);
     }
-    if (P.piece[0]) oatk_hip_destroy(P.piece[0]);
-    if (P.piece[1]) oatk_hip_destroy(P.piece[1]);
+    packed_pieces_give(oatk_hip_device(ctx), P.piece, rc);
     free(P.rel[0]); free(P.rel[1]);
     pthread_mutex_destroy(&P.mu);
     pthread_cond_destroy(&P.cv);
@@ -162,8 +189,10 @@ static int sr_read_packed_pipelined(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, cons
 int oatk_sr_read_packed(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, const uint8_t *seq, const uint64_t *off, const uint32_t *len,
                         uint64_t n_reads, uint64_t seq_bytes, char **names)
 {
+    /* (opt-in: with the piece handles created per call it was slower than one pass -- 135.7 against 99.6 ms at 1.5 GB, profiles/r04m_bench.json `results_back` --,
+     *  with the handles kept between calls it is as fast and no faster: 67.9 against 69.1 ms with arenas, 99.8 against 109.1 without, profiles/r04n_packed_ab.txt) */
     const char *e = getenv("OATK_HOST_PACKED_PIECES");
-    if (seq_bytes > 2 * PACKED_PIECE && n_reads > 1 && !(e && e[0] == '0')) return sr_read_packed_pipelined(ctx, sr_db, seq, off, len, n_reads, seq_bytes, names);
+    if (seq_bytes > 2 * PACKED_PIECE && n_reads > 1 && e && e[0] == '1') return sr_read_packed_pipelined(ctx, sr_db, seq, off, len, n_reads, seq_bytes, names);
     int rc = oatk_hip_scan_host(ctx, seq, off, len, n_reads, seq_bytes, 0, sr_db->k, sr_db->s);
     if (rc) return rc;
     return oatk_sr_db_fill_resident(ctx, sr_db, off, n_reads, names);

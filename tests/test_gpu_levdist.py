@@ -3,6 +3,8 @@ against the reference's wf_ed / wf_ed_core (levdist.c:265-345): all of tests/gol
 known answer (levdist.c:445-446: ED=8 t_EN=59 q_EN=56) and the band cut-offs, 120 resumable traces -- then fresh random jobs against the CPU
 oracle (oracle/levdist.c, itself pinned to the same goldens and to the compiled reference), long strings and many-diagonal wavefronts included.
 "north_star: edit distances match exactly"."""
+import os
+
 import numpy as np
 import pytest
 
@@ -109,7 +111,21 @@ def test_fresh_jobs_against_the_oracle(hip):
     assert n_wide > 10                                                                      # wavefronts wider than one lane group per diagonal
 
 
-def test_myers_bit_vector_variant_gives_the_same_distances(hip):
+EXPERIMENTS_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "experiments", "liboatk_hip_experiments.so")
+
+
+@pytest.mark.skipif(not os.path.exists(EXPERIMENTS_LIB), reason="tools/experiments/build.sh not run: Myers' kernel is not part of liboatk_hip.so (round 4)")
+def test_myers_bit_vector_variant_gives_the_same_distances():
+    """(runs in a process of its own over tools/experiments/liboatk_hip_experiments.so: the product library no longer carries the experiment)"""
+    import subprocess
+    import sys
+    env = dict(os.environ, OATK_HIP_LIB=EXPERIMENTS_LIB, OATK_TEST_MYERS_CHILD="1")
+    p = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", __file__ + "::test_myers_child"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+
+
+@pytest.mark.skipif(not os.environ.get("OATK_TEST_MYERS_CHILD"), reason="the child of test_myers_bit_vector_variant_gives_the_same_distances")
+def test_myers_child(hip):
     """north_star names a bit-parallel (Myers) kernel, SURVEY 7-5 asks to benchmark both: the bit-vector algorithm with one lane per pair
     (ec_wave.hpp: myers_ed_kernel) returns wf_ed's (score, t_end, q_end) on every golden pair and on fresh ones, band cut-offs included -- the
     closed form the wavefront equals (minimum over last row and last column, smallest diagonal first).  tools/edbench.py times the two."""

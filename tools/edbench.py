@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""SURVEY 7-5 "benchmark both": the wavefront (Landau-Vishkin) edit distance the correction uses against Myers' bit-vector algorithm, on pairs shaped like
+"""(needs tools/experiments/liboatk_hip_experiments.so: bash tools/experiments/build.sh, then OATK_HIP_LIB=... python tools/edbench.py)
+SURVEY 7-5 "benchmark both": the wavefront (Landau-Vishkin) edit distance the correction uses against Myers' bit-vector algorithm, on pairs shaped like
 error blocks -- a target of ~2000 hoco bases, a query that is the target with a few differences plus the overhang of the last appended k-mer, band 2 % --
 and on the other extreme, unrelated strings.  GPU only.  Output goes to profiles/ by hand."""
 import os, sys

@@ -15,11 +15,12 @@ normal = [bytes(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 15000)].toli
 rep = [(u * (20000 // len(u) + 1))[:20000] for u in (b"TTAGGG", b"AC", b"GAA", b"ACGTTGCAAGT", b"ACGTTGCAAGTCCATGACTGATCGATCGGATC" * 3)]
 hip = HipSyncasm(0)
 hip.set_timing(True)
-for name, reads in (("ordinary", normal), ("ordinary + 5 repeat reads", normal + rep), ("ordinary + 50 repeat reads", normal + rep * 10)):
+for name, reads in (("ordinary", normal), ("ordinary + 5 repeat reads", normal + rep), ("ordinary + 50 repeat reads", normal + rep * 10),
+                    ("ordinary + 1 % repeat reads (200)", normal + rep * 40), ("ordinary + 10 % repeat reads (2000)", normal + rep * 400)):
     seq, off, lens = pack_reads(reads)
     t = []
     for it in range(4):
         hip.scan_host(seq, off, lens, 1001, 31)
         if it:
             t.append(hip.timing()["syncmer"])
-    print("%-28s syncmer %.3f ms" % (name, sum(t) / len(t)))
+    print("%-36s syncmer %.3f ms" % (name, sum(t) / len(t)), flush=True)
