@@ -587,7 +587,7 @@ static int sr_read_stream(oatk_hip_ctx **ctxs, int n_ctx, uint64_t *first, oatk_
     const int log = lg && lg[0] && lg[0] != '0';
     const int threads = oatk_host_threads();
     const double t_begin = now_s();
-    double t_wait = 0, t_dev = 0, t_fill = 0, t_app = 0;
+    double t_wait = 0, t_dev = 0, t_fill = 0, t_app = 0, t_room = 0, t_names = 0;
     stream_t st;
     stream_dev_t res[64];
     int res_of_rank[64];
@@ -634,7 +634,12 @@ static int sr_read_stream(oatk_hip_ctx **ctxs, int n_ctx, uint64_t *first, oatk_
         }
     }
     if (rc) goto done;
-    oatk_host_set_threads_internal(threads > 1? threads / 2 : 1);  /* the other half reads the file */
+    {
+        int fill_threads = threads > 1? threads / 2 : 1;            /* the other half reads the file */
+        const char *e = getenv("OATK_HOST_FILL_THREADS");           /* (experiments: the split between the two halves) */
+        if (e && atoi(e) > 0) fill_threads = atoi(e);
+        oatk_host_set_threads_internal(fill_threads);
+    }
     if (streamed && !(h_carry = (uint8_t *) malloc(CARRY_CAP))) { rc = OATK_E_NOMEM; goto done; }
     if (pthread_create(&th, 0, streamed? uploader_src : uploader, &st) != 0) { rc = OATK_E_NOMEM; goto done; }
     started = 1;
@@ -765,6 +770,7 @@ static int sr_read_stream(oatk_hip_ctx **ctxs, int n_ctx, uint64_t *first, oatk_
                 if (rc) break;
             }
         }
+        t_room += now_s() - t0, t0 = now_s();
         if (!sr_db) {                                               /* the scan only: no structs to fill */
             rc = oatk_hip_scan_append(ctx, D->piece[s]);
             if (rc) break;
@@ -784,10 +790,11 @@ static int sr_read_stream(oatk_hip_ctx **ctxs, int n_ctx, uint64_t *first, oatk_
             if (!rc) rc = oatk_hip_d2h(D->piece[s], hdr, d, 8 * n);
         }
         if (rc) break;
-        if (!streamed) {
+        if (!streamed) {                                            /* (cutting the names on threads of their own beside the download was tried in r04: the download slows down by what the names took) */
             name_job_t nj = {seg, n_files, hdr, text0, n, names, sr_db};
             oatk_par_run(name_worker, &nj);
         }
+        t_names += now_s() - t0, t0 = now_s();
         rc = oatk_sr_db_fill_range(D->piece[s], sr_db, n_done, off, n, names);
         free(off); free(hdr); free(names);
         off = hdr = 0, names = 0;
@@ -827,7 +834,7 @@ done:
         if (na) sr_db->a = na, sr_db->m = sr_db->n;
     }
     if (log) fprintf(stderr, "[M::oatk_sr_read_files] %.2f GB of text in %lu windows, %lu reads into %d handle(s): %.3f s (waiting for the uploader %.3f, record + syncmer scan %.3f, "
-                             "structs %.3f, append %.3f)\n", (double) text_done / 1e9, (unsigned long) w, (unsigned long) n_done, n_ctx, now_s() - t_begin, t_wait, t_dev, t_fill, t_app);
+                             "room for the batch %.3f, names %.3f, structs %.3f, append %.3f)\n", (double) text_done / 1e9, (unsigned long) w, (unsigned long) n_done, n_ctx, now_s() - t_begin, t_wait, t_dev, t_room, t_names, t_fill, t_app);
     return rc;
 }
 

@@ -295,8 +295,14 @@ static void release_worker(void *arg, int tid, int n_threads)
     const release_job_t *j = (const release_job_t *) arg;
     size_t i;
     for (i = (size_t) tid; i < j->n; i += (size_t) n_threads) {
-        if (j->blk[i].raw) munmap(j->blk[i].raw, j->blk[i].raw_size);
-        else free(j->blk[i].base);
+        if (j->blk[i].raw) {
+            /* (the pages go first, under the mapping lock held for READING -- threads do that side by side; munmap takes it for writing, and what is left
+             *  for it to do is the empty mapping.  OATK_HOST_RELEASE_PLAIN=1: munmap alone, as until r04) */
+            static int plain = -1;
+            if (plain < 0) { const char *e = getenv("OATK_HOST_RELEASE_PLAIN"); plain = e && e[0] == '1'; }
+            if (!plain) (void) madvise(j->blk[i].raw, j->blk[i].raw_size, MADV_DONTNEED);
+            munmap(j->blk[i].raw, j->blk[i].raw_size);
+        } else free(j->blk[i].base);
     }
 }
 static void arena_release(const void *owner)
@@ -616,16 +622,23 @@ static int fill_range_zero_copy(oatk_hip_ctx *ctx, zc_job_t *j, uint64_t n_reads
     j->cur = 0, j->next = &pc[0];
     oatk_par_run(zc_worker, j);
     *t_prep += host_now() - t0;
+    /* Page-locking a piece and releasing the one before it both run while a piece is on the bus (r04: they were done around the copy, ~1.5 ms per 256 MB piece
+     * of which the copy itself takes 4.4): lock the first piece, then per piece -- queue its copy, unlock the piece before, map + touch + lock the next, wait. */
+    int locked[2] = {0, 0};
+    zc_piece_t *prev = 0;
+    int prev_locked = 0;
+    locked[0] = oatk_hip_host_register(ctx, pc[0].base, pc[0].size) == OATK_OK;      /* (not page-locked the copies still arrive, staged by the runtime) */
     for (;;) {
         zc_piece_t *P = &pc[cur];
         t0 = host_now();
-        const int locked = oatk_hip_host_register(ctx, P->base, P->size) == OATK_OK;      /* (not page-locked the copies still arrive, staged by the runtime) */
         rc = oatk_hip_d2h_async(ctx, P->rl, (const uint8_t *) d_rl + j->off[P->i0], P->rl_bytes);
         if (!rc) rc = oatk_hip_d2h_async(ctx, P->hs, (const uint8_t *) d_hs + j->off[P->i0] / 4, (P->rl_bytes + 3) / 4 + 1);
         if (!rc) rc = oatk_hip_d2h_async(ctx, P->m_pos, (const uint32_t *) d_mp + j->scm_off[P->i0], P->ns * 4);
         if (!rc) rc = oatk_hip_d2h_async(ctx, P->s_mer, (const uint64_t *) d_sm + j->scm_off[P->i0], P->ns * 8);
         if (!rc) rc = oatk_hip_d2h_async(ctx, P->k_hash, (const uint64_t *) d_kh + j->scm_off[P->i0], P->ns * 8);
-        /* while it is on the bus: the next piece's mapping is made and touched, this piece's structs are set */
+        if (prev && prev_locked) (void) oatk_hip_host_unregister(ctx, prev->base);
+        prev = 0;
+        /* while it is on the bus: the next piece's mapping is made, touched and locked, this piece's structs are set */
         p0 = P->i1, have_next = 0;
         if (!rc && p0 < n_reads) {
             NEXT_END(p0, p1);
@@ -634,16 +647,21 @@ static int fill_range_zero_copy(oatk_hip_ctx *ctx, zc_job_t *j, uint64_t n_reads
         }
         j->cur = P, j->next = have_next? &pc[cur ^ 1] : 0;
         if (!rc) oatk_par_run(zc_worker, j);
+        if (have_next) locked[cur ^ 1] = oatk_hip_host_register(ctx, pc[cur ^ 1].base, pc[cur ^ 1].size) == OATK_OK;
         *t_prep += host_now() - t0, t0 = host_now();
         {
             const int rs = oatk_hip_sync(ctx);                 /* the piece has landed */
             if (!rc) rc = rs;
         }
-        if (locked) (void) oatk_hip_host_unregister(ctx, P->base);
         *t_wait += host_now() - t0;
-        if (rc) return rc;
+        if (rc || !have_next) {                                /* (nothing is on the bus any more) */
+            if (locked[cur]) (void) oatk_hip_host_unregister(ctx, P->base);
+            if (have_next && locked[cur ^ 1]) (void) oatk_hip_host_unregister(ctx, pc[cur ^ 1].base);
+            if (rc) return rc;
+        }
         j->sr_db->n = j->first + P->i1;
         if (!have_next) break;
+        prev = P, prev_locked = locked[cur];
         cur ^= 1;
     }
 #undef NEXT_END

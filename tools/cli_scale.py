@@ -26,6 +26,7 @@ ap.add_argument("--workload", default="config3")
 ap.add_argument("--dir", default="/dev/shm")
 ap.add_argument("--keep", action="store_true")
 ap.add_argument("--devices", default="", help="also run the drop-in over several handles (OATK_DEVICES, e.g. 0,0)")
+ap.add_argument("--variants", default="", help="also run the drop-in under these environments, on the same file in the same session: 'A=1,B=2;C=3' (A/B of host-side switches)")
 args = ap.parse_args()
 
 cfg = dict(CONFIGS[args.workload])
@@ -87,6 +88,13 @@ if args.devices:
     report["dropin_several_handles"] = dict(rm, devices=args.devices, same_gfa_as_one_handle=all(rm.get(k) == r.get(k) and rm.get(k) for k in ("md5.utg.gfa", "md5.utg.final.gfa")))
     report["dropin_several_handles_log"] = [l for l in errm.splitlines() if "oatk_dropin]" in l or "oatk_sr_read_files]" in l]
     print("\n".join(l for l in errm.splitlines() if "oatk_" in l), flush=True)
+for k, spec in enumerate(v for v in args.variants.split(";") if v):
+    env = dict(x.split("=", 1) for x in spec.split(","))
+    for rep in range(2):
+        rv, errv = run("syncasm_dropin", "var%d" % k, dict(env, OATK_DROPIN_LOG="1"))
+        line = [l for l in errv.splitlines() if "oatk_sr_read_files]" in l]
+        print("[variant %s] wall %.2f s; %s" % (spec, rv["wall_s"], line[0] if line else ""), flush=True)
+        report.setdefault("variants", []).append({"env": spec, "wall_s": rv["wall_s"], "sr_read": line[0] if line else None})
 if args.ref:
     r2, _ = run("syncasm", "ref")
     report["reference"] = r2
