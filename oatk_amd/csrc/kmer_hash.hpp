@@ -23,7 +23,7 @@ struct KmerHashArgs {
 };
 
 #define KMH_REC 16                // records per wave: most lanes idle in the short chain phase, but four times the waves fit a CU's LDS (64: 1.12 ms, 32: 0.75, 16: 0.56, 8: 0.67)
-#define KMH_WPL 8                 // Murmur blocks a lane prepares in one go (their source words are loaded together)
+#define KMH_WPL 8                 // Murmur blocks a lane prepares in one go (their source words are loaded together; four: 3.68 against 2.95 ms, r04)
 
 // r03: FOUR LANES PER RECORD, each preparing a run of consecutive 8-byte Murmur blocks of its record.  A run of blocks is a run of consecutive source
 // words, so a lane loads 2 n + 1 dwords for n blocks (three per block before) with no division, no shuffles and no per-block address arithmetic in
@@ -67,32 +67,35 @@ __global__ __launch_bounds__(64, OATK_KMH_WAVES) void kmer_hash_kernel(KmerHashA
             // block j is made of chunk n - 1 - j) -- so block j always finds its three words at d[2j], d[2j + 1], d[2j + 2].  A full run (n = 8, every
             // lane at K = 1001) fetches them as four 16-byte loads and one dword: seventeen single-dword loads touch 64 cache lines EACH (the lanes of
             // a wave sit 64 bytes apart) and the vector cache looks up every line of every load -- that, not arithmetic, was the kernel's run time.
-            uint32_t d[2 * KMH_WPL + 1];
+            // (r04: the words stay in STRING order in their registers and the loop below goes over the CHUNKS c; which block a chunk makes -- j = c, or n - 1 - c for a
+            //  reverse occurrence -- only moves the LDS address it is written to.  Until then a second array held them in block order, seventeen selects put them
+            //  there, and nine of its words lived in scratch: 5.6 GB of scratch writes per step at config 3 for 0.34 GB of hashes.)
+            uint32_t asc[2 * KMH_WPL + 1];
             const int64_t gbase = hsw + wi;
             if (n == KMH_WPL && gbase >= 0) {
                 struct __attribute__((packed, aligned(4))) W4 { uint32_t a, b, c, e; };
                 const W4 *src = (const W4 *) (hs32 + gbase);
                 const W4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
                 const uint32_t v4 = hs32[gbase + 16];
-                const uint32_t asc[17] = {v0.a, v0.b, v0.c, v0.e, v1.a, v1.b, v1.c, v1.e, v2.a, v2.b, v2.c, v2.e, v3.a, v3.b, v3.c, v3.e, v4};
+                const uint32_t raw[17] = {v0.a, v0.b, v0.c, v0.e, v1.a, v1.b, v1.c, v1.e, v2.a, v2.b, v2.c, v2.e, v3.a, v3.b, v3.c, v3.e, v4};
 #pragma unroll
-                for (int j = 0; j < 17; ++j) d[j] = __builtin_bswap32(rev? asc[16 - j] : asc[j]);
+                for (int i = 0; i < 17; ++i) asc[i] = __builtin_bswap32(raw[i]);
             } else {
-                const int64_t g0 = gbase + (rev? 2 * n : 0);
 #pragma unroll
-                for (int j = 0; j < 2 * KMH_WPL + 1; ++j) {
-                    int64_t gi = rev? g0 - j : g0 + j;
+                for (int i = 0; i < 2 * KMH_WPL + 1; ++i) {
+                    int64_t gi = gbase + i;
                     gi = gi < 0? 0 : gi;                                      // (only the very first read of a slab: what is read there is masked)
-                    d[j] = j < 2 * n + 1? __builtin_bswap32(hs32[gi]) : 0u;
+                    asc[i] = i < 2 * n + 1? __builtin_bswap32(hs32[gi]) : 0u;
                 }
             }
 #pragma unroll
-            for (int j = 0; j < KMH_WPL; ++j) {
-                if (j >= n) break;
+            for (int c = 0; c < KMH_WPL; ++c) {
+                if (c >= n) break;
                 // sixty-four bits from bit offset sh of the chunk's three words (first, middle, last in string order)
-                const uint32_t x0 = rev? d[2 * j + 2] : d[2 * j], x1 = d[2 * j + 1], x2 = rev? d[2 * j] : d[2 * j + 2];
+                const uint32_t x0 = asc[2 * c], x1 = asc[2 * c + 1], x2 = asc[2 * c + 2];
                 const uint32_t hi = (uint32_t) (((uint64_t) x0 << 32 | x1) >> (32u - sh));
                 const uint32_t lo = (uint32_t) (((uint64_t) x1 << 32 | x2) >> (32u - sh));
+                const int j = rev? n - 1 - c : c;
                 const int wd = w0 + j;
                 int nb = K - 32 * wd;
                 nb = nb > 32? 32 : nb;
