@@ -194,7 +194,7 @@ struct __attribute__((aligned(16))) EcWork {   // one block, self-contained for 
     int32_t l, r;
     uint32_t hs16;                // hoco byte offset / 16 of the read
     uint32_t lp, ln;              // live arcs of beg_utg
-    uint32_t pad;
+    uint32_t pad;                 // (list kernel -> ec_new_n_kernel) chain entries the read keeps if this block is NOT corrected (syncerr.c:533-542)
 };
 
 __global__ void ec_live_flag_kernel(uint64_t n_arc, const uint8_t *arc_del, uint32_t *live)
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void ec_count_blocks_wave_kernel(EcReads rd, c
     }
 }
 
-__global__ __launch_bounds__(256) void ec_list_blocks_wave_kernel(EcReads rd, EcLive lv, const uint8_t *scm_del, const uint64_t *blk_off, EcWork *work)
+__global__ __launch_bounds__(256) void ec_list_blocks_wave_kernel(EcReads rd, EcLive lv, const uint8_t *scm_del, const uint64_t *blk_off, EcWork *work, uint32_t *copy_n)
 {
     const uint64_t r0 = ((uint64_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * ECR_RPW;
     const int lane = threadIdx.x & 63;
@@ -386,23 +386,50 @@ __global__ __launch_bounds__(256) void ec_list_blocks_wave_kernel(EcReads rd, Ec
         if (x.n < 0) continue;
         EcWork *w = wq[k];
         const uint32_t hs16 = hq[k];
+        const int32_t n = x.n;
         auto put = [&](int i, const EcBlock &b) {
             EcWork y;
             y.beg_utg = b.beg_utg, y.end_utg = b.end_utg, y.read = (uint32_t) x.r, y.beg_pos = b.beg_pos, y.l = b.l, y.r = b.r;
-            y.hs16 = hs16, y.lp = lv.idx_p[b.beg_utg], y.ln = lv.idx_n[b.beg_utg], y.pad = 0;
+            y.hs16 = hs16, y.lp = lv.idx_p[b.beg_utg], y.ln = lv.idx_n[b.beg_utg];
+            // what the assembly copies when the block is not corrected (ec_assemble_wave_kernel: copy(0, beg) / copy(beg + 1, min(end, n)))
+            const int32_t last = b.end < n? b.end : n;
+            y.pad = b.r? (uint32_t) b.beg : (b.beg + 1 < n && last > b.beg + 1? (uint32_t) (last - b.beg - 1) : 0u);
             w[i] = y;
         };
+        // ... and what it copies between the blocks whatever becomes of them; a read without a good syncmer keeps its chain (syncerr.c:562-572)
+        uint32_t cp = 0;
+        auto on_copy = [&](int32_t first, int32_t last) { if (last > first) cp += (uint32_t) (last - first); };
         if (x.n > 64) {
-            if (lane == 0) ec_blocks(scm_del, rd.k_mer + x.o, rd.m_pos + x.o, x.n, x.hoco_l, rd.K, put, [](int32_t, int32_t) {});
+            if (lane == 0) {
+                const int nbs = ec_blocks(scm_del, rd.k_mer + x.o, rd.m_pos + x.o, x.n, x.hoco_l, rd.K, put, on_copy);
+                copy_n[x.r] = nbs < 0? (uint32_t) n : cp;
+            }
             continue;
         }
         // lane i keeps block i and writes it after the walk, so the gathers of a read's blocks are in flight together
         EcBlock mine;
         mine.beg_utg = 0, mine.end_utg = 0, mine.beg_pos = 0, mine.l = 0, mine.beg = 0, mine.end = 0, mine.r = 0;
         const int nb = ec_blocks_wave(lane, x.n, x.km, x.mp, x.del, x.hoco_l, rd.K,
-                                      [&](int i, const EcBlock &b) { if (i < 64) { if (lane == i) mine = b; } else if (lane == 0) put(i, b); }, [](int32_t, int32_t) {});
+                                      [&](int i, const EcBlock &b) { if (i < 64) { if (lane == i) mine = b; } else if (lane == 0) put(i, b); }, on_copy);
         if (lane < nb) put(lane, mine);
+        if (lane == 0) copy_n[x.r] = nb < 0? (uint32_t) n : cp;
     }
+}
+
+// the corrected chains' lengths from the blocks' outcomes (r04; until then a third walk over the chains, ec_assemble_wave_kernel<0>): what the read keeps between
+// its blocks, plus per block the optimum path's interior (syncerr.c:513-532) or the originals it keeps
+__global__ __launch_bounds__(256) void ec_new_n_kernel(uint64_t n_reads, const uint32_t *copy_n, const uint64_t *blk_off, const EcWork *work, const EcBlockOut *out, uint32_t *new_n)
+{
+    const uint64_t r = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    uint32_t s = copy_n[r];
+    for (uint64_t i = blk_off[r]; i < blk_off[r + 1]; ++i) {
+        if (out[i].status == EC_SUCCESS) {
+            const int32_t np = (int32_t) out[i].np;
+            s += work[i].r? (uint32_t) (np >= 1? np - 1 : 0) : (uint32_t) ((np >= 2? np - 2 : 0) + (work[i].end_utg == EC_NONE && np > 1? 1 : 0));
+        } else s += work[i].pad;
+    }
+    new_n[r] = s;
 }
 
 // stats[11] of read_error_correction (syncerr.c:502-504, :513-542) from the solved blocks; a small fixed grid strides over them and every
