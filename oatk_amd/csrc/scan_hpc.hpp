@@ -239,15 +239,17 @@ __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
             constexpr uint32_t EL = 0x43FF41FFu, EH = 0x47FF5554u;               // idx 1 'A', 3 'C', 4 'T', 5 'U', 7 'G'; 0xFF never matches
             const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
             uint32_t diff = 0, f = 0;
+            // (r04) the code of an ACGTU byte in either case is ((b >> 1) ^ (b >> 2)) & 3 -- A 0, C 1, G 2, T / U 3 --, and one product gathers the four codes of a word
+            // into its top byte: code i sits at bit 8 i and goes to bit 24 + 2 i, the other partial products land on bits of their own below or fall off the top
+            uint32_t pk[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const uint32_t sel = wds[q] & 0x07070707u;
-                uint32_t c = __builtin_amdgcn_perm(TH, TL, sel);
                 diff |= (wds[q] & 0xDFDFDFDFu) ^ __builtin_amdgcn_perm(EH, EL, sel);
-                c = (c | c >> 6) & 0x000F000Fu;                                   // four codes in four bytes -> four 2-bit fields
-                c = (c | c >> 12) & 0xFFu;
-                f |= c << (8 * q);
+                const uint32_t c = ((wds[q] >> 1) ^ (wds[q] >> 2)) & 0x03030303u;
+                pk[q] = c * 0x01041040u;
             }
+            f = __builtin_amdgcn_perm(__builtin_amdgcn_perm(pk[3], pk[2], 0x00000703u), __builtin_amdgcn_perm(pk[1], pk[0], 0x00000703u), 0x05040100u);      // the four top bytes, word 0's lowest
             uint32_t cu = 0;
             if (b0) {
                 const uint32_t sel = upb & 7u;
