@@ -606,6 +606,7 @@ static void zc_worker(void *arg, int tid, int n_threads)
     }
 }
 
+static double g_zc_t[4];          /* (log only) mapping, first touch + pointers, page-locking, unlocking: summed over the pieces of a call */
 static int fill_range_zero_copy(oatk_hip_ctx *ctx, zc_job_t *j, uint64_t n_reads, const void *d_rl, const void *d_hs, const void *d_mp, const void *d_sm, const void *d_kh,
                                 double *t_prep, double *t_wait)
 {
@@ -636,18 +637,20 @@ static int fill_range_zero_copy(oatk_hip_ctx *ctx, zc_job_t *j, uint64_t n_reads
         if (!rc) rc = oatk_hip_d2h_async(ctx, P->m_pos, (const uint32_t *) d_mp + j->scm_off[P->i0], P->ns * 4);
         if (!rc) rc = oatk_hip_d2h_async(ctx, P->s_mer, (const uint64_t *) d_sm + j->scm_off[P->i0], P->ns * 8);
         if (!rc) rc = oatk_hip_d2h_async(ctx, P->k_hash, (const uint64_t *) d_kh + j->scm_off[P->i0], P->ns * 8);
-        if (prev && prev_locked) (void) oatk_hip_host_unregister(ctx, prev->base);
+        { const double tu = host_now(); if (prev && prev_locked) (void) oatk_hip_host_unregister(ctx, prev->base); g_zc_t[3] += host_now() - tu; }
         prev = 0;
         /* while it is on the bus: the next piece's mapping is made, touched and locked, this piece's structs are set */
         p0 = P->i1, have_next = 0;
         if (!rc && p0 < n_reads) {
             NEXT_END(p0, p1);
+            const double tm = host_now();
             rc = zc_map(&pc[cur ^ 1], j, p0, p1);
+            g_zc_t[0] += host_now() - tm;
             have_next = !rc;
         }
         j->cur = P, j->next = have_next? &pc[cur ^ 1] : 0;
-        if (!rc) oatk_par_run(zc_worker, j);
-        if (have_next) locked[cur ^ 1] = oatk_hip_host_register(ctx, pc[cur ^ 1].base, pc[cur ^ 1].size) == OATK_OK;
+        { const double tt = host_now(); if (!rc) oatk_par_run(zc_worker, j); g_zc_t[1] += host_now() - tt; }
+        { const double tr = host_now(); if (have_next) locked[cur ^ 1] = oatk_hip_host_register(ctx, pc[cur ^ 1].base, pc[cur ^ 1].size) == OATK_OK; g_zc_t[2] += host_now() - tr; }
         *t_prep += host_now() - t0, t0 = host_now();
         {
             const int rs = oatk_hip_sync(ctx);                 /* the piece has landed */
@@ -789,6 +792,10 @@ int oatk_sr_db_fill_range(oatk_hip_ctx *ctx, oatk_sr_db_t *sr_db, uint64_t first
 done:
     free(hoco_l); free(n_nn); free(n_lrl); free(nn_key); free(lrl_val); free(scm_off); free(o_nn); free(o_lrl);
     if (heap_tune) { (void) mallopt(M_TOP_PAD, 128 * 1024); (void) mallopt(M_TRIM_THRESHOLD, 128 * 1024); }      /* glibc's defaults back: the host program's heap is its own again */
+    if (host_log() && g_use_arena && zc_wanted()) {
+        fprintf(stderr, "[M::%s] ... of the preparation: mapping %.4f, first touch + pointers %.4f, page-locking %.4f, unlocking %.4f s\n", __func__, g_zc_t[0], g_zc_t[1], g_zc_t[2], g_zc_t[3]);
+        g_zc_t[0] = g_zc_t[1] = g_zc_t[2] = g_zc_t[3] = 0;
+    }
     if (host_log()) fprintf(stderr, "[M::%s] %lu reads into sr_db_t: %.3f s on %d host threads (setup %.3f, %s %.3f beside %s %.3f, waiting for PCIe %.3f)\n",
                             __func__, (unsigned long) n_reads, host_now() - t_begin, oatk_host_threads(), t_setup, g_use_arena && zc_wanted()? "no host copy: block allocation" : "block allocation", job.t_alloc,
                             g_use_arena && zc_wanted()? "mapping + first touch + page-locking + pointers" : "copying", t_copy, t_wait);
