@@ -51,6 +51,10 @@ int oatk_hip_debug_ec_tiers(oatk_hip_ctx *ctx, int cap_t0, int cap_t1);
  * values 0..3 -- the alphabet of sr_t.hoco_s, which is all the correction ever aligns.  All pointers are HOST memory. */
 int oatk_hip_debug_wf_ed(oatk_hip_ctx *ctx, uint64_t n_jobs, const uint8_t *t_codes, const uint64_t *t_off, const uint8_t *q_codes, const uint64_t *q_off,
                          const int32_t *bw, const int32_t *step_ql, const uint64_t *step_off, int32_t *out3);
+/* The same jobs through the step of the workgroup solver (round 5: the blocks that are not small, one workgroup per block with the wavefront in
+ * registers, R = 1, 2 or 6 diagonals per lane).  A job needs 2 bw + 3 (no band: tl + ql + 3) <= 256 R diagonals; otherwise OATK_E_ARG. */
+int oatk_hip_debug_wf_ed_wg(oatk_hip_ctx *ctx, int R, uint64_t n_jobs, const uint8_t *t_codes, const uint64_t *t_off, const uint8_t *q_codes, const uint64_t *q_off,
+                            const int32_t *bw, const int32_t *step_ql, const uint64_t *step_off, int32_t *out3);
 
 /* Resident results of oatk_hip_ec (ids for oatk_hip_buffer):
  *   EC_N_SCM   u32[n_reads]      sr_t.n after correction
@@ -65,8 +69,8 @@ enum {
     OATK_BUF_EC_SCM_FWD,        /* u32[n_scm]  forward-strand occurrences per syncmer after correction (del = !fwd, syncerr.c:803-812) */
     OATK_BUF_EC_VTX_SRC,        /* u64[n_scm]  after oatk_hip_ec_mark: byte offset of the hoco string holding the vertex's k-mer, ~0 = none here */
     /* what the search cost, block by block (measurement aid; the layout may change): 12 u32 per error block -- beg_utg lo/hi, end_utg lo/hi, read,
-     * beg_pos, length l, r, then 4 words of launch data -- and 10 u32 per block -- status, path entries, path offset lo/hi, flags, short, arcs tried
-     * (DFS steps), dead ends counted (n_path, syncerr.c:147), wavefront steps, diagonals covered / 64 */
+     * beg_pos, length l, r, then 4 words of launch data -- and 12 u32 per block -- status, path entries, path offset lo/hi, flags, short, arcs tried
+     * (DFS steps), dead ends counted (n_path, syncerr.c:147), wavefront steps, diagonals covered / 64, time on the wave that finished it (10 ns units), kernel variant */
     OATK_BUF_EC_BLOCK_WORK, OATK_BUF_EC_BLOCK_OUT
 };
 

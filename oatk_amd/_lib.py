@@ -48,7 +48,7 @@ EXPORTS = [
     "oatk_hip_scan_begin", "oatk_hip_scan_reserve", "oatk_hip_scan_append", "oatk_hip_device", "oatk_hip_d2d",
     "oatk_hip_info", "oatk_hip_buffer", "oatk_hip_d2h", "oatk_hip_d2h_async", "oatk_hip_h2d_async", "oatk_hip_staging", "oatk_hip_ingest_text_buffer", "oatk_hip_set_timing", "oatk_hip_get_timing",
     "oatk_hip_debug_hash_mask", "oatk_hip_debug_force_general", "oatk_hip_debug_list_cap",
-    "oatk_hip_ec_graph", "oatk_hip_ec_graph_light", "oatk_hip_ec", "oatk_hip_ec_stats", "oatk_hip_debug_ec_tiers", "oatk_hip_debug_wf_ed", "oatk_hip_ec_mark", "oatk_hip_ec_correct",
+    "oatk_hip_ec_graph", "oatk_hip_ec_graph_light", "oatk_hip_ec", "oatk_hip_ec_stats", "oatk_hip_debug_ec_tiers", "oatk_hip_debug_wf_ed", "oatk_hip_debug_wf_ed_wg", "oatk_hip_ec_mark", "oatk_hip_ec_correct",
     "oatk_hip_ec_set_global", "oatk_hip_ec_pairs", "oatk_hip_ec_graph_from_pairs", "oatk_hip_ec_graph_from_segments", "oatk_hip_ec_export_kmers", "oatk_hip_ec_import_kmers",
     "oatk_hip_ec_reserve_import", "oatk_hip_consensus", "oatk_hip_consensus_ids", "oatk_hip_ingest", "oatk_hip_ingest_host", "oatk_hip_scan_ingested", "oatk_hip_stat", "oatk_hip_stat_keys", "oatk_hip_stat_from_keys",
     "oatk_hip_asm_graph", "oatk_hip_asm_pairs", "oatk_hip_asm_graph_from_pairs", "oatk_hip_overlap_hist", "oatk_hip_overlap_pairs", "oatk_hip_overlap_hist_from_pairs", "oatk_hip_read_alignment", "oatk_hip_debug_align_two_pass",
@@ -155,6 +155,8 @@ def load():
     L.oatk_hip_ec_stats.argtypes = [vp, vp]
     L.oatk_hip_debug_ec_tiers.argtypes = [vp, C.c_int, C.c_int]
     L.oatk_hip_debug_wf_ed.argtypes = [vp, C.c_uint64, vp, vp, vp, vp, vp, vp, vp, vp]
+    if hasattr(L, "oatk_hip_debug_wf_ed_wg"):      # (an experiments library built before round 5 lacks it)
+        L.oatk_hip_debug_wf_ed_wg.argtypes = [vp, C.c_int, C.c_uint64, vp, vp, vp, vp, vp, vp, vp, vp]
     if hasattr(L, "oatk_hip_debug_ed_ab"):      # tools/experiments/liboatk_hip_experiments.so only
         L.oatk_hip_debug_ed_ab.argtypes = [vp, C.c_int, C.c_uint64, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_float)]
     L.oatk_hip_ec_mark.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double]

@@ -172,6 +172,7 @@ struct EcBlockOut {
     uint32_t short_block;         // 1 = l < EC_MIN_ERR_SEQ_LEN (stats[10])
     uint32_t tried, n_path;       // the search's effort: arcs followed (DFS steps), dead ends counted (syncerr.c:147) -- OATK_BUF_EC_BLOCK_OUT
     uint32_t wf_steps, wf_diag;   // ... wavefront steps taken, and the diagonals they covered in all (>> 6: units of 64)
+    uint32_t ticks, tier;         // ... the time the wave that finished the block spent on it (s_memrealtime, 100 MHz), and the tier it ran in
 };
 
 // The arcs the search may follow: the graph's arc array with the deleted arcs squeezed out (same order), each carrying

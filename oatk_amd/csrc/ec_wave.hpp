@@ -788,7 +788,8 @@ __global__ __launch_bounds__(64 * WPB) void ec_wave_kernel(EcwArgs a)
             wk.hs16 = ecw_lane(m2.x, i), wk.lp = ecw_lane(m2.y, i), wk.ln = ecw_lane(m2.z, i), wk.pad = 0;
             if (ECW_RARE(wk.l > a.skip_l)) continue;
             EcBlockOut o;
-            o.status = EC_FAILURE, o.np = 0, o.path_off = 0, o.flags = 0, o.short_block = 0, o.tried = 0, o.n_path = 0, o.wf_steps = 0, o.wf_diag = 0;
+            o.status = EC_FAILURE, o.np = 0, o.path_off = 0, o.flags = 0, o.short_block = 0, o.tried = 0, o.n_path = 0, o.wf_steps = 0, o.wf_diag = 0, o.tier = (uint32_t) MODE;
+            const uint64_t tick0 = MODE != 0? __builtin_amdgcn_s_memrealtime() : 0;      // (the first tier does without: millions of small blocks)
             if (ECW_RARE(wk.l < EC_MIN_ERR_SEQ_LEN)) {
                 o.short_block = 1;                     // syncerr.c:502-504
             } else {
@@ -811,6 +812,7 @@ __global__ __launch_bounds__(64 * WPB) void ec_wave_kernel(EcwArgs a)
                     }
                 }
             }
+            o.ticks = MODE != 0? (uint32_t) (__builtin_amdgcn_s_memrealtime() - tick0) : 0u;
             if (lane == 0) a.out[wi] = o;
             ecw_sync();
             ECW_C(10, 1);                              // 10: blocks

@@ -54,6 +54,7 @@ struct oatk_gzsrc {
     uint64_t gen; int busy, quit;
     uint64_t next_blk;                       /* claimed with an atomic add */
     uint8_t *dst;
+    struct { struct oatk_gzsrc *g; uint64_t seen0; } targ[GZ_MAX_THREADS];     /* what a worker starts with: the generation that was current when it was created */
 };
 
 /* length of the gzip header at p (RFC 1952), or 0 if there is none / it is cut; *bsize = the BGZF block size if the member carries a BC field */
@@ -84,9 +85,12 @@ static uint32_t gzs_header(const uint8_t *p, uint64_t n, uint32_t *bsize)
 
 static void *gz_worker(void *arg)
 {
-    oatk_gzsrc_t *g = (oatk_gzsrc_t *) arg;
+    /* A worker created in a LATER call of bgzf_read (an earlier one had fewer blocks than threads, or pthread_create failed part of the way) must
+     * not take the generations that went before it for work it has not done: it would run a phantom round and count `busy` down once too often
+     * (the caller then hung, or went on before every block was inflated).  It starts from the generation current at its creation. */
+    oatk_gzsrc_t *g = ((oatk_gzsrc_t **) arg)[0];
     z_stream z;
-    uint64_t seen = 0;
+    uint64_t seen = ((uint64_t *) arg)[1];
     int live = 0;
     memset(&z, 0, sizeof(z));
     for (;;) {
@@ -209,7 +213,8 @@ static int64_t bgzf_read(oatk_gzsrc_t *g, uint8_t *dst, uint64_t cap)
     __atomic_store_n(&g->next_blk, 0, __ATOMIC_RELAXED);
     const int want = g->n_blk < (uint64_t) g->n_threads? (int) g->n_blk : g->n_threads;
     while (g->started < want) {
-        if (pthread_create(&g->th[g->started], 0, gz_worker, g) != 0) break;
+        g->targ[g->started].g = g, g->targ[g->started].seen0 = g->gen;       /* (gen is written by this thread only, under the mutex, below) */
+        if (pthread_create(&g->th[g->started], 0, gz_worker, &g->targ[g->started]) != 0) break;
         ++g->started;
     }
     if (g->started == 0) return -1;

@@ -171,8 +171,8 @@ class HipSyncasm:
         self._check(self.L.oatk_hip_ec_stats(self.h, st.ctypes.data), "oatk_hip_ec_stats")
         return st
 
-    def wf_ed(self, jobs):
-        """the device edit distance on its own (oatk_hip_debug_wf_ed): jobs = [(target, query, bw, [ql, ...]), ...] with target / query as
+    def wf_ed(self, jobs, wg=0):
+        """the device edit distance on its own (oatk_hip_debug_wf_ed; wg = 1, 2 or 6: through the step of the workgroup solver, oatk_hip_debug_wf_ed_wg): jobs = [(target, query, bw, [ql, ...]), ...] with target / query as
         bytes over ACGT (any case); returns, per job, the list of (score, t_end, q_end) after each query length -- what wf_ed_core
         (levdist.c:265-312, extension mode) leaves in a wf_config_t that is resumed with a longer and longer query"""
         code = np.full(256, 255, np.uint8)
@@ -189,8 +189,12 @@ class HipSyncasm:
         ql = np.array([x for j in jobs for x in j[3]], np.int32)
         out = np.zeros((len(ql), 3), np.int32)
         tc, qc = np.ascontiguousarray(tc), np.ascontiguousarray(qc)
-        self._check(self.L.oatk_hip_debug_wf_ed(self.h, len(jobs), tc.ctypes.data, t_off.ctypes.data, qc.ctypes.data, q_off.ctypes.data, bw.ctypes.data,
-                                                ql.ctypes.data, s_off.ctypes.data, out.ctypes.data), "oatk_hip_debug_wf_ed")
+        if wg:
+            self._check(self.L.oatk_hip_debug_wf_ed_wg(self.h, wg, len(jobs), tc.ctypes.data, t_off.ctypes.data, qc.ctypes.data, q_off.ctypes.data, bw.ctypes.data,
+                                                       ql.ctypes.data, s_off.ctypes.data, out.ctypes.data), "oatk_hip_debug_wf_ed_wg")
+        else:
+            self._check(self.L.oatk_hip_debug_wf_ed(self.h, len(jobs), tc.ctypes.data, t_off.ctypes.data, qc.ctypes.data, q_off.ctypes.data, bw.ctypes.data,
+                                                    ql.ctypes.data, s_off.ctypes.data, out.ctypes.data), "oatk_hip_debug_wf_ed")
         return [[tuple(int(v) for v in out[s]) for s in range(int(s_off[j]), int(s_off[j + 1]))] for j in range(len(jobs))]
 
     def ed_ab(self, pairs, myers):

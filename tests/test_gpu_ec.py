@@ -144,17 +144,21 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("graph", ["host", "device", "device-tiers", "device-tiers-serial", "device-rows4", "device-rows2"])
+@pytest.mark.parametrize("graph", ["host", "device", "device-tiers", "device-tiers-serial", "device-heavy", "device-heavy-mix", "device-heavy-spill"])
 @pytest.mark.parametrize("case", range(len(CASES)))
 def test_device_ec_matches_reference(hip, case, graph, monkeypatch):
     K, S, c, mk = CASES[case]
     reads = mk()
-    # tiny first tiers: most blocks run in the large-LDS tier and in the HBM-slab tier -- routed there by length and run beside the first tier,
-    # or (serial) found too long by each tier in turn
-    t0, t1 = (48, 160) if graph.startswith("device-tiers") else (0, 0)
+    # tiny first tier: most blocks run in the classes behind it -- routed there by length and run beside the first tier, or left over by it.
+    #   device-tiers[-serial]: the tiers of round 4 (one wave per block, larger LDS carve-ups, HBM slabs: OATK_DEBUG_EC_HEAVY=0)
+    #   device-heavy:          everything longer than 48 bases in the first class of the workgroup solver (ec_heavy.hpp, one diagonal per lane)
+    #   device-heavy-mix:      48 < l <= 160 in the first class, <= 400 in the second (two diagonals per lane), the rest in the third (six)
+    #   device-heavy-spill:    as device-heavy with an LDS frame arena of 64 bytes: every DFS frame goes to the HBM slab
+    t0, t1 = (48, 160) if graph.startswith("device-tiers") or graph == "device-heavy-mix" else ((48, 0) if graph.startswith("device-heavy") else (0, 0))
     monkeypatch.setenv("OATK_DEBUG_EC_SERIAL_TIERS", "1" if graph == "device-tiers-serial" else "0")
-    # the first tier with several blocks per wave, a row of 16 or 32 lanes each (ec_quad.hpp; measured, not the default: profiles/r03b_solver_ab.txt)
-    monkeypatch.setenv("OATK_DEBUG_EC_QUAD", {"device-rows4": "1", "device-rows2": "2"}.get(graph, "0"))
+    monkeypatch.setenv("OATK_DEBUG_EC_HEAVY", "0" if graph.startswith("device-tiers") else "1")
+    monkeypatch.setenv("OATK_DEBUG_EC_HEAVY_CAP2", "400" if graph == "device-heavy-mix" else "0")
+    monkeypatch.setenv("OATK_DEBUG_EC_HEAVY_FL", "64" if graph == "device-heavy-spill" else "0")
     hip._check(hip.L.oatk_hip_debug_ec_tiers(hip.h, t0, t1), "oatk_hip_debug_ec_tiers")
     db, scm = device_dbs(hip, reads, K, S)                  # reference-layout structs built from the device scan + count
     L = R.lib()
@@ -185,7 +189,7 @@ def test_device_ec_matches_reference(hip, case, graph, monkeypatch):
     assert total == summary["total"] and total > 0
     assert int(st[2] + st[7]) == summary["corrected"] and int(st[1] + st[6]) == summary["uncorrected"]
     assert int(st[3] + st[8]) == summary["ambiseq"] and int(st[4] + st[9]) == summary["ambipath"]   # the reference prints stats[3]+[8] under "ambiguous seqs"
-    if graph.startswith("device-tiers"):
+    if graph.startswith("device-tiers") or graph.startswith("device-heavy"):
         assert int(st[11]) > 0                               # blocks did fall through
         hip._check(hip.L.oatk_hip_debug_ec_tiers(hip.h, 0, 0), "oatk_hip_debug_ec_tiers")
     L.refx_scg_destroy(g)

@@ -40,26 +40,43 @@ def test_known_answer_of_the_reference(hip):
     assert hip.wf_ed([(ts, q2, -1, [len(q2)])]) == [[(8, 59, 56)]]
 
 
-def test_golden_pairs(hip):
+def fits(job, wg):
+    """does the job's wavefront fit the registers of the workgroup solver's variant (include/oatk_hip_ec.h: oatk_hip_debug_wf_ed_wg)?"""
+    ts, qs, bw, steps = job
+    return wg == 0 or (2 * bw + 3 if bw >= 0 else len(ts) + len(qs) + 3) <= 256 * wg
+
+
+WG = pytest.mark.parametrize("wg", [0, 1, 2, 6])          # 0: ecw_step (a wave per block); 1, 2, 6: ech_step, a workgroup per block with 1, 2, 6 diagonals per lane
+
+
+@WG
+def test_golden_pairs(hip, wg):
     g = G.load("levdist")
     jobs, want = [], []
     for ts, qs, bw, out in list(zip(g["pairs_t"], g["pairs_q"], g["pairs_bw"], g["pairs_out"]))[1:]:
         jobs.append((ts, qs, int(bw), [len(qs)]))
         want.append([tuple(int(v) for v in out)])
     assert len(jobs) == 600 and sum(1 for j, w in zip(jobs, want) if j[2] >= 0 and w[0][0] > j[2]) > 20      # band cut-offs are among them
-    got = hip.wf_ed(jobs)
+    keep = [i for i, j in enumerate(jobs) if fits(j, wg)]
+    assert len(keep) > 300
+    jobs, want = [jobs[i] for i in keep], [want[i] for i in keep]
+    got = hip.wf_ed(jobs, wg)
     for j, (a, b) in enumerate(zip(got, want)):
         assert a == b, (j, jobs[j], a, b)
 
 
-def test_golden_resumable_traces(hip):
+@WG
+def test_golden_resumable_traces(hip, wg):
     g = G.load("levdist")
     jobs, want = [], []
     for ts, qs, bw, steps in zip(g["tr_t"], g["tr_q"], g["tr_bw"], g["tr_steps"]):
         jobs.append((ts, qs, int(bw), [int(s[0]) for s in steps]))
         want.append([(int(s[1]), int(s[2]), int(s[3])) for s in steps])
     assert len(jobs) == 120 and sum(len(w) for w in want) > 300
-    got = hip.wf_ed(jobs)
+    keep = [i for i, j in enumerate(jobs) if fits(j, wg)]
+    assert len(keep) > 60
+    jobs, want = [jobs[i] for i in keep], [want[i] for i in keep]
+    got = hip.wf_ed(jobs, wg)
     for j, (a, b) in enumerate(zip(got, want)):
         assert a == b, (j, a, b)
 
@@ -79,7 +96,8 @@ def mutate(rng, ts, n_edits, alpha=b"ACGT"):
     return bytes(q) or b"A"
 
 
-def test_fresh_jobs_against_the_oracle(hip):
+@WG
+def test_fresh_jobs_against_the_oracle(hip, wg):
     rng = np.random.default_rng(265)
     jobs, want = [], []
     for it in range(400):
@@ -92,6 +110,13 @@ def test_fresh_jobs_against_the_oracle(hip):
         if it % 7 == 0:
             q = A.rand_dna(rng, int(rng.integers(1, 120)), alpha)                          # unrelated: every diagonal is alive, up to 200 of them
         bw = [-1, 2, 6, 12, 40, 100][it % 6]
+        if wg and it % 5 == 0:
+            bw = [126, 254, 300, 760][it % 4]                                              # the widest band each variant takes: 2 bw + 3 <= 256 R
+            tl = int(rng.integers(2000, 6000))
+            ts = A.rand_dna(rng, tl, alpha)
+            q = mutate(rng, ts, int(rng.integers(0, 2 * bw)), alpha) if it % 10 else A.rand_dna(rng, tl, alpha)   # (unrelated: the climb to the band's edge on wavefronts as wide as the band)
+        if not fits((ts, q, bw, None), wg):
+            continue
         steps, ql = [], 0
         w = O.Wavefront(ts, bw)
         res = []
@@ -103,7 +128,8 @@ def test_fresh_jobs_against_the_oracle(hip):
                 break
         w.close()
         jobs.append((ts, q, bw, steps)), want.append(res)
-    got = hip.wf_ed(jobs)
+    assert len(jobs) > 150
+    got = hip.wf_ed(jobs, wg)
     n_wide = 0
     for j, (a, b) in enumerate(zip(got, want)):
         assert a == b, (j, jobs[j][2], jobs[j][3], a, b)

@@ -109,3 +109,35 @@ def test_damage_is_reported(H, files, tmp_path):
         open(cut, "wb").write(open(paths[name], "rb").read()[:-100])
         got, status, _, _ = slurp(H, cut, 1 << 20)
         assert status == -1 or (name == "bgzf" and got != text), name       # (a BGZF file cut at a member boundary simply ends early: bgzip's end marker is what tells)
+
+
+def _bgzf_blocks(data, block=20_000):
+    """`data` as BGZF members (RFC 1952 with the BC extra field, SAM spec 4.1), no end marker"""
+    import struct
+    import zlib
+    out = bytearray()
+    for a in range(0, len(data), block):
+        piece = data[a:a + block]
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = co.compress(piece) + co.flush()
+        bsize = 12 + 6 + len(body) + 8
+        out += b"\x1f\x8b\x08\x04" + b"\0" * 4 + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1) + body
+        out += struct.pack("<II", zlib.crc32(piece) & 0xFFFFFFFF, len(piece))
+    return bytes(out)
+
+
+def test_workers_created_in_a_later_round_do_not_run_a_phantom_one(H, tmp_path):
+    """three BGZF blocks (three workers start), a plain member, then three hundred blocks (the pool grows in a later call): a worker created
+    late began at generation 0, ran a round nobody had started and counted `busy` down once too often -- the reader hung or returned half-filled text."""
+    rng = np.random.default_rng(5)
+    def text(n):
+        return bytes(rng.choice(np.frombuffer(b"ACGT\n", np.uint8), n))
+    a, b, c = text(3 * 20_000), text(50_000), text(300 * 20_000)
+    p = str(tmp_path / "few_plain_many.gz")
+    open(p, "wb").write(_bgzf_blocks(a) + gzip.compress(b) + _bgzf_blocks(c))
+    for rep in range(40):
+        got, status, _, _ = slurp(H, p, 1 << 24, threads=32)
+        assert status == 0 and got == a + b + c, rep
+    for cap in (70_000, 1 << 20):                                        # and with windows that cut the runs of blocks into many calls
+        got, status, _, _ = slurp(H, p, cap, threads=16)
+        assert status == 0 and got == a + b + c, cap

@@ -20,7 +20,7 @@ hip = HipSyncasm(0); hip.set_timing(True)
 hip.scan_host(seq, off, lens, K, S); hip.count(); hip.ec_graph(light_c=c)
 t0 = time.perf_counter(); st = hip.ec(0.02, c, 0.35); hip.sync(); dt = time.perf_counter() - t0
 tm = hip.timing()
-w = hip.fetch("EC_BLOCK_WORK").reshape(-1, 12); o = hip.fetch("EC_BLOCK_OUT").reshape(-1, 10)
+w = hip.fetch("EC_BLOCK_WORK").reshape(-1, 12); o = hip.fetch("EC_BLOCK_OUT").reshape(-1, 12)
 tried, npath, status, l, r = o[:, 6].astype(np.int64), o[:, 7].astype(np.int64), o[:, 0], w[:, 6].astype(np.int64), w[:, 7]
 end_none = (w[:, 2] == 0xFFFFFFFF) & (w[:, 3] == 0xFFFFFFFF)
 print("%s, %d reads: ec %.1f ms (mark %.1f solve %.1f refresh %.1f); %d blocks, %d DFS steps in all" % (wl, n, dt * 1e3, tm["ec_mark"], tm["ec_solve"], tm["ec_refresh"], len(o), tried.sum()))
@@ -30,8 +30,10 @@ for lo, hi in ((0, 1), (1, 4), (4, 16), (16, 64), (64, 256), (256, 1024), (1024,
         print("  steps [%6d, %6s): %8d blocks, %12d steps (%.1f %%), mean length %6.0f, dead ends %d" % (lo, hi if hi < 1 << 40 else "inf", m.sum(), tried[m].sum(), 100.0 * tried[m].sum() / max(tried.sum(), 1), l[m].mean(), npath[m].sum()))
 wfs, wfd = o[:, 8].astype(np.int64), o[:, 9].astype(np.int64) * 64
 print("wavefront steps %d, diagonal extensions %d in all" % (wfs.sum(), wfd.sum()))
-for name, key in (("DFS steps", tried), ("diagonal extensions", wfd)):
+tk, tier = o[:, 10].astype(np.int64), o[:, 11]
+print("time on the waves: %.1f ms in all, longest block %.2f ms; by kernel variant: %s" % (tk.sum() * 1e-5, tk.max() * 1e-5, {int(t): "%d blocks %.1f ms" % ((tier == t).sum(), tk[tier == t].sum() * 1e-5) for t in np.unique(tier)}))
+for name, key in (("DFS steps", tried), ("diagonal extensions", wfd), ("time", tk)):
     print("heaviest by %s:" % name)
     for i in np.argsort(-key)[:10]:
-        print("  block %8d: read %7d len %6d %s arcs %7d dead ends %6d wavefront steps %8d diagonals %10d status %d path %d" % (
-              i, w[i, 4], l[i], "leading" if r[i] else ("trailing" if end_none[i] else "middle"), tried[i], npath[i], wfs[i], wfd[i], status[i], o[i, 1]))
+        print("  block %8d: read %7d len %6d %s arcs %7d dead ends %6d wavefront steps %8d diagonals %10d status %d path %d  %.2f ms (variant %d): %.0f ns per step" % (
+              i, w[i, 4], l[i], "leading" if r[i] else ("trailing" if end_none[i] else "middle"), tried[i], npath[i], wfs[i], wfd[i], status[i], o[i, 1], tk[i] * 1e-5, tier[i], tk[i] * 10.0 / max(wfs[i], 1)))
