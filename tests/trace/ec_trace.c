@@ -25,6 +25,7 @@ typedef struct {
     uint64_t post_cap_arcs;       /* arcs tried after the dead-end counter hit its cap */
     uint64_t depth_at_dead_sum;
     uint64_t ret_dist_sum, ret_cnt;    /* after a dead end: how many levels up is the next arc taken */
+    uint64_t sub_steps[8], sub_cnt[8];                 /* at levels with several live arcs: wavefront steps in the subtree below the i-th live arc (7: seventh and later) */
     uint64_t cat_arcs[6], cat_steps[6], cat_diag[6];   /* alive first / alive sibling / dead-by-score first / dead-by-score sibling / dead-otherwise first / sibling */
 } ctr_t;
 
@@ -178,6 +179,7 @@ static void dfs(S *s, uint64_t source, int depth)
             s->n_path++, s->c->dead++, s->c->depth_at_dead_sum += (uint64_t) depth;
             s->last_dead_depth = depth;
         }
+        if (live > 1) { const int li = live_seen - 1 < 7? live_seen - 1 : 7; s->c->sub_steps[li] += s->c->steps - st_before, s->c->sub_cnt[li]++; }
         s->cl = l0, s->chash = h0;
         s->n = n0, s->d0 = d00, s->score = sc0, s->t_end = te0, s->q_end = qe0;
         wf_need(s, n0 + 4);
@@ -263,6 +265,8 @@ uint64_t ect_trace(const orc_graph_t *g, const uint8_t *scm_del, int K, double m
                         fprintf(fo, " cat_arcs"); for (i = 0; i < 6; ++i) fprintf(fo, " %llu", (unsigned long long) c.cat_arcs[i]);
                         fprintf(fo, " cat_steps"); for (i = 0; i < 6; ++i) fprintf(fo, " %llu", (unsigned long long) c.cat_steps[i]);
                         fprintf(fo, " cat_diag"); for (i = 0; i < 6; ++i) fprintf(fo, " %llu", (unsigned long long) c.cat_diag[i]);
+                        fprintf(fo, " sub_steps"); for (i = 0; i < 8; ++i) fprintf(fo, " %llu", (unsigned long long) c.sub_steps[i]);
+                        fprintf(fo, " sub_cnt"); for (i = 0; i < 8; ++i) fprintf(fo, " %llu", (unsigned long long) c.sub_cnt[i]);
                         fprintf(fo, "\n");
                         fflush(fo);
                     }

@@ -30,10 +30,11 @@ for lo, hi in ((0, 1), (1, 4), (4, 16), (16, 64), (64, 256), (256, 1024), (1024,
         print("  steps [%6d, %6s): %8d blocks, %12d steps (%.1f %%), mean length %6.0f, dead ends %d" % (lo, hi if hi < 1 << 40 else "inf", m.sum(), tried[m].sum(), 100.0 * tried[m].sum() / max(tried.sum(), 1), l[m].mean(), npath[m].sum()))
 wfs, wfd = o[:, 8].astype(np.int64), o[:, 9].astype(np.int64) * 64
 print("wavefront steps %d, diagonal extensions %d in all" % (wfs.sum(), wfd.sum()))
-tk, tier = o[:, 10].astype(np.int64), o[:, 11]
+tk, tier, steals = o[:, 10].astype(np.int64), o[:, 11] & 0xFF, (o[:, 11] >> 8).astype(np.int64)      # (the tree solver leaves the number of sub-tasks thieves ran above its tier)
+print("sub-tasks run by thieves (tree solver): %d in %d blocks" % (steals.sum(), (steals > 0).sum()))
 print("time on the waves: %.1f ms in all, longest block %.2f ms; by kernel variant: %s" % (tk.sum() * 1e-5, tk.max() * 1e-5, {int(t): "%d blocks %.1f ms" % ((tier == t).sum(), tk[tier == t].sum() * 1e-5) for t in np.unique(tier)}))
 for name, key in (("DFS steps", tried), ("diagonal extensions", wfd), ("time", tk)):
     print("heaviest by %s:" % name)
     for i in np.argsort(-key)[:10]:
-        print("  block %8d: read %7d len %6d %s arcs %7d dead ends %6d wavefront steps %8d diagonals %10d status %d path %d  %.2f ms (variant %d): %.0f ns per step" % (
-              i, w[i, 4], l[i], "leading" if r[i] else ("trailing" if end_none[i] else "middle"), tried[i], npath[i], wfs[i], wfd[i], status[i], o[i, 1], tk[i] * 1e-5, tier[i], tk[i] * 10.0 / max(wfs[i], 1)))
+        print("  block %8d: read %7d len %6d %s arcs %7d dead ends %6d wavefront steps %8d diagonals %10d status %d path %d  %.2f ms (variant %d, %d sub-tasks): %.0f ns per step" % (
+              i, w[i, 4], l[i], "leading" if r[i] else ("trailing" if end_none[i] else "middle"), tried[i], npath[i], wfs[i], wfd[i], status[i], o[i, 1], tk[i] * 1e-5, tier[i], steals[i], tk[i] * 10.0 / max(wfs[i], 1)))
