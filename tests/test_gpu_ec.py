@@ -144,7 +144,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("graph", ["host", "device", "device-tiers", "device-tiers-serial", "device-heavy", "device-heavy-mix", "device-heavy-spill", "device-tree", "device-tree-smalllog"])
+@pytest.mark.parametrize("graph", ["host", "device", "device-tiers", "device-tiers-serial", "device-heavy", "device-heavy-mix", "device-heavy-spill", "device-tree", "device-tree-smalllog", "device-fused", "device-fused-spill"])
 @pytest.mark.parametrize("case", range(len(CASES)))
 def test_device_ec_matches_reference(hip, case, graph, monkeypatch):
     K, S, c, mk = CASES[case]
@@ -156,13 +156,14 @@ def test_device_ec_matches_reference(hip, case, graph, monkeypatch):
     #   device-heavy-spill:    as device-heavy with an LDS frame arena of 64 bytes: every DFS frame goes to the HBM slab
     #   device-tree:           everything longer than 48 bases in the tree solver (ec_tree.hpp: eight waves share a block's search tree; device-heavy-mix has it as its first class too)
     #   device-tree-smalllog:  ... with a log arena of 512 bytes per wave: sub-tasks give their arcs back, the owners run them
-    t0, t1 = (48, 160) if graph.startswith("device-tiers") or graph == "device-heavy-mix" else ((48, 0) if graph.startswith("device-heavy") or graph.startswith("device-tree") else (0, 0))
-    monkeypatch.setenv("OATK_DEBUG_EC_TREE", "0" if graph in ("device-heavy", "device-heavy-spill") else "1")
+    t0, t1 = (48, 160) if graph.startswith("device-tiers") or graph == "device-heavy-mix" else ((48, 0) if graph.startswith("device-heavy") or graph.startswith("device-tree") or graph.startswith("device-fused") else (0, 0))
+    monkeypatch.setenv("OATK_DEBUG_EC_TREE", "1" if graph.startswith("device-tree") else "0")
+    monkeypatch.setenv("OATK_DEBUG_EC_FUSED", "0" if graph in ("device-heavy", "device-heavy-spill") else "1")      # (device-heavy-mix: ec_fused.hpp is the first class; the default road too)
     monkeypatch.setenv("OATK_DEBUG_EC_TREE_LOG", "512" if graph == "device-tree-smalllog" else "0")
     monkeypatch.setenv("OATK_DEBUG_EC_SERIAL_TIERS", "1" if graph == "device-tiers-serial" else "0")
     monkeypatch.setenv("OATK_DEBUG_EC_HEAVY", "0" if graph.startswith("device-tiers") else "1")
     monkeypatch.setenv("OATK_DEBUG_EC_HEAVY_CAP2", "400" if graph == "device-heavy-mix" else "0")
-    monkeypatch.setenv("OATK_DEBUG_EC_HEAVY_FL", "64" if graph == "device-heavy-spill" else "0")
+    monkeypatch.setenv("OATK_DEBUG_EC_HEAVY_FL", "64" if graph in ("device-heavy-spill", "device-fused-spill") else "0")
     hip._check(hip.L.oatk_hip_debug_ec_tiers(hip.h, t0, t1), "oatk_hip_debug_ec_tiers")
     db, scm = device_dbs(hip, reads, K, S)                  # reference-layout structs built from the device scan + count
     L = R.lib()
@@ -193,7 +194,7 @@ def test_device_ec_matches_reference(hip, case, graph, monkeypatch):
     assert total == summary["total"] and total > 0
     assert int(st[2] + st[7]) == summary["corrected"] and int(st[1] + st[6]) == summary["uncorrected"]
     assert int(st[3] + st[8]) == summary["ambiseq"] and int(st[4] + st[9]) == summary["ambipath"]   # the reference prints stats[3]+[8] under "ambiguous seqs"
-    if graph.startswith("device-tiers") or graph.startswith("device-heavy") or graph.startswith("device-tree"):
+    if graph.startswith("device-tiers") or graph.startswith("device-heavy") or graph.startswith("device-tree") or graph.startswith("device-fused"):
         assert int(st[11]) > 0                               # blocks did fall through
         hip._check(hip.L.oatk_hip_debug_ec_tiers(hip.h, 0, 0), "oatk_hip_debug_ec_tiers")
     L.refx_scg_destroy(g)

@@ -43,10 +43,10 @@ def test_known_answer_of_the_reference(hip):
 def fits(job, wg):
     """does the job's wavefront fit the registers of the workgroup solver's variant (include/oatk_hip_ec.h: oatk_hip_debug_wf_ed_wg)?"""
     ts, qs, bw, steps = job
-    return wg == 0 or (2 * bw + 3 if bw >= 0 else len(ts) + len(qs) + 3) <= (512 if wg == 8 else 256 * wg)
+    return wg == 0 or (2 * bw + 3 if bw >= 0 else len(ts) + len(qs) + 3) <= (512 if wg == 8 else 896 if wg == 16 else 256 * wg)
 
 
-WG = pytest.mark.parametrize("wg", [0, 1, 2, 6, 8])       # 0: ecw_step (a wave per block); 1, 2, 6: ech_step, a workgroup per block with 1, 2, 6 diagonals per lane; 8: ect_step (the tree solver: ONE wave, 8 diagonals per lane)
+WG = pytest.mark.parametrize("wg", [0, 1, 2, 6, 8, 16])       # 0: ecw_step (a wave per block); 1, 2, 6: ech_step, a workgroup per block with 1, 2, 6 diagonals per lane; 8: ect_step (the tree solver: ONE wave, 8 diagonals per lane); 16: ecf_align (sixteen waves, four steps per barrier)
 
 
 @WG
@@ -111,7 +111,7 @@ def test_fresh_jobs_against_the_oracle(hip, wg):
             q = A.rand_dna(rng, int(rng.integers(1, 120)), alpha)                          # unrelated: every diagonal is alive, up to 200 of them
         bw = [-1, 2, 6, 12, 40, 100][it % 6]
         if wg and it % 5 == 0:
-            bw = [126, 254, 300, 760][it % 4]                                              # the widest band each variant takes: 2 bw + 3 <= 256 R
+            bw = [126, 254, 300, 760, 446][it % 5 if wg == 16 else it % 4]                                              # the widest band each variant takes: 2 bw + 3 <= 256 R
             tl = int(rng.integers(2000, 6000))
             ts = A.rand_dna(rng, tl, alpha)
             q = mutate(rng, ts, int(rng.integers(0, 2 * bw)), alpha) if it % 10 else A.rand_dna(rng, tl, alpha)   # (unrelated: the climb to the band's edge on wavefronts as wide as the band)

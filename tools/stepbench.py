@@ -24,8 +24,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
             for _ in range(n_jobs):
                 t, q = mk()
                 jobs.append((t, q, bw, [len(q)]))
-            for wg in (0, 1, 2, 6, 8):
-                if wg and 2 * bw + 3 > (512 if wg == 8 else 256 * wg): continue
+            for wg in (0, 1, 2, 6, 8, 16):
+                if wg and 2 * bw + 3 > (512 if wg == 8 else 896 if wg == 16 else 256 * wg): continue
                 hip.wf_ed(jobs[:8], wg)
                 sys.stderr.write("[case] %s | %d jobs | variant %d\n" % (name, n_jobs, wg)); sys.stderr.flush()
                 res = hip.wf_ed(jobs, wg)
