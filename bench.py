@@ -72,6 +72,7 @@ def parse_args():
     ap.add_argument("--cli-reads", type=int, default=2000000, help="reads of the CLI comparison (BASELINE.json quotes the north-star target at 2 M reads; the reference binary takes ~5 min there)")
     ap.add_argument("--cli-threads", type=int, default=32, help="-t of both binaries in the CLI comparison")
     ap.add_argument("--config1s-reads", type=int, default=200000, help="reads of the config-1 surrogate's resident step (0: leave the `config1s` object out)")
+    ap.add_argument("--config1s-cpu-reads", type=int, default=40000, help="reads of the config-1 surrogate the compiled reference's read_error_correction is timed on (its `cpu_baseline`)")
     ap.add_argument("--config1s-cli-reads", type=int, default=100000, help="reads of its CLI comparison from the .fa.gz (0: none)")
     ap.add_argument("--cpu-sample-reads", type=int, default=80000)
     ap.add_argument("--cpu-threads", type=int, default=8)
@@ -165,6 +166,65 @@ def pmc_traffic(kernel_name, workload, per_gpu):
         if row and row[0].startswith(kernel_name):
             return int((2.0 * float(row[1]) + float(row[2])) * 1024), os.path.basename(files[-1])
     return None, None
+
+
+def config1s_cpu_baseline(hip, sq, of, ln, n, K, S, c):
+    """config1s.cpu_baseline: the compiled reference's read_error_correction (syncerr.c:759-866) on the first n reads of the surrogate at -t 8 and at every core of this
+    host, beside the device's on the same reads.  The structs the reference works on are filled from the device scan and count (liboatk_host.so; the reference's own scan of
+    n reads would take minutes and is not what is compared); its own make_syncmer_graph and consensus build the graph it corrects on."""
+    import ctypes as C
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    try:
+        import ref_lib as R
+        from oatk_amd import _lib
+        if not R.available():
+            return {"skipped": "oracle/_ref is built only where the reference's sources are"}
+        H, L = C.CDLL(_lib.HOST_LIB_PATH), R.lib()
+        vp = C.c_void_p
+        H.oatk_sr_db_new.restype = vp; H.oatk_sr_db_new.argtypes = [C.c_int, C.c_int]
+        H.oatk_sr_read_packed.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, C.c_uint64, vp]
+        H.oatk_collect_syncmer_from_reads.restype = vp; H.oatk_collect_syncmer_from_reads.argtypes = [vp, vp, C.POINTER(C.c_int)]
+        L.refx_make_graph.restype = vp; L.refx_make_graph.argtypes = [vp, vp, C.c_int, C.c_double]
+        L.refx_consensus.argtypes = [vp, vp, C.c_int, C.c_int]
+        L.refx_ec.argtypes = [vp, vp, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int]
+        off_n, len_n = np.ascontiguousarray(of[:n]), np.ascontiguousarray(ln[:n])
+        nb = int(off_n[-1] + len_n[-1]) if n else 0
+        cores = os.cpu_count() or 8
+        out = {"kind": "reference", "sample": "the first %d reads (%.2f Gbases): read_error_correction alone, graph built by the reference, scan and count by the device" % (n, int(len_n.sum()) / 1e9),
+               "unit": "s", "threads": {}}
+        saved = os.dup(2)
+        for th in sorted({8, cores}):
+            db = H.oatk_sr_db_new(K, S)
+            if H.oatk_sr_read_packed(hip.h, db, sq.ctypes.data, off_n.ctypes.data, len_n.ctypes.data, n, nb, None):
+                return {"error": "oatk_sr_read_packed failed: %s" % hip.L.oatk_hip_last_error(hip.h)}
+            rcc = C.c_int(0)
+            scm = H.oatk_collect_syncmer_from_reads(hip.h, db, C.byref(rcc))
+            if rcc.value or not scm:
+                return {"error": "oatk_collect_syncmer_from_reads failed"}
+            g = L.refx_make_graph(db, scm, 0, 0.0)
+            L.refx_consensus(db, g, 1, 1)
+            devnull = os.open(os.devnull, os.O_WRONLY)
+            os.dup2(devnull, 2)
+            try:
+                t0 = time.perf_counter()
+                L.refx_ec(db, g, 0.02, c, c * 10, c, 0.35, th)
+                dt = time.perf_counter() - t0
+            finally:
+                os.dup2(saved, 2); os.close(devnull)
+            out["threads"][str(th)] = round(dt, 2)
+            L.refx_scg_destroy(g); L.refx_scmdb_destroy(scm); L.refx_srdb_destroy(db)
+        os.close(saved)
+        # the device on the same reads: mark + solve + refresh, the graph (light) built on the device
+        hip.scan_host(sq, off_n, len_n, K, S); hip.count(); hip.ec_graph(light_c=c)
+        hip.sync(); t0 = time.perf_counter(); hip.ec(0.02, c, 0.35); hip.sync()
+        out["device_ec_s"] = round(time.perf_counter() - t0, 4)
+        out["value"] = out["threads"]["8"]; out["cores"] = 8
+        out["device_over_reference_t8"] = round(out["threads"]["8"] / max(out["device_ec_s"], 1e-9), 1)
+        out["device_over_reference_all_cores"] = round(out["threads"][str(cores)] / max(out["device_ec_s"], 1e-9), 1)
+        return out
+    except Exception as ex:      # noqa: BLE001
+        return {"error": "%s: %s" % (type(ex).__name__, ex)}
 
 
 def main():
@@ -565,6 +625,8 @@ def main():
                                       "syncmer_syncerr": {"value": round(b1 / d1s / 1e9, 3), "unit": "Gbases/s", "ms_per_step": round(d1s * 1e3, 3)},
                                       "phases_ms": ph1, "error_blocks": int(s1[0] + s1[5] + s1[10]), "syncmers": {"occurrences": int(inf1["n_occ"]), "distinct": int(inf1["n_scm"])}}
                 del t_sq, t_of, t_ln
+                if not args.no_cpu_baseline:
+                    extras["config1s"]["cpu_baseline"] = config1s_cpu_baseline(hip, sq, of, ln, min(args.config1s_cpu_reads, n1), K, S, cc1)
                 if args.config1s_cli_reads and not args.no_cpu_baseline:
                     sys.path.insert(0, os.path.join(ROOT, "tests"))
                     import cli_util

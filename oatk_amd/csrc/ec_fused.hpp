@@ -160,10 +160,57 @@ __device__ void ecf_align(const EcfShared &sh, int32_t tl, int32_t ql, int32_t b
         par ^= 1u;
         return first;
     };
+    // one step the careful way, from a state whose halos are fresh (every lane's entry is right, so every lane's run down its diagonal is): the lowest slot of all that
+    // reached an end decides (levdist.c:166-180); without one the waves' next entries cross in the same meeting.  One barrier.
+    auto careful_step = [&]() -> bool {
+        int32_t s_lo1 = s_lo, n1 = n;
+        const EcfLane o = ecf_lane_step<NW>(ts, qs, tl, ql, bw, OFF, s, d, lim, k, s_lo1, n1, 0);
+        int32_t first_slot = ECH_INF, first_k = 0;
+        const uint64_t rb = __ballot(o.reached && owned);
+        if (rb) { const int fl = __builtin_ctzll(rb); first_slot = wave * ECF_OWN - ECF_S + fl, first_k = (int32_t) ecw_lane((uint32_t) o.kn, fl); }
+        int32_t *red = sh.red + par * (NW * 2), *bnd = sh.bnd + par * (NW * 2 * ECF_S);
+        if (lane == 0) red[wave * 2] = first_slot, red[wave * 2 + 1] = first_k;
+        if (lane >= ECF_S && lane < 2 * ECF_S) bnd[wave * 2 * ECF_S + (lane - ECF_S)] = o.knext;
+        if (lane >= 64 - 2 * ECF_S && lane < 64 - ECF_S) bnd[wave * 2 * ECF_S + ECF_S + (lane - (64 - 2 * ECF_S))] = o.knext;
+        __syncthreads();
+        {
+            const int32_t fs = lane < NW? red[lane * 2] : ECH_INF;
+            uint64_t eb = __ballot(fs != ECH_INF);
+            while (eb) {
+                const int l = __builtin_ctzll(eb);
+                eb &= eb - 1;
+                const int32_t v = (int32_t) ecw_lane((uint32_t) fs, l);
+                if (v < first_slot) first_slot = v, first_k = ecw_uni(red[l * 2 + 1]);
+            }
+        }
+        par ^= 1u;
+        if (first_slot != ECH_INF) {
+            if (o.act && s < first_slot) k = o.kn;     // only the diagonals below it are stored; the wavefront stays the one the step began with
+            t_end = first_k, q_end = first_k + (first_slot - OFF);
+            return true;
+        }
+        k = o.knext;
+        if (lane < ECF_S) k = wave > 0? bnd[(wave - 1) * 2 * ECF_S + ECF_S + lane] : ECH_NEG;
+        if (lane >= 64 - ECF_S) k = wave < NW - 1? bnd[(wave + 1) * 2 * ECF_S + (lane - (64 - ECF_S))] : ECH_NEG;
+        s_lo = s_lo1, n = n1;
+        return false;
+    };
     t_end = q_end = -1;
+    // (most alignments of a search end within a step or two -- the path that follows the read: a run of four steps and the way back would triple their cost.  Runs begin
+    //  with one step and double while no end is met; the alignments that matter here are a hundred steps long)
+    int grow = 1;
     for (;;) {
         const int32_t left = bw - score + 1;           // steps before `score > bw` (bw < 0: no band, wf_ed in the tests)
-        const int L = bw < 0 || left > ECF_S? ECF_S : left;
+        int L = bw < 0 || left > ECF_S? ECF_S : left;
+        L = L < grow? L : grow;
+        grow = grow < ECF_S? grow * 2 : ECF_S;
+        if (L == 1) {
+            ++wf_steps, wf_diag += (uint64_t) n;
+            if (careful_step()) return;
+            ++score;
+            if (bw >= 0 && score > bw) return;
+            continue;
+        }
         const int32_t k0 = k, s_lo0 = s_lo, n0 = n;
         int32_t note = ECH_INF;
 #ifdef ECF_PROF
@@ -190,6 +237,7 @@ __device__ void ecf_align(const EcfShared &sh, int32_t tl, int32_t ql, int32_t b
         }
         // a step of this run reached an end: back, the steps before it once more, and that one with the lowest slot of all
         k = k0, s_lo = s_lo0, n = n0;
+        if (first == 0) { ++wf_steps, wf_diag += (uint64_t) n0; (void) careful_step(); return; }
         for (int i = 0; i < first; ++i) {
             const EcfLane o = ecf_lane_step<NW>(ts, qs, tl, ql, bw, OFF, s, d, lim, k, s_lo, n, i);
             k = o.knext;

@@ -61,6 +61,7 @@ struct EchShared {
     uint32_t *os;
     uint64_t *c_path, *o_path;
     int32_t cap_t, cap_c, cap_path, cap_fl, cap_fh;
+    int32_t step_budget;          // wavefront steps after which a block is given up here (0: never): it starts again where several steps share a barrier (ec_fused.hpp)
 };
 
 // One wavefront step (levdist.c:156-224, extension mode, no traceback) over the registers k[R]; returns 1 when an end was reached.
@@ -418,6 +419,7 @@ __device__ bool ech_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
             ++score;
             if (ECW_RARE(score > bw)) break;
         }
+        if (ECW_RARE(sh.step_budget > 0 && wf_steps > (uint32_t) sh.step_budget)) return false;
         t_end += 1, q_end += 1;
         const int32_t ql = c_len;
         const int32_t sc = score + tl - t_end;        // syncerr.c:209
@@ -488,6 +490,7 @@ __global__ __launch_bounds__(64 * NW) void ec_heavy_kernel(EcwArgs a)
     const int t = (int) threadIdx.x;
     EchShared sh;
     sh.cap_t = a.cap_t, sh.cap_c = a.cap_c, sh.cap_path = a.cap_path, sh.cap_fl = a.cap_f, sh.cap_fh = (int32_t) a.os_words;
+    sh.step_budget = a.cap_w;
     sh.red = (int32_t *) ech_lds, sh.edge = sh.red + 2 * NW * 2, sh.any = sh.edge + 2 * R * NW * 2, sh.bc = sh.any + 2 * NW;
     sh.ts = ech_lds + ech_misc_words(R), sh.cs = sh.ts + ecw_words(a.cap_t);
     uint32_t *p = sh.cs + ecw_words(a.cap_c);

@@ -664,6 +664,19 @@ struct EcRoute {
 // (r03: one global atomic per WORKGROUP and tier.  With one per wave and tier -- ~250 k atomics on three addresses at config 3 -- the kernel took 1.4 ms for a
 //  pass over 7.9 M lengths; the lists are work queues, so their order is free.)
 #define ECW_ROUTE_ITEMS 8          // work items per thread
+// a class's blocks, longest first: the longest search of a batch should not be the last one to start (keys for a radix sort: ~length)
+__global__ void ec_route_keys_kernel(const EcWork *work, const uint32_t *list, uint64_t n, uint32_t *keys)
+{
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = ~(uint32_t) work[list[i]].l;
+}
+// ... and how many of them are longer than `cap` (in a list sorted longest first: the head of the list)
+__global__ void ec_route_longer_kernel(const EcWork *work, const uint32_t *list, uint64_t n, int32_t cap, unsigned long long *cnt)
+{
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t b = __ballot(i < n && work[list[i]].l > cap);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(cnt, (unsigned long long) __builtin_popcountll(b));
+}
 __global__ __launch_bounds__(256) void ec_route_kernel(const EcWork *work, uint64_t n_work, EcRoute rt)
 {
     __shared__ uint32_t cnt[4], base_lo[4], base_hi[4];

@@ -158,7 +158,10 @@ def test_device_ec_matches_reference(hip, case, graph, monkeypatch):
     #   device-tree-smalllog:  ... with a log arena of 512 bytes per wave: sub-tasks give their arcs back, the owners run them
     t0, t1 = (48, 160) if graph.startswith("device-tiers") or graph == "device-heavy-mix" else ((48, 0) if graph.startswith("device-heavy") or graph.startswith("device-tree") or graph.startswith("device-fused") else (0, 0))
     monkeypatch.setenv("OATK_DEBUG_EC_TREE", "1" if graph.startswith("device-tree") else "0")
-    monkeypatch.setenv("OATK_DEBUG_EC_FUSED", "0" if graph in ("device-heavy", "device-heavy-spill") else "1")      # (device-heavy-mix: ec_fused.hpp is the first class; the default road too)
+    monkeypatch.setenv("OATK_DEBUG_EC_FUSED", "0" if graph in ("device-heavy", "device-heavy-spill") else "1")
+    # device-fused: every block that takes more than one wavefront step goes past its budget and starts again in ec_fused.hpp (several steps per barrier); device-heavy-mix:
+    # more than eight; by default three thousand
+    monkeypatch.setenv("OATK_DEBUG_EC_STEP_BUDGET", "1" if graph.startswith("device-fused") else ("8" if graph == "device-heavy-mix" else "0"))
     monkeypatch.setenv("OATK_DEBUG_EC_TREE_LOG", "512" if graph == "device-tree-smalllog" else "0")
     monkeypatch.setenv("OATK_DEBUG_EC_SERIAL_TIERS", "1" if graph == "device-tiers-serial" else "0")
     monkeypatch.setenv("OATK_DEBUG_EC_HEAVY", "0" if graph.startswith("device-tiers") else "1")
