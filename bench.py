@@ -189,7 +189,7 @@ def config1s_cpu_baseline(hip, sq, of, ln, n, K, S, c):
         L.refx_consensus.argtypes = [vp, vp, C.c_int, C.c_int]
         L.refx_ec.argtypes = [vp, vp, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int]
         off_n, len_n = np.ascontiguousarray(of[:n]), np.ascontiguousarray(ln[:n])
-        nb = int(off_n[-1] + len_n[-1]) if n else 0
+        nb = int(of[n]) if n < len(of) else int(sq.size)          # (up to where the next read begins: the stream's padding behind a read belongs to it)
         cores = os.cpu_count() or 8
         out = {"kind": "reference", "sample": "the first %d reads (%.2f Gbases): read_error_correction alone, graph built by the reference, scan and count by the device" % (n, int(len_n.sum()) / 1e9),
                "unit": "s", "threads": {}}

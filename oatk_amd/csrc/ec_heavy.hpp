@@ -523,7 +523,7 @@ __global__ __launch_bounds__(64 * NW) void ec_heavy_kernel(EcwArgs a)
             wk.hs16 = ecw_uniu(m2.x), wk.lp = ecw_uniu(m2.y), wk.ln = ecw_uniu(m2.z), wk.pad = 0;
         }
         EcBlockOut o;
-        o.status = EC_FAILURE, o.np = 0, o.path_off = 0, o.flags = 0, o.short_block = 0, o.tried = 0, o.n_path = 0, o.wf_steps = 0, o.wf_diag = 0, o.tier = 8u + (uint32_t) R;
+        o.status = EC_FAILURE, o.np = 0, o.path_off = 0, o.flags = 0, o.short_block = 0, o.tried = 0, o.n_path = 0, o.wf_steps = 0, o.wf_diag = 0, o.tier = (NW == 1? 16u : 8u) + (uint32_t) R;
         const uint64_t tick0 = __builtin_amdgcn_s_memrealtime();
         if (ECW_RARE(wk.l < EC_MIN_ERR_SEQ_LEN)) {
             o.short_block = 1;                         // syncerr.c:502-504

@@ -1,0 +1,504 @@
+/*
+ * oatk_amd/csrc/host/gzpar.c -- ONE gzip member inflated on many threads (round 5), for host/gzsrc.c.
+ *
+ * BASELINE.json's configs[0] is a plain `.fa.gz`: one member, which zlib inflates on one thread at ~0.4 GB/s of text -- 3.5 s of a 5.8 s run of the drop-in CLI on the
+ * config-1 surrogate's 100 k reads, on a host with 128 cores (the reference waits for the same thread: sstream.c:39-54 reads through gzread).  A deflate stream has no
+ * index, but it can be entered at any BLOCK boundary by a decoder that does not know the 32 KiB of text before it (the construction of pugz / rapidgzip):
+ *   1. the compressed bytes are cut into chunks; for every chunk but the first a thread looks for a block header at or after the chunk's first bit -- a dynamic-Huffman
+ *      header whose code lengths form complete codes, whose block decodes to its end-of-block symbol with nothing but text in its literals and no distance beyond the
+ *      window, and which is followed by another valid header;
+ *   2. every chunk is decoded from its boundary into 16-bit SYMBOLS: a byte, or "whatever stood at position w of the window before this chunk" -- a back-reference into
+ *      the unknown copies such symbols like any other.  A chunk is decoded up to the boundary the next chunk claims; the decoder of the chunk before it arrives there
+ *      block by block from a known state, so a claim it arrives at EXACTLY is a true boundary and the symbols behind it are the true text, and a claim it passes is false:
+ *      it then simply decodes that chunk's part as well;
+ *   3. in order, each chunk's last 32 KiB are turned into bytes with the window handed down from the chunk before (that is all the serial work there is), and then all
+ *      chunks are turned into bytes at their places in the caller's buffer, in parallel, with a CRC each (combined: crc32_combine).
+ * The member's CRC-32 and length are checked at its end as gzread checks them.  Text that does not look like text (no boundary found in the first chunks) is left to zlib.
+ * Nothing of this changes a byte of what is delivered: tests/test_host_gzsrc.py compares with zlib on files of every kind.
+ */
+#define _GNU_SOURCE
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+
+#include "oatk_hip.h"
+#include "host_internal.h"
+
+#define GP_WIN 32768
+#define GP_FAST 10
+#define GP_MAX_THREADS 64
+#define GP_INF (~0ULL)
+
+typedef struct { const uint8_t *base, *p, *end; uint64_t bits; int nb; int over; } br_t;
+
+static inline void br_init(br_t *b, const uint8_t *base, uint64_t n, uint64_t bitpos)
+{
+    b->base = base, b->end = base + n, b->p = base + (bitpos >> 3), b->bits = 0, b->nb = 0, b->over = 0;
+    const int skip = (int) (bitpos & 7);
+    if (skip) {
+        if (b->p < b->end) { b->bits = (uint64_t) *b->p++ >> skip, b->nb = 8 - skip; }
+        else b->over = 1;
+    }
+}
+static inline void br_refill(br_t *b)
+{
+    if (b->p + 8 <= b->end) {                    /* eight bytes at once: what does not fit stays where it is and is read again */
+        uint64_t w;
+        memcpy(&w, b->p, 8);
+        b->bits |= w << b->nb;
+        const int adv = (63 - b->nb) >> 3;
+        b->p += adv, b->nb += adv << 3;
+        return;
+    }
+    while (b->nb <= 56) {
+        if (b->p < b->end) b->bits |= (uint64_t) *b->p++ << b->nb;
+        else b->over++;                          /* (zeros; taking them is an error the caller sees through br_pos) */
+        b->nb += 8;
+    }
+}
+static inline uint32_t br_peek(const br_t *b, int n) { return (uint32_t) (b->bits & ((1ULL << n) - 1)); }
+static inline void br_drop(br_t *b, int n) { b->bits >>= n, b->nb -= n; }
+static inline uint32_t br_get(br_t *b, int n) { if (b->nb < n) br_refill(b); const uint32_t v = br_peek(b, n); br_drop(b, n); return v; }
+/* the position of the next unread bit; past the end of the input when zeros were taken */
+static inline uint64_t br_pos(const br_t *b) { return (uint64_t) (b->p - b->base) * 8 + (uint64_t) b->over * 8 - (uint64_t) b->nb; }
+
+typedef struct {
+    uint16_t fast[1 << GP_FAST];                 /* sym | len << 12; 0: a longer code (or none) */
+    uint16_t count[16], sym[288];                /* canonical decoding for the long codes (puff.c's way) */
+    int max_len;
+} huff_t;
+
+/* 0: a complete code; 1: incomplete (allowed for a single distance code); -1: over-subscribed or empty where that is not allowed */
+static int huff_build(huff_t *h, const uint8_t *len, int n)
+{
+    int i, l, left = 1;
+    uint16_t offs[16];
+    memset(h->count, 0, sizeof(h->count));
+    for (i = 0; i < n; ++i) h->count[len[i]]++;
+    if (h->count[0] == n) return -1;
+    for (l = 1; l <= 15; ++l) { left <<= 1; left -= h->count[l]; if (left < 0) return -1; }
+    offs[1] = 0;
+    for (l = 1; l < 15; ++l) offs[l + 1] = offs[l] + h->count[l];
+    for (i = 0; i < n; ++i) if (len[i]) h->sym[offs[len[i]]++] = (uint16_t) i;
+    memset(h->fast, 0, sizeof(h->fast));
+    h->max_len = 0;
+    {   /* codes in canonical order; the table is indexed by the code's bits as they come (least significant first) */
+        uint32_t code = 0;
+        int idx = 0;
+        for (l = 1; l <= 15; ++l) {
+            int c;
+            for (c = 0; c < h->count[l]; ++c, ++idx, ++code) {
+                h->max_len = l;
+                if (l <= GP_FAST) {
+                    uint32_t rev = 0, t = code;
+                    int k;
+                    for (k = 0; k < l; ++k) rev = rev << 1 | (t & 1), t >>= 1;
+                    const uint16_t e = (uint16_t) (h->sym[idx] | l << 12);
+                    for (t = rev; t < (1u << GP_FAST); t += 1u << l) h->fast[t] = e;
+                }
+            }
+            code <<= 1;
+        }
+    }
+    return left > 0;
+}
+/* (at least 15 bits in the buffer) -1: no such code */
+static inline int huff_decode(const huff_t *h, br_t *b)
+{
+    const uint16_t e = h->fast[br_peek(b, GP_FAST)];
+    if (e) { br_drop(b, e >> 12); return e & 0xFFF; }
+    {
+        int code = 0, first = 0, index = 0, l;
+        uint64_t bits = b->bits;
+        for (l = 1; l <= 15; ++l) {
+            code |= (int) (bits & 1), bits >>= 1;
+            const int c = h->count[l];
+            if (code - c < first) { br_drop(b, l); return h->sym[index + (code - first)]; }
+            index += c, first += c, first <<= 1, code <<= 1;
+        }
+    }
+    return -1;
+}
+
+static const uint16_t LBASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+static const uint8_t LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+static const uint16_t DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+static const uint8_t DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+static const uint8_t CLORD[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+typedef struct { uint16_t *s; uint64_t n, m; } sym_t;            /* a chunk's text as symbols: < 256 a byte, else 256 + position in the window before the chunk */
+
+static int sym_room(sym_t *o, uint64_t more)
+{
+    if (o->n + more <= o->m) return 0;
+    uint64_t m = o->m? o->m : 1 << 20;
+    while (m < o->n + more) m += m >> 1;
+    uint16_t *s = (uint16_t *) realloc(o->s, m * 2);
+    if (!s) return -1;
+    o->s = s, o->m = m;
+    return 0;
+}
+
+/* the dynamic block's two codes (RFC 1951 3.2.7); strict: what zlib refuses is refused.  0 ok */
+static int read_dynamic(br_t *b, huff_t *lit, huff_t *dst)
+{
+    uint8_t len[320], cl[19];
+    huff_t clh;
+    int i;
+    br_refill(b);
+    const int hlit = (int) br_get(b, 5) + 257, hdist = (int) br_get(b, 5) + 1, hclen = (int) br_get(b, 4) + 4;
+    if (hlit > 286 || hdist > 30) return -1;
+    memset(cl, 0, sizeof(cl));
+    for (i = 0; i < hclen; ++i) cl[CLORD[i]] = (uint8_t) br_get(b, 3);
+    if (huff_build(&clh, cl, 19) != 0) return -1;
+    for (i = 0; i < hlit + hdist; ) {
+        br_refill(b);
+        const int s = huff_decode(&clh, b);
+        if (s < 0) return -1;
+        if (s < 16) len[i++] = (uint8_t) s;
+        else {
+            int rep, v = 0;
+            if (s == 16) { if (i == 0) return -1; v = len[i - 1]; rep = 3 + (int) br_get(b, 2); }
+            else if (s == 17) rep = 3 + (int) br_get(b, 3);
+            else rep = 11 + (int) br_get(b, 7);
+            if (i + rep > hlit + hdist) return -1;
+            while (rep--) len[i++] = (uint8_t) v;
+        }
+    }
+    if (len[256] == 0) return -1;
+    if (huff_build(lit, len, hlit) != 0) return -1;              /* (zlib: an incomplete literal/length code is an error) */
+    {
+        const int r = huff_build(dst, len + hlit, hdist);
+        if (r < 0) { int nz = 0; for (i = 0; i < hdist; ++i) nz += len[hlit + i] != 0; if (nz) return -1; memset(dst, 0, sizeof(*dst)); }      /* (no distance codes at all: a block of literals) */
+        else if (r > 0 && dst->count[1] + dst->count[2] + dst->count[3] + dst->count[4] + dst->count[5] + dst->count[6] + dst->count[7] + dst->count[8] + dst->count[9] + dst->count[10] + dst->count[11] + dst->count[12] + dst->count[13] + dst->count[14] + dst->count[15] != 1) return -1;
+    }
+    return 0;
+}
+static huff_t g_fix_lit, g_fix_dst;
+static pthread_once_t g_fix_once = PTHREAD_ONCE_INIT;
+static void fixed_init(void)
+{
+    uint8_t len[288];
+    int i;
+    for (i = 0; i < 144; ++i) len[i] = 8;
+    for (; i < 256; ++i) len[i] = 9;
+    for (; i < 280; ++i) len[i] = 7;
+    for (; i < 288; ++i) len[i] = 8;
+    (void) huff_build(&g_fix_lit, len, 288);
+    for (i = 0; i < 30; ++i) len[i] = 5;
+    (void) huff_build(&g_fix_dst, len, 30);
+}
+
+/* One block's data (the header's three bits are read) into o.  text_only: literals must be text (a candidate boundary is being tried).  0 ok, -1 not a block / corrupt */
+static int decode_block(br_t *b, int btype, sym_t *o, int text_only, uint64_t total_bits)
+{
+    if (btype == 0) {
+        br_drop(b, b->nb & 7);
+        br_refill(b);
+        const uint32_t len = br_get(b, 16), nlen = br_get(b, 16);
+        if ((len ^ nlen) != 0xFFFF) return -1;
+        if (br_pos(b) + (uint64_t) len * 8 > total_bits) return -1;
+        if (sym_room(o, len)) return -1;
+        /* (the buffer holds whole bytes now) */
+        uint32_t i;
+        for (i = 0; i < len; ++i) {
+            const uint32_t c = br_get(b, 8);
+            if (text_only && !(c == '\n' || c == '\r' || c == '\t' || (c >= 32 && c < 127))) return -1;
+            o->s[o->n++] = (uint16_t) c;
+        }
+        return 0;
+    }
+    huff_t lit_d, dst_d;
+    const huff_t *lit = &g_fix_lit, *dst = &g_fix_dst;
+    if (btype == 2) { if (read_dynamic(b, &lit_d, &dst_d)) return -1; lit = &lit_d, dst = &dst_d; }
+    else if (btype != 1) return -1;
+    for (;;) {
+        if (sym_room(o, 260)) return -1;
+        br_refill(b);
+        int s = huff_decode(lit, b);
+        if (s < 0) return -1;
+        if (s < 256) {
+            if (text_only && !(s == '\n' || s == '\r' || s == '\t' || (s >= 32 && s < 127))) return -1;
+            o->s[o->n++] = (uint16_t) s;
+            continue;
+        }
+        if (s == 256) break;
+        s -= 257;
+        if (s >= 29) return -1;
+        const uint32_t len = LBASE[s] + br_get(b, LEXT[s]);
+        br_refill(b);
+        const int ds = huff_decode(dst, b);
+        if (ds < 0 || ds >= 30) return -1;
+        const uint64_t dist = DBASE[ds] + br_get(b, DEXT[ds]);
+        if (dist > o->n + GP_WIN) return -1;
+        {
+            uint64_t at = o->n;
+            uint32_t i;
+            for (i = 0; i < len; ++i, ++at) {
+                if (at >= dist) o->s[at] = o->s[at - dist];
+                else o->s[at] = (uint16_t) (256 + (GP_WIN + at - dist));           /* before the chunk: position in the window */
+            }
+            o->n = at;
+        }
+        if (br_pos(b) > total_bits) return -1;
+    }
+    return br_pos(b) > total_bits? -1 : 0;
+}
+
+/* a block header that can be trusted at or after bit `from` (below `to`): dynamic, not the last, decodes as text and is followed by another header.  GP_INF: none */
+static uint64_t find_boundary(const uint8_t *in, uint64_t n_in, uint64_t from, uint64_t to)
+{
+    const uint64_t total_bits = n_in * 8;
+    sym_t tmp = {0, 0, 0};
+    uint64_t at, found = GP_INF;
+    for (at = from; at < to && at + 64 < total_bits; ++at) {
+        /* cheap tests first: BFINAL = 0, BTYPE = 2 (bits 0, 0, 1), HLIT <= 29, HDIST <= 29 */
+        const uint64_t byte = at >> 3;
+        uint32_t w = (uint32_t) in[byte] | (uint32_t) in[byte + 1] << 8 | (uint32_t) in[byte + 2] << 16 | (uint32_t) in[byte + 3] << 24;
+        w >>= at & 7;
+        if ((w & 7) != 4) continue;
+        if (((w >> 3) & 31) > 29 || ((w >> 8) & 31) > 29) continue;
+        br_t b;
+        br_init(&b, in, n_in, at);
+        br_refill(&b);
+        br_drop(&b, 3);
+        tmp.n = 0;
+        if (decode_block(&b, 2, &tmp, 1, total_bits)) continue;
+        if (tmp.n < 1024) continue;                                  /* (a real block of a text file is not this small; chance finds are) */
+        {   /* what follows must be a header too */
+            br_refill(&b);
+            const uint32_t h = br_peek(&b, 3);
+            const int bt = (int) (h >> 1);
+            if (bt == 3) continue;
+            if (bt == 2) {
+                huff_t l2, d2;
+                br_t c = b;
+                br_drop(&c, 3);
+                if (read_dynamic(&c, &l2, &d2)) continue;
+            } else if (bt == 0) {
+                br_t c = b;
+                br_drop(&c, 3);
+                br_drop(&c, c.nb & 7);
+                br_refill(&c);
+                const uint32_t len = br_get(&c, 16), nlen = br_get(&c, 16);
+                if ((len ^ nlen) != 0xFFFF) continue;
+            }
+        }
+        found = at;
+        break;
+    }
+    free(tmp.s);
+    return found;
+}
+
+typedef struct {
+    uint64_t nominal, start, end;                /* bits: where the chunk was cut, the boundary it claims (GP_INF none), where its decoding stopped */
+    sym_t o;
+    int ok, last;                                /* decoded without error; reached the member's last block */
+    int chained;                                 /* a chunk before it arrived exactly at its boundary: its symbols are the text */
+    uint64_t out_off, take, given;               /* where its bytes go in this call, how many of its symbols go there, how many went before */
+    uint8_t win[GP_WIN];                         /* the window before it */
+    uint32_t crc;
+} chunk_t;
+
+struct oatk_gzpar {
+    const uint8_t *in; uint64_t n_in;
+    int n_threads;
+    uint64_t chunk_bits;
+    uint64_t pos;                                /* the boundary the next batch begins at (bits) */
+    uint8_t win[GP_WIN];                         /* the text before it */
+    uint64_t total_out; uint32_t crc;
+    int done, failed, first;
+    chunk_t *ch; int n_ch, next_out;             /* the batch at hand, and the first of its chunks not delivered yet */
+    /* work sharing */
+    int phase; volatile int next;
+    uint8_t *dst;
+};
+
+static void decode_chunk(oatk_gzpar_t *p, int j)
+{
+    chunk_t *c = &p->ch[j];
+    const uint64_t total_bits = p->n_in * 8;
+    br_t b;
+    int nxt = j + 1;
+    c->o.n = 0, c->ok = 0, c->last = 0;
+    if (c->start == GP_INF) return;
+    br_init(&b, p->in, p->n_in, c->start);
+    for (;;) {
+        br_refill(&b);
+        const uint32_t h = br_get(&b, 3);
+        if (decode_block(&b, (int) (h >> 1), &c->o, 0, total_bits)) return;
+        const uint64_t at = br_pos(&b);
+        if (h & 1) { c->last = 1, c->end = at, c->ok = 1; return; }
+        /* the first boundary at or after the cut of the next chunk that claims one: there or beyond it this chunk stops */
+        while (nxt < p->n_ch && (p->ch[nxt].start == GP_INF || p->ch[nxt].start < at)) ++nxt;
+        if (nxt < p->n_ch) { if (at == p->ch[nxt].start) { c->end = at, c->ok = 1; return; } }
+        else if (at >= p->ch[p->n_ch - 1].nominal + p->chunk_bits) { c->end = at, c->ok = 1; return; }       /* the batch's last: the first boundary past the batch */
+    }
+}
+static void resolve_chunk(oatk_gzpar_t *p, int j)
+{
+    chunk_t *c = &p->ch[j];
+    uint8_t *d = p->dst + c->out_off;
+    const uint16_t *s = c->o.s + c->given;
+    uint64_t i;
+    for (i = 0; i < c->take; ++i) d[i] = s[i] < 256? (uint8_t) s[i] : c->win[s[i] - 256];
+    c->crc = (uint32_t) crc32(0L, Z_NULL, 0);
+    for (i = 0; i < c->take; i += 1u << 30) { const uint64_t m = c->take - i < (1u << 30)? c->take - i : (1u << 30); c->crc = (uint32_t) crc32(c->crc, d + i, (uInt) m); }
+}
+static void *gp_worker(void *arg)
+{
+    oatk_gzpar_t *p = (oatk_gzpar_t *) arg;
+    for (;;) {
+        const int j = __atomic_fetch_add(&p->next, 1, __ATOMIC_RELAXED);
+        if (j >= p->n_ch) break;
+        chunk_t *c = &p->ch[j];
+        if (p->phase == 0) { if (j > 0) c->start = find_boundary(p->in, p->n_in, c->nominal, c->nominal + p->chunk_bits); }
+        else if (p->phase == 1) decode_chunk(p, j);
+        else if (c->chained && j >= p->next_out && c->out_off != GP_INF && c->take) resolve_chunk(p, j);
+    }
+    return 0;
+}
+static int run_phase(oatk_gzpar_t *p, int phase)
+{
+    pthread_t th[GP_MAX_THREADS];
+    int i, n = p->n_threads < p->n_ch? p->n_threads : p->n_ch, started = 0;
+    p->phase = phase, p->next = 0;
+    for (i = 0; i < n - 1; ++i) { if (pthread_create(&th[started], 0, gp_worker, p) != 0) break; ++started; }
+    gp_worker(p);
+    for (i = 0; i < started; ++i) pthread_join(th[i], 0);
+    return 0;
+}
+
+oatk_gzpar_t *oatk_gzpar_open(const uint8_t *deflate, uint64_t n_in, int n_threads)
+{
+    oatk_gzpar_t *p = (oatk_gzpar_t *) calloc(1, sizeof(*p));
+    if (!p) return 0;
+    pthread_once(&g_fix_once, fixed_init);
+    p->in = deflate, p->n_in = n_in;
+    p->n_threads = n_threads < 1? 1 : (n_threads > GP_MAX_THREADS? GP_MAX_THREADS : n_threads);
+    {
+        const char *e = getenv("OATK_HOST_GZ_CHUNK_KB");
+        uint64_t kb = e && atoi(e) > 0? (uint64_t) atoi(e) : 2048;
+        p->chunk_bits = kb * 1024 * 8;
+    }
+    p->first = 1;
+    p->crc = (uint32_t) crc32(0L, Z_NULL, 0);
+    p->ch = (chunk_t *) calloc((size_t) p->n_threads, sizeof(chunk_t));
+    if (!p->ch) { free(p); return 0; }
+    return p;
+}
+void oatk_gzpar_close(oatk_gzpar_t *p)
+{
+    int j;
+    if (!p) return;
+    for (j = 0; j < p->n_threads; ++j) free(p->ch[j].o.s);
+    free(p->ch);
+    free(p);
+}
+uint64_t oatk_gzpar_in_used(const oatk_gzpar_t *p) { return (p->pos + 7) >> 3; }
+uint32_t oatk_gzpar_crc(const oatk_gzpar_t *p) { return p->crc; }
+uint64_t oatk_gzpar_total(const oatk_gzpar_t *p) { return p->total_out; }
+
+/* the next batch of chunks, decoded to symbols and chained.  0 ok; -1 corrupt; -2 (first batch only) this is not text one can enter in the middle: zlib's job */
+static int next_batch(oatk_gzpar_t *p)
+{
+    int j;
+    const uint64_t total_bits = p->n_in * 8;
+    p->n_ch = 0;
+    for (j = 0; j < p->n_threads; ++j) {
+        const uint64_t nominal = p->pos + (uint64_t) j * p->chunk_bits;
+        if (j > 0 && nominal + 1024 >= total_bits) break;
+        p->ch[j].nominal = nominal, p->ch[j].start = j == 0? p->pos : GP_INF, p->ch[j].chained = 0, p->ch[j].out_off = GP_INF, p->ch[j].take = 0, p->ch[j].given = 0;
+        ++p->n_ch;
+    }
+    p->next_out = 0;
+    run_phase(p, 0);
+    if (p->first && p->n_ch >= 4) {
+        int found = 0;
+        for (j = 1; j < p->n_ch; ++j) found += p->ch[j].start != GP_INF;
+        if (2 * found < p->n_ch - 1) return -2;
+    }
+    p->first = 0;
+    run_phase(p, 1);
+    /* the chain: chunk 0 begins at a known boundary; a chunk is the text if the chained chunk before it stopped exactly where it begins */
+    {
+        uint64_t at = p->pos;
+        int prev = -1;
+        for (j = 0; j < p->n_ch; ++j) {
+            chunk_t *c = &p->ch[j];
+            if (c->start != at) continue;
+            if (!c->ok) return -1;               /* (decoded from a true boundary and failed: the stream is damaged) */
+            c->chained = 1, prev = j, at = c->end;
+            if (c->last) break;
+        }
+        if (prev < 0) return -1;
+    }
+    /* windows, in order: a chunk's is the 32 KiB of text before it */
+    {
+        uint8_t win[GP_WIN];
+        memcpy(win, p->win, GP_WIN);
+        for (j = 0; j < p->n_ch; ++j) {
+            chunk_t *c = &p->ch[j];
+            if (!c->chained) continue;
+            memcpy(c->win, win, GP_WIN);
+            const uint64_t n = c->o.n, tail = n < GP_WIN? n : GP_WIN;
+            uint64_t i;
+            if (tail < GP_WIN) memmove(win, win + tail, GP_WIN - tail);
+            for (i = 0; i < tail; ++i) { const uint16_t s = c->o.s[n - tail + i]; win[GP_WIN - tail + i] = s < 256? (uint8_t) s : c->win[s - 256]; }
+        }
+    }
+    return 0;
+}
+
+int oatk_gzpar_done(const oatk_gzpar_t *p) { return p->done && p->next_out >= p->n_ch; }
+
+/* text of the member into dst, at most cap bytes; fewer than cap (even 0) while oatk_gzpar_done() is false: call again; -1 corrupt; -2 see next_batch.  When it is done
+ * oatk_gzpar_in_used / _crc / _total say where the deflate data ended and what came out. */
+int64_t oatk_gzpar_read(oatk_gzpar_t *p, uint8_t *dst, uint64_t cap)
+{
+    uint64_t out = 0;
+    if (!p || p->failed) return -1;
+    while (out < cap) {
+        int j, stop;
+        if (p->next_out >= p->n_ch) {
+            if (p->done) break;
+            const int rc = next_batch(p);
+            if (rc) { if (rc == -1) p->failed = 1; return out? (int64_t) out : rc; }      /* (-2 only before anything was delivered) */
+        }
+        /* the chunks that fit (the last of them perhaps in part), at their places */
+        {
+            uint64_t at = out;
+            for (j = p->next_out; j < p->n_ch && at < cap; ++j) {
+                chunk_t *c = &p->ch[j];
+                c->out_off = GP_INF, c->take = 0;
+                if (!c->chained) continue;
+                c->take = c->o.n - c->given < cap - at? c->o.n - c->given : cap - at;
+                c->out_off = at, at += c->take;
+            }
+            stop = j;
+            p->dst = dst;
+            run_phase(p, 2);
+            for (j = p->next_out; j < stop; ++j) {
+                chunk_t *c = &p->ch[j];
+                if (!c->chained) { p->next_out = j + 1; continue; }
+                p->crc = (uint32_t) crc32_combine(p->crc, c->crc, (z_off_t) c->take);
+                p->total_out += c->take;
+                if (c->take) {                   /* the window for the batch after this one */
+                    const uint64_t tail = c->take < GP_WIN? c->take : GP_WIN;
+                    if (tail < GP_WIN) memmove(p->win, p->win + tail, GP_WIN - tail);
+                    memcpy(p->win + GP_WIN - tail, dst + c->out_off + c->take - tail, tail);
+                }
+                c->given += c->take, c->out_off = GP_INF;
+                if (c->given < c->o.n) { p->next_out = j; break; }          /* the caller's buffer is full in the middle of this chunk */
+                p->pos = c->end, p->next_out = j + 1;
+                if (c->last) { p->done = 1, p->next_out = p->n_ch; break; }
+            }
+            out = at;
+        }
+    }
+    return (int64_t) out;
+}

@@ -42,6 +42,8 @@ struct oatk_gzsrc {
     /* serial member decoding */
     z_stream z; int z_live, in_member;
     uint32_t crc; uint64_t member_out;
+    oatk_gzpar_t *par;                       /* the member at hand is inflated on many threads (host/gzpar.c) */
+    int par_kind;                            /* (statistics: 1 once a member went that way) */
     /* pipe fallback */
     gzFile gzf;
     /* BGZF */
@@ -169,6 +171,7 @@ void oatk_gzsrc_close(oatk_gzsrc_t *g)
         for (i = 0; i < g->started; ++i) pthread_join(g->th[i], 0);
     }
     if (g->z_live) inflateEnd(&g->z);
+    if (g->par) oatk_gzpar_close(g->par);
     if (g->gzf) gzclose(g->gzf);                     /* (closes the descriptor) */
     else {
         if (g->map) munmap((void *) g->map, (size_t) g->size);
@@ -242,7 +245,30 @@ static int64_t serial_read(oatk_gzsrc_t *g, uint8_t *dst, uint64_t cap)
         if (!g->z_live) { if (inflateInit2(&g->z, -15) != Z_OK) return -1; g->z_live = 1; }
         else inflateReset(&g->z);
         g->pos += hl, g->in_member = 1, g->crc = (uint32_t) crc32(0L, Z_NULL, 0), g->member_out = 0;
+        /* a large member and threads to spare: many threads enter it at block boundaries (host/gzpar.c); OATK_HOST_GZ_PARALLEL=0: zlib on one thread */
+        {
+            const char *e = getenv("OATK_HOST_GZ_PARALLEL");
+            const uint64_t least = e && atoi(e) > 1? (uint64_t) atoi(e) : (8u << 20);
+            if (!(e && e[0] == '0' && !e[1]) && g->n_threads >= 4 && g->size - g->pos >= least) g->par = oatk_gzpar_open(g->map + g->pos, g->size - g->pos, g->n_threads);
+        }
     }
+    while (g->par && out < cap) {
+        const int64_t n = oatk_gzpar_read(g->par, dst + out, cap - out);
+        if (n == -2) { oatk_gzpar_close(g->par); g->par = 0; break; }          /* nothing was taken: this is not text one can enter in the middle -- zlib from the member's start */
+        if (n < 0) return -1;
+        out += (uint64_t) n, g->member_out += (uint64_t) n, g->par_kind = 1;
+        if (oatk_gzpar_done(g->par)) {
+            uint32_t t[2];
+            g->pos += oatk_gzpar_in_used(g->par);
+            if (g->size - g->pos < 8) return -1;
+            memcpy(t, g->map + g->pos, 8);
+            if (t[0] != oatk_gzpar_crc(g->par) || t[1] != (uint32_t) oatk_gzpar_total(g->par)) return -1;
+            g->pos += 8, g->in_member = 0;
+            oatk_gzpar_close(g->par), g->par = 0;
+            return (int64_t) out;
+        }
+    }
+    if (g->par) return (int64_t) out;
     while (out < cap && g->in_member) {
         const uint64_t in_left = g->size - g->pos, want = cap - out;
         g->z.next_in = (Bytef *) (g->map + g->pos), g->z.avail_in = in_left > (1u << 30)? (1u << 30) : (uInt) in_left;

@@ -43,5 +43,14 @@ uint64_t oatk_gzsrc_tell_in(const oatk_gzsrc_t *g);
 uint64_t oatk_gzsrc_size_in(const oatk_gzsrc_t *g);
 int oatk_gzsrc_kind(const oatk_gzsrc_t *g);          /* 1 plain member(s), 2 BGZF, 3 not a regular file (zlib's gzread) */
 void oatk_gzsrc_close(oatk_gzsrc_t *g);
+/* one member's deflate data inflated on many threads (host/gzpar.c) */
+typedef struct oatk_gzpar oatk_gzpar_t;
+oatk_gzpar_t *oatk_gzpar_open(const uint8_t *deflate, uint64_t n_in, int n_threads);
+int64_t oatk_gzpar_read(oatk_gzpar_t *p, uint8_t *dst, uint64_t cap);
+int oatk_gzpar_done(const oatk_gzpar_t *p);
+uint64_t oatk_gzpar_in_used(const oatk_gzpar_t *p);
+uint32_t oatk_gzpar_crc(const oatk_gzpar_t *p);
+uint64_t oatk_gzpar_total(const oatk_gzpar_t *p);
+void oatk_gzpar_close(oatk_gzpar_t *p);
 
 #endif
