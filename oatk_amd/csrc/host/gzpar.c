@@ -215,35 +215,48 @@ static int decode_block(br_t *b, int btype, sym_t *o, int text_only, uint64_t to
     const huff_t *lit = &g_fix_lit, *dst = &g_fix_dst;
     if (btype == 2) { if (read_dynamic(b, &lit_d, &dst_d)) return -1; lit = &lit_d, dst = &dst_d; }
     else if (btype != 1) return -1;
-    for (;;) {
-        if (sym_room(o, 260)) return -1;
-        br_refill(b);
-        int s = huff_decode(lit, b);
-        if (s < 0) return -1;
-        if (s < 256) {
-            if (text_only && !(s == '\n' || s == '\r' || s == '\t' || (s >= 32 && s < 127))) return -1;
-            o->s[o->n++] = (uint16_t) s;
-            continue;
-        }
-        if (s == 256) break;
-        s -= 257;
-        if (s >= 29) return -1;
-        const uint32_t len = LBASE[s] + br_get(b, LEXT[s]);
-        br_refill(b);
-        const int ds = huff_decode(dst, b);
-        if (ds < 0 || ds >= 30) return -1;
-        const uint64_t dist = DBASE[ds] + br_get(b, DEXT[ds]);
-        if (dist > o->n + GP_WIN) return -1;
-        {
-            uint64_t at = o->n;
-            uint32_t i;
-            for (i = 0; i < len; ++i, ++at) {
-                if (at >= dist) o->s[at] = o->s[at - dist];
-                else o->s[at] = (uint16_t) (256 + (GP_WIN + at - dist));           /* before the chunk: position in the window */
+    {
+        uint16_t *os = o->s;
+        uint64_t n = o->n, room = o->m;
+        for (;;) {
+            if (n + 260 > room) { o->n = n; if (sym_room(o, 260)) return -1; os = o->s, room = o->m; }
+            br_refill(b);
+            int s = huff_decode(lit, b);
+            if (s < 256) {
+                if (s < 0) return -1;
+                if (text_only && !(s == '\n' || s == '\r' || s == '\t' || (s >= 32 && s < 127))) return -1;
+                os[n++] = (uint16_t) s;
+                /* (a second literal from the same refill: at most 2 x 15 bits are gone) */
+                s = huff_decode(lit, b);
+                if (s < 256) {
+                    if (s < 0) return -1;
+                    if (text_only && !(s == '\n' || s == '\r' || s == '\t' || (s >= 32 && s < 127))) return -1;
+                    os[n++] = (uint16_t) s;
+                    continue;
+                }
+                br_refill(b);
             }
-            o->n = at;
+            if (s == 256) break;
+            s -= 257;
+            if (s >= 29) return -1;
+            const uint32_t len = LBASE[s] + br_get(b, LEXT[s]);
+            br_refill(b);
+            const int ds = huff_decode(dst, b);
+            if (ds < 0 || ds >= 30) return -1;
+            const uint64_t dist = DBASE[ds] + br_get(b, DEXT[ds]);
+            if (dist > n + GP_WIN) return -1;
+            {
+                uint32_t i = 0;
+                if (dist > n) {                  /* it begins before the chunk: positions in the window */
+                    const uint32_t pre = (uint32_t) (dist - n < len? dist - n : len);
+                    for (; i < pre; ++i) os[n + i] = (uint16_t) (256 + (GP_WIN + n + i - dist));
+                }
+                for (; i < len; ++i) os[n + i] = os[n + i - dist];
+                n += len;
+            }
+            if ((n & 0xFFF) < 260 && br_pos(b) > total_bits) return -1;
         }
-        if (br_pos(b) > total_bits) return -1;
+        o->n = n;
     }
     return br_pos(b) > total_bits? -1 : 0;
 }

@@ -141,3 +141,90 @@ def test_workers_created_in_a_later_round_do_not_run_a_phantom_one(H, tmp_path):
     for cap in (70_000, 1 << 20):                                        # and with windows that cut the runs of blocks into many calls
         got, status, _, _ = slurp(H, p, cap, threads=16)
         assert status == 0 and got == a + b + c, cap
+
+
+# ---- one member on many threads (host/gzpar.c): every byte equal to zlib's, whatever the member looks like ----
+
+def _reads_text(rng, n_bytes):
+    out, tot, i = [], 0, 0
+    while tot < n_bytes:
+        ln = int(rng.integers(2000, 20000))
+        rec = b">r%d a header with words\n" % i + bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), ln)) + b"\n"
+        out.append(rec)
+        tot += len(rec)
+        i += 1
+    return b"".join(out)
+
+
+@pytest.fixture(scope="module")
+def big_member(tmp_path_factory):
+    d = tmp_path_factory.mktemp("gzpar")
+    rng = np.random.default_rng(11)
+    text = _reads_text(rng, 24_000_000)
+    paths = {}
+    for level in (1, 6, 9):
+        paths[level] = str(d / ("l%d.fa.gz" % level))
+        open(paths[level], "wb").write(gzip.compress(text, compresslevel=level))
+    return paths, text, d
+
+
+@pytest.mark.parametrize("chunk_kb", ["64", "512"])
+@pytest.mark.parametrize("cap", [70_001, 1 << 22, 1 << 26])
+def test_one_member_on_many_threads_equals_zlib(H, big_member, monkeypatch, cap, chunk_kb):
+    paths, text, _ = big_member
+    monkeypatch.setenv("OATK_HOST_GZ_PARALLEL", "100000")            # members of 100 kB and more go that way
+    monkeypatch.setenv("OATK_HOST_GZ_CHUNK_KB", chunk_kb)            # (many chunks: many boundaries to find and to arrive at)
+    for level, p in paths.items():
+        for threads in (4, 13):
+            got, status, kind, consumed = slurp(H, p, cap, threads=threads)
+            assert status == 0 and got == text, (level, threads)
+            assert kind == 1 and consumed == os.path.getsize(p)
+
+
+def test_members_that_cannot_be_entered_in_the_middle(H, tmp_path, monkeypatch):
+    """stored blocks (level 0), bytes that are no text (no boundary passes for one: zlib takes the member), a member of fixed-Huffman blocks, text with long runs
+    (distances of one, matches of 258), and several large members one after the other"""
+    import zlib
+    monkeypatch.setenv("OATK_HOST_GZ_PARALLEL", "100000")
+    monkeypatch.setenv("OATK_HOST_GZ_CHUNK_KB", "64")
+    rng = np.random.default_rng(12)
+    text = _reads_text(rng, 3_000_000)
+    cases = {
+        "stored": (gzip.compress(text, compresslevel=0), text),
+        "binary": (gzip.compress(bytes(rng.integers(0, 256, 2_000_000, dtype=np.uint8)) + text), None),
+        "runs": (gzip.compress((b"A" * 100_000 + b"\n" + b"ACGT" * 50_000 + b"\n") * 8 + text), None),
+        "several": (gzip.compress(text) + gzip.compress(text[::-1].replace(b">", b"N")) + gzip.compress(text), None),
+    }
+    co = zlib.compressobj(6, zlib.DEFLATED, 31, 8, zlib.Z_FIXED)
+    cases["fixed"] = (co.compress(text) + co.flush(), text)
+    for name, (raw, want) in cases.items():
+        p = str(tmp_path / (name + ".gz"))
+        open(p, "wb").write(raw)
+        want = gzip.open(p).read() if want is None else want
+        for cap in (50_000, 1 << 24):
+            got, status, _, consumed = slurp(H, p, cap, threads=8)
+            assert status == 0 and got == want, (name, cap)
+            assert consumed == len(raw)
+
+
+def test_damage_in_a_member_on_many_threads_is_reported(H, big_member, tmp_path, monkeypatch):
+    paths, text, _ = big_member
+    monkeypatch.setenv("OATK_HOST_GZ_PARALLEL", "100000")
+    monkeypatch.setenv("OATK_HOST_GZ_CHUNK_KB", "256")
+    raw = open(paths[6], "rb").read()
+    for where in (len(raw) // 7, len(raw) // 2, len(raw) - 5, len(raw) - 2):      # inside the data (twice), in the CRC, in the length
+        bad = bytearray(raw)
+        bad[where] ^= 0x10
+        p = str(tmp_path / ("bad%d.gz" % where))
+        open(p, "wb").write(bytes(bad))
+        got, status, _, _ = slurp(H, p, 1 << 24, threads=8)
+        assert status == -1 or got != text, where
+        assert status == -1, where
+    for keep in (len(raw) - 9, len(raw) // 2, 100_000):              # the file ends inside the trailer, inside the data
+        p = str(tmp_path / ("cut%d.gz" % keep))
+        open(p, "wb").write(raw[:keep])
+        got, status, _, _ = slurp(H, p, 1 << 24, threads=8)
+        assert status == -1, keep
+    monkeypatch.setenv("OATK_HOST_GZ_PARALLEL", "0")                 # the switch: zlib on one thread
+    got, status, _, _ = slurp(H, paths[6], 1 << 24, threads=8)
+    assert status == 0 and got == text
