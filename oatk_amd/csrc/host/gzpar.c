@@ -129,11 +129,12 @@ static const uint16_t DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 
 static const uint8_t DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 static const uint8_t CLORD[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
-typedef struct { uint16_t *s; uint64_t n, m; } sym_t;            /* a chunk's text as symbols: < 256 a byte, else 256 + position in the window before the chunk */
+typedef struct { uint16_t *s; uint64_t n, m, lim; } sym_t;          /* lim: more symbols than this are refused (0: no limit) -- a decoder that entered the stream at a wrong place must not eat the machine's memory */            /* a chunk's text as symbols: < 256 a byte, else 256 + position in the window before the chunk */
 
 static int sym_room(sym_t *o, uint64_t more)
 {
     if (o->n + more <= o->m) return 0;
+    if (o->lim && o->n + more > o->lim) return -1;
     uint64_t m = o->m? o->m : 1 << 20;
     while (m < o->n + more) m += m >> 1;
     uint16_t *s = (uint16_t *) realloc(o->s, m * 2);
@@ -265,7 +266,7 @@ static int decode_block(br_t *b, int btype, sym_t *o, int text_only, uint64_t to
 static uint64_t find_boundary(const uint8_t *in, uint64_t n_in, uint64_t from, uint64_t to)
 {
     const uint64_t total_bits = n_in * 8;
-    sym_t tmp = {0, 0, 0};
+    sym_t tmp = {0, 0, 0, 16u << 20};             /* (a block of sixteen million symbols is no block zlib, pigz or bgzip writes) */
     uint64_t at, found = GP_INF;
     for (at = from; at < to && at + 64 < total_bits; ++at) {
         /* cheap tests first: BFINAL = 0, BTYPE = 2 (bits 0, 0, 1), HLIT <= 29, HDIST <= 29 */
@@ -311,6 +312,7 @@ typedef struct {
     uint64_t nominal, start, end;                /* bits: where the chunk was cut, the boundary it claims (GP_INF none), where its decoding stopped */
     sym_t o;
     int ok, last;                                /* decoded without error; reached the member's last block */
+    int capped;                                  /* given up because it grew beyond anything a chunk of this size inflates to (it may still be the text: then it is decoded again, unbounded) */
     int chained;                                 /* a chunk before it arrived exactly at its boundary: its symbols are the text */
     uint64_t out_off, take, given;               /* where its bytes go in this call, how many of its symbols go there, how many went before */
     uint8_t win[GP_WIN];                         /* the window before it */
@@ -331,19 +333,22 @@ struct oatk_gzpar {
     uint8_t *dst;
 };
 
-static void decode_chunk(oatk_gzpar_t *p, int j)
+static void decode_chunk(oatk_gzpar_t *p, int j, int bounded)
 {
     chunk_t *c = &p->ch[j];
     const uint64_t total_bits = p->n_in * 8;
     br_t b;
     int nxt = j + 1;
-    c->o.n = 0, c->ok = 0, c->last = 0;
+    c->o.n = 0, c->ok = 0, c->last = 0, c->capped = 0;
+    /* a chunk entered on a guess (every one but the batch's first) gets room for what two chunks of text compressed fortyfold would need: garbage that decodes as one long
+     * run of matches stops there, instead of at the end of a gigabyte of input */
+    c->o.lim = bounded? (p->chunk_bits >> 3) * 40 + (32u << 20) : 0;
     if (c->start == GP_INF) return;
     br_init(&b, p->in, p->n_in, c->start);
     for (;;) {
         br_refill(&b);
         const uint32_t h = br_get(&b, 3);
-        if (decode_block(&b, (int) (h >> 1), &c->o, 0, total_bits)) return;
+        if (decode_block(&b, (int) (h >> 1), &c->o, 0, total_bits)) { c->capped = c->o.lim && c->o.n + 260 > c->o.lim; return; }
         const uint64_t at = br_pos(&b);
         if (h & 1) { c->last = 1, c->end = at, c->ok = 1; return; }
         /* the first boundary at or after the cut of the next chunk that claims one: there or beyond it this chunk stops */
@@ -370,7 +375,7 @@ static void *gp_worker(void *arg)
         if (j >= p->n_ch) break;
         chunk_t *c = &p->ch[j];
         if (p->phase == 0) { if (j > 0) c->start = find_boundary(p->in, p->n_in, c->nominal, c->nominal + p->chunk_bits); }
-        else if (p->phase == 1) decode_chunk(p, j);
+        else if (p->phase == 1) decode_chunk(p, j, j > 0);
         else if (c->chained && j >= p->next_out && c->out_off != GP_INF && c->take) resolve_chunk(p, j);
     }
     return 0;
@@ -444,6 +449,7 @@ static int next_batch(oatk_gzpar_t *p)
         for (j = 0; j < p->n_ch; ++j) {
             chunk_t *c = &p->ch[j];
             if (c->start != at) continue;
+            if (!c->ok && c->capped) decode_chunk(p, j, 0);      /* (it IS the text, and longer than the guess allowed: once more, without the bound) */
             if (!c->ok) return -1;               /* (decoded from a true boundary and failed: the stream is damaged) */
             c->chained = 1, prev = j, at = c->end;
             if (c->last) break;

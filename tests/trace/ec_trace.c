@@ -120,10 +120,37 @@ static uint32_t *memo_slot(memo_t *m, uint64_t key, int *found)
     return &m->sub_arcs[h];
 }
 
+/* frame-scoped memo WITH skipping (what the device could do exactly): a state (vertex, consensus) met before under the SAME nearest branching level, within
+ * `hop_max` arcs of it, whose subtree held no in-band arrival and fits the budget that is left, is not searched again: its dead ends are added.  ECT_SKIP=1 switches it on. */
+typedef struct { uint64_t key, frame; uint32_t dead, ok; } m2_t;
+static m2_t *g_m2; static size_t g_m2_m, g_m2_n; static int g_skip = -1, g_hop_max = 4; static uint64_t g_frame_serial, g_m2_hits, g_m2_saved_dead;
+static m2_t *m2_slot(uint64_t key, uint64_t frame)
+{
+    if (!g_m2_m) { g_m2_m = 1 << 20; g_m2 = (m2_t *) calloc(g_m2_m, sizeof(m2_t)); }
+    size_t h = mix64(key ^ frame * 0x9E3779B97F4A7C15ULL) & (g_m2_m - 1);
+    while (g_m2[h].key && !(g_m2[h].key == key && g_m2[h].frame == frame)) h = (h + 1) & (g_m2_m - 1);
+    return &g_m2[h];
+}
+static uint64_t g_cur_frame; static int g_cur_hops;
+static uint64_t g_fs_serial[4096]; static size_t g_fs_l0[4096]; static int g_fs_n; static size_t g_win = 2048;
+
 static void dfs(S *s, uint64_t source, int depth)
 {
     static const uint64_t SL[7] = {1, 2, 4, 8, 16, 32, 64}, EL[7] = {1, 2, 4, 8, 16, 64, 256};
     if (s->n_path >= MAX_DFS_PATH) return;
+    if (g_skip < 0) { g_skip = getenv("ECT_SKIP") != 0; if (getenv("ECT_HOPS")) g_hop_max = atoi(getenv("ECT_HOPS")); }
+    m2_t *m2 = 0;
+    uint64_t my_frame = 0; const int my_hops = 0;
+    if (getenv("ECT_WIN")) g_win = (size_t) atoi(getenv("ECT_WIN"));
+    { int i_; for (i_ = 0; i_ < g_fs_n; ++i_) if (g_fs_l0[i_] + g_win >= s->cl) { my_frame = g_fs_serial[i_]; break; } }      /* the shallowest live branching level within the window */
+    const int32_t np_at_entry = s->n_path; const uint64_t succ_at_entry = s->c->succ_events;
+    if (g_skip && my_frame && my_hops <= g_hop_max && (!g_m2_m || g_m2_n * 2 < g_m2_m)) {
+        m2 = m2_slot(mix64(source * 0x9E3779B97F4A7C15ULL ^ s->chash ^ ((uint64_t) s->cl << 40)) | 1ULL, my_frame);
+        if (m2->key) {
+            if (m2->ok && s->n_path + (int32_t) m2->dead < MAX_DFS_PATH) { s->n_path += (int32_t) m2->dead, s->c->dead += m2->dead, g_m2_hits++, g_m2_saved_dead += m2->dead; return; }
+            m2 = 0;
+        }
+    }
     const orc_graph_t *g = s->g;
     const size_t l0 = s->cl;
     const uint64_t p = g->idx_p[source], na = g->idx_n[source], h0 = s->chash;
@@ -134,6 +161,8 @@ static void dfs(S *s, uint64_t source, int depth)
     for (i = 0; i < na; ++i) if (!g->arc_del[p + i]) ++live;
     s->c->levels++;
     if (live > 1) s->c->frames++;
+    const uint64_t child_frame = 0; const int child_hops = 0;
+    if (live > 1 && g_fs_n < 4096) g_fs_serial[g_fs_n] = ++g_frame_serial, g_fs_l0[g_fs_n] = l0, ++g_fs_n;
     if ((uint64_t) depth > s->c->max_depth) s->c->max_depth = (uint64_t) depth;
     /* memo probe: (vertex, consensus) -- with the same string the wavefront, score and ends are the same too */
     int found = 0;
@@ -141,6 +170,11 @@ static void dfs(S *s, uint64_t source, int depth)
     uint32_t *slot = memo_slot(s->memo, mix64(source * 0x9E3779B97F4A7C15ULL ^ h0 ^ ((uint64_t) l0 << 40)) | 1ULL, &found);
     size_t slot_idx = (size_t) (slot - s->memo->sub_arcs);
     if (found) s->c->memo_hit++, s->c->memo_hit_arcs += *slot;
+    if (found && getenv("ECT_DEBUG") && s->c->memo_hit <= 6 && s->tl == 7746) {
+        int i_; fprintf(stderr, "[hit] vertex %llu l0 %zu depth %d n_path %d sub_arcs %u my_frame %llu skipflag %d; live frames:", (unsigned long long) source, l0, depth, s->n_path, *slot, (unsigned long long) my_frame, g_skip);
+        for (i_ = 0; i_ < g_fs_n; ++i_) fprintf(stderr, " (%llu, l0 %zu)", (unsigned long long) g_fs_serial[i_], g_fs_l0[i_]);
+        fprintf(stderr, "\n");
+    }
     for (i = 0; i < na; ++i) {
         if (g->arc_del[p + i]) continue;
         const uint64_t w = g->arc_w[p + i];
@@ -173,8 +207,10 @@ static void dfs(S *s, uint64_t source, int depth)
         if (score <= s->bw && (s->sink == UINT64_MAX || s->sink == w)) s->c->succ_events++;
         const int alive = s->score <= s->bw && ql - l_seq <= s->tl + s->bw && ((s->sink != UINT64_MAX && s->sink != w) || s->t_end < s->tl);
         { const int cat = (alive? 0 : (s->score > s->bw? 2 : 4)) + sib; s->c->cat_arcs[cat]++, s->c->cat_steps[cat] += s->c->steps - st_before, s->c->cat_diag[cat] += s->c->diag - dg_before; }
-        if (alive)
+        if (alive) {
+            g_cur_frame = child_frame, g_cur_hops = child_hops;
             dfs(s, w, depth + 1);
+        }
         else {
             s->n_path++, s->c->dead++, s->c->depth_at_dead_sum += (uint64_t) depth;
             s->last_dead_depth = depth;
@@ -184,6 +220,12 @@ static void dfs(S *s, uint64_t source, int depth)
         s->n = n0, s->d0 = d00, s->score = sc0, s->t_end = te0, s->q_end = qe0;
         wf_need(s, n0 + 4);
         memcpy(s->k, sv, sizeof(int32_t) * (size_t) n0);
+    }
+    if (live > 1 && g_fs_n > 0) --g_fs_n;
+    if (m2 && !m2->key) {
+        m2->key = mix64(source * 0x9E3779B97F4A7C15ULL ^ h0 ^ ((uint64_t) l0 << 40)) | 1ULL, m2->frame = my_frame, m2->dead = (uint32_t) (s->n_path - np_at_entry);
+        m2->ok = s->c->succ_events == succ_at_entry && s->n_path < MAX_DFS_PATH;
+        g_m2_n++;
     }
     if (!found) s->memo->sub_arcs[slot_idx] = (uint32_t) (s->c->tried - arcs_before);      /* (the table may have moved: index, not pointer -- and it may have been rehashed; good enough for a hit rate) */
     free(sv);
@@ -248,6 +290,8 @@ uint64_t ect_trace(const orc_graph_t *g, const uint8_t *scm_del, int K, double m
                     s.memo = &memo;
                     s.last_dead_depth = -1;
                     s.nv_seen = s.na_seen = 0;
+                    if (g_m2) memset(g_m2, 0, g_m2_m * sizeof(m2_t));
+                    g_m2_n = 0, g_frame_serial = 0, g_cur_frame = 0, g_cur_hops = 0, g_m2_hits = 0, g_m2_saved_dead = 0, g_fs_n = 0;
                     dfs(&s, beg_utg, 0);
                     ++n_blocks, tot_tried += c.tried;
                     if (c.tried >= min_tried) {
@@ -265,6 +309,7 @@ uint64_t ect_trace(const orc_graph_t *g, const uint8_t *scm_del, int K, double m
                         fprintf(fo, " cat_arcs"); for (i = 0; i < 6; ++i) fprintf(fo, " %llu", (unsigned long long) c.cat_arcs[i]);
                         fprintf(fo, " cat_steps"); for (i = 0; i < 6; ++i) fprintf(fo, " %llu", (unsigned long long) c.cat_steps[i]);
                         fprintf(fo, " cat_diag"); for (i = 0; i < 6; ++i) fprintf(fo, " %llu", (unsigned long long) c.cat_diag[i]);
+                        fprintf(fo, " m2_hits %llu m2_saved_dead %llu", (unsigned long long) g_m2_hits, (unsigned long long) g_m2_saved_dead);
                         fprintf(fo, " sub_steps"); for (i = 0; i < 8; ++i) fprintf(fo, " %llu", (unsigned long long) c.sub_steps[i]);
                         fprintf(fo, " sub_cnt"); for (i = 0; i < 8; ++i) fprintf(fo, " %llu", (unsigned long long) c.sub_cnt[i]);
                         fprintf(fo, "\n");
