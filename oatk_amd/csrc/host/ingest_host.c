@@ -26,6 +26,10 @@
 #define UP_CHUNK ((uint64_t) 96 << 20)                 /* bytes per upload piece */
 
 /* one input file as a segment of the text: either a descriptor to pread from or inflated bytes in memory */
+/* set by sr_read_stream when what it returns OATK_E_NOMEM for is a record that did not fit a window (a genuine allocation failure must not be answered with windows
+ * eight times the size, and a pipe cannot be read again) */
+static __thread int g_record_too_long;
+
 typedef struct {
     int fd;                        /* >= 0: plain file */
     uint8_t *mem;                  /* inflated content (gzip'ed file), malloc'ed */
@@ -342,6 +346,16 @@ static void touch_worker(void *arg, int tid, int n_threads)
 }
 
 /* text [g0, g1) of ONE plain file from its mapping to the device; anything else than OATK_OK: the caller stages the window instead (nothing has been sent) */
+
+/* the upload straight from the file's page-locked mapping is given up for this file (its windows are read and staged instead): said once, so that a run whose reader got
+ * slower can be told from one that did not.  Such a mapping also means a file truncated WHILE it is read ends the process with SIGBUS where pread would have
+ * returned short -- OATK_HOST_MAP_UPLOAD=0 is the opt-out */
+static void map_abandoned(const char *why)
+{
+    static int said;
+    if (!__atomic_exchange_n(&said, 1, __ATOMIC_RELAXED)) fprintf(stderr, "[oatk host] upload from the mapped file abandoned (%s): windows are read and staged from here on\n", why);
+}
+
 static int upload_mapped(stream_t *st, stream_dev_t *D, int slot, uint64_t g0, uint64_t g1)
 {
     int i;
@@ -353,17 +367,17 @@ static int upload_mapped(stream_t *st, stream_dev_t *D, int slot, uint64_t g0, u
     if (!sg || sg->no_map) return OATK_E_ARG;
     if (!sg->map) {
         sg->map = (uint8_t *) mmap(0, (size_t) sg->size, PROT_READ, MAP_SHARED, sg->fd, 0);
-        if (sg->map == MAP_FAILED) { sg->map = 0, sg->no_map = 1; return OATK_E_ARG; }
+        if (sg->map == MAP_FAILED) { sg->map = 0, sg->no_map = 1; map_abandoned("mmap of the file failed"); return OATK_E_ARG; }
     }
     const uint64_t a = (g0 - sg->base) & ~(uint64_t) 4095, b = g1 - sg->base;           /* the mapping covers whole pages */
     const uint64_t blen = ((b - a) + 4095) & ~(uint64_t) 4095;
     touch_job_t tj = {sg->map + a, b - a};
     oatk_par_run_n(touch_worker, &tj, st->n_up);
-    if (oatk_hip_host_register(D->up, sg->map + a, blen) != OATK_OK) { sg->no_map = 1; return OATK_E_ARG; }
+    if (oatk_hip_host_register(D->up, sg->map + a, blen) != OATK_OK) { sg->no_map = 1; map_abandoned("hipHostRegister refused the read-only mapping"); return OATK_E_ARG; }
     int rc = oatk_hip_h2d_async(D->up, D->d_win[slot], sg->map + (g0 - sg->base), g1 - g0);
     if (!rc) rc = oatk_hip_sync(D->up);
     (void) oatk_hip_host_unregister(D->up, sg->map + a);
-    if (rc) sg->no_map = 1;
+    if (rc) sg->no_map = 1, map_abandoned("the copy from the mapping failed");
     return rc;
 }
 
@@ -718,7 +732,7 @@ static int sr_read_stream(oatk_hip_ctx **ctxs, int n_ctx, uint64_t *first, oatk_
         }
         const uint64_t next_carry = len - used;
         if (!final && !capped) {
-            if (next_carry > CARRY_CAP || used == 0) { rc = OATK_E_NOMEM; break; }       /* a record longer than a window: the caller retries in one piece */
+            if (next_carry > CARRY_CAP || used == 0) { rc = OATK_E_NOMEM, g_record_too_long = 1; break; }       /* a record longer than a window: the caller retries in one piece */
             rc = oatk_hip_d2d(D->piece[s], D->d_win[s ^ 1] - next_carry, d_text + used, next_carry);      /* (moved on above if the next window lands on another device) */
             if (rc) break;
         }
@@ -863,8 +877,11 @@ int oatk_host_sr_read_files_n(oatk_hip_ctx **ctxs, int n_ctx, oatk_sr_db_t *sr_d
         int attempt;
         if (win < 4096) win = 4096;
         for (attempt = 0;; ++attempt) {
+            int rewindable = 1;
+            for (i = 0; i < n_files; ++i) if (seg[i].gz && oatk_gzsrc_kind(seg[i].gz) == 3) rewindable = 0;       /* a pipe: what has been read is gone */
+            g_record_too_long = 0;
             rc = sr_read_stream(ctxs, n_ctx, first, sr_db, sr_db->k, sr_db->s, seg, n_files, 0, win, m_data, 1);
-            if (rc != OATK_E_NOMEM || attempt == 2) break;
+            if (rc != OATK_E_NOMEM || !g_record_too_long || !rewindable || attempt == 2) break;
             /* a record longer than a window: the stream cannot be rewound, so the files are opened again and read with windows eight times the size */
             seg_close(seg, n_files);
             oatk_sr_db_clean(sr_db);
