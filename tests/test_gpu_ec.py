@@ -2,6 +2,7 @@
 (syncerr.c:819) on the same databases and the same EC graph.  Bit-exact: corrected chains, refreshed syncmer table,
 error-syncmer marks and the block statistics."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -147,6 +148,8 @@ CASES = [
 @pytest.mark.parametrize("graph", ["host", "device", "device-tiers", "device-tiers-serial", "device-heavy", "device-heavy-mix", "device-heavy-spill", "device-tree", "device-tree-smalllog", "device-fused", "device-fused-spill"])
 @pytest.mark.parametrize("case", range(len(CASES)))
 def test_device_ec_matches_reference(hip, case, graph, monkeypatch):
+    if graph.startswith("device-tree") and not os.environ.get("OATK_TEST_EC_TREE"):
+        pytest.skip("the tree solver is an experiment that is switched off (DESIGN.md 8.3, round 5): OATK_TEST_EC_TREE=1 runs its cases")
     K, S, c, mk = CASES[case]
     reads = mk()
     # tiny first tier: most blocks run in the classes behind it -- routed there by length and run beside the first tier, or left over by it.
