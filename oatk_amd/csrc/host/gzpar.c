@@ -28,7 +28,7 @@
 #include "host_internal.h"
 
 #define GP_WIN 32768
-#define GP_FAST 10
+#define GP_FAST 11
 #define GP_MAX_THREADS 64
 #define GP_INF (~0ULL)
 
@@ -220,7 +220,7 @@ static int decode_block(br_t *b, int btype, sym_t *o, int text_only, uint64_t to
         uint16_t *os = o->s;
         uint64_t n = o->n, room = o->m;
         for (;;) {
-            if (n + 260 > room) { o->n = n; if (sym_room(o, 260)) return -1; os = o->s, room = o->m; }
+            if (n + 264 > room) { o->n = n; if (sym_room(o, 264)) return -1; os = o->s, room = o->m; }
             br_refill(b);
             int s = huff_decode(lit, b);
             if (s < 256) {
@@ -252,7 +252,14 @@ static int decode_block(br_t *b, int btype, sym_t *o, int text_only, uint64_t to
                     const uint32_t pre = (uint32_t) (dist - n < len? dist - n : len);
                     for (; i < pre; ++i) os[n + i] = (uint16_t) (256 + (GP_WIN + n + i - dist));
                 }
-                for (; i < len; ++i) os[n + i] = os[n + i - dist];
+                if (dist >= 4 && i == 0) {      /* four symbols at a time (the source lies at least four behind: no overlap within a move; up to three symbols beyond the match are
+                                                   scribbled on and overwritten by what follows -- there is room: 264 were asked for) */
+                    const uint16_t *src = os + n - dist;
+                    uint16_t *dst2 = os + n;
+                    for (; i < len; i += 4) memcpy(dst2 + i, src + i, 8);
+                } else {
+                    for (; i < len; ++i) os[n + i] = os[n + i - dist];
+                }
                 n += len;
             }
             if ((n & 0xFFF) < 260 && br_pos(b) > total_bits) return -1;
@@ -348,7 +355,7 @@ static void decode_chunk(oatk_gzpar_t *p, int j, int bounded)
     for (;;) {
         br_refill(&b);
         const uint32_t h = br_get(&b, 3);
-        if (decode_block(&b, (int) (h >> 1), &c->o, 0, total_bits)) { c->capped = c->o.lim && c->o.n + 260 > c->o.lim; return; }
+        if (decode_block(&b, (int) (h >> 1), &c->o, 0, total_bits)) { c->capped = c->o.lim && c->o.n + 264 > c->o.lim; return; }
         const uint64_t at = br_pos(&b);
         if (h & 1) { c->last = 1, c->end = at, c->ok = 1; return; }
         /* the first boundary at or after the cut of the next chunk that claims one: there or beyond it this chunk stops */
