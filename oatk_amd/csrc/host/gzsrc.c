@@ -184,7 +184,10 @@ void oatk_gzsrc_close(oatk_gzsrc_t *g)
     free(g);
 }
 
-uint64_t oatk_gzsrc_tell_in(const oatk_gzsrc_t *g) { return g->gzf? 0 : g->pos; }
+/* compressed bytes consumed so far.  Inside a member that is inflated on many threads (host/gzpar.c) that is the boundary its delivered chunks have reached -- the reader of
+ * host/ingest_host.c sizes its arrays and the device's batch by "text of this window per compressed byte it took": a position that stood still through a member made that
+ * estimate a ten-million-fold over-estimate (r05: a box lost to the memset of what realloc had promised) */
+uint64_t oatk_gzsrc_tell_in(const oatk_gzsrc_t *g) { return g->gzf? 0 : g->pos + (g->par? oatk_gzpar_in_used(g->par) : 0); }
 uint64_t oatk_gzsrc_size_in(const oatk_gzsrc_t *g) { return g->size; }
 int oatk_gzsrc_kind(const oatk_gzsrc_t *g) { return g->gzf? 3 : (g->bgzf? 2 : 1); }
 

@@ -763,9 +763,13 @@ static int sr_read_stream(oatk_hip_ctx **ctxs, int n_ctx, uint64_t *first, oatk_
         if (rc) break;
         t_dev += now_s() - t0, t0 = now_s();
         /* room for the reads: from the first piece's density, generously; grown when a later piece needs more */
+        /* (how much of the input this window took, as the estimates below see it: a source that cannot say -- or says something no deflate stream can mean, less than a
+         *  fortieth of the window's text -- is not extrapolated from: the arrays then grow window by window) */
+        const int trust_in = wf1 > wf0 && (double) (wf1 - wf0) * 40.0 >= (double) (g1 - text0);
         if (sr_db && sr_db->m < n_done + n) {
             uint64_t m = n_done + n;
-            if (!final && !capped && used && wf1 > wf0) m = n_done + (uint64_t) ((double) n * ((double) (ftotal > wf0? ftotal - wf0 : wf1 - wf0) / (double) (wf1 - wf0)) * 1.05) + 1024;
+            if (!final && !capped && used && trust_in) m = n_done + (uint64_t) ((double) n * ((double) (ftotal > wf0? ftotal - wf0 : wf1 - wf0) / (double) (wf1 - wf0)) * 1.05) + 1024;
+            else if (!final && !capped && m < 2 * sr_db->m) m = 2 * sr_db->m;          /* (no estimate: geometric growth) */
             oatk_sr_t *na = (oatk_sr_t *) realloc(sr_db->a, sizeof(oatk_sr_t) * m);
             if (!na) { rc = OATK_E_NOMEM; break; }
             memset(na + sr_db->m, 0, sizeof(oatk_sr_t) * (m - sr_db->m));
@@ -774,7 +778,7 @@ static int sr_read_stream(oatk_hip_ctx **ctxs, int n_ctx, uint64_t *first, oatk_
         {   /* ... and for the batch assembled in this handle, at its first piece */
             oatk_hip_info_t have;
             oatk_hip_info(ctx, &have);
-            if (have.n_reads == 0 && !final && !capped && used && wf1 > wf0) {
+            if (have.n_reads == 0 && !final && !capped && used && trust_in) {
                 oatk_hip_info_t inf;
                 oatk_hip_info(D->piece[s], &inf);
                 const double share = (double) ftotal / (double) n_ctx, left = ftotal > wf0? (double) (ftotal - wf0) : (double) (wf1 - wf0);

@@ -228,3 +228,34 @@ def test_damage_in_a_member_on_many_threads_is_reported(H, big_member, tmp_path,
     monkeypatch.setenv("OATK_HOST_GZ_PARALLEL", "0")                 # the switch: zlib on one thread
     got, status, _, _ = slurp(H, paths[6], 1 << 24, threads=8)
     assert status == 0 and got == text
+
+
+def test_the_position_in_the_file_moves_while_a_member_is_inflated_on_many_threads(H, big_member, monkeypatch):
+    """host/ingest_host.c sizes the reads' array and the device's batch by the text a window holds per compressed byte it took (oatk_gzsrc_tell_in before and after): a
+    position that stands still through a member turns that into an over-estimate by the file's size (round 5: a box was lost to it)"""
+    paths, text, _ = big_member
+    monkeypatch.setenv("OATK_HOST_GZ_PARALLEL", "100000")
+    monkeypatch.setenv("OATK_HOST_GZ_CHUNK_KB", "256")
+    rc = C.c_int(0)
+    g = H.oatk_gzsrc_open(paths[6].encode(), 8, C.byref(rc))
+    cap = 4 << 20
+    buf = np.empty(cap, np.uint8)
+    size, last, out, seen = os.path.getsize(paths[6]), 0, 0, []
+    while True:
+        n = H.oatk_gzsrc_read(g, buf.ctypes.data, cap)
+        assert n >= 0
+        if n == 0:
+            break
+        out += n
+        at = H.oatk_gzsrc_tell_in(g)
+        assert last <= at <= size
+        seen.append((out, at))
+        last = at
+    H.oatk_gzsrc_close(g)
+    assert out == len(text) and last == size
+    mid = [a for o, a in seen if len(text) // 4 < o < 3 * len(text) // 4]
+    assert mid and min(mid) > size // 10 and max(mid) < size, "the position follows the text"
+    # what the reader asks of it: a window's text over forty is no more than the compressed bytes the window took, from the second window on
+    for (o0, a0), (o1, a1) in zip(seen[1:], seen[2:]):
+        if o1 < len(text):
+            assert (a1 - a0) * 40 >= (o1 - o0) or a1 == a0, (o0, a0, o1, a1)
