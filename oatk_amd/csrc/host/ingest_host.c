@@ -612,6 +612,7 @@ static int sr_read_stream(oatk_hip_ctx **ctxs, int n_ctx, uint64_t *first, oatk_
     uint8_t *hop = 0;                                               /* a carried record tail on its way from one device to the next */
     uint8_t *h_carry = 0;                                           /* streamed input: the same tail on the host (the names are cut out of the host's copy of the text) */
     char **names = 0, **early_names = 0;
+    uint64_t early_n = 0, names_n = 0;                /* entries of the two arrays that hold names not yet handed to the reads (freed one by one on the way out when they are blocks of their own: ADVICE r04) */
     uint64_t ftotal = 0;
     int all_done = 0;
     memset(&st, 0, sizeof(st));
@@ -746,6 +747,7 @@ static int sr_read_stream(oatk_hip_ctx **ctxs, int n_ctx, uint64_t *first, oatk_
                 if (!rc) rc = oatk_hip_d2h(D->piece[s], hdr, dh, 8 * n);
                 if (rc) break;
                 hname_job_t hj = {h_text, len, hdr, n, early_names, sr_db};
+                early_n = n;
                 oatk_par_run(hname_worker, &hj);
                 free(hdr), hdr = 0;
             }
@@ -798,7 +800,7 @@ static int sr_read_stream(oatk_hip_ctx **ctxs, int n_ctx, uint64_t *first, oatk_
         }
         const void *d = 0;
         off = (uint64_t *) malloc(8 * n);
-        if (streamed) names = early_names, early_names = 0;           /* (cut out of the host's window above) */
+        if (streamed) names = early_names, early_names = 0, names_n = early_n, early_n = 0;           /* (cut out of the host's window above) */
         else hdr = (uint64_t *) malloc(8 * n), names = (char **) calloc(n, sizeof(char *));
         if (!off || (!streamed && !hdr) || !names) { rc = OATK_E_NOMEM; break; }
         rc = oatk_hip_buffer(D->piece[s], OATK_BUF_INGEST_OFF, &d, &b);
@@ -839,6 +841,11 @@ done:
         pthread_join(th, 0);
     }
     oatk_host_set_threads_internal(threads);
+    if (rc && !oatk_host_arena()) {                                 /* names that never reached a read: blocks of their own without arenas */
+        uint64_t q;
+        for (q = 0; names && q < names_n; ++q) free(names[q]);
+        for (q = 0; early_names && q < early_n; ++q) free(early_names[q]);
+    }
     free(off); free(hdr); free(names); free(hop); free(h_carry);
     free(early_names);
     for (r = 0; r < st.n_res; ++r) {
