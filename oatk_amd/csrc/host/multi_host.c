@@ -30,12 +30,40 @@ struct oatk_multi {
     char err[512];
 };
 
-typedef struct { const uint8_t *id; int rank, n, dev; oatk_comm *c; } mk_comm_t;
+/* ---- one host thread per handle ---- */
+typedef struct { pthread_mutex_t mu; pthread_cond_t cv; int open, go; } rank_gate_t;
+typedef struct { const uint8_t *id; int rank, n, dev; oatk_comm *c; rank_gate_t *gate; } mk_comm_t;
+
+/* (test hook: OATK_DEBUG_FAIL_THREAD=r makes the r-th thread of the next fan-out fail to start, as pthread_create does when the process is out of threads) */
+static int start_thread(pthread_t *th, void *(*fn)(void *), void *arg, int r)
+{
+    const char *ev = getenv("OATK_DEBUG_FAIL_THREAD");
+    if (ev && *ev && atoi(ev) == r) return -1;
+    return pthread_create(th, 0, fn, arg);
+}
+
+static int gate_wait(rank_gate_t *g)
+{
+    pthread_mutex_lock(&g->mu);
+    while (!g->open) pthread_cond_wait(&g->cv, &g->mu);
+    const int go = g->go;
+    pthread_mutex_unlock(&g->mu);
+    return go;
+}
+
+static void gate_open(rank_gate_t *g, int go)
+{
+    pthread_mutex_lock(&g->mu);
+    g->open = 1, g->go = go;
+    pthread_cond_broadcast(&g->cv);
+    pthread_mutex_unlock(&g->mu);
+}
 
 static void *mk_comm_entry(void *p)
 {
     mk_comm_t *k = (mk_comm_t *) p;
-    k->c = oatk_comm_create(k->id, k->rank, k->n, k->dev);
+    /* ncclCommInitRank returns when every rank has called it: nobody calls it before every rank has a thread to call it on */
+    if (gate_wait(k->gate)) k->c = oatk_comm_create(k->id, k->rank, k->n, k->dev);
     return 0;
 }
 
@@ -46,20 +74,14 @@ static void *xmalloc(size_t n)
     return p;
 }
 
-/* ---- one host thread per handle ---- */
 typedef int (*rank_fn)(oatk_multi *m, int rank, void *arg);
-typedef struct { pthread_mutex_t mu; pthread_cond_t cv; int open, go; } rank_gate_t;
 typedef struct { oatk_multi *m; int rank; rank_fn fn; void *arg; int rc; rank_gate_t *gate; } rank_job_t;
 
 static void *rank_entry(void *p)
 {
     rank_job_t *j = (rank_job_t *) p;
     /* nobody enters a collective before every rank has a thread to enter it on */
-    pthread_mutex_lock(&j->gate->mu);
-    while (!j->gate->open) pthread_cond_wait(&j->gate->cv, &j->gate->mu);
-    const int go = j->gate->go;
-    pthread_mutex_unlock(&j->gate->mu);
-    j->rc = go? j->fn(j->m, j->rank, j->arg) : OATK_E_STATE;
+    j->rc = gate_wait(j->gate)? j->fn(j->m, j->rank, j->arg) : OATK_E_STATE;
     return 0;
 }
 
@@ -74,15 +96,12 @@ static int run_ranks(oatk_multi *m, rank_fn fn, void *arg)
     pthread_mutex_init(&gate.mu, 0), pthread_cond_init(&gate.cv, 0), gate.open = 0, gate.go = 0;
     for (r = 0; r < m->n; ++r) {
         job[r].m = m, job[r].rank = r, job[r].fn = fn, job[r].arg = arg, job[r].rc = OATK_OK, job[r].gate = &gate;
-        started[r] = r > 0 && pthread_create(&th[r], 0, rank_entry, &job[r]) == 0;
+        started[r] = r > 0 && start_thread(&th[r], rank_entry, &job[r], r) == 0;
         if (r > 0 && !started[r]) all = 0;
     }
     /* (a rank without a thread cannot be run after the others: they would wait for it inside the collective.  The threads that did start are
      * sent home and the call fails as a whole) */
-    pthread_mutex_lock(&gate.mu);
-    gate.open = 1, gate.go = all;
-    pthread_cond_broadcast(&gate.cv);
-    pthread_mutex_unlock(&gate.mu);
+    gate_open(&gate, all);
     rank_entry(&job[0]);
     for (r = 1; r < m->n; ++r) if (started[r]) pthread_join(th[r], 0);
     pthread_mutex_destroy(&gate.mu), pthread_cond_destroy(&gate.cv);
@@ -113,10 +132,16 @@ oatk_multi *oatk_multi_create(const int *devices, int n)
         /* ncclCommInitRank blocks until every rank has called it: one thread per rank */
         mk_comm_t mk[64];
         pthread_t th[64];
-        for (r = 0; r < n; ++r) { mk[r].id = id, mk[r].rank = r, mk[r].n = n, mk[r].dev = devices[r], mk[r].c = 0; }
-        for (r = 1; r < n; ++r) if (pthread_create(&th[r], 0, mk_comm_entry, &mk[r]) != 0) { oatk_multi_destroy(m); return 0; }
+        rank_gate_t gate;
+        int started[64], all = 1;
+        pthread_mutex_init(&gate.mu, 0), pthread_cond_init(&gate.cv, 0), gate.open = 0, gate.go = 0;
+        for (r = 0; r < n; ++r) { mk[r].id = id, mk[r].rank = r, mk[r].n = n, mk[r].dev = devices[r], mk[r].c = 0, mk[r].gate = &gate; }
+        for (r = 1; r < n; ++r) { started[r] = start_thread(&th[r], mk_comm_entry, &mk[r], r) == 0; if (!started[r]) all = 0; }
+        /* (a rank without a thread: the threads that did start are sent home before any of them is inside ncclCommInitRank, joined, and the call fails as a whole) */
+        gate_open(&gate, all);
         mk_comm_entry(&mk[0]);
-        for (r = 1; r < n; ++r) pthread_join(th[r], 0);
+        for (r = 1; r < n; ++r) if (started[r]) pthread_join(th[r], 0);
+        pthread_mutex_destroy(&gate.mu), pthread_cond_destroy(&gate.cv);
         for (r = 0; r < n; ++r) m->comm[r] = mk[r].c;
         for (r = 0; r < n; ++r) if (!m->comm[r]) { oatk_multi_destroy(m); return 0; }
     } else {

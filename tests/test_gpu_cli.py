@@ -238,3 +238,16 @@ def test_cli_over_several_handles_without_ec_falls_back_after_the_count(tmp_path
     tab, _ = both(tmp_path, fa, 301, 21, 6, extra=["--no-read-ec", "--unzip-round", "0"], env={"OATK_DEVICES": "0,0", "OATK_DEBUG_WINDOW": "300000"})
     assert tab["sr_read"][0] == 1 and tab["collect_syncmer_from_reads"][0] == 1 and tab["sr_db_stat"][0] == 1
     assert tab["make_syncmer_graph"][2] == 1
+
+
+def test_cli_over_several_handles_when_a_host_thread_cannot_start(tmp_path):
+    """one host thread per handle runs every collective step (host/multi_host.c run_ranks); when one of them cannot be started the threads that did start
+    are sent home before any of them is inside a collective, the call fails as a whole, and the original body serves it: the reference's bytes still,
+    and no hang (OATK_DEBUG_FAIL_THREAD is the test hook that makes the start of thread r fail)"""
+    reads = A.hifi_like(260, 50000, 5000, seed=23, err=0.0008)
+    fa = str(tmp_path / "reads.fa")
+    R.write_fasta(reads, fa)
+    tab, log = both(tmp_path, fa, 301, 21, 6, env={"OATK_DEVICES": "0,0,0", "OATK_DEBUG_FAIL_THREAD": "2", "OATK_DEBUG_WINDOW": "300000"})
+    assert tab["sr_read"][0] == 1 and tab["sr_read"][2] == 0, tab["sr_read"]                     # (read on one thread: nothing to start)
+    assert tab["sr_db_stat"][2] >= 1 and tab["collect_syncmer_from_reads"][2] == 1, (tab["sr_db_stat"], tab["collect_syncmer_from_reads"])
+    assert "could not start one host thread per handle" in log, log[-3000:]
