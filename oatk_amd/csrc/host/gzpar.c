@@ -22,6 +22,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <zlib.h>
 
 #include "oatk_hip.h"
@@ -72,7 +73,9 @@ typedef struct {
 } huff_t;
 
 /* 0: a complete code; 1: incomplete (allowed for a single distance code); -1: over-subscribed or empty where that is not allowed */
-static int huff_build(huff_t *h, const uint8_t *len, int n)
+/* (need_complete: an incomplete code is of no use to the caller -- said before any table is filled: the boundary search asks this of a hundred thousand chance headers
+ *  per chunk, and nearly all of them end here) */
+static int huff_build(huff_t *h, const uint8_t *len, int n, int need_complete)
 {
     int i, l, left = 1;
     uint16_t offs[16];
@@ -80,6 +83,7 @@ static int huff_build(huff_t *h, const uint8_t *len, int n)
     for (i = 0; i < n; ++i) h->count[len[i]]++;
     if (h->count[0] == n) return -1;
     for (l = 1; l <= 15; ++l) { left <<= 1; left -= h->count[l]; if (left < 0) return -1; }
+    if (left > 0 && need_complete) return 1;
     offs[1] = 0;
     for (l = 1; l < 15; ++l) offs[l + 1] = offs[l] + h->count[l];
     for (i = 0; i < n; ++i) if (len[i]) h->sym[offs[len[i]]++] = (uint16_t) i;
@@ -154,7 +158,7 @@ static int read_dynamic(br_t *b, huff_t *lit, huff_t *dst)
     if (hlit > 286 || hdist > 30) return -1;
     memset(cl, 0, sizeof(cl));
     for (i = 0; i < hclen; ++i) cl[CLORD[i]] = (uint8_t) br_get(b, 3);
-    if (huff_build(&clh, cl, 19) != 0) return -1;
+    if (huff_build(&clh, cl, 19, 1) != 0) return -1;
     for (i = 0; i < hlit + hdist; ) {
         br_refill(b);
         const int s = huff_decode(&clh, b);
@@ -170,16 +174,19 @@ static int read_dynamic(br_t *b, huff_t *lit, huff_t *dst)
         }
     }
     if (len[256] == 0) return -1;
-    if (huff_build(lit, len, hlit) != 0) return -1;              /* (zlib: an incomplete literal/length code is an error) */
+    if (huff_build(lit, len, hlit, 1) != 0) return -1;              /* (zlib: an incomplete literal/length code is an error) */
     {
-        const int r = huff_build(dst, len + hlit, hdist);
+        const int r = huff_build(dst, len + hlit, hdist, 0);
         if (r < 0) { int nz = 0; for (i = 0; i < hdist; ++i) nz += len[hlit + i] != 0; if (nz) return -1; memset(dst, 0, sizeof(*dst)); }      /* (no distance codes at all: a block of literals) */
         else if (r > 0 && dst->count[1] + dst->count[2] + dst->count[3] + dst->count[4] + dst->count[5] + dst->count[6] + dst->count[7] + dst->count[8] + dst->count[9] + dst->count[10] + dst->count[11] + dst->count[12] + dst->count[13] + dst->count[14] + dst->count[15] != 1) return -1;
     }
     return 0;
 }
 static huff_t g_fix_lit, g_fix_dst;
+static uint16_t g_kraft3[512];                  /* three 3-bit code lengths -> their Kraft weights in 128ths */
 static pthread_once_t g_fix_once = PTHREAD_ONCE_INIT;
+static void crc_init(void);
+static const char *gp_crc_kind(void);
 static void fixed_init(void)
 {
     uint8_t len[288];
@@ -188,9 +195,11 @@ static void fixed_init(void)
     for (; i < 256; ++i) len[i] = 9;
     for (; i < 280; ++i) len[i] = 7;
     for (; i < 288; ++i) len[i] = 8;
-    (void) huff_build(&g_fix_lit, len, 288);
+    (void) huff_build(&g_fix_lit, len, 288, 0);
     for (i = 0; i < 30; ++i) len[i] = 5;
-    (void) huff_build(&g_fix_dst, len, 30);
+    (void) huff_build(&g_fix_dst, len, 30, 0);
+    crc_init();
+    for (i = 0; i < 512; ++i) { int q; g_kraft3[i] = 0; for (q = 0; q < 9; q += 3) { const int l = i >> q & 7; g_kraft3[i] += (uint16_t) (l? 128 >> l : 0); } }
 }
 
 /* One block's data (the header's three bits are read) into o.  text_only: literals must be text (a candidate boundary is being tried).  0 ok, -1 not a block / corrupt */
@@ -220,7 +229,7 @@ static int decode_block(br_t *b, int btype, sym_t *o, int text_only, uint64_t to
         uint16_t *os = o->s;
         uint64_t n = o->n, room = o->m;
         for (;;) {
-            if (n + 264 > room) { o->n = n; if (sym_room(o, 264)) return -1; os = o->s, room = o->m; }
+            if (n + 288 > room) { o->n = n; if (sym_room(o, 288)) return -1; os = o->s, room = o->m; }
             br_refill(b);
             int s = huff_decode(lit, b);
             if (s < 256) {
@@ -252,8 +261,12 @@ static int decode_block(br_t *b, int btype, sym_t *o, int text_only, uint64_t to
                     const uint32_t pre = (uint32_t) (dist - n < len? dist - n : len);
                     for (; i < pre; ++i) os[n + i] = (uint16_t) (256 + (GP_WIN + n + i - dist));
                 }
-                if (dist >= 4 && i == 0) {      /* four symbols at a time (the source lies at least four behind: no overlap within a move; up to three symbols beyond the match are
-                                                   scribbled on and overwritten by what follows -- there is room: 264 were asked for) */
+                if (dist >= 16 && i == 0) {     /* sixteen symbols at a time (the source lies at least sixteen behind: no overlap within a move; up to fifteen symbols beyond the match
+                                                   are scribbled on and overwritten by what follows -- there is room: 288 were asked for) */
+                    const uint16_t *src = os + n - dist;
+                    uint16_t *dst2 = os + n;
+                    for (; i < len; i += 16) memcpy(dst2 + i, src + i, 32);
+                } else if (dist >= 4 && i == 0) {      /* four at a time */
                     const uint16_t *src = os + n - dist;
                     uint16_t *dst2 = os + n;
                     for (; i < len; i += 4) memcpy(dst2 + i, src + i, 8);
@@ -275,13 +288,23 @@ static uint64_t find_boundary(const uint8_t *in, uint64_t n_in, uint64_t from, u
     const uint64_t total_bits = n_in * 8;
     sym_t tmp = {0, 0, 0, 16u << 20};             /* (a block of sixteen million symbols is no block zlib, pigz or bgzip writes) */
     uint64_t at, found = GP_INF;
-    for (at = from; at < to && at + 64 < total_bits; ++at) {
+    uint64_t x = 0;
+    for (at = from; at < to && at + 192 < total_bits; ++at) {
         /* cheap tests first: BFINAL = 0, BTYPE = 2 (bits 0, 0, 1), HLIT <= 29, HDIST <= 29 */
         const uint64_t byte = at >> 3;
-        uint32_t w = (uint32_t) in[byte] | (uint32_t) in[byte + 1] << 8 | (uint32_t) in[byte + 2] << 16 | (uint32_t) in[byte + 3] << 24;
-        w >>= at & 7;
+        if ((at & 7) == 0 || at == from) memcpy(&x, in + byte, 8);        /* (eight positions from one load) */
+        const uint32_t w = (uint32_t) (x >> (at & 7));
         if ((w & 7) != 4) continue;
         if (((w >> 3) & 31) > 29 || ((w >> 8) & 31) > 29) continue;
+        {   /* ... and the code-length code must be complete (Kraft's sum over its 4 .. 19 three-bit lengths, the header's bits 17 ..): one chance header in hundreds is */
+            uint64_t hi;
+            memcpy(&hi, in + byte + 8, 8);                               /* (the loop's bound leaves these sixteen bytes inside the input) */
+            const int sh = (int) (at & 7) + 17, ncl = (int) ((w >> 13) & 15) + 4;
+            uint64_t c = (x >> sh | hi << (64 - sh)) & ((1ULL << (3 * ncl)) - 1);
+            uint32_t kraft = 0;
+            for (; c; c >>= 9) kraft += g_kraft3[c & 511];
+            if (kraft != 128) continue;
+        }
         br_t b;
         br_init(&b, in, n_in, at);
         br_refill(&b);
@@ -322,7 +345,8 @@ typedef struct {
     int capped;                                  /* given up because it grew beyond anything a chunk of this size inflates to (it may still be the text: then it is decoded again, unbounded) */
     int chained;                                 /* a chunk before it arrived exactly at its boundary: its symbols are the text */
     uint64_t out_off, take, given;               /* where its bytes go in this call, how many of its symbols go there, how many went before */
-    uint8_t win[GP_WIN];                         /* the window before it */
+    uint8_t lut[256 + GP_WIN];                   /* symbol -> byte: 256 bytes as they are, then the window before the chunk (one load a symbol, no branch: in DNA text most
+                                                    symbols of a chunk stay window references -- short matches into short matches -- to its end) */
     uint32_t crc;
 } chunk_t;
 
@@ -335,17 +359,28 @@ struct oatk_gzpar {
     uint64_t total_out; uint32_t crc;
     int done, failed, first;
     chunk_t *ch; int n_ch, next_out;             /* the batch at hand, and the first of its chunks not delivered yet */
-    /* work sharing */
+    int n_slots;                                 /* chunks a batch may hold: more than there are threads, so that a thread that is done early takes another */
+    /* work sharing: the threads live as long as the member (created at open; a phase is a generation they all take part in) */
     int phase; volatile int next;
     uint8_t *dst;
+    pthread_mutex_t mu; pthread_cond_t cv_go, cv_done;
+    pthread_t th[GP_MAX_THREADS];
+    int n_started, gen, busy, quit;
+    /* OATK_GZPAR_LOG=1: where the time goes, on stderr when the member is closed */
+    int log, n_batches, n_again, n_gaps;
+    uint64_t gap_syms;
+    double t_phase[4];                           /* boundaries, symbols, chain + windows, bytes */
+    uint64_t n_chunks, n_chained;
 };
+static double gp_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double) t.tv_sec + 1e-9 * (double) t.tv_nsec; }
 
+/* chunk j from the boundary it claims to the first block boundary at or after the next chunk's cut (where the next chunk looks for ITS boundary: if both are right they
+ * meet; nothing here depends on what another thread finds) */
 static void decode_chunk(oatk_gzpar_t *p, int j, int bounded)
 {
     chunk_t *c = &p->ch[j];
-    const uint64_t total_bits = p->n_in * 8;
+    const uint64_t total_bits = p->n_in * 8, stop = c->nominal + p->chunk_bits;
     br_t b;
-    int nxt = j + 1;
     c->o.n = 0, c->ok = 0, c->last = 0, c->capped = 0;
     /* a chunk entered on a guess (every one but the batch's first) gets room for what two chunks of text compressed fortyfold would need: garbage that decodes as one long
      * run of matches stops there, instead of at the end of a gigabyte of input */
@@ -355,72 +390,230 @@ static void decode_chunk(oatk_gzpar_t *p, int j, int bounded)
     for (;;) {
         br_refill(&b);
         const uint32_t h = br_get(&b, 3);
-        if (decode_block(&b, (int) (h >> 1), &c->o, 0, total_bits)) { c->capped = c->o.lim && c->o.n + 264 > c->o.lim; return; }
+        if (decode_block(&b, (int) (h >> 1), &c->o, 0, total_bits)) { c->capped = c->o.lim && c->o.n + 288 > c->o.lim; return; }
         const uint64_t at = br_pos(&b);
         if (h & 1) { c->last = 1, c->end = at, c->ok = 1; return; }
-        /* the first boundary at or after the cut of the next chunk that claims one: there or beyond it this chunk stops */
-        while (nxt < p->n_ch && (p->ch[nxt].start == GP_INF || p->ch[nxt].start < at)) ++nxt;
-        if (nxt < p->n_ch) { if (at == p->ch[nxt].start) { c->end = at, c->ok = 1; return; } }
-        else if (at >= p->ch[p->n_ch - 1].nominal + p->chunk_bits) { c->end = at, c->ok = 1; return; }       /* the batch's last: the first boundary past the batch */
+        if (at >= stop) { c->end = at, c->ok = 1; return; }
     }
 }
+/* the chained chunk j goes on from the boundary `*at` (where it stopped), block by block, until it stands at or beyond `target`: the blocks between its end and a later
+ * chunk's claim -- a flush marker the search does not take for a boundary, a chunk whose claim was false or that found none.  Its symbols are the text: no bound.  0 ok */
+static int extend_chunk(oatk_gzpar_t *p, int j, uint64_t *at, uint64_t target)
+{
+    chunk_t *c = &p->ch[j];
+    const uint64_t total_bits = p->n_in * 8;
+    br_t b;
+    c->o.lim = 0;
+    br_init(&b, p->in, p->n_in, *at);
+    for (;;) {
+        br_refill(&b);
+        const uint32_t h = br_get(&b, 3);
+        if (decode_block(&b, (int) (h >> 1), &c->o, 0, total_bits)) return -1;
+        const uint64_t pos = br_pos(&b);
+        c->end = *at = pos;
+        if (h & 1) { c->last = 1; return 0; }
+        if (pos >= target) return 0;
+    }
+}
+/* ---- CRC-32 of the text, as gzip defines it ----
+ * zlib 1.2.11's crc32 does ~1.1 GB/s on a core, a third of what turning symbols into bytes costs.  Where the processor multiplies without carries (PCLMULQDQ) the CRC is
+ * folded sixty-four bytes at a time instead (Gopal et al., "Fast CRC computation for generic polynomials using PCLMULQDQ", Intel 2009; the constants are x^n mod P for the
+ * reflected polynomial 0xEDB88320: 4 x 128 + 64 / 4 x 128 bits for the four-lane fold, 128 + 64 / 128 for the one-lane fold, 64 -> 32, and P' with mu for Barrett's
+ * reduction).  It is checked against zlib's on the first use -- all lengths 0 .. 300 and a few long ones -- and zlib's is used if they differ or the instruction is absent. */
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("pclmul,sse4.1")))
+static uint32_t crc_fold(uint32_t crc, const uint8_t *buf, uint64_t len)          /* len a multiple of 16, at least 64; crc and the result WITHOUT zlib's inversions */
+{
+    const __m128i k1k2 = _mm_set_epi64x(0x01c6e41596LL, 0x0154442bd4LL), k3k4 = _mm_set_epi64x(0x00ccaa009eLL, 0x01751997d0LL);
+    const __m128i k5 = _mm_set_epi64x(0, 0x0163cd6124LL), pm = _mm_set_epi64x(0x01f7011641LL, 0x01db710641LL), lo32 = _mm_setr_epi32(~0, 0, ~0, 0);
+    __m128i x1 = _mm_loadu_si128((const __m128i *) buf), x2 = _mm_loadu_si128((const __m128i *) (buf + 16));
+    __m128i x3 = _mm_loadu_si128((const __m128i *) (buf + 32)), x4 = _mm_loadu_si128((const __m128i *) (buf + 48)), t;
+    x1 = _mm_xor_si128(x1, _mm_cvtsi32_si128((int) crc));
+    buf += 64, len -= 64;
+    for (; len >= 64; buf += 64, len -= 64) {
+        __m128i a = _mm_clmulepi64_si128(x1, k1k2, 0x00), b = _mm_clmulepi64_si128(x2, k1k2, 0x00), c = _mm_clmulepi64_si128(x3, k1k2, 0x00), d = _mm_clmulepi64_si128(x4, k1k2, 0x00);
+        x1 = _mm_clmulepi64_si128(x1, k1k2, 0x11), x2 = _mm_clmulepi64_si128(x2, k1k2, 0x11), x3 = _mm_clmulepi64_si128(x3, k1k2, 0x11), x4 = _mm_clmulepi64_si128(x4, k1k2, 0x11);
+        x1 = _mm_xor_si128(_mm_xor_si128(x1, a), _mm_loadu_si128((const __m128i *) buf));
+        x2 = _mm_xor_si128(_mm_xor_si128(x2, b), _mm_loadu_si128((const __m128i *) (buf + 16)));
+        x3 = _mm_xor_si128(_mm_xor_si128(x3, c), _mm_loadu_si128((const __m128i *) (buf + 32)));
+        x4 = _mm_xor_si128(_mm_xor_si128(x4, d), _mm_loadu_si128((const __m128i *) (buf + 48)));
+    }
+    t = _mm_clmulepi64_si128(x1, k3k4, 0x00), x1 = _mm_clmulepi64_si128(x1, k3k4, 0x11), x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), t);
+    t = _mm_clmulepi64_si128(x1, k3k4, 0x00), x1 = _mm_clmulepi64_si128(x1, k3k4, 0x11), x1 = _mm_xor_si128(_mm_xor_si128(x1, x3), t);
+    t = _mm_clmulepi64_si128(x1, k3k4, 0x00), x1 = _mm_clmulepi64_si128(x1, k3k4, 0x11), x1 = _mm_xor_si128(_mm_xor_si128(x1, x4), t);
+    for (; len >= 16; buf += 16, len -= 16) {
+        t = _mm_clmulepi64_si128(x1, k3k4, 0x00), x1 = _mm_clmulepi64_si128(x1, k3k4, 0x11);
+        x1 = _mm_xor_si128(_mm_xor_si128(x1, _mm_loadu_si128((const __m128i *) buf)), t);
+    }
+    /* 128 -> 64 -> 32 bits, then Barrett */
+    x2 = _mm_clmulepi64_si128(x1, k3k4, 0x10);
+    x1 = _mm_xor_si128(_mm_srli_si128(x1, 8), x2);
+    x2 = _mm_srli_si128(x1, 4);
+    x1 = _mm_xor_si128(_mm_clmulepi64_si128(_mm_and_si128(x1, lo32), k5, 0x00), x2);
+    x2 = _mm_and_si128(_mm_clmulepi64_si128(_mm_and_si128(x1, lo32), pm, 0x10), lo32);
+    x2 = _mm_clmulepi64_si128(x2, pm, 0x00);
+    x1 = _mm_xor_si128(x1, x2);
+    return (uint32_t) _mm_extract_epi32(x1, 1);
+}
+static int g_crc_fast;                           /* decided once (pthread_once with the fixed codes) */
+static uint32_t gp_crc32(uint32_t crc, const uint8_t *d, uint64_t n)
+{
+    if (g_crc_fast && n >= 64) {
+        const uint64_t m = n & ~15ULL;
+        crc = ~crc_fold(~crc, d, m);
+        d += m, n -= m;
+    }
+    for (; n; ) { const uint64_t m = n < (1u << 30)? n : (1u << 30); crc = (uint32_t) crc32(crc, d, (uInt) m); d += m, n -= m; }
+    return crc;
+}
+static void crc_init(void)
+{
+    g_crc_fast = 0;
+    if (!__builtin_cpu_supports("pclmul") || !__builtin_cpu_supports("sse4.1")) return;
+    {
+        enum { N = 70000 };
+        uint8_t *t = (uint8_t *) malloc(N);
+        uint32_t x = 12345, ok = 1;
+        int n;
+        if (!t) return;
+        for (n = 0; n < N; ++n) x = x * 1664525u + 1013904223u, t[n] = (uint8_t) (x >> 24);
+        g_crc_fast = 1;
+        for (n = 0; n <= 300 && ok; ++n) ok = gp_crc32(0x1234u + (uint32_t) n, t + (n & 7), (uint64_t) n) == (uint32_t) crc32(0x1234u + (uint32_t) n, t + (n & 7), (uInt) n);
+        for (n = 4093; n < N && ok; n = n * 2 + 3) ok = gp_crc32(0, t + 1, (uint64_t) n) == (uint32_t) crc32(0L, t + 1, (uInt) n);
+        g_crc_fast = (int) ok;
+        free(t);
+    }
+}
+/* sixteen symbols that are all bytes become sixteen bytes in one move */
+static inline uint64_t resolve_run(uint8_t *d, const uint16_t *s, uint64_t n, const uint8_t *lut)
+{
+    uint64_t i = 0;
+    for (; i + 16 <= n; i += 16) {
+        const __m128i a = _mm_loadu_si128((const __m128i *) (s + i)), b = _mm_loadu_si128((const __m128i *) (s + i + 8));
+        if (_mm_movemask_epi8(_mm_cmpeq_epi16(_mm_srli_epi16(_mm_or_si128(a, b), 8), _mm_setzero_si128())) == 0xFFFF) _mm_storeu_si128((__m128i *) (d + i), _mm_packus_epi16(a, b));
+        else { int q; for (q = 0; q < 16; ++q) d[i + q] = lut[s[i + q]]; }
+    }
+    for (; i < n; ++i) d[i] = lut[s[i]];
+    return n;
+}
+#else
+static uint32_t gp_crc32(uint32_t crc, const uint8_t *d, uint64_t n)
+{
+    for (; n; ) { const uint64_t m = n < (1u << 30)? n : (1u << 30); crc = (uint32_t) crc32(crc, d, (uInt) m); d += m, n -= m; }
+    return crc;
+}
+static void crc_init(void) {}
+static inline uint64_t resolve_run(uint8_t *d, const uint16_t *s, uint64_t n, const uint8_t *lut)
+{
+    uint64_t i;
+    for (i = 0; i < n; ++i) d[i] = lut[s[i]];
+    return n;
+}
+#endif
+
+#if defined(__x86_64__)
+static const char *gp_crc_kind(void) { return g_crc_fast? "folded" : "zlib's"; }
+#else
+static const char *gp_crc_kind(void) { return "zlib's"; }
+#endif
+/* a chunk's symbols -> bytes at their place, with their CRC: a piece at a time, so that the CRC reads what the cache still holds */
 static void resolve_chunk(oatk_gzpar_t *p, int j)
 {
     chunk_t *c = &p->ch[j];
     uint8_t *d = p->dst + c->out_off;
     const uint16_t *s = c->o.s + c->given;
     uint64_t i;
-    for (i = 0; i < c->take; ++i) d[i] = s[i] < 256? (uint8_t) s[i] : c->win[s[i] - 256];
     c->crc = (uint32_t) crc32(0L, Z_NULL, 0);
-    for (i = 0; i < c->take; i += 1u << 30) { const uint64_t m = c->take - i < (1u << 30)? c->take - i : (1u << 30); c->crc = (uint32_t) crc32(c->crc, d + i, (uInt) m); }
+    for (i = 0; i < c->take; i += 32768) {
+        const uint64_t m = c->take - i < 32768? c->take - i : 32768;
+        resolve_run(d + i, s + i, m, c->lut);
+        c->crc = gp_crc32(c->crc, d + i, m);
+    }
 }
-static void *gp_worker(void *arg)
+static void gp_work(oatk_gzpar_t *p)
 {
-    oatk_gzpar_t *p = (oatk_gzpar_t *) arg;
     for (;;) {
         const int j = __atomic_fetch_add(&p->next, 1, __ATOMIC_RELAXED);
         if (j >= p->n_ch) break;
         chunk_t *c = &p->ch[j];
-        if (p->phase == 0) { if (j > 0) c->start = find_boundary(p->in, p->n_in, c->nominal, c->nominal + p->chunk_bits); }
-        else if (p->phase == 1) decode_chunk(p, j, j > 0);
-        else if (c->chained && j >= p->next_out && c->out_off != GP_INF && c->take) resolve_chunk(p, j);
+        if (p->phase == 0) {
+            if (j > 0) c->start = find_boundary(p->in, p->n_in, c->nominal, c->nominal + p->chunk_bits);
+            decode_chunk(p, j, j > 0);
+        } else if (c->chained && j >= p->next_out && c->out_off != GP_INF && c->take) resolve_chunk(p, j);
     }
-    return 0;
+}
+static void *gp_worker(void *arg)
+{
+    oatk_gzpar_t *p = (oatk_gzpar_t *) arg;
+    int seen = 0;                                /* (every worker is created in oatk_gzpar_open, before the first generation) */
+    for (;;) {
+        pthread_mutex_lock(&p->mu);
+        while (p->gen == seen && !p->quit) pthread_cond_wait(&p->cv_go, &p->mu);
+        if (p->quit) { pthread_mutex_unlock(&p->mu); return 0; }
+        seen = p->gen;
+        pthread_mutex_unlock(&p->mu);
+        gp_work(p);
+        pthread_mutex_lock(&p->mu);
+        if (--p->busy == 0) pthread_cond_signal(&p->cv_done);
+        pthread_mutex_unlock(&p->mu);
+    }
 }
 static int run_phase(oatk_gzpar_t *p, int phase)
 {
-    pthread_t th[GP_MAX_THREADS];
-    int i, n = p->n_threads < p->n_ch? p->n_threads : p->n_ch, started = 0;
-    p->phase = phase, p->next = 0;
-    for (i = 0; i < n - 1; ++i) { if (pthread_create(&th[started], 0, gp_worker, p) != 0) break; ++started; }
-    gp_worker(p);
-    for (i = 0; i < started; ++i) pthread_join(th[i], 0);
+    const double t0 = gp_now();
+    pthread_mutex_lock(&p->mu);
+    p->phase = phase, p->next = 0, p->busy = p->n_started, ++p->gen;
+    pthread_cond_broadcast(&p->cv_go);
+    pthread_mutex_unlock(&p->mu);
+    gp_work(p);
+    pthread_mutex_lock(&p->mu);
+    while (p->busy) pthread_cond_wait(&p->cv_done, &p->mu);
+    pthread_mutex_unlock(&p->mu);
+    p->t_phase[phase == 2? 3 : phase] += gp_now() - t0;
     return 0;
 }
 
 oatk_gzpar_t *oatk_gzpar_open(const uint8_t *deflate, uint64_t n_in, int n_threads)
 {
     oatk_gzpar_t *p = (oatk_gzpar_t *) calloc(1, sizeof(*p));
+    int i;
     if (!p) return 0;
     pthread_once(&g_fix_once, fixed_init);
     p->in = deflate, p->n_in = n_in;
     p->n_threads = n_threads < 1? 1 : (n_threads > GP_MAX_THREADS? GP_MAX_THREADS : n_threads);
     {
         const char *e = getenv("OATK_HOST_GZ_CHUNK_KB");
-        uint64_t kb = e && atoi(e) > 0? (uint64_t) atoi(e) : 2048;
+        uint64_t kb = e && atoi(e) > 0? (uint64_t) atoi(e) : 1024;
         p->chunk_bits = kb * 1024 * 8;
+        e = getenv("OATK_HOST_GZ_SLOTS");         /* chunks per batch and thread (3: a batch is done when its slowest chunk is, and chunks differ by a third) */
+        p->n_slots = p->n_threads * (e && atoi(e) > 0 && atoi(e) <= 16? atoi(e) : 3);
     }
     p->first = 1;
+    { const char *e = getenv("OATK_GZPAR_LOG"); p->log = e && e[0] == '1'; }
     p->crc = (uint32_t) crc32(0L, Z_NULL, 0);
-    p->ch = (chunk_t *) calloc((size_t) p->n_threads, sizeof(chunk_t));
+    p->ch = (chunk_t *) calloc((size_t) p->n_slots, sizeof(chunk_t));
     if (!p->ch) { free(p); return 0; }
+    { int q; for (i = 0; i < p->n_slots; ++i) for (q = 0; q < 256; ++q) p->ch[i].lut[q] = (uint8_t) q; }
+    pthread_mutex_init(&p->mu, 0), pthread_cond_init(&p->cv_go, 0), pthread_cond_init(&p->cv_done, 0);
+    for (i = 0; i < p->n_threads - 1; ++i) { if (pthread_create(&p->th[p->n_started], 0, gp_worker, p) != 0) break; ++p->n_started; }      /* (fewer than asked for: the others do their share) */
     return p;
 }
 void oatk_gzpar_close(oatk_gzpar_t *p)
 {
     int j;
     if (!p) return;
-    for (j = 0; j < p->n_threads; ++j) free(p->ch[j].o.s);
+    pthread_mutex_lock(&p->mu);
+    p->quit = 1;
+    pthread_cond_broadcast(&p->cv_go);
+    pthread_mutex_unlock(&p->mu);
+    for (j = 0; j < p->n_started; ++j) pthread_join(p->th[j], 0);
+    pthread_mutex_destroy(&p->mu), pthread_cond_destroy(&p->cv_go), pthread_cond_destroy(&p->cv_done);
+    if (p->log)
+        fprintf(stderr, "[M::gzpar] %d threads, %d batches, %lu chunks of %lu KB (%lu the text, %d decoded again, %d gaps of %lu symbols closed in order), crc %s: boundaries and symbols %.3f s, chain and windows %.3f s, bytes %.3f s\n",
+                p->n_started + 1, p->n_batches, (unsigned long) p->n_chunks, (unsigned long) (p->chunk_bits >> 13), (unsigned long) p->n_chained, p->n_again, p->n_gaps, (unsigned long) p->gap_syms, gp_crc_kind(),
+                p->t_phase[0], p->t_phase[2], p->t_phase[3]);
+    for (j = 0; j < p->n_slots; ++j) free(p->ch[j].o.s);
     free(p->ch);
     free(p);
 }
@@ -434,7 +627,7 @@ static int next_batch(oatk_gzpar_t *p)
     int j;
     const uint64_t total_bits = p->n_in * 8;
     p->n_ch = 0;
-    for (j = 0; j < p->n_threads; ++j) {
+    for (j = 0; j < p->n_slots; ++j) {
         const uint64_t nominal = p->pos + (uint64_t) j * p->chunk_bits;
         if (j > 0 && nominal + 1024 >= total_bits) break;
         p->ch[j].nominal = nominal, p->ch[j].start = j == 0? p->pos : GP_INF, p->ch[j].chained = 0, p->ch[j].out_off = GP_INF, p->ch[j].take = 0, p->ch[j].given = 0;
@@ -448,17 +641,28 @@ static int next_batch(oatk_gzpar_t *p)
         if (2 * found < p->n_ch - 1) return -2;
     }
     p->first = 0;
-    run_phase(p, 1);
-    /* the chain: chunk 0 begins at a known boundary; a chunk is the text if the chained chunk before it stopped exactly where it begins */
+    const double t_chain = gp_now();
+    p->n_batches++, p->n_chunks += (uint64_t) p->n_ch;
+    /* the chain: chunk 0 begins at a known boundary and stops at a boundary; a later chunk is the text if the chain stands exactly where it begins.  Where the chain stands
+     * BEFORE a claim (the boundary it stopped at was one the search does not accept -- a flush marker, a stored or a short block -- or a chunk between found none) its last
+     * chunk goes on, in order, until it stands there or has passed it; a claim the chain has passed was false */
     {
         uint64_t at = p->pos;
         int prev = -1;
         for (j = 0; j < p->n_ch; ++j) {
             chunk_t *c = &p->ch[j];
-            if (c->start != at) continue;
-            if (!c->ok && c->capped) decode_chunk(p, j, 0);      /* (it IS the text, and longer than the guess allowed: once more, without the bound) */
+            if (c->start == GP_INF || c->start < at) continue;
+            if (c->start > at) {
+                if (prev < 0) return -1;
+                const uint64_t n0 = p->ch[prev].o.n;
+                if (extend_chunk(p, prev, &at, c->start)) return -1;
+                p->n_gaps++, p->gap_syms += p->ch[prev].o.n - n0;
+                if (p->ch[prev].last) break;
+                if (at != c->start) continue;
+            }
+            if (!c->ok && c->capped) { decode_chunk(p, j, 0); p->n_again++; }      /* (it IS the text, and longer than the guess allowed: once more, without the bound) */
             if (!c->ok) return -1;               /* (decoded from a true boundary and failed: the stream is damaged) */
-            c->chained = 1, prev = j, at = c->end;
+            c->chained = 1, prev = j, at = c->end, p->n_chained++;
             if (c->last) break;
         }
         if (prev < 0) return -1;
@@ -470,13 +674,14 @@ static int next_batch(oatk_gzpar_t *p)
         for (j = 0; j < p->n_ch; ++j) {
             chunk_t *c = &p->ch[j];
             if (!c->chained) continue;
-            memcpy(c->win, win, GP_WIN);
+            memcpy(c->lut + 256, win, GP_WIN);
             const uint64_t n = c->o.n, tail = n < GP_WIN? n : GP_WIN;
             uint64_t i;
             if (tail < GP_WIN) memmove(win, win + tail, GP_WIN - tail);
-            for (i = 0; i < tail; ++i) { const uint16_t s = c->o.s[n - tail + i]; win[GP_WIN - tail + i] = s < 256? (uint8_t) s : c->win[s - 256]; }
+            for (i = 0; i < tail; ++i) { const uint16_t s = c->o.s[n - tail + i]; win[GP_WIN - tail + i] = c->lut[s]; }
         }
     }
+    p->t_phase[2] += gp_now() - t_chain;
     return 0;
 }
 

@@ -207,6 +207,35 @@ def test_members_that_cannot_be_entered_in_the_middle(H, tmp_path, monkeypatch):
             assert consumed == len(raw)
 
 
+def test_flush_markers_and_blocks_the_search_does_not_accept(H, tmp_path, monkeypatch):
+    """a chunk stops at the first block boundary past its cut, the next one starts at the first boundary its search ACCEPTS (a dynamic block of a thousand symbols that is
+    not the last): between the two may lie flush markers (empty stored blocks: pigz -i, Z_FULL_FLUSH / Z_SYNC_FLUSH writers), stored or fixed blocks, short blocks --
+    the chain's last chunk goes on over them in order (host/gzpar.c extend_chunk).  Same bytes as zlib whatever the cut, the slots per thread and the buffer"""
+    import zlib
+    rng = np.random.default_rng(21)
+    text = _reads_text(rng, 9_000_000)
+    co = zlib.compressobj(6, zlib.DEFLATED, 31)
+    parts, at, i = [], 0, 0
+    while at < len(text):
+        n = int(rng.integers(300, 120_000))
+        parts.append(co.compress(text[at:at + n]))
+        parts.append(co.flush((zlib.Z_FULL_FLUSH, zlib.Z_SYNC_FLUSH, zlib.Z_SYNC_FLUSH)[i % 3]))
+        at += n
+        i += 1
+    parts.append(co.flush())
+    raw = b"".join(parts)
+    p = str(tmp_path / "flushes.gz")
+    open(p, "wb").write(raw)
+    monkeypatch.setenv("OATK_HOST_GZ_PARALLEL", "100000")
+    for chunk_kb, slots in (("32", "1"), ("64", "3"), ("200", "5")):
+        monkeypatch.setenv("OATK_HOST_GZ_CHUNK_KB", chunk_kb)
+        monkeypatch.setenv("OATK_HOST_GZ_SLOTS", slots)
+        for cap in (33_333, 1 << 23):
+            got, status, _, consumed = slurp(H, p, cap, threads=6)
+            assert status == 0 and got == text, (chunk_kb, slots, cap)
+            assert consumed == len(raw)
+
+
 def test_damage_in_a_member_on_many_threads_is_reported(H, big_member, tmp_path, monkeypatch):
     paths, text, _ = big_member
     monkeypatch.setenv("OATK_HOST_GZ_PARALLEL", "100000")
