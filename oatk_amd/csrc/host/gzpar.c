@@ -66,16 +66,42 @@ static inline uint32_t br_get(br_t *b, int n) { if (b->nb < n) br_refill(b); con
 /* the position of the next unread bit; past the end of the input when zeros were taken */
 static inline uint64_t br_pos(const br_t *b) { return (uint64_t) (b->p - b->base) * 8 + (uint64_t) b->over * 8 - (uint64_t) b->nb; }
 
+/* A code's table: 2^11 entries indexed by the next bits as they come.  An entry says everything the decoder needs without a second look-up:
+ *   bits 0-3 the code's length (0: longer than eleven bits, or no such code -- the canonical walk decides), bits 4-7 the number of extra bits that follow,
+ *   bit 8 literal, bit 9 end of block, bit 10 a symbol that must not occur (286, 287; distances 30, 31), bits 16-31 the literal / the length's or distance's base */
+#define E_LIT (1u << 8)
+#define E_EOB (1u << 9)
+#define E_BAD (1u << 10)
+enum { K_PLAIN = 0, K_LITLEN = 1, K_DIST = 2 };
 typedef struct {
-    uint16_t fast[1 << GP_FAST];                 /* sym | len << 12; 0: a longer code (or none) */
+    uint32_t fast[1 << GP_FAST];
     uint16_t count[16], sym[288];                /* canonical decoding for the long codes (puff.c's way) */
-    int max_len;
+    int max_len, kind;
 } huff_t;
+
+static const uint16_t LBASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+static const uint8_t LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+static const uint16_t DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+static const uint8_t DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+static const uint8_t CLORD[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+static inline uint32_t entry_of(int kind, int sym, int l)
+{
+    if (kind == K_PLAIN) return (uint32_t) sym << 16 | (uint32_t) l;
+    if (kind == K_LITLEN) {
+        if (sym < 256) return (uint32_t) sym << 16 | E_LIT | (uint32_t) l;
+        if (sym == 256) return E_EOB | (uint32_t) l;
+        if (sym >= 286) return E_BAD | (uint32_t) l;
+        return (uint32_t) LBASE[sym - 257] << 16 | (uint32_t) LEXT[sym - 257] << 4 | (uint32_t) l;
+    }
+    if (sym >= 30) return E_BAD | (uint32_t) l;
+    return (uint32_t) DBASE[sym] << 16 | (uint32_t) DEXT[sym] << 4 | (uint32_t) l;
+}
 
 /* 0: a complete code; 1: incomplete (allowed for a single distance code); -1: over-subscribed or empty where that is not allowed */
 /* (need_complete: an incomplete code is of no use to the caller -- said before any table is filled: the boundary search asks this of a hundred thousand chance headers
  *  per chunk, and nearly all of them end here) */
-static int huff_build(huff_t *h, const uint8_t *len, int n, int need_complete)
+static int huff_build(huff_t *h, const uint8_t *len, int n, int need_complete, int kind)
 {
     int i, l, left = 1;
     uint16_t offs[16];
@@ -88,7 +114,7 @@ static int huff_build(huff_t *h, const uint8_t *len, int n, int need_complete)
     for (l = 1; l < 15; ++l) offs[l + 1] = offs[l] + h->count[l];
     for (i = 0; i < n; ++i) if (len[i]) h->sym[offs[len[i]]++] = (uint16_t) i;
     memset(h->fast, 0, sizeof(h->fast));
-    h->max_len = 0;
+    h->max_len = 0, h->kind = kind;
     {   /* codes in canonical order; the table is indexed by the code's bits as they come (least significant first) */
         uint32_t code = 0;
         int idx = 0;
@@ -100,7 +126,7 @@ static int huff_build(huff_t *h, const uint8_t *len, int n, int need_complete)
                     uint32_t rev = 0, t = code;
                     int k;
                     for (k = 0; k < l; ++k) rev = rev << 1 | (t & 1), t >>= 1;
-                    const uint16_t e = (uint16_t) (h->sym[idx] | l << 12);
+                    const uint32_t e = entry_of(kind, h->sym[idx], l);
                     for (t = rev; t < (1u << GP_FAST); t += 1u << l) h->fast[t] = e;
                 }
             }
@@ -109,29 +135,26 @@ static int huff_build(huff_t *h, const uint8_t *len, int n, int need_complete)
     }
     return left > 0;
 }
-/* (at least 15 bits in the buffer) -1: no such code */
+/* the canonical walk for a code the table does not hold (at least 15 bits in `bits`): its entry, 0: no such code */
+static inline uint32_t huff_long(const huff_t *h, uint64_t bits)
+{
+    int code = 0, first = 0, index = 0, l;
+    for (l = 1; l <= 15; ++l) {
+        code |= (int) (bits & 1), bits >>= 1;
+        const int c = h->count[l];
+        if (code - c < first) return entry_of(h->kind, h->sym[index + (code - first)], l);
+        index += c, first += c, first <<= 1, code <<= 1;
+    }
+    return 0;
+}
+/* (at least 15 bits in the buffer) a plain code's next symbol; -1: no such code */
 static inline int huff_decode(const huff_t *h, br_t *b)
 {
-    const uint16_t e = h->fast[br_peek(b, GP_FAST)];
-    if (e) { br_drop(b, e >> 12); return e & 0xFFF; }
-    {
-        int code = 0, first = 0, index = 0, l;
-        uint64_t bits = b->bits;
-        for (l = 1; l <= 15; ++l) {
-            code |= (int) (bits & 1), bits >>= 1;
-            const int c = h->count[l];
-            if (code - c < first) { br_drop(b, l); return h->sym[index + (code - first)]; }
-            index += c, first += c, first <<= 1, code <<= 1;
-        }
-    }
-    return -1;
+    uint32_t e = h->fast[br_peek(b, GP_FAST)];
+    if (!(e & 15)) { e = huff_long(h, b->bits); if (!e) return -1; }
+    br_drop(b, (int) (e & 15));
+    return (int) (e >> 16);
 }
-
-static const uint16_t LBASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-static const uint8_t LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-static const uint16_t DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-static const uint8_t DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
-static const uint8_t CLORD[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 typedef struct { uint16_t *s; uint64_t n, m, lim; } sym_t;          /* lim: more symbols than this are refused (0: no limit) -- a decoder that entered the stream at a wrong place must not eat the machine's memory */            /* a chunk's text as symbols: < 256 a byte, else 256 + position in the window before the chunk */
 
@@ -158,7 +181,7 @@ static int read_dynamic(br_t *b, huff_t *lit, huff_t *dst)
     if (hlit > 286 || hdist > 30) return -1;
     memset(cl, 0, sizeof(cl));
     for (i = 0; i < hclen; ++i) cl[CLORD[i]] = (uint8_t) br_get(b, 3);
-    if (huff_build(&clh, cl, 19, 1) != 0) return -1;
+    if (huff_build(&clh, cl, 19, 1, K_PLAIN) != 0) return -1;
     for (i = 0; i < hlit + hdist; ) {
         br_refill(b);
         const int s = huff_decode(&clh, b);
@@ -174,15 +197,16 @@ static int read_dynamic(br_t *b, huff_t *lit, huff_t *dst)
         }
     }
     if (len[256] == 0) return -1;
-    if (huff_build(lit, len, hlit, 1) != 0) return -1;              /* (zlib: an incomplete literal/length code is an error) */
+    if (huff_build(lit, len, hlit, 1, K_LITLEN) != 0) return -1;              /* (zlib: an incomplete literal/length code is an error) */
     {
-        const int r = huff_build(dst, len + hlit, hdist, 0);
-        if (r < 0) { int nz = 0; for (i = 0; i < hdist; ++i) nz += len[hlit + i] != 0; if (nz) return -1; memset(dst, 0, sizeof(*dst)); }      /* (no distance codes at all: a block of literals) */
+        const int r = huff_build(dst, len + hlit, hdist, 0, K_DIST);
+        if (r < 0) { int nz = 0; for (i = 0; i < hdist; ++i) nz += len[hlit + i] != 0; if (nz) return -1; memset(dst, 0, sizeof(*dst)); dst->kind = K_DIST; }      /* (no distance codes at all: a block of literals) */
         else if (r > 0 && dst->count[1] + dst->count[2] + dst->count[3] + dst->count[4] + dst->count[5] + dst->count[6] + dst->count[7] + dst->count[8] + dst->count[9] + dst->count[10] + dst->count[11] + dst->count[12] + dst->count[13] + dst->count[14] + dst->count[15] != 1) return -1;
     }
     return 0;
 }
 static huff_t g_fix_lit, g_fix_dst;
+static uint8_t g_not_text[256];                  /* 1: a byte no FASTA / FASTQ file holds (the boundary search refuses a block with such a literal) */
 static uint16_t g_kraft3[512];                  /* three 3-bit code lengths -> their Kraft weights in 128ths */
 static pthread_once_t g_fix_once = PTHREAD_ONCE_INIT;
 static void crc_init(void);
@@ -195,11 +219,99 @@ static void fixed_init(void)
     for (; i < 256; ++i) len[i] = 9;
     for (; i < 280; ++i) len[i] = 7;
     for (; i < 288; ++i) len[i] = 8;
-    (void) huff_build(&g_fix_lit, len, 288, 0);
+    (void) huff_build(&g_fix_lit, len, 288, 0, K_LITLEN);
     for (i = 0; i < 30; ++i) len[i] = 5;
-    (void) huff_build(&g_fix_dst, len, 30, 0);
+    (void) huff_build(&g_fix_dst, len, 30, 0, K_DIST);
     crc_init();
+    for (i = 0; i < 256; ++i) g_not_text[i] = !(i == '\n' || i == '\r' || i == '\t' || (i >= 32 && i < 127));
     for (i = 0; i < 512; ++i) { int q; g_kraft3[i] = 0; for (q = 0; q < 9; q += 3) { const int l = i >> q & 7; g_kraft3[i] += (uint16_t) (l? 128 >> l : 0); } }
+}
+
+
+/* The symbols of one Huffman-coded block.  One refill (56 bits and more) serves three literals (45 bits at most) or a whole match: length code, its extra bits, distance
+ * code, its extra bits (15 + 5 + 15 + 13); the table's entry says what a code is and what follows it, so nothing else is looked up on the way.  0 ok, -1 not a block / corrupt */
+static inline __attribute__((always_inline)) int decode_huff(br_t *bp, const huff_t *lit, const huff_t *dst, sym_t *o, const int text_only, uint64_t total_bits)
+{
+    br_t b = *bp;
+    uint16_t *os = o->s;
+    uint64_t n = o->n, room = o->m;
+    int rc = -1;
+    for (;;) {
+        if (__builtin_expect(n + 288 > room, 0)) { o->n = n; if (sym_room(o, 288)) goto out; os = o->s, room = o->m; if (br_pos(&b) > total_bits) goto out; }
+        br_refill(&b);
+        uint32_t e = lit->fast[b.bits & ((1u << GP_FAST) - 1)];
+        if (e & E_LIT) {
+            if (text_only && g_not_text[e >> 16]) goto out;
+            b.bits >>= e & 15, b.nb -= (int) (e & 15);
+            os[n++] = (uint16_t) (e >> 16);
+            e = lit->fast[b.bits & ((1u << GP_FAST) - 1)];
+            if (e & E_LIT) {
+                if (text_only && g_not_text[e >> 16]) goto out;
+                b.bits >>= e & 15, b.nb -= (int) (e & 15);
+                os[n++] = (uint16_t) (e >> 16);
+                e = lit->fast[b.bits & ((1u << GP_FAST) - 1)];
+                if (e & E_LIT) {
+                    if (text_only && g_not_text[e >> 16]) goto out;
+                    b.bits >>= e & 15, b.nb -= (int) (e & 15);
+                    os[n++] = (uint16_t) (e >> 16);
+                    continue;
+                }
+            }
+            br_refill(&b);                       /* (what was looked up is not a literal, or a long code: it is still in the buffer, and now so is all that can follow it) */
+        }
+        if (__builtin_expect(!(e & 15), 0)) {   /* a code of twelve bits and more */
+            e = huff_long(lit, b.bits);
+            if (!e) goto out;
+            if (e & E_LIT) {
+                if (text_only && g_not_text[e >> 16]) goto out;
+                b.bits >>= e & 15, b.nb -= (int) (e & 15);
+                os[n++] = (uint16_t) (e >> 16);
+                continue;
+            }
+        }
+        if (__builtin_expect(e & (E_EOB | E_BAD), 0)) {
+            if (e & E_BAD) goto out;
+            b.bits >>= e & 15, b.nb -= (int) (e & 15);
+            break;
+        }
+        b.bits >>= e & 15, b.nb -= (int) (e & 15);
+        const uint32_t lx = e >> 4 & 15, len = (e >> 16) + (uint32_t) (b.bits & ((1u << lx) - 1));
+        b.bits >>= lx, b.nb -= (int) lx;
+        uint32_t d = dst->fast[b.bits & ((1u << GP_FAST) - 1)];
+        if (__builtin_expect(!(d & 15), 0)) { d = huff_long(dst, b.bits); if (!d) goto out; }
+        if (__builtin_expect(d & E_BAD, 0)) goto out;
+        b.bits >>= d & 15, b.nb -= (int) (d & 15);
+        const uint32_t dx = d >> 4 & 15;
+        const uint64_t dist = (d >> 16) + (b.bits & ((1u << dx) - 1));
+        b.bits >>= dx, b.nb -= (int) dx;
+        if (__builtin_expect(dist > n + GP_WIN, 0)) goto out;
+        {
+            uint32_t i = 0;
+            if (__builtin_expect(dist > n, 0)) {                  /* it begins before the chunk: positions in the window */
+                const uint32_t pre = (uint32_t) (dist - n < len? dist - n : len);
+                for (; i < pre; ++i) os[n + i] = (uint16_t) (256 + (GP_WIN + n + i - dist));
+            }
+            if (dist >= 16 && i == 0) {         /* sixteen symbols at a time (the source lies at least sixteen behind: no overlap within a move; up to fifteen symbols beyond the match
+                                                   are scribbled on and overwritten by what follows -- there is room: 288 were asked for) */
+                const uint16_t *src = os + n - dist;
+                uint16_t *dst2 = os + n;
+                for (; i < len; i += 16) memcpy(dst2 + i, src + i, 32);
+            } else if (dist >= 4 && i == 0) {   /* four at a time */
+                const uint16_t *src = os + n - dist;
+                uint16_t *dst2 = os + n;
+                for (; i < len; i += 4) memcpy(dst2 + i, src + i, 8);
+            } else {
+                for (; i < len; ++i) os[n + i] = os[n + i - dist];
+            }
+            n += len;
+        }
+        if (__builtin_expect(b.over > 16, 0)) goto out;           /* (far beyond the input's end: zeros decode for ever) */
+    }
+    o->n = n;
+    rc = br_pos(&b) > total_bits? -1 : 0;
+out:
+    *bp = b;
+    return rc;
 }
 
 /* One block's data (the header's three bits are read) into o.  text_only: literals must be text (a candidate boundary is being tried).  0 ok, -1 not a block / corrupt */
@@ -216,7 +328,7 @@ static int decode_block(br_t *b, int btype, sym_t *o, int text_only, uint64_t to
         uint32_t i;
         for (i = 0; i < len; ++i) {
             const uint32_t c = br_get(b, 8);
-            if (text_only && !(c == '\n' || c == '\r' || c == '\t' || (c >= 32 && c < 127))) return -1;
+            if (text_only && g_not_text[c]) return -1;
             o->s[o->n++] = (uint16_t) c;
         }
         return 0;
@@ -225,61 +337,7 @@ static int decode_block(br_t *b, int btype, sym_t *o, int text_only, uint64_t to
     const huff_t *lit = &g_fix_lit, *dst = &g_fix_dst;
     if (btype == 2) { if (read_dynamic(b, &lit_d, &dst_d)) return -1; lit = &lit_d, dst = &dst_d; }
     else if (btype != 1) return -1;
-    {
-        uint16_t *os = o->s;
-        uint64_t n = o->n, room = o->m;
-        for (;;) {
-            if (n + 288 > room) { o->n = n; if (sym_room(o, 288)) return -1; os = o->s, room = o->m; }
-            br_refill(b);
-            int s = huff_decode(lit, b);
-            if (s < 256) {
-                if (s < 0) return -1;
-                if (text_only && !(s == '\n' || s == '\r' || s == '\t' || (s >= 32 && s < 127))) return -1;
-                os[n++] = (uint16_t) s;
-                /* (a second literal from the same refill: at most 2 x 15 bits are gone) */
-                s = huff_decode(lit, b);
-                if (s < 256) {
-                    if (s < 0) return -1;
-                    if (text_only && !(s == '\n' || s == '\r' || s == '\t' || (s >= 32 && s < 127))) return -1;
-                    os[n++] = (uint16_t) s;
-                    continue;
-                }
-                br_refill(b);
-            }
-            if (s == 256) break;
-            s -= 257;
-            if (s >= 29) return -1;
-            const uint32_t len = LBASE[s] + br_get(b, LEXT[s]);
-            br_refill(b);
-            const int ds = huff_decode(dst, b);
-            if (ds < 0 || ds >= 30) return -1;
-            const uint64_t dist = DBASE[ds] + br_get(b, DEXT[ds]);
-            if (dist > n + GP_WIN) return -1;
-            {
-                uint32_t i = 0;
-                if (dist > n) {                  /* it begins before the chunk: positions in the window */
-                    const uint32_t pre = (uint32_t) (dist - n < len? dist - n : len);
-                    for (; i < pre; ++i) os[n + i] = (uint16_t) (256 + (GP_WIN + n + i - dist));
-                }
-                if (dist >= 16 && i == 0) {     /* sixteen symbols at a time (the source lies at least sixteen behind: no overlap within a move; up to fifteen symbols beyond the match
-                                                   are scribbled on and overwritten by what follows -- there is room: 288 were asked for) */
-                    const uint16_t *src = os + n - dist;
-                    uint16_t *dst2 = os + n;
-                    for (; i < len; i += 16) memcpy(dst2 + i, src + i, 32);
-                } else if (dist >= 4 && i == 0) {      /* four at a time */
-                    const uint16_t *src = os + n - dist;
-                    uint16_t *dst2 = os + n;
-                    for (; i < len; i += 4) memcpy(dst2 + i, src + i, 8);
-                } else {
-                    for (; i < len; ++i) os[n + i] = os[n + i - dist];
-                }
-                n += len;
-            }
-            if ((n & 0xFFF) < 260 && br_pos(b) > total_bits) return -1;
-        }
-        o->n = n;
-    }
-    return br_pos(b) > total_bits? -1 : 0;
+    return text_only? decode_huff(b, lit, dst, o, 1, total_bits) : decode_huff(b, lit, dst, o, 0, total_bits);
 }
 
 /* a block header that can be trusted at or after bit `from` (below `to`): dynamic, not the last, decodes as text and is followed by another header.  GP_INF: none */
