@@ -8,9 +8,10 @@
  *      header whose code lengths form complete codes, whose block decodes to its end-of-block symbol with nothing but text in its literals and no distance beyond the
  *      window, and which is followed by another valid header;
  *   2. every chunk is decoded from its boundary into 16-bit SYMBOLS: a byte, or "whatever stood at position w of the window before this chunk" -- a back-reference into
- *      the unknown copies such symbols like any other.  A chunk is decoded up to the boundary the next chunk claims; the decoder of the chunk before it arrives there
- *      block by block from a known state, so a claim it arrives at EXACTLY is a true boundary and the symbols behind it are the true text, and a claim it passes is false:
- *      it then simply decodes that chunk's part as well;
+ *      the unknown copies such symbols like any other.  A chunk is decoded up to the first block boundary at or after the next chunk's cut, which is where the next chunk
+ *      looks for ITS boundary.  The chain starts from a known state (the member's first bit) and moves block by block, so a claim it arrives at EXACTLY is a true
+ *      boundary and the symbols behind it are the true text; where it stands before a claim (a flush marker or another block the search does not accept lies between, or
+ *      a chunk found nothing) its last chunk goes on, in order, until it stands there; a claim it passes was false;
  *   3. in order, each chunk's last 32 KiB are turned into bytes with the window handed down from the chunk before (that is all the serial work there is), and then all
  *      chunks are turned into bytes at their places in the caller's buffer, in parallel, with a CRC each (combined: crc32_combine).
  * The member's CRC-32 and length are checked at its end as gzread checks them.  Text that does not look like text (no boundary found in the first chunks) is left to zlib.
