@@ -772,6 +772,14 @@ static int sr_read_stream(oatk_hip_ctx **ctxs, int n_ctx, uint64_t *first, oatk_
             uint64_t m = n_done + n;
             if (!final && !capped && used && trust_in) m = n_done + (uint64_t) ((double) n * ((double) (ftotal > wf0? ftotal - wf0 : wf1 - wf0) / (double) (wf1 - wf0)) * 1.05) + 1024;
             else if (!final && !capped && m < 2 * sr_db->m) m = 2 * sr_db->m;          /* (no estimate: geometric growth) */
+            {   /* an estimate is a guess: one that asks for more than a quarter of the machine's memory is not believed (the array is zeroed below, i.e. touched) */
+                const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGESIZE);
+                const uint64_t phys = pages > 0 && psz > 0? (uint64_t) pages * (uint64_t) psz : 0;
+                if (phys && m > n_done + n && (m - sr_db->m) > phys / 4 / sizeof(oatk_sr_t)) {
+                    m = n_done + n > 2 * sr_db->m? n_done + n : 2 * sr_db->m;
+                    if ((m - sr_db->m) > phys / 4 / sizeof(oatk_sr_t)) m = n_done + n;
+                }
+            }
             oatk_sr_t *na = (oatk_sr_t *) realloc(sr_db->a, sizeof(oatk_sr_t) * m);
             if (!na) { rc = OATK_E_NOMEM; break; }
             memset(na + sr_db->m, 0, sizeof(oatk_sr_t) * (m - sr_db->m));
