@@ -216,7 +216,7 @@ def config1s_cpu_baseline(hip, sq, of, ln, n, K, S, c):
             L.refx_scg_destroy(g); L.refx_scmdb_destroy(scm); L.refx_srdb_destroy(db)
         os.close(saved)
         # the device on the same reads: mark + solve + refresh, the graph (light) built on the device
-        hip.scan_host(sq, off_n, len_n, K, S); hip.count(); hip.ec_graph(light_c=c)
+        hip.scan_host(sq[:nb], off_n, len_n, K, S); hip.count(); hip.ec_graph(light_c=c)
         hip.sync(); t0 = time.perf_counter(); hip.ec(0.02, c, 0.35); hip.sync()
         out["device_ec_s"] = round(time.perf_counter() - t0, 4)
         out["value"] = out["threads"]["8"]; out["cores"] = 8
