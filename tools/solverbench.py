@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 from oatk_amd import HipSyncasm
-from oatk_amd.synth import CONFIGS, ReadSet
+from oatk_amd.synth import CONFIGS, CONFIG1S, MixReadSet, ReadSet
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="config3")
@@ -16,11 +16,11 @@ ap.add_argument("--reads", type=int, default=0)
 ap.add_argument("--set", action="append", default=[])
 ap.add_argument("--reps", type=int, default=3)
 a = ap.parse_args()
-cfg = dict(CONFIGS[a.workload])
+cfg = dict(CONFIG1S if a.workload == "config1s" else CONFIGS[a.workload])          # (config1s: the config-1 surrogate, oatk_amd/synth.py)
 if a.reads:
     cfg["n_reads"] = a.reads
 c = int(cfg.get("min_k_cov", 30))
-rs = ReadSet(**cfg)
+rs = MixReadSet(**cfg) if a.workload == "config1s" else ReadSet(**cfg)
 seq, off, lens = rs.slice(0, cfg["n_reads"])
 dev = torch.device("cuda", 0)
 d_seq = torch.from_numpy(seq).to(dev); d_off = torch.from_numpy(off.view(np.int64)).to(dev); d_len = torch.from_numpy(lens.view(np.int32)).to(dev)
