@@ -231,7 +231,7 @@ static void fixed_init(void)
 
 /* The symbols of one Huffman-coded block.  One refill (56 bits and more) serves three literals (45 bits at most) or a whole match: length code, its extra bits, distance
  * code, its extra bits (15 + 5 + 15 + 13); the table's entry says what a code is and what follows it, so nothing else is looked up on the way.  0 ok, -1 not a block / corrupt */
-static inline __attribute__((always_inline)) int decode_huff(br_t *bp, const huff_t *lit, const huff_t *dst, sym_t *o, const int text_only, uint64_t total_bits)
+static inline __attribute__((always_inline)) int decode_huff(br_t *bp, const huff_t *lit, const huff_t *dst, sym_t *o, const int text_only, uint64_t total_bits, uint64_t have)
 {
     br_t b = *bp;
     uint16_t *os = o->s;
@@ -285,7 +285,7 @@ static inline __attribute__((always_inline)) int decode_huff(br_t *bp, const huf
         const uint32_t dx = d >> 4 & 15;
         const uint64_t dist = (d >> 16) + (b.bits & ((1u << dx) - 1));
         b.bits >>= dx, b.nb -= (int) dx;
-        if (__builtin_expect(dist > n + GP_WIN, 0)) goto out;
+        if (__builtin_expect(dist > n + have, 0)) goto out;        /* (zlib: "invalid distance too far back" -- `have` is the text before the chunk, at most a window's worth) */
         {
             uint32_t i = 0;
             if (__builtin_expect(dist > n, 0)) {                  /* it begins before the chunk: positions in the window */
@@ -316,7 +316,7 @@ out:
 }
 
 /* One block's data (the header's three bits are read) into o.  text_only: literals must be text (a candidate boundary is being tried).  0 ok, -1 not a block / corrupt */
-static int decode_block(br_t *b, int btype, sym_t *o, int text_only, uint64_t total_bits)
+static int decode_block(br_t *b, int btype, sym_t *o, int text_only, uint64_t total_bits, uint64_t have)
 {
     if (btype == 0) {
         br_drop(b, b->nb & 7);
@@ -338,7 +338,7 @@ static int decode_block(br_t *b, int btype, sym_t *o, int text_only, uint64_t to
     const huff_t *lit = &g_fix_lit, *dst = &g_fix_dst;
     if (btype == 2) { if (read_dynamic(b, &lit_d, &dst_d)) return -1; lit = &lit_d, dst = &dst_d; }
     else if (btype != 1) return -1;
-    return text_only? decode_huff(b, lit, dst, o, 1, total_bits) : decode_huff(b, lit, dst, o, 0, total_bits);
+    return text_only? decode_huff(b, lit, dst, o, 1, total_bits, have) : decode_huff(b, lit, dst, o, 0, total_bits, have);
 }
 
 /* a block header that can be trusted at or after bit `from` (below `to`): dynamic, not the last, decodes as text and is followed by another header.  GP_INF: none */
@@ -369,7 +369,7 @@ static uint64_t find_boundary(const uint8_t *in, uint64_t n_in, uint64_t from, u
         br_refill(&b);
         br_drop(&b, 3);
         tmp.n = 0;
-        if (decode_block(&b, 2, &tmp, 1, total_bits)) continue;
+        if (decode_block(&b, 2, &tmp, 1, total_bits, GP_WIN)) continue;
         if (tmp.n < 1024) continue;                                  /* (a real block of a text file is not this small; chance finds are) */
         {   /* what follows must be a header too */
             br_refill(&b);
@@ -398,6 +398,7 @@ static uint64_t find_boundary(const uint8_t *in, uint64_t n_in, uint64_t from, u
 }
 
 typedef struct {
+    uint64_t have;                               /* the text known to lie before it, at most GP_WIN (a chunk entered on a guess: GP_WIN; checked when it is chained) */
     uint64_t nominal, start, end;                /* bits: where the chunk was cut, the boundary it claims (GP_INF none), where its decoding stopped */
     sym_t o;
     int ok, last;                                /* decoded without error; reached the member's last block */
@@ -449,7 +450,7 @@ static void decode_chunk(oatk_gzpar_t *p, int j, int bounded)
     for (;;) {
         br_refill(&b);
         const uint32_t h = br_get(&b, 3);
-        if (decode_block(&b, (int) (h >> 1), &c->o, 0, total_bits)) { c->capped = c->o.lim && c->o.n + 288 > c->o.lim; return; }
+        if (decode_block(&b, (int) (h >> 1), &c->o, 0, total_bits, c->have)) { c->capped = c->o.lim && c->o.n + 288 > c->o.lim; return; }
         const uint64_t at = br_pos(&b);
         if (h & 1) { c->last = 1, c->end = at, c->ok = 1; return; }
         if (at >= stop) { c->end = at, c->ok = 1; return; }
@@ -467,7 +468,7 @@ static int extend_chunk(oatk_gzpar_t *p, int j, uint64_t *at, uint64_t target)
     for (;;) {
         br_refill(&b);
         const uint32_t h = br_get(&b, 3);
-        if (decode_block(&b, (int) (h >> 1), &c->o, 0, total_bits)) return -1;
+        if (decode_block(&b, (int) (h >> 1), &c->o, 0, total_bits, c->have)) return -1;
         const uint64_t pos = br_pos(&b);
         c->end = *at = pos;
         if (h & 1) { c->last = 1; return 0; }
@@ -690,6 +691,7 @@ static int next_batch(oatk_gzpar_t *p)
         const uint64_t nominal = p->pos + (uint64_t) j * p->chunk_bits;
         if (j > 0 && nominal + 1024 >= total_bits) break;
         p->ch[j].nominal = nominal, p->ch[j].start = j == 0? p->pos : GP_INF, p->ch[j].chained = 0, p->ch[j].out_off = GP_INF, p->ch[j].take = 0, p->ch[j].given = 0;
+        p->ch[j].have = j == 0 && p->total_out < GP_WIN? p->total_out : GP_WIN;
         ++p->n_ch;
     }
     p->next_out = 0;
@@ -706,7 +708,7 @@ static int next_batch(oatk_gzpar_t *p)
      * BEFORE a claim (the boundary it stopped at was one the search does not accept -- a flush marker, a stored or a short block -- or a chunk between found none) its last
      * chunk goes on, in order, until it stands there or has passed it; a claim the chain has passed was false */
     {
-        uint64_t at = p->pos;
+        uint64_t at = p->pos, before = p->total_out;         /* (bits; bytes of text before the chunk at hand) */
         int prev = -1;
         for (j = 0; j < p->n_ch; ++j) {
             chunk_t *c = &p->ch[j];
@@ -716,12 +718,18 @@ static int next_batch(oatk_gzpar_t *p)
                 const uint64_t n0 = p->ch[prev].o.n;
                 if (extend_chunk(p, prev, &at, c->start)) return -1;
                 p->n_gaps++, p->gap_syms += p->ch[prev].o.n - n0;
+                before += p->ch[prev].o.n - n0;
                 if (p->ch[prev].last) break;
                 if (at != c->start) continue;
             }
             if (!c->ok && c->capped) { decode_chunk(p, j, 0); p->n_again++; }      /* (it IS the text, and longer than the guess allowed: once more, without the bound) */
             if (!c->ok) return -1;               /* (decoded from a true boundary and failed: the stream is damaged) */
+            if (before < GP_WIN && j > 0) {      /* entered on a guess within the member's first 32 KiB: a reference to text before the member's first byte is zlib's "invalid distance too far back" */
+                uint64_t q;
+                for (q = 0; q < c->o.n; ++q) if (c->o.s[q] >= 256 && (uint64_t) (c->o.s[q] - 256) < GP_WIN - before) return -1;
+            }
             c->chained = 1, prev = j, at = c->end, p->n_chained++;
+            before += c->o.n;
             if (c->last) break;
         }
         if (prev < 0) return -1;
