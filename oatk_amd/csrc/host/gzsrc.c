@@ -106,18 +106,21 @@ static void *gz_worker(void *arg)
             if (b >= g->n_blk) break;
             const bg_block_t *B = &g->blk[b];
             int ok = 1;
-            if (B->out_len) {
+            {   /* (a block that says it holds no text -- bgzip's end marker -- is inflated like any other, into a few bytes of its own: a damaged block whose length field
+                 *  happens to read 0 must not pass for an empty one; found by tests/c/gzsrc_fuzz.c) */
+                uint8_t none[8];
+                uint8_t *to = B->out_len? g->dst + B->out_off : none;
                 if (!live) { live = inflateInit2(&z, -15) == Z_OK; if (!live) ok = 0; }
                 else inflateReset(&z);
                 if (ok) {
                     z.next_in = (Bytef *) (g->map + B->in_off + B->hdr_len), z.avail_in = B->in_len - B->hdr_len - 8;
-                    z.next_out = g->dst + B->out_off, z.avail_out = B->out_len;
-                    ok = inflate(&z, Z_FINISH) == Z_STREAM_END && z.avail_out == 0;
+                    z.next_out = to, z.avail_out = B->out_len? B->out_len : (uInt) sizeof(none);
+                    ok = inflate(&z, Z_FINISH) == Z_STREAM_END && z.total_out == B->out_len && z.avail_in == 0;
                 }
                 if (ok) {
                     uint32_t want;
                     memcpy(&want, g->map + B->in_off + B->in_len - 8, 4);
-                    ok = (uint32_t) crc32(crc32(0L, Z_NULL, 0), g->dst + B->out_off, B->out_len) == want;
+                    ok = (uint32_t) crc32(crc32(0L, Z_NULL, 0), to, B->out_len) == want;
                 }
             }
             if (!ok) __atomic_store_n(&g->failed, 1, __ATOMIC_RELAXED);
