@@ -22,6 +22,7 @@
 #include "oatk_hip_ingest.h"
 #include "oatk_syncasm.h"
 #include "host_internal.h"
+#include "ingest_estimate.h"
 
 #define UP_CHUNK ((uint64_t) 96 << 20)                 /* bytes per upload piece */
 
@@ -767,19 +768,12 @@ static int sr_read_stream(oatk_hip_ctx **ctxs, int n_ctx, uint64_t *first, oatk_
         /* room for the reads: from the first piece's density, generously; grown when a later piece needs more */
         /* (how much of the input this window took, as the estimates below see it: a source that cannot say -- or says something no deflate stream can mean, less than a
          *  fortieth of the window's text -- is not extrapolated from: the arrays then grow window by window) */
-        const int trust_in = wf1 > wf0 && (double) (wf1 - wf0) * 40.0 >= (double) (g1 - text0);
+        const int trust_in = oatk_est_trust(wf0, wf1, g1 - text0);
         if (sr_db && sr_db->m < n_done + n) {
-            uint64_t m = n_done + n;
-            if (!final && !capped && used && trust_in) m = n_done + (uint64_t) ((double) n * ((double) (ftotal > wf0? ftotal - wf0 : wf1 - wf0) / (double) (wf1 - wf0)) * 1.05) + 1024;
-            else if (!final && !capped && m < 2 * sr_db->m) m = 2 * sr_db->m;          /* (no estimate: geometric growth) */
-            {   /* an estimate is a guess: one that asks for more than a quarter of the machine's memory is not believed (the array is zeroed below, i.e. touched) */
-                const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGESIZE);
-                const uint64_t phys = pages > 0 && psz > 0? (uint64_t) pages * (uint64_t) psz : 0;
-                if (phys && m > n_done + n && (m - sr_db->m) > phys / 4 / sizeof(oatk_sr_t)) {
-                    m = n_done + n > 2 * sr_db->m? n_done + n : 2 * sr_db->m;
-                    if ((m - sr_db->m) > phys / 4 / sizeof(oatk_sr_t)) m = n_done + n;
-                }
-            }
+            /* (an estimate is a guess: one that asks for more than a quarter of the machine's memory is not believed -- the array is zeroed below, i.e. touched) */
+            const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGESIZE);
+            const uint64_t phys = pages > 0 && psz > 0? (uint64_t) pages * (uint64_t) psz : 0;
+            const uint64_t m = oatk_est_reads(n_done, n, sr_db->m, wf0, wf1, ftotal, trust_in && used, final || capped, phys / 4 / sizeof(oatk_sr_t));
             oatk_sr_t *na = (oatk_sr_t *) realloc(sr_db->a, sizeof(oatk_sr_t) * m);
             if (!na) { rc = OATK_E_NOMEM; break; }
             memset(na + sr_db->m, 0, sizeof(oatk_sr_t) * (m - sr_db->m));
@@ -791,8 +785,7 @@ static int sr_read_stream(oatk_hip_ctx **ctxs, int n_ctx, uint64_t *first, oatk_
             if (have.n_reads == 0 && !final && !capped && used && trust_in) {
                 oatk_hip_info_t inf;
                 oatk_hip_info(D->piece[s], &inf);
-                const double share = (double) ftotal / (double) n_ctx, left = ftotal > wf0? (double) (ftotal - wf0) : (double) (wf1 - wf0);
-                const double scale = (share < left? share : left) / (double) (wf1 - wf0) * 1.03 + (n_ctx > 1? 1.0 : 0.0);       /* (a handle's part ends on a window boundary) */
+                const double scale = oatk_est_scale(wf0, wf1, ftotal, n_ctx);
                 rc = oatk_hip_scan_reserve(ctx, (uint64_t) ((double) inf.seq_bytes * scale) + (1 << 20), (uint64_t) ((double) n * scale) + 1024,
                                            (uint64_t) ((double) inf.n_occ * scale * 1.1) + 4096);
                 if (rc) break;
