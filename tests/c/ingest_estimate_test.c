@@ -30,8 +30,10 @@ int main(void)
     /* ... and what that cost, had it been believed: 46 million windows' worth of reads -- cut down to what is needed by the cap on new entries */
     m = oatk_est_reads(0, 51200, 0, 0, 20, 925 * MB, 1, 0, 100000000);
     CHECK(m == 51200);
-    m = oatk_est_reads(0, 51200, 0, 0, 20, 925 * MB, 1, 0, 0);                  /* (no cap known: the estimate as it is -- the trust test is what guards) */
-    CHECK(m > 1000000000ULL && m < (1ULL << 36));
+    m = oatk_est_reads(0, 51200, 0, 0, 20, 925 * MB, 1, 0, 0);                  /* (no cap known: 2.6 x 10^12 reads are beyond anything -- what is needed) */
+    CHECK(m == 51200);
+    m = oatk_est_reads(0, 51200, 0, 0, 20000, 925 * MB, 1, 0, 0);               /* (no cap known and a number one could believe: the estimate as it is -- the trust test is what guards) */
+    CHECK(m > 2000000000ULL && m < (1ULL << 36));
     /* the last window, a capped read: exactly what is needed */
     CHECK(oatk_est_reads(1000, 500, 1000, 0, 10 * MB, 20 * MB, 1, 1, 1ULL << 40) == 1500);
     /* an estimate below what is already here (the file's end is nearer than the position says) never shrinks the array below the need */
