@@ -26,7 +26,10 @@ typedef struct {
     uint64_t depth_at_dead_sum;
     uint64_t ret_dist_sum, ret_cnt;    /* after a dead end: how many levels up is the next arc taken */
     uint64_t sub_steps[8], sub_cnt[8];                 /* at levels with several live arcs: wavefront steps in the subtree below the i-th live arc (7: seventh and later) */
-    uint64_t cat_arcs[6], cat_steps[6], cat_diag[6];   /* alive first / alive sibling / dead-by-score first / dead-by-score sibling / dead-otherwise first / sibling */
+    uint64_t cat_arcs[6], cat_steps[6], cat_diag[6];
+    /* the extension's cost as ec_fused.hpp pays it, per step the slowest of the waves (56 diagonals each): window turns of 16 bases (the first, up to three more lane by
+     * lane), lanes that still go on after 64 bases (run down one after the other by the whole wave), and the turns windows of 64 bases would take */
+    uint64_t x_steps, x_w16_turns, x_long_lanes, x_long_steps, x_w64_turns, x_w64_long, x_act_lanes, x_ext_hist[8];   /* alive first / alive sibling / dead-by-score first / dead-by-score sibling / dead-otherwise first / sibling */
 } ctr_t;
 
 typedef struct { uint64_t *k; uint32_t *sub_arcs; size_t m, n; } memo_t;       /* open addressing: key -> arcs in the subtree below */
@@ -69,15 +72,42 @@ static int wf_step(S *s, int32_t ql)
     int32_t j;
     s->t_end = s->q_end = -1;
     s->c->steps++, s->c->diag += (uint64_t) n, s->c->n_hist[bucket8((uint64_t) n, NL)]++;
+    uint64_t w_turn16 = 0, w_long = 0, w_turn64 = 0, w_long64 = 0, m_turn16 = 0, m_long = 0, m_turn64 = 0, m_long64 = 0;
+    static const uint64_t XL[7] = {0, 15, 31, 63, 127, 255, 1023};
     for (j = 0; j < n; ++j) {
         int32_t k = s->k[j], d = s->d0 + j;
+        if (j % 56 == 0) {
+            if (w_turn16 > m_turn16) m_turn16 = w_turn16;
+            if (w_long > m_long) m_long = w_long;
+            if (w_turn64 > m_turn64) m_turn64 = w_turn64;
+            if (w_long64 > m_long64) m_long64 = w_long64;
+            w_turn16 = w_long = w_turn64 = w_long64 = 0;
+        }
         if (k >= tl || k + d >= ql) continue;
         int32_t lim = (ql - d < tl? ql - d : tl) - 1;
+        const int32_t kb = k;
         while (k < lim && ts[k + 1] == qs[k + d + 1]) ++k, s->c->cmp++;
         s->c->cmp++;
-        if (k + d == ql - 1 || k == tl - 1) { s->t_end = k, s->q_end = k + d; return 1; }
+        {
+            const uint64_t e = (uint64_t) (k - kb);                      /* bases matched */
+            const uint64_t t16 = e / 16 + 1 < 4? e / 16 + 1 : 4, t64 = e / 64 + 1 < 4? e / 64 + 1 : 4;
+            s->c->x_act_lanes++, s->c->x_ext_hist[bucket8(e, XL)]++;
+            if (t16 > w_turn16) w_turn16 = t16;
+            if (e >= 64) ++w_long;
+            if (t64 > w_turn64) w_turn64 = t64;
+            if (e >= 256) ++w_long64;
+        }
+        if (k + d == ql - 1 || k == tl - 1) { s->t_end = k, s->q_end = k + d; s->c->x_steps++; goto acc; }
         s->k[j] = k;
     }
+    s->c->x_steps++;
+acc:
+    if (w_turn16 > m_turn16) m_turn16 = w_turn16;
+    if (w_long > m_long) m_long = w_long;
+    if (w_turn64 > m_turn64) m_turn64 = w_turn64;
+    if (w_long64 > m_long64) m_long64 = w_long64;
+    s->c->x_w16_turns += m_turn16, s->c->x_long_lanes += m_long, s->c->x_long_steps += m_long > 0, s->c->x_w64_turns += m_turn64, s->c->x_w64_long += m_long64;
+    if (s->t_end >= 0) return 1;
     wf_need(s, n + 4);
     int32_t *a = s->k, *b = s->nk;
     for (j = 0; j < n + 2; ++j) {
@@ -133,6 +163,141 @@ static m2_t *m2_slot(uint64_t key, uint64_t frame)
 }
 static uint64_t g_cur_frame; static int g_cur_hops;
 static uint64_t g_fs_serial[4096]; static size_t g_fs_l0[4096]; static int g_fs_n; static size_t g_win = 2048;
+
+/* ---- ECT_DP=1: is the search's wavefront alignment (wf_ed_core, resumed arc by arc) the banded edit-distance matrix in disguise?  Beside the wavefront a plain DP row per
+ * query base is kept (rows are pushed and popped with the consensus), and after every arc the call's outcome is PREDICTED from the matrix alone: the score is the least value
+ * on the matrix's boundary (the query's last row, the target's last column) but not below the parent's score, the end is the boundary cell of the LOWEST diagonal that has
+ * reached that value, and the arc dies by score when that least value is beyond the band.  Counted: arcs where prediction and wavefront differ. ---- */
+static int g_dp = -1;
+static int32_t *g_dp_rows; static size_t g_dp_m;
+static int32_t g_dp_R, g_dp_W;
+static uint64_t g_dp_checked, g_dp_bad, g_dp_bad_dead, g_dp_cells;
+#define DP_INF 1000000
+static inline int32_t dp_get(const S *s, int32_t q, int32_t t)
+{
+    if (q < -1 || t < -1) return DP_INF;
+    const int32_t d = q - t;
+    if (d > g_dp_R || d < -g_dp_R) return DP_INF;
+    if (q == -1) return t + 1;
+    if (t == -1) return q + 1;
+    if (t >= s->tl) return DP_INF;
+    return g_dp_rows[(size_t) q * (size_t) g_dp_W + (size_t) (t - q + g_dp_R)];
+}
+static uint64_t g_dp_rows_all, g_dp_rows_cut, g_dp_cut_arcs;
+static void dp_rows(const S *s, size_t from, size_t to)
+{
+    if (to * (size_t) g_dp_W > g_dp_m) { g_dp_m = to * (size_t) g_dp_W * 2; g_dp_rows = (int32_t *) realloc(g_dp_rows, g_dp_m * sizeof(int32_t)); }
+    size_t q;
+    int cut = 0;
+    g_dp_rows_all += to - from;
+    for (q = from; q < to; ++q) {
+        int32_t t, lo = (int32_t) q - g_dp_R, hi = (int32_t) q + g_dp_R, rmin = DP_INF;
+        int32_t *row = g_dp_rows + q * (size_t) g_dp_W;
+        if (!cut) g_dp_rows_cut++;
+        for (t = lo; t <= hi; ++t) {
+            int32_t v = DP_INF;
+            if (t >= 0 && t < s->tl) {
+                const int32_t a = dp_get(s, (int32_t) q - 1, t - 1) + (s->ts[t] != s->cs[q]), b = dp_get(s, (int32_t) q - 1, t) + 1;
+                const int32_t c = t - 1 >= lo? (t - 1 == -1? (int32_t) q + 1 : row[t - 1 - lo]) + 1 : DP_INF;
+                v = a < b? a : b; v = v < c? v : c;
+                if (v > DP_INF) v = DP_INF;
+                g_dp_cells++;
+                if (v < rmin) rmin = v;
+            }
+            row[t - lo] = v;
+        }
+        /* (a row whose least value is beyond the band: so is every later row's -- a solver that works by rows could stop here and call the arc dead, once the
+         *  target's last column is out of reach of the rows that are left) */
+        if (!cut && rmin > s->bw && (int32_t) to + s->bw < s->tl) cut = 1, g_dp_cut_arcs++;
+    }
+}
+/* the call's predicted outcome: *score (bw + 1: dead by score), *t_end, *q_end as wf_ed_core leaves them (one past the last aligned base; 0 0 when it dies) */
+static void dp_predict(const S *s, int32_t ql, int32_t parent_score, int32_t *score, int32_t *t_end, int32_t *q_end)
+{
+    int32_t best = DP_INF, t, q;
+    const int32_t qr = ql - 1, tc = s->tl - 1;
+    for (t = qr - g_dp_R < 0? 0 : qr - g_dp_R; t <= qr + g_dp_R && t < s->tl; ++t) { const int32_t v = dp_get(s, qr, t); if (v < best) best = v; }
+    for (q = tc - g_dp_R < 0? 0 : tc - g_dp_R; q <= tc + g_dp_R && q < ql; ++q) { const int32_t v = dp_get(s, q, tc); if (v < best) best = v; }
+    int32_t sc = best > parent_score? best : parent_score;
+    if (sc > s->bw) { *score = s->bw + 1, *t_end = 0, *q_end = 0; return; }
+    /* the lowest diagonal (q - t) whose boundary cell is within sc: on the last column diagonals descend with q, on the last row they descend as t grows */
+    int32_t bd = DP_INF, bt = -1, bq = -1;
+    for (t = qr - g_dp_R < 0? 0 : qr - g_dp_R; t <= qr + g_dp_R && t < s->tl; ++t) if (dp_get(s, qr, t) <= sc && qr - t < bd) bd = qr - t, bt = t, bq = qr;
+    for (q = tc - g_dp_R < 0? 0 : tc - g_dp_R; q <= tc + g_dp_R && q < ql; ++q) if (dp_get(s, q, tc) <= sc && q - tc < bd) bd = q - tc, bt = tc, bq = q;
+    *score = sc, *t_end = bt + 1, *q_end = bq + 1;
+}
+
+/* ---- ECT_CERT=1: how many of the arcs that die by score could be KNOWN to die without aligning anything?  By (ECT_DP) the call's outcome is the matrix's: an arc whose
+ * appended string cannot be fitted ANYWHERE into the target within bw edits (semi-global edit distance of the string against the whole target, free ends in the target)
+ * leaves every cell of the query's new last row beyond the band -- it dies by score, whatever the path before it, as long as the target's last column is out of the new
+ * rows' reach.  That distance depends on (oriented vertex, overlap) and the block only: computed once per block and arc target, here by plain DP. ---- */
+static int g_cert = -1;
+static int32_t *g_cert_m; static uint64_t *g_cert_key; static size_t g_cert_n, g_cert_cap;       /* per block: key (w, ls) -> least cost (capped at bw + 1) */
+static uint64_t g_cert_arcs, g_cert_steps, g_cert_wrong, g_cert_tables, g_cert_cells, g_cert_dead_arcs, g_cert_dead_steps;
+static int32_t cert_cost(const S *s, uint64_t key, const char *ext, int32_t m)
+{
+    size_t i;
+    for (i = 0; i < g_cert_n; ++i) if (g_cert_key[i] == key) return g_cert_m[i];
+    if (g_cert_n == g_cert_cap) { g_cert_cap = g_cert_cap? 2 * g_cert_cap : 64; g_cert_key = (uint64_t *) realloc(g_cert_key, 8 * g_cert_cap); g_cert_m = (int32_t *) realloc(g_cert_m, 4 * g_cert_cap); }
+    const int32_t tl = s->tl;
+    int32_t *prev = (int32_t *) malloc(sizeof(int32_t) * (size_t) (tl + 1)), *cur = (int32_t *) malloc(sizeof(int32_t) * (size_t) (tl + 1)), r, t, best;
+    for (t = 0; t <= tl; ++t) prev[t] = 0;                              /* the string may begin anywhere in the target */
+    for (r = 1; r <= m; ++r) {
+        cur[0] = r;
+        int32_t rmin = cur[0];
+        for (t = 1; t <= tl; ++t) {
+            int32_t v = prev[t - 1] + (ext[r - 1] != s->ts[t - 1]);
+            if (prev[t] + 1 < v) v = prev[t] + 1;
+            if (cur[t - 1] + 1 < v) v = cur[t - 1] + 1;
+            cur[t] = v;
+            if (v < rmin) rmin = v;
+        }
+        g_cert_cells += (uint64_t) tl;
+        { int32_t *x = prev; prev = cur, cur = x; }
+        if (rmin > s->bw) { r = m + 1; break; }                           /* (row minima only grow) */
+    }
+    best = s->bw + 1;
+    if (r == m + 1 && 0) {}
+    else for (t = 0; t <= tl; ++t) if (prev[t] < best) best = prev[t];
+    free(prev), free(cur);
+    g_cert_key[g_cert_n] = key, g_cert_m[g_cert_n] = best, ++g_cert_n, ++g_cert_tables;
+    return best;
+}
+
+/* ---- ECT_ROWS=1 (with ECT_DP=1): what a solver that keeps the matrix's last ROW instead of a wavefront would have to compute.  A short appended string costs its rows.
+ * A long one (>= 32 bases) is first asked whether it can be alive at all: the least value of the new last row is min over t' of (parent's row at t' + the least cost of
+ * fitting the string into the target FROM t' on) -- the second term a table per (vertex, overlap) and block (one pass over the target), the minimum one pass over the band;
+ * beyond the band: the arc dies by score, no row computed.  Only when the target's last column is within the new rows' reach, or the arc is alive, its rows are computed.
+ * Counted: row-equivalents, and arcs where this prediction of "dies by score" differs from the wavefront's (must be none). ---- */
+static int g_rows = -1;
+static int32_t **g_prof; static uint64_t *g_prof_key; static size_t g_prof_n, g_prof_cap;
+static uint64_t g_rw_rows, g_rw_tests, g_rw_dead_by_test, g_rw_wrong, g_rw_tables;
+static const int32_t *prof_of(const S *s, uint64_t key, const char *ext, int32_t m)
+{
+    size_t i;
+    for (i = 0; i < g_prof_n; ++i) if (g_prof_key[i] == key) return g_prof[i];
+    if (g_prof_n == g_prof_cap) { g_prof_cap = g_prof_cap? 2 * g_prof_cap : 64; g_prof_key = (uint64_t *) realloc(g_prof_key, 8 * g_prof_cap); g_prof = (int32_t **) realloc(g_prof, sizeof(int32_t *) * g_prof_cap); }
+    const int32_t tl = s->tl;
+    /* both strings backwards: F[r][j] = least cost of the last r bases of ext against a piece of the target that ENDS (backwards) at j, i.e. begins (forwards) at tl - j */
+    int32_t *prev = (int32_t *) malloc(sizeof(int32_t) * (size_t) (tl + 1)), *cur = (int32_t *) malloc(sizeof(int32_t) * (size_t) (tl + 1)), r, j;
+    for (j = 0; j <= tl; ++j) prev[j] = 0;
+    for (r = 1; r <= m; ++r) {
+        cur[0] = r;
+        for (j = 1; j <= tl; ++j) {
+            int32_t v = prev[j - 1] + (ext[m - r] != s->ts[tl - j]);
+            if (prev[j] + 1 < v) v = prev[j] + 1;
+            if (cur[j - 1] + 1 < v) v = cur[j - 1] + 1;
+            cur[j] = v;
+        }
+        { int32_t *x = prev; prev = cur, cur = x; }
+    }
+    /* prof[t' + 1], t' = -1 .. tl - 1: the string fitted into target[t' + 1 ..]: begins at tl - j = t' + 1 */
+    int32_t *prof = (int32_t *) malloc(sizeof(int32_t) * (size_t) (tl + 1));
+    for (j = 0; j <= tl; ++j) prof[tl - j] = prev[j];
+    free(prev), free(cur);
+    g_prof_key[g_prof_n] = key, g_prof[g_prof_n] = prof, ++g_prof_n, ++g_rw_tables;
+    return prof;
+}
 
 static void dfs(S *s, uint64_t source, int depth)
 {
@@ -203,6 +368,52 @@ static void dfs(S *s, uint64_t source, int depth)
         }
         s->c->steps_hist[bucket8(s->c->steps - st_before, SL)]++;
         s->t_end += 1, s->q_end += 1;
+        if (g_cert < 0) g_cert = getenv("ECT_CERT") != 0;
+        if (g_cert && ext >= 32) {
+            /* (the last column out of the new rows' reach: no cell (q, tl - 1) with q < ql lies within bw of the diagonal) */
+            const int far = ql - 1 + s->bw < s->tl - 1;
+            const int dead_by_score = s->score > s->bw;
+            if (dead_by_score) g_cert_dead_arcs++, g_cert_dead_steps += s->c->steps - st_before;
+            if (far) {
+                const int32_t m = cert_cost(s, (w << 20) ^ (uint64_t) ls, s->cs + l0, (int32_t) ext);
+                if (m > s->bw) {
+                    g_cert_arcs++, g_cert_steps += s->c->steps - st_before;
+                    if (!dead_by_score) { g_cert_wrong++; if (g_cert_wrong < 6) fprintf(stderr, "[cert] WRONG: tl %d bw %d ql %d ext %zu least cost %d, wavefront score %d\n", s->tl, s->bw, ql, ext, m, s->score); }
+                }
+            }
+        }
+        if (g_dp < 0) g_dp = getenv("ECT_DP") != 0;
+        if (g_rows < 0) g_rows = getenv("ECT_ROWS") != 0;
+        if (g_dp && g_rows && ext > 0) {
+            const int dead_a = s->score > s->bw;
+            const int far = ql - 1 + s->bw < s->tl - 1;
+            if (ext >= 32 && far) {
+                const int32_t *prof = prof_of(s, (w << 20) ^ (uint64_t) ls, s->cs + l0, (int32_t) ext);
+                int32_t t, best = DP_INF;
+                const int32_t qp = (int32_t) l0 - 1;
+                for (t = qp - g_dp_R < -1? -1 : qp - g_dp_R; t <= qp + g_dp_R && t < s->tl; ++t) { const int32_t v = dp_get(s, qp, t) + prof[t + 1]; if (v < best) best = v; }
+                g_rw_tests++;
+                const int dead_p = best > s->bw || (best < sc0? sc0 : best) > s->bw;
+                if (dead_p != dead_a) { if (g_rw_wrong++ < 8) fprintf(stderr, "[rows] tl %d bw %d ql %d ext %zu parent score %d: least value of the new last row by the table %d, wavefront score %d\n", s->tl, s->bw, ql, ext, sc0, best, s->score); }
+                if (dead_p) g_rw_dead_by_test++, g_rw_rows += 2;            /* (a pass over the band: about two rows' worth) */
+                else g_rw_rows += ext;
+            } else if (ext >= 32) {
+                const int64_t reach = (int64_t) s->tl + s->bw - (int64_t) l0;    /* rows beyond which the band has left the matrix */
+                g_rw_rows += reach > 0 && (uint64_t) reach < ext? (uint64_t) reach : ext;
+            } else g_rw_rows += ext;
+        }
+        if (g_dp && ext > 0) {
+            int32_t ps, pt, pq;
+            dp_rows(s, l0, s->cl);
+            dp_predict(s, ql, sc0, &ps, &pt, &pq);
+            const int dead_a = s->score > s->bw, dead_p = ps > s->bw;
+            g_dp_checked++;
+            if (dead_a != dead_p || (!dead_a && (ps != s->score || pt != s->t_end || pq != s->q_end))) {
+                if (dead_a != dead_p) g_dp_bad_dead++;
+                if (g_dp_bad++ < 12)
+                    fprintf(stderr, "[dp] tl %d bw %d ql %d ext %zu parent score %d: wavefront score %d t_end %d q_end %d | matrix score %d t_end %d q_end %d\n", s->tl, s->bw, ql, ext, sc0, s->score, s->t_end, s->q_end, ps, pt, pq);
+            }
+        }
         const int32_t score = s->score + s->tl - s->t_end;
         if (score <= s->bw && (s->sink == UINT64_MAX || s->sink == w)) s->c->succ_events++;
         const int alive = s->score <= s->bw && ql - l_seq <= s->tl + s->bw && ((s->sink != UINT64_MAX && s->sink != w) || s->t_end < s->tl);
@@ -292,7 +503,18 @@ uint64_t ect_trace(const orc_graph_t *g, const uint8_t *scm_del, int K, double m
                     s.nv_seen = s.na_seen = 0;
                     if (g_m2) memset(g_m2, 0, g_m2_m * sizeof(m2_t));
                     g_m2_n = 0, g_frame_serial = 0, g_cur_frame = 0, g_cur_hops = 0, g_m2_hits = 0, g_m2_saved_dead = 0, g_fs_n = 0;
+                    { size_t i_; for (i_ = 0; i_ < g_prof_n; ++i_) free(g_prof[i_]); g_prof_n = 0; }
+                    const uint64_t rw_r0 = g_rw_rows, rw_t0 = g_rw_tests, rw_d0 = g_rw_dead_by_test, rw_b0 = g_rw_tables;
+                    g_cert_n = 0;
+                    const uint64_t c_a0 = g_cert_arcs, c_s0 = g_cert_steps, c_t0 = g_cert_tables, c_c0 = g_cert_cells, c_da0 = g_cert_dead_arcs, c_ds0 = g_cert_dead_steps;
+                    g_dp_R = bw + 2, g_dp_W = 2 * g_dp_R + 1;
+                    const uint64_t ra0 = g_dp_rows_all, rc0 = g_dp_rows_cut, ca0 = g_dp_cut_arcs;
                     dfs(&s, beg_utg, 0);
+                    if (g_cert > 0 && c.tried >= min_tried) fprintf(fo, "cert_arcs %llu cert_steps %llu cert_tables %llu cert_cells %llu long_dead_arcs %llu long_dead_steps %llu ", (unsigned long long) (g_cert_arcs - c_a0), (unsigned long long) (g_cert_steps - c_s0),
+                                                                   (unsigned long long) (g_cert_tables - c_t0), (unsigned long long) (g_cert_cells - c_c0), (unsigned long long) (g_cert_dead_arcs - c_da0), (unsigned long long) (g_cert_dead_steps - c_ds0));
+                    if (g_rows > 0 && c.tried >= min_tried) fprintf(fo, "rw_rows %llu rw_tests %llu rw_dead_by_test %llu rw_tables %llu ", (unsigned long long) (g_rw_rows - rw_r0), (unsigned long long) (g_rw_tests - rw_t0),
+                                                                    (unsigned long long) (g_rw_dead_by_test - rw_d0), (unsigned long long) (g_rw_tables - rw_b0));
+                    if (g_dp > 0 && c.tried >= min_tried) fprintf(fo, "dp_rows %llu dp_rows_cut %llu dp_cut_arcs %llu ", (unsigned long long) (g_dp_rows_all - ra0), (unsigned long long) (g_dp_rows_cut - rc0), (unsigned long long) (g_dp_cut_arcs - ca0));
                     ++n_blocks, tot_tried += c.tried;
                     if (c.tried >= min_tried) {
                         int i;
@@ -312,6 +534,9 @@ uint64_t ect_trace(const orc_graph_t *g, const uint8_t *scm_del, int K, double m
                         fprintf(fo, " m2_hits %llu m2_saved_dead %llu", (unsigned long long) g_m2_hits, (unsigned long long) g_m2_saved_dead);
                         fprintf(fo, " sub_steps"); for (i = 0; i < 8; ++i) fprintf(fo, " %llu", (unsigned long long) c.sub_steps[i]);
                         fprintf(fo, " sub_cnt"); for (i = 0; i < 8; ++i) fprintf(fo, " %llu", (unsigned long long) c.sub_cnt[i]);
+                        fprintf(fo, " x_steps %llu x_w16_turns %llu x_long_lanes %llu x_long_steps %llu x_w64_turns %llu x_w64_long %llu x_act_lanes %llu x_ext_hist", (unsigned long long) c.x_steps, (unsigned long long) c.x_w16_turns,
+                                (unsigned long long) c.x_long_lanes, (unsigned long long) c.x_long_steps, (unsigned long long) c.x_w64_turns, (unsigned long long) c.x_w64_long, (unsigned long long) c.x_act_lanes);
+                        for (i = 0; i < 8; ++i) fprintf(fo, " %llu", (unsigned long long) c.x_ext_hist[i]);
                         fprintf(fo, "\n");
                         fflush(fo);
                     }
@@ -325,6 +550,23 @@ uint64_t ect_trace(const orc_graph_t *g, const uint8_t *scm_del, int K, double m
         in_off += (uint64_t) n;
     }
     fprintf(fo, "# %llu blocks, %llu arcs tried in all\n", (unsigned long long) n_blocks, (unsigned long long) tot_tried);
+    if (g_cert > 0) {
+        fprintf(fo, "# ECT_CERT: %llu arcs (%llu wavefront steps) known to die by score from their string's least cost in the target alone; %llu of them did NOT die (must be 0); arcs of >= 32 bases that died by score: %llu (%llu steps); %llu tables, %llu cells\n",
+                (unsigned long long) g_cert_arcs, (unsigned long long) g_cert_steps, (unsigned long long) g_cert_wrong, (unsigned long long) g_cert_dead_arcs, (unsigned long long) g_cert_dead_steps, (unsigned long long) g_cert_tables, (unsigned long long) g_cert_cells);
+        fprintf(stderr, "ECT_CERT: %llu arcs / %llu steps certified, %llu wrong; long dead arcs %llu / %llu steps; %llu tables %llu cells\n", (unsigned long long) g_cert_arcs, (unsigned long long) g_cert_steps, (unsigned long long) g_cert_wrong,
+                (unsigned long long) g_cert_dead_arcs, (unsigned long long) g_cert_dead_steps, (unsigned long long) g_cert_tables, (unsigned long long) g_cert_cells);
+    }
+    if (g_rows > 0) {
+        fprintf(fo, "# ECT_ROWS: a solver by rows: %llu row-equivalents in all; %llu long arcs asked by table whether they can be alive, %llu of them die by score there; %llu differ from the wavefront (must be 0); %llu tables\n",
+                (unsigned long long) g_rw_rows, (unsigned long long) g_rw_tests, (unsigned long long) g_rw_dead_by_test, (unsigned long long) g_rw_wrong, (unsigned long long) g_rw_tables);
+        fprintf(stderr, "ECT_ROWS: %llu row-equivalents, %llu tests, %llu dead by test, %llu wrong, %llu tables\n", (unsigned long long) g_rw_rows, (unsigned long long) g_rw_tests, (unsigned long long) g_rw_dead_by_test, (unsigned long long) g_rw_wrong, (unsigned long long) g_rw_tables);
+    }
+    if (g_dp > 0) {
+        fprintf(fo, "# ECT_DP: %llu arcs checked against the banded matrix (%llu cells): %llu differ, %llu of them in whether the arc dies by score\n", (unsigned long long) g_dp_checked, (unsigned long long) g_dp_cells,
+                (unsigned long long) g_dp_bad, (unsigned long long) g_dp_bad_dead);
+        fprintf(stderr, "ECT_DP: %llu arcs checked, %llu differ (%llu in dead-by-score); rows %llu, with the cut at the first row beyond the band %llu (%llu arcs cut)\n", (unsigned long long) g_dp_checked, (unsigned long long) g_dp_bad,
+                (unsigned long long) g_dp_bad_dead, (unsigned long long) g_dp_rows_all, (unsigned long long) g_dp_rows_cut, (unsigned long long) g_dp_cut_arcs);
+    }
     fclose(fo);
     free(seq); free(s.cs); free(s.k); free(s.nk); free(s.vseen); free(s.aseen); free(memo.k); free(memo.sub_arcs);
     return n_blocks;
