@@ -299,6 +299,60 @@ static const int32_t *prof_of(const S *s, uint64_t key, const char *ext, int32_t
     return prof;
 }
 
+/* ---- ECT_SLOTS=1: the row solver's state as a kernel would hold it -- one value per DIAGONAL (slot = diagonal + bw + 2, like the wavefront's slots), nothing else: the
+ * cell of the current row on that diagonal, or, once the diagonal has run past the target's last column, the value it had THERE (frozen).  Every diagonal then holds its one
+ * boundary cell when the arc's last row is done, and the call's outcome is read off the slots: least value (not below the parent's score), lowest slot within it.  Saved and
+ * restored per level like the wavefront.  Checked against the wavefront arc by arc. ---- */
+static int g_slots = -1;
+static int32_t *g_sl; static int32_t g_sl_n, g_sl_off;
+static uint64_t g_sl_checked, g_sl_bad;
+static void slots_init(const S *s)
+{
+    int32_t i;
+    g_sl_off = s->bw + 2, g_sl_n = 2 * g_sl_off + 1;
+    g_sl = (int32_t *) realloc(g_sl, sizeof(int32_t) * (size_t) (g_sl_n + 2));
+    for (i = 0; i < g_sl_n; ++i) { const int32_t d = i - g_sl_off, t = -1 - d; g_sl[i] = t >= -1 && t < s->tl? t + 1 : DP_INF; }       /* the row before the first: D(-1, t) = t + 1 */
+}
+static void slots_rows(const S *s, size_t from, size_t to)
+{
+    size_t qq;
+    const int32_t tl = s->tl;
+    for (qq = from; qq < to; ++qq) {
+        const int32_t q = (int32_t) qq;
+        const char c = s->cs[q];
+        int32_t i, carry = DP_INF;                       /* the new value of the slot above (the cell to the left in the row) */
+        for (i = g_sl_n - 1; i >= 0; --i) {
+            const int32_t d = i - g_sl_off, t = q - d;
+            int32_t v;
+            if (t >= tl) break;                          /* this diagonal and all below it have left the matrix: they keep what they had on its last column */
+            if (t < -1) v = DP_INF;
+            else if (t == -1) v = q + 1;
+            else {
+                const int32_t a = g_sl[i] + (s->ts[t] != c), b = (i >= 1? g_sl[i - 1] : DP_INF) + 1;      /* (old values: slot i is read before it is written, slot i - 1 is written later) */
+                v = a < b? a : b;
+                if (carry + 1 < v) v = carry + 1;
+                if (v > DP_INF) v = DP_INF;
+            }
+            g_sl[i] = v, carry = v;
+        }
+    }
+}
+static void slots_predict(const S *s, int32_t ql, int32_t parent_score, int32_t *score, int32_t *t_end, int32_t *q_end)
+{
+    int32_t i, best = DP_INF;
+    for (i = 0; i < g_sl_n; ++i) { const int32_t d = i - g_sl_off, t = ql - 1 - d; if (t >= 0 && g_sl[i] < best) best = g_sl[i]; }       /* (t >= tl: frozen on the last column; t = -1: no cell of the target) */
+    const int32_t sc = best > parent_score? best : parent_score;
+    if (sc > s->bw) { *score = s->bw + 1, *t_end = 0, *q_end = 0; return; }
+    for (i = 0; i < g_sl_n; ++i) {
+        const int32_t d = i - g_sl_off, t = ql - 1 - d;
+        if (t < 0 || g_sl[i] > sc) continue;
+        *score = sc;
+        if (t < s->tl) *t_end = t + 1, *q_end = ql;
+        else *t_end = s->tl, *q_end = s->tl + d;
+        return;
+    }
+}
+
 static void dfs(S *s, uint64_t source, int depth)
 {
     static const uint64_t SL[7] = {1, 2, 4, 8, 16, 32, 64}, EL[7] = {1, 2, 4, 8, 16, 64, 256};
@@ -322,6 +376,9 @@ static void dfs(S *s, uint64_t source, int depth)
     const int32_t n0 = s->n, d00 = s->d0, sc0 = s->score, te0 = s->t_end, qe0 = s->q_end;
     int32_t *sv = (int32_t *) malloc(sizeof(int32_t) * (size_t) (n0 + 1));
     memcpy(sv, s->k, sizeof(int32_t) * (size_t) n0);
+    if (g_slots < 0) g_slots = getenv("ECT_SLOTS") != 0;
+    int32_t *sl_sv = 0;
+    if (g_slots) { sl_sv = (int32_t *) malloc(sizeof(int32_t) * (size_t) g_sl_n); memcpy(sl_sv, g_sl, sizeof(int32_t) * (size_t) g_sl_n); }
     uint64_t i, live = 0; int live_seen = 0;
     for (i = 0; i < na; ++i) if (!g->arc_del[p + i]) ++live;
     s->c->levels++;
@@ -368,6 +425,16 @@ static void dfs(S *s, uint64_t source, int depth)
         }
         s->c->steps_hist[bucket8(s->c->steps - st_before, SL)]++;
         s->t_end += 1, s->q_end += 1;
+        if (g_slots && ext > 0) {
+            int32_t ps = 0, pt = 0, pq = 0;
+            slots_rows(s, l0, s->cl);
+            slots_predict(s, ql, sc0, &ps, &pt, &pq);
+            const int dead_a = s->score > s->bw, dead_p = ps > s->bw;
+            g_sl_checked++;
+            if (dead_a != dead_p || (!dead_a && (ps != s->score || pt != s->t_end || pq != s->q_end))) {
+                if (g_sl_bad++ < 12) fprintf(stderr, "[slots] tl %d bw %d ql %d ext %zu parent score %d: wavefront score %d t_end %d q_end %d | slots score %d t_end %d q_end %d\n", s->tl, s->bw, ql, ext, sc0, s->score, s->t_end, s->q_end, ps, pt, pq);
+            }
+        }
         if (g_cert < 0) g_cert = getenv("ECT_CERT") != 0;
         if (g_cert && ext >= 32) {
             /* (the last column out of the new rows' reach: no cell (q, tl - 1) with q < ql lies within bw of the diagonal) */
@@ -431,7 +498,9 @@ static void dfs(S *s, uint64_t source, int depth)
         s->n = n0, s->d0 = d00, s->score = sc0, s->t_end = te0, s->q_end = qe0;
         wf_need(s, n0 + 4);
         memcpy(s->k, sv, sizeof(int32_t) * (size_t) n0);
+        if (g_slots) memcpy(g_sl, sl_sv, sizeof(int32_t) * (size_t) g_sl_n);
     }
+    free(sl_sv);
     if (live > 1 && g_fs_n > 0) --g_fs_n;
     if (m2 && !m2->key) {
         m2->key = mix64(source * 0x9E3779B97F4A7C15ULL ^ h0 ^ ((uint64_t) l0 << 40)) | 1ULL, m2->frame = my_frame, m2->dead = (uint32_t) (s->n_path - np_at_entry);
@@ -507,6 +576,7 @@ uint64_t ect_trace(const orc_graph_t *g, const uint8_t *scm_del, int K, double m
                     const uint64_t rw_r0 = g_rw_rows, rw_t0 = g_rw_tests, rw_d0 = g_rw_dead_by_test, rw_b0 = g_rw_tables;
                     g_cert_n = 0;
                     const uint64_t c_a0 = g_cert_arcs, c_s0 = g_cert_steps, c_t0 = g_cert_tables, c_c0 = g_cert_cells, c_da0 = g_cert_dead_arcs, c_ds0 = g_cert_dead_steps;
+                    if (getenv("ECT_SLOTS")) slots_init(&s);
                     g_dp_R = bw + 2, g_dp_W = 2 * g_dp_R + 1;
                     const uint64_t ra0 = g_dp_rows_all, rc0 = g_dp_rows_cut, ca0 = g_dp_cut_arcs;
                     dfs(&s, beg_utg, 0);
@@ -555,6 +625,10 @@ uint64_t ect_trace(const orc_graph_t *g, const uint8_t *scm_del, int K, double m
                 (unsigned long long) g_cert_arcs, (unsigned long long) g_cert_steps, (unsigned long long) g_cert_wrong, (unsigned long long) g_cert_dead_arcs, (unsigned long long) g_cert_dead_steps, (unsigned long long) g_cert_tables, (unsigned long long) g_cert_cells);
         fprintf(stderr, "ECT_CERT: %llu arcs / %llu steps certified, %llu wrong; long dead arcs %llu / %llu steps; %llu tables %llu cells\n", (unsigned long long) g_cert_arcs, (unsigned long long) g_cert_steps, (unsigned long long) g_cert_wrong,
                 (unsigned long long) g_cert_dead_arcs, (unsigned long long) g_cert_dead_steps, (unsigned long long) g_cert_tables, (unsigned long long) g_cert_cells);
+    }
+    if (g_slots > 0) {
+        fprintf(fo, "# ECT_SLOTS: one value per diagonal, frozen on the target's last column: %llu arcs checked against the wavefront, %llu differ\n", (unsigned long long) g_sl_checked, (unsigned long long) g_sl_bad);
+        fprintf(stderr, "ECT_SLOTS: %llu arcs checked, %llu differ\n", (unsigned long long) g_sl_checked, (unsigned long long) g_sl_bad);
     }
     if (g_rows > 0) {
         fprintf(fo, "# ECT_ROWS: a solver by rows: %llu row-equivalents in all; %llu long arcs asked by table whether they can be alive, %llu of them die by score there; %llu differ from the wavefront (must be 0); %llu tables\n",
