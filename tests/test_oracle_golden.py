@@ -57,6 +57,46 @@ def test_levdist_resumable_traces():
         w.close()
 
 
+def _matrix_steps(ts, qs, bw, qls):
+    """what wf_ed_core, resumed from one query length to the next, returns -- said by the edit-distance MATRIX alone: the score is the least value on
+    the boundary (the query's last row, the target's last column) but not below the call before; the end is the boundary cell of the lowest diagonal within that score; beyond
+    the band the call ends with score bw + 1 and no end"""
+    tl, T = len(ts), np.frombuffer(ts, np.uint8)
+    prev = np.arange(tl + 1, dtype=np.int64)               # the row before the first: D(-1, t) = t + 1, at index t + 1
+    idx = np.arange(tl + 1)
+    lastcol, out, score, done = [], [], 0, 0
+    for ql in qls:
+        for q in range(done, ql):
+            m = np.minimum(prev[:-1] + (T != qs[q]), prev[1:] + 1)
+            prev = np.minimum.accumulate(np.concatenate(([q + 1], m)) - idx) + idx      # ... and from the cell to the left: a min-plus scan
+            lastcol.append(int(prev[tl]))
+        done = ql
+        cells = [(int(prev[t + 1]), ql - 1 - t, t, ql - 1) for t in range(tl)] + [(lastcol[q], q - (tl - 1), tl - 1, q) for q in range(ql)]
+        sc = max(min(c[0] for c in cells), score)
+        if bw >= 0 and sc > bw:
+            score = bw + 1
+            out.append((bw + 1, 0, 0))
+            continue
+        _, t, q = min((c[1], c[2], c[3]) for c in cells if c[0] <= sc)
+        score = sc
+        out.append((sc, t + 1, q + 1))
+    return out
+
+
+def test_levdist_resumable_traces_are_the_matrix():
+    """the reference's own resumed calls (tests/golden/levdist.npz: 120 traces, 515 calls written by the compiled reference) equal the closed form above: the wavefront's
+    lowest-diagonal-first end, its skipped diagonals and its one-sided pruning (levdist.c:99-113,156-224) add nothing to the matrix -- which is what lets a search keep the
+    matrix's last row instead of a wavefront (tests/trace/ec_trace.c checks the same on 7.6 M arcs of the config-1 surrogate)"""
+    g = G.load("levdist")
+    n = 0
+    for ts, qs, bw, steps in zip(g["tr_t"], g["tr_q"], g["tr_bw"], g["tr_steps"]):
+        got = _matrix_steps(ts, qs, int(bw), [int(s[0]) for s in steps])
+        for p, s in zip(got, steps):
+            assert p == (int(s[1]), int(s[2]), int(s[3])), (ts, qs, bw, s, p)
+            n += 1
+    assert n > 500
+
+
 def test_hash64_is_a_bijection_sample():
     mask = (1 << 62) - 1
     L = O.lib()
