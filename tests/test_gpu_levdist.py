@@ -45,11 +45,13 @@ def fits(job, wg):
     ts, qs, bw, steps = job
     if wg == 32:
         return (2 * bw + 5 if bw >= 0 else len(ts) + len(qs) + 5) <= 512
+    if wg == 33:
+        return bw >= 0 and 2 * bw + 5 <= 640
     return wg == 0 or (2 * bw + 3 if bw >= 0 else len(ts) + len(qs) + 3) <= (512 if wg == 8 else 896 if wg == 16 else 256 * wg)
 
 
-# (32: ec_rows.hpp, the alignment by matrix rows -- written in round 5 after the last GPU run, never executed: on request until it has been seen green)
-WG = pytest.mark.parametrize("wg", [0, 1, 2, 6, 8, 16] + ([32] if os.environ.get("OATK_TEST_EC_ROWS") == "1" else []))       # 0: ecw_step (a wave per block); 1, 2, 6: ech_step, a workgroup per block with 1, 2, 6 diagonals per lane; 8: ect_step (the tree solver: ONE wave, 8 diagonals per lane); 16: ecf_align (sixteen waves, four steps per barrier)
+# (32, 33: ec_rows.hpp, the alignment by matrix rows, as numbers and as bits -- written in round 5 after the last GPU run, never executed: on request until seen green)
+WG = pytest.mark.parametrize("wg", [0, 1, 2, 6, 8, 16] + ([32, 33] if os.environ.get("OATK_TEST_EC_ROWS") == "1" else []))       # 0: ecw_step (a wave per block); 1, 2, 6: ech_step, a workgroup per block with 1, 2, 6 diagonals per lane; 8: ect_step (the tree solver: ONE wave, 8 diagonals per lane); 16: ecf_align (sixteen waves, four steps per barrier)
 
 
 @WG
