@@ -126,6 +126,32 @@ static void ref_row(ref_t *r, int c)
     free(r->row), r->row = n, r->q = q + 1;
 }
 
+/* ---- the read-off as the device does it (oatk_amd/csrc/ec_rows.hpp: ecb_read): 32-bit words, per-word sums of differences, a cell's value from popcounts under a
+ * mask, the last row's qualifying cell with the LARGEST band index against the last column's first qualifying row ---- */
+static uint32_t upto(int k) { return k == 31? 0xFFFFFFFFu : (1u << (k + 1)) - 1u; }
+static void dev_read(const bp_t *p, int tl, int ql, int bw, const int *lc /* by row */, int before, int *out)
+{
+    const int W = p->W, OFF = p->OFF, nw = (W + 31) / 32;
+    uint32_t pv[2 * NWMAX], mv[2 * NWMAX];
+    int wpre[2 * NWMAX], w, b, acc = 0;
+    for (w = 0; w < nw; ++w) pv[w] = (uint32_t) (p->pv[w >> 1] >> ((w & 1) * 32)), mv[w] = (uint32_t) (p->mv[w >> 1] >> ((w & 1) * 32));
+    for (w = 0; w < nw; ++w) { wpre[w] = acc; acc += __builtin_popcount(pv[w]) - __builtin_popcount(mv[w]); }
+    const int c_off = wpre[OFF >> 5] + __builtin_popcount(pv[OFF >> 5] & upto(OFF & 31)) - __builtin_popcount(mv[OFF >> 5] & upto(OFF & 31));
+    const int lc0 = tl - 1 - OFF, q_lo = lc0 > 0? lc0 : 0;
+    int best = INF, qq;
+#define VAL(b) (p->mid + wpre[(b) >> 5] + __builtin_popcount(pv[(b) >> 5] & upto((b) & 31)) - __builtin_popcount(mv[(b) >> 5] & upto((b) & 31)) - c_off)
+    for (b = 0; b < W; ++b) { const int t = ql - 1 - OFF + b; if (t >= 0 && t < tl && VAL(b) < best) best = VAL(b); }
+    for (qq = q_lo; qq < ql && qq < lc0 + W; ++qq) if (lc[qq] < best) best = lc[qq];
+    const int sc = best > before? best : before;
+    if (sc > bw) { out[0] = bw + 1, out[1] = out[2] = 0; return; }
+    int d_col = INF, q_col = 0, d_row = INF, t_row = 0;
+    for (qq = q_lo; qq < ql && qq < lc0 + W; ++qq) if (lc[qq] <= sc) { q_col = qq, d_col = qq - (tl - 1); break; }
+    for (b = W - 1; b >= 0; --b) { const int t = ql - 1 - OFF + b; if (t >= 0 && t < tl && VAL(b) <= sc) { t_row = t, d_row = OFF - b; break; } }
+#undef VAL
+    out[0] = sc;
+    if (d_col <= d_row) out[1] = tl, out[2] = q_col + 1; else out[1] = t_row + 1, out[2] = ql;
+}
+
 int main(int argc, char **argv)
 {
     const int rounds = argc > 1? atoi(argv[1]) : 300;
@@ -162,7 +188,7 @@ int main(int argc, char **argv)
         ref_t f;
         bp_init(&p, ts, tl, bw), ref_init(&f, ts, tl, bw);
         int *val = (int *) malloc(sizeof(int) * (size_t) p.W), *lastcol = (int *) malloc(sizeof(int) * (size_t) (ql + 1)), *lastcol_b = (int *) malloc(sizeof(int) * (size_t) (ql + 1));
-        int q = 0, score_f = 0, score_b = 0;
+        int q = 0, score_f = 0, score_b = 0, score_dev = 0;
         while (q < ql) {
             int to = q + 1 + (int) (rnd() % 60), b;
             if (to > ql) to = ql;
@@ -195,6 +221,12 @@ int main(int argc, char **argv)
                     *score = sc, out[which][0] = sc, out[which][1] = bt + 1, out[which][2] = bq + 1;
                 }
                 ++n_calls;
+                {
+                    int dv[3];
+                    dev_read(&p, tl, to, bw, lastcol_b, score_dev, dv);
+                    score_dev = dv[0];
+                    if (memcmp(out[0], dv, sizeof(dv))) { fprintf(stderr, "round %d tl %d bw %d ql %d: matrix (%d %d %d), the device's read-off (%d %d %d)\n", r, tl, bw, to, out[0][0], out[0][1], out[0][2], dv[0], dv[1], dv[2]); return 1; }
+                }
                 if (memcmp(out[0], out[1], sizeof(out[0]))) { fprintf(stderr, "round %d tl %d bw %d ql %d: matrix (%d %d %d), bits (%d %d %d)\n", r, tl, bw, to, out[0][0], out[0][1], out[0][2], out[1][0], out[1][1], out[1][2]); return 1; }
                 if (score_f > bw && rnd() % 3 == 0) break;
             }
