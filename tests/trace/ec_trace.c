@@ -272,6 +272,7 @@ static int32_t cert_cost(const S *s, uint64_t key, const char *ext, int32_t m)
 static int g_rows = -1;
 static int32_t **g_prof; static uint64_t *g_prof_key; static size_t g_prof_n, g_prof_cap;
 static uint64_t g_rw_rows, g_rw_tests, g_rw_dead_by_test, g_rw_wrong, g_rw_tables;
+static uint64_t g_lvc_arcs, g_lvc_steps, g_lvc_wrong, g_lvc_dead_arcs, g_lvc_dead_steps;
 static const int32_t *prof_of(const S *s, uint64_t key, const char *ext, int32_t m)
 {
     size_t i;
@@ -460,6 +461,25 @@ static void dfs(S *s, uint64_t source, int depth)
                 const int32_t qp = (int32_t) l0 - 1;
                 for (t = qp - g_dp_R < -1? -1 : qp - g_dp_R; t <= qp + g_dp_R && t < s->tl; ++t) { const int32_t v = dp_get(s, qp, t) + prof[t + 1]; if (v < best) best = v; }
                 g_rw_tests++;
+                {   /* the same test with what a WAVEFRONT knows of the parent's row instead of the row itself: a cell the parent's wavefront has passed (t' <= its k on that
+                     * diagonal) costs at least |diagonal|, one it has not reached at least the parent's score + 1 */
+                    int32_t lb_best = DP_INF;
+                    for (t = qp - g_dp_R < -1? -1 : qp - g_dp_R; t <= qp + g_dp_R && t < s->tl; ++t) {
+                        const int32_t d = qp - t, j = d - d00;
+                        int reached = 0;
+                        if (j >= 0 && j < n0) {                        /* (the parent's call stored only the diagonals below the one it ended on extended: the others are extended here, as its child's first step would) */
+                            int32_t k = sv[j];
+                            const int32_t qlp = (int32_t) l0;
+                            if (!(k >= s->tl || k + d >= qlp)) { const int32_t lim = (qlp - d < s->tl? qlp - d : s->tl) - 1; while (k < lim && s->ts[k + 1] == s->cs[k + d + 1]) ++k; }
+                            reached = k >= t;
+                        }
+                        int32_t lb = d < 0? -d : d;
+                        if (!reached && sc0 + 1 > lb) lb = sc0 + 1;
+                        if (lb + prof[t + 1] < lb_best) lb_best = lb + prof[t + 1];
+                    }
+                    if (lb_best > s->bw) { g_lvc_arcs++, g_lvc_steps += s->c->steps - st_before; if (!dead_a) g_lvc_wrong++; }
+                    if (dead_a) g_lvc_dead_arcs++, g_lvc_dead_steps += s->c->steps - st_before;
+                }
                 const int dead_p = best > s->bw || (best < sc0? sc0 : best) > s->bw;
                 if (dead_p != dead_a) { if (g_rw_wrong++ < 8) fprintf(stderr, "[rows] tl %d bw %d ql %d ext %zu parent score %d: least value of the new last row by the table %d, wavefront score %d\n", s->tl, s->bw, ql, ext, sc0, best, s->score); }
                 if (dead_p) g_rw_dead_by_test++, g_rw_rows += 2;            /* (a pass over the band: about two rows' worth) */
@@ -573,6 +593,7 @@ uint64_t ect_trace(const orc_graph_t *g, const uint8_t *scm_del, int K, double m
                     if (g_m2) memset(g_m2, 0, g_m2_m * sizeof(m2_t));
                     g_m2_n = 0, g_frame_serial = 0, g_cur_frame = 0, g_cur_hops = 0, g_m2_hits = 0, g_m2_saved_dead = 0, g_fs_n = 0;
                     { size_t i_; for (i_ = 0; i_ < g_prof_n; ++i_) free(g_prof[i_]); g_prof_n = 0; }
+                    const uint64_t lv_a0 = g_lvc_arcs, lv_s0 = g_lvc_steps;
                     const uint64_t rw_r0 = g_rw_rows, rw_t0 = g_rw_tests, rw_d0 = g_rw_dead_by_test, rw_b0 = g_rw_tables;
                     g_cert_n = 0;
                     const uint64_t c_a0 = g_cert_arcs, c_s0 = g_cert_steps, c_t0 = g_cert_tables, c_c0 = g_cert_cells, c_da0 = g_cert_dead_arcs, c_ds0 = g_cert_dead_steps;
@@ -582,6 +603,7 @@ uint64_t ect_trace(const orc_graph_t *g, const uint8_t *scm_del, int K, double m
                     dfs(&s, beg_utg, 0);
                     if (g_cert > 0 && c.tried >= min_tried) fprintf(fo, "cert_arcs %llu cert_steps %llu cert_tables %llu cert_cells %llu long_dead_arcs %llu long_dead_steps %llu ", (unsigned long long) (g_cert_arcs - c_a0), (unsigned long long) (g_cert_steps - c_s0),
                                                                    (unsigned long long) (g_cert_tables - c_t0), (unsigned long long) (g_cert_cells - c_c0), (unsigned long long) (g_cert_dead_arcs - c_da0), (unsigned long long) (g_cert_dead_steps - c_ds0));
+                    if (g_rows > 0 && c.tried >= min_tried) fprintf(fo, "lvc_arcs %llu lvc_steps %llu ", (unsigned long long) (g_lvc_arcs - lv_a0), (unsigned long long) (g_lvc_steps - lv_s0));
                     if (g_rows > 0 && c.tried >= min_tried) fprintf(fo, "rw_rows %llu rw_tests %llu rw_dead_by_test %llu rw_tables %llu ", (unsigned long long) (g_rw_rows - rw_r0), (unsigned long long) (g_rw_tests - rw_t0),
                                                                     (unsigned long long) (g_rw_dead_by_test - rw_d0), (unsigned long long) (g_rw_tables - rw_b0));
                     if (g_dp > 0 && c.tried >= min_tried) fprintf(fo, "dp_rows %llu dp_rows_cut %llu dp_cut_arcs %llu ", (unsigned long long) (g_dp_rows_all - ra0), (unsigned long long) (g_dp_rows_cut - rc0), (unsigned long long) (g_dp_cut_arcs - ca0));
@@ -633,6 +655,10 @@ uint64_t ect_trace(const orc_graph_t *g, const uint8_t *scm_del, int K, double m
     if (g_rows > 0) {
         fprintf(fo, "# ECT_ROWS: a solver by rows: %llu row-equivalents in all; %llu long arcs asked by table whether they can be alive, %llu of them die by score there; %llu differ from the wavefront (must be 0); %llu tables\n",
                 (unsigned long long) g_rw_rows, (unsigned long long) g_rw_tests, (unsigned long long) g_rw_dead_by_test, (unsigned long long) g_rw_wrong, (unsigned long long) g_rw_tables);
+        fprintf(fo, "# ECT_ROWS, the table test fed from the parent's WAVEFRONT (lower bounds) instead of its row: %llu of %llu long arcs that die by score are known to (%llu of %llu wavefront steps); known to die but alive (must be 0): %llu\n",
+                (unsigned long long) g_lvc_arcs, (unsigned long long) g_lvc_dead_arcs, (unsigned long long) g_lvc_steps, (unsigned long long) g_lvc_dead_steps, (unsigned long long) g_lvc_wrong);
+        fprintf(stderr, "ECT_ROWS/wavefront bounds: %llu of %llu dead long arcs certified (%llu of %llu steps), wrong %llu\n", (unsigned long long) g_lvc_arcs, (unsigned long long) g_lvc_dead_arcs, (unsigned long long) g_lvc_steps,
+                (unsigned long long) g_lvc_dead_steps, (unsigned long long) g_lvc_wrong);
         fprintf(stderr, "ECT_ROWS: %llu row-equivalents, %llu tests, %llu dead by test, %llu wrong, %llu tables\n", (unsigned long long) g_rw_rows, (unsigned long long) g_rw_tests, (unsigned long long) g_rw_dead_by_test, (unsigned long long) g_rw_wrong, (unsigned long long) g_rw_tables);
     }
     if (g_dp > 0) {
