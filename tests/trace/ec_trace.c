@@ -272,7 +272,7 @@ static int32_t cert_cost(const S *s, uint64_t key, const char *ext, int32_t m)
 static int g_rows = -1;
 static int32_t **g_prof; static uint64_t *g_prof_key; static size_t g_prof_n, g_prof_cap;
 static uint64_t g_rw_rows, g_rw_tests, g_rw_dead_by_test, g_rw_wrong, g_rw_tables;
-static uint64_t g_lvc_arcs, g_lvc_steps, g_lvc_wrong, g_lvc_dead_arcs, g_lvc_dead_steps;
+static uint64_t g_lvc_arcs, g_lvc_steps, g_lvc_wrong, g_lvc_dead_arcs, g_lvc_dead_steps, g_rw_near;
 static const int32_t *prof_of(const S *s, uint64_t key, const char *ext, int32_t m)
 {
     size_t i;
@@ -293,8 +293,26 @@ static const int32_t *prof_of(const S *s, uint64_t key, const char *ext, int32_t
         { int32_t *x = prev; prev = cur, cur = x; }
     }
     /* prof[t' + 1], t' = -1 .. tl - 1: the string fitted into target[t' + 1 ..]: begins at tl - j = t' + 1 */
-    int32_t *prof = (int32_t *) malloc(sizeof(int32_t) * (size_t) (tl + 1));
+    int32_t *prof = (int32_t *) malloc(sizeof(int32_t) * (size_t) (2 * (tl + 1)));
     for (j = 0; j <= tl; ++j) prof[tl - j] = prev[j];
+    /* ... and behind it prof2[u], u = t' + 1: the least cost of some PREFIX of the string against target[u ..] TO ITS END (what a cell of the target's last column in one of
+     * the new rows costs on top of the parent's row): G[i][u] = min(G[i+1][u+1] + mismatch, G[i+1][u] + 1, G[i][u+1] + 1), G[i][tl] = 0, G[m][u] = tl - u */
+    {
+        int32_t *g1 = prev, *g0 = cur, i, u;
+        for (u = 0; u <= tl; ++u) g1[u] = tl - u;                      /* i = m */
+        for (i = m - 1; i >= 0; --i) {
+            g0[tl] = 0;
+            for (u = tl - 1; u >= 0; --u) {
+                int32_t v = g1[u + 1] + (ext[i] != s->ts[u]);
+                if (g1[u] + 1 < v) v = g1[u] + 1;
+                if (g0[u + 1] + 1 < v) v = g0[u + 1] + 1;
+                g0[u] = v;
+            }
+            { int32_t *x = g1; g1 = g0, g0 = x; }
+        }
+        for (u = 0; u <= tl; ++u) prof[tl + 1 + u] = g1[u];
+        prev = g1, cur = g0;
+    }
     free(prev), free(cur);
     g_prof_key[g_prof_n] = key, g_prof[g_prof_n] = prof, ++g_prof_n, ++g_rw_tables;
     return prof;
@@ -455,8 +473,12 @@ static void dfs(S *s, uint64_t source, int depth)
         if (g_dp && g_rows && ext > 0) {
             const int dead_a = s->score > s->bw;
             const int far = ql - 1 + s->bw < s->tl - 1;
-            if (ext >= 32 && far) {
-                const int32_t *prof = prof_of(s, (w << 20) ^ (uint64_t) ls, s->cs + l0, (int32_t) ext);
+            const int near_ok = !far && (int32_t) l0 - 1 + g_dp_R < s->tl - 1;      /* the last column is within the NEW rows' reach only: no cell of it in the rows before */
+            if (near_ok && ext >= 32) g_rw_near++;
+            if (ext >= 32 && (far || near_ok)) {
+                const int32_t *prof0 = prof_of(s, (w << 20) ^ (uint64_t) ls, s->cs + l0, (int32_t) ext);
+                int32_t *prof = (int32_t *) prof0, *pmix = 0;
+                if (near_ok) { int32_t u; pmix = (int32_t *) malloc(sizeof(int32_t) * (size_t) (s->tl + 1)); for (u = 0; u <= s->tl; ++u) pmix[u] = prof0[u] < prof0[s->tl + 1 + u]? prof0[u] : prof0[s->tl + 1 + u]; prof = pmix; }
                 int32_t t, best = DP_INF;
                 const int32_t qp = (int32_t) l0 - 1;
                 for (t = qp - g_dp_R < -1? -1 : qp - g_dp_R; t <= qp + g_dp_R && t < s->tl; ++t) { const int32_t v = dp_get(s, qp, t) + prof[t + 1]; if (v < best) best = v; }
@@ -483,7 +505,9 @@ static void dfs(S *s, uint64_t source, int depth)
                 const int dead_p = best > s->bw || (best < sc0? sc0 : best) > s->bw;
                 if (dead_p != dead_a) { if (g_rw_wrong++ < 8) fprintf(stderr, "[rows] tl %d bw %d ql %d ext %zu parent score %d: least value of the new last row by the table %d, wavefront score %d\n", s->tl, s->bw, ql, ext, sc0, best, s->score); }
                 if (dead_p) g_rw_dead_by_test++, g_rw_rows += 2;            /* (a pass over the band: about two rows' worth) */
-                else g_rw_rows += ext;
+                else if (far) g_rw_rows += ext;
+                else { const int64_t reach = (int64_t) s->tl + s->bw - (int64_t) l0; g_rw_rows += reach > 0 && (uint64_t) reach < ext? (uint64_t) reach : ext; }
+                free(pmix);
             } else if (ext >= 32) {
                 const int64_t reach = (int64_t) s->tl + s->bw - (int64_t) l0;    /* rows beyond which the band has left the matrix */
                 g_rw_rows += reach > 0 && (uint64_t) reach < ext? (uint64_t) reach : ext;
@@ -659,6 +683,7 @@ uint64_t ect_trace(const orc_graph_t *g, const uint8_t *scm_del, int K, double m
                 (unsigned long long) g_lvc_arcs, (unsigned long long) g_lvc_dead_arcs, (unsigned long long) g_lvc_steps, (unsigned long long) g_lvc_dead_steps, (unsigned long long) g_lvc_wrong);
         fprintf(stderr, "ECT_ROWS/wavefront bounds: %llu of %llu dead long arcs certified (%llu of %llu steps), wrong %llu\n", (unsigned long long) g_lvc_arcs, (unsigned long long) g_lvc_dead_arcs, (unsigned long long) g_lvc_steps,
                 (unsigned long long) g_lvc_dead_steps, (unsigned long long) g_lvc_wrong);
+        fprintf(stderr, "ECT_ROWS: %llu of the tests with the last column within the new rows' reach\n", (unsigned long long) g_rw_near);
         fprintf(stderr, "ECT_ROWS: %llu row-equivalents, %llu tests, %llu dead by test, %llu wrong, %llu tables\n", (unsigned long long) g_rw_rows, (unsigned long long) g_rw_tests, (unsigned long long) g_rw_dead_by_test, (unsigned long long) g_rw_wrong, (unsigned long long) g_rw_tables);
     }
     if (g_dp > 0) {
