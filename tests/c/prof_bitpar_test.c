@@ -34,17 +34,39 @@ static void prof_plain(const uint8_t *ts, int tl, const uint8_t *ext, int m, int
     free(prev), free(cur);
 }
 
+/* prof2[u], u = t' + 1 = 0 .. tl, by the plain matrix (as tests/trace/ec_trace.c): G[i][u] = min(G[i+1][u+1] + mismatch, G[i+1][u] + 1, G[i][u+1] + 1), G[i][tl] = 0, G[m][u] = tl - u */
+static void prof2_plain(const uint8_t *ts, int tl, const uint8_t *ext, int m, int *prof)
+{
+    int *g1 = malloc(sizeof(int) * (size_t) (tl + 1)), *g0 = malloc(sizeof(int) * (size_t) (tl + 1)), i, u;
+    for (u = 0; u <= tl; ++u) g1[u] = tl - u;
+    for (i = m - 1; i >= 0; --i) {
+        g0[tl] = 0;
+        for (u = tl - 1; u >= 0; --u) {
+            int v = g1[u + 1] + (ext[i] != ts[u]);
+            if (g1[u] + 1 < v) v = g1[u] + 1;
+            if (g0[u + 1] + 1 < v) v = g0[u + 1] + 1;
+            g0[u] = v;
+        }
+        { int *x = g1; g1 = g0, g0 = x; }
+    }
+    for (u = 0; u <= tl; ++u) prof[u] = g1[u];
+    free(g1), free(g0);
+}
+
 /* the same in bits: word w of a vector = pattern positions 32 w .. 32 w + 31 of the reversed string */
-static void prof_bits(const uint8_t *ts, int tl, const uint8_t *ext, int m, int *prof)
+/* second = 0: the whole string into the target from t' + 1 on, any end (rows start at i, the first row at 0);  second = 1: some PREFIX of the string against the target
+ * from t' + 1 TO ITS END (backwards: the piece of the reversed target begins at its first base -- the first row counts the columns -- and the reversed string may be
+ * entered at any row for nothing) */
+static void prof_bits(const uint8_t *ts, int tl, const uint8_t *ext, int m, int *prof, int second)
 {
     uint32_t peq[4][NW], pv[NW], mv[NW];
     const int nw = (m + 31) / 32;
     const uint32_t last = m & 31? (1u << (m & 31)) - 1u : 0xFFFFFFFFu, top = 1u << ((m - 1) & 31);
-    int w, i, j, score = m;
+    int w, i, j, score = second? 0 : m;
     memset(peq, 0, sizeof(peq));
     for (i = 0; i < m; ++i) peq[ext[m - 1 - i]][i >> 5] |= 1u << (i & 31);
-    for (w = 0; w < nw; ++w) pv[w] = w == nw - 1? last : 0xFFFFFFFFu, mv[w] = 0;
-    prof[tl] = m;                                                     /* j = 0: nothing of the target */
+    for (w = 0; w < nw; ++w) pv[w] = second? 0u : (w == nw - 1? last : 0xFFFFFFFFu), mv[w] = 0;
+    prof[tl] = score;                                                     /* j = 0: nothing of the target */
     for (j = 1; j <= tl; ++j) {
         const uint32_t *eq = peq[ts[tl - j]];
         uint32_t xv[NW], ph[NW], mh[NW];
@@ -64,7 +86,7 @@ static void prof_bits(const uint8_t *ts, int tl, const uint8_t *ext, int m, int 
         }
         ph[nw - 1] &= last, mh[nw - 1] &= last;
         score += (ph[nw - 1] & top) != 0, score -= (mh[nw - 1] & top) != 0;
-        for (w = nw - 1; w >= 0; --w) ph[w] = ph[w] << 1 | (w? ph[w - 1] >> 31 : 0u), mh[w] = mh[w] << 1 | (w? mh[w - 1] >> 31 : 0u);      /* (free start: nothing comes in) */
+        for (w = nw - 1; w >= 0; --w) ph[w] = ph[w] << 1 | (w? ph[w - 1] >> 31 : (uint32_t) second), mh[w] = mh[w] << 1 | (w? mh[w - 1] >> 31 : 0u);      /* (free start in the target: nothing comes in; the second table's first row counts the columns: +1) */
         for (w = 0; w < nw; ++w) pv[w] = mh[w] | ~(xv[w] | ph[w]), mv[w] = ph[w] & xv[w];
         pv[nw - 1] &= last, mv[nw - 1] &= last;
         prof[tl - j] = score;
@@ -83,8 +105,10 @@ int main(int argc, char **argv)
         for (i = 0; i < tl; ++i) ts[i] = (uint8_t) (period && i >= period && rnd() % 40? ts[i - period] : rnd() % (uint64_t) alpha);
         if (r % 2 && m < tl) { const int at = (int) (rnd() % (uint64_t) (tl - m + 1)); for (i = 0; i < m; ++i) ext[i] = (uint8_t) (rnd() % 25? ts[at + i] : rnd() % (uint64_t) alpha); }
         else for (i = 0; i < m; ++i) ext[i] = (uint8_t) (rnd() % (uint64_t) alpha);
-        prof_plain(ts, tl, ext, m, a), prof_bits(ts, tl, ext, m, b);
+        prof_plain(ts, tl, ext, m, a), prof_bits(ts, tl, ext, m, b, 0);
         for (i = 0; i <= tl; ++i) if (a[i] != b[i]) { fprintf(stderr, "round %d tl %d m %d: prof[%d] plain %d bits %d\n", r, tl, m, i, a[i], b[i]); return 1; }
+        prof2_plain(ts, tl, ext, m, a), prof_bits(ts, tl, ext, m, b, 1);
+        for (i = 0; i <= tl; ++i) if (a[i] != b[i]) { fprintf(stderr, "round %d tl %d m %d: prof2[%d] plain %d bits %d\n", r, tl, m, i, a[i], b[i]); return 1; }
         n += tl + 1;
         free(ts), free(ext), free(a), free(b);
     }
