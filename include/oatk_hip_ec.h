@@ -55,6 +55,12 @@ int oatk_hip_debug_wf_ed(oatk_hip_ctx *ctx, uint64_t n_jobs, const uint8_t *t_co
  * registers, R = 1, 2 or 6 diagonals per lane).  A job needs 2 bw + 3 (no band: tl + ql + 3) <= 256 R diagonals; otherwise OATK_E_ARG. */
 int oatk_hip_debug_wf_ed_wg(oatk_hip_ctx *ctx, int R, uint64_t n_jobs, const uint8_t *t_codes, const uint64_t *t_off, const uint8_t *q_codes, const uint64_t *q_off,
                             const int32_t *bw, const int32_t *step_ql, const uint64_t *step_off, int32_t *out3);
+/* (R = 32, 33: the same outcomes by MATRIX ROWS -- a value per diagonal, 2 bw + 5 <= 512; the row in bits, banded jobs of 2 bw + 5 <= 640: oatk_amd/csrc/ec_rows.hpp, experimental.)
+ * The two tables by which a long arc of the error-block search can be known to die by score without a step (ec_rows.hpp: ecb_table; experimental): for job j,
+ * target t_codes[t_off[j], t_off[j + 1]) of tl bases and string s_codes[s_off[j], s_off[j + 1]) of at most 1024, out[out_off[j] + u], u = 0 .. tl, receives the least edit
+ * cost of fitting the WHOLE string into the target from position u on (any end), and out[out_off[j] + tl + 1 + u] that of some PREFIX of the string against the target from
+ * u to its end.  out_off[j + 1] - out_off[j] >= 2 (tl + 1).  Host pointers. */
+int oatk_hip_debug_tables(oatk_hip_ctx *ctx, uint64_t n_jobs, const uint8_t *t_codes, const uint64_t *t_off, const uint8_t *s_codes, const uint64_t *s_off, int32_t *out, const uint64_t *out_off);
 
 /* Resident results of oatk_hip_ec (ids for oatk_hip_buffer):
  *   EC_N_SCM   u32[n_reads]      sr_t.n after correction

@@ -312,4 +312,58 @@ __global__ __launch_bounds__(64) void ecb_wf_ed_kernel(const uint32_t *tw, const
     }
 }
 
+// ---------------------------------------------------------------- the tables of a long arc ----------------------------------------------------------------
+// An arc that appends a long string can be KNOWN to die by score without a step (tests/trace/ec_trace.c ECT_ROWS: from the parent's wavefront alone 92.8 % of
+// the steps of such arcs on the config-1 surrogate, and no arc that lives): min over the band of (a bound on the parent's last row at t' + table[t' + 1]) > bw, with
+//   table 0 [u] = the least cost of fitting the WHOLE string into the target from position u on, any end           (a cell of the new last row)
+//   table 1 [u] = the least cost of some PREFIX of the string against the target from u TO ITS END                  (a cell of the last column in one of the new rows)
+// Both are approximate matching of the reversed string against the reversed target (Myers 1999), one pass over the target each: the string's words in the lanes (<= 1024
+// bases), carries by ballots.  tests/c/prof_bitpar_test.c is this on the CPU against the plain recurrences.  (oatk_hip_debug_tables; never executed: OATK_TEST_EC_ROWS=1)
+__device__ __forceinline__ void ecb_table(const uint32_t *ts, int32_t tl, const uint32_t *cs, int32_t s0, int32_t m, int second, int32_t *out)
+{
+    const int lane = (int) threadIdx.x & 63;
+    const int32_t wl = (m - 1) >> 5;
+    const uint32_t top = 1u << ((m - 1) & 31);
+    const uint32_t wmask = lane < wl? 0xFFFFFFFFu : (lane == wl? ((m & 31)? (1u << (m & 31)) - 1u : 0xFFFFFFFFu) : 0u);
+    uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+    for (int i = 0; i < 32; ++i) {                                             // pattern position p = 32 lane + i is the string's base m - 1 - p
+        const int32_t pp = (lane << 5) + i;
+        if (pp >= m) break;
+        const uint32_t x = ecr_base(cs, s0 + m - 1 - pp);
+        e0 |= (uint32_t) (x == 0) << i, e1 |= (uint32_t) (x == 1) << i, e2 |= (uint32_t) (x == 2) << i, e3 |= (uint32_t) (x == 3) << i;
+    }
+    uint32_t pv = second? 0u : wmask, mv = 0;
+    int32_t score = second? 0 : m;
+    if (lane == 0) out[tl] = score;
+    for (int32_t j = 1; j <= tl; ++j) {
+        const uint32_t c = ecw_uniu(ecr_base(ts, tl - j));
+        const uint32_t eq = c == 0? e0 : (c == 1? e1 : (c == 2? e2 : e3));
+        const uint32_t a = eq & pv, s1 = a + pv;
+        const uint64_t G = __ballot(s1 < a), P = __ballot(s1 == 0xFFFFFFFFu), U = G << 1, C = (P + U) ^ P;
+        const uint32_t s2 = s1 + (uint32_t) (C >> lane & 1ULL);
+        const uint32_t xh = (s2 ^ pv) | eq, xv = eq | mv;
+        uint32_t ph = (mv | ~(xh | pv)) & wmask, mh = pv & xh;
+        score += (ecw_lane(ph, wl) & top) != 0u, score -= (ecw_lane(mh, wl) & top) != 0u;
+        ph = ecb_shl1(ph, (uint32_t) second) & wmask, mh = ecb_shl1(mh, 0u) & wmask;      // (a free start in the target: nothing comes in; the second table's first row counts the columns)
+        pv = (mh | ~(xv | ph)) & wmask, mv = ph & xv;
+        if (lane == 0) out[tl - j] = score;
+    }
+}
+
+// test entry (include/oatk_hip_ec.h: oatk_hip_debug_tables): one wave per job, both tables behind each other: out[out_off[j] ..] = table 0 [0 .. tl], table 1 [0 .. tl]
+__global__ __launch_bounds__(64) void ecb_tables_kernel(const uint32_t *tw, const uint64_t *tw_off, const int32_t *tl, const uint32_t *qw, const uint64_t *qw_off, const int32_t *ql,
+                                                        int32_t *out, const uint64_t *out_off, int32_t cap_words)
+{
+    extern __shared__ uint32_t ecb_lds2[];
+    const uint64_t j = blockIdx.x;
+    const int t = (int) threadIdx.x;
+    uint32_t *ts = ecb_lds2, *cs = ecb_lds2 + cap_words;
+    const uint64_t nt = tw_off[j + 1] - tw_off[j], nq = qw_off[j + 1] - qw_off[j];
+    for (uint64_t i = t; i < nt; i += 64) ts[i] = tw[tw_off[j] + i];
+    for (uint64_t i = t; i < nq; i += 64) cs[i] = qw[qw_off[j] + i];
+    ecw_sync();
+    ecb_table(ts, tl[j], cs, 0, ql[j], 0, out + out_off[j]);
+    ecb_table(ts, tl[j], cs, 0, ql[j], 1, out + out_off[j] + (uint64_t) tl[j] + 1);
+}
+
 }  // namespace oatk

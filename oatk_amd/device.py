@@ -197,6 +197,25 @@ class HipSyncasm:
                                                     ql.ctypes.data, s_off.ctypes.data, out.ctypes.data), "oatk_hip_debug_wf_ed")
         return [[tuple(int(v) for v in out[s]) for s in range(int(s_off[j]), int(s_off[j + 1]))] for j in range(len(jobs))]
 
+    def tables(self, jobs):
+        """the two tables of a long arc (oatk_hip_debug_tables; experimental): jobs = [(target, string), ...] over ACGT -> per job (table0, table1), int32[tl + 1] each"""
+        code = np.full(256, 255, np.uint8)
+        for i, ch in enumerate(b"ACGT"):
+            code[ch] = code[ch + 32] = i
+        t_off, s_off, o_off = np.zeros(len(jobs) + 1, np.uint64), np.zeros(len(jobs) + 1, np.uint64), np.zeros(len(jobs) + 1, np.uint64)
+        for j, (t, q) in enumerate(jobs):
+            t_off[j + 1], s_off[j + 1], o_off[j + 1] = t_off[j] + len(t), s_off[j] + len(q), o_off[j] + 2 * (len(t) + 1)
+        tc = np.ascontiguousarray(code[np.frombuffer(b"".join(j[0] for j in jobs), np.uint8)])
+        sc = np.ascontiguousarray(code[np.frombuffer(b"".join(j[1] for j in jobs), np.uint8)])
+        out = np.zeros(int(o_off[-1]), np.int32)
+        self.L.oatk_hip_debug_tables.argtypes = [C.c_void_p] + [C.c_uint64] + [C.c_void_p] * 6
+        self._check(self.L.oatk_hip_debug_tables(self.h, len(jobs), tc.ctypes.data, t_off.ctypes.data, sc.ctypes.data, s_off.ctypes.data, out.ctypes.data, o_off.ctypes.data), "oatk_hip_debug_tables")
+        res = []
+        for j, (t, _) in enumerate(jobs):
+            a = int(o_off[j])
+            res.append((out[a:a + len(t) + 1].copy(), out[a + len(t) + 1:a + 2 * (len(t) + 1)].copy()))
+        return res
+
     def ed_ab(self, pairs, myers):
         """SURVEY 7-5's A/B (oatk_hip_debug_ed_ab): pairs = [(target, query, bw), ...] through the wavefront routine (myers = False) or Myers' bit-vector
         algorithm, one lane per pair (True); returns ([(score, t_end, q_end), ...], kernel milliseconds)"""

@@ -189,3 +189,43 @@ def test_bad_arguments_are_refused(hip):
         hip.wf_ed([(b"ACGT", b"ACGT", 2, [3, 2])])                                          # query lengths must ascend
     with pytest.raises(ValueError):
         hip.wf_ed([(b"ACGN", b"ACGT", 2, [4])])
+
+
+@pytest.mark.skipif(os.environ.get("OATK_TEST_EC_ROWS") != "1", reason="ec_rows.hpp was written in round 5 after the last GPU run and never executed: on request until it has been seen green")
+def test_tables_of_a_long_arc(hip):
+    """the two tables by which a long arc can be known to die without a step (oatk_hip_debug_tables, ec_rows.hpp: ecb_table) against their plain recurrences
+    (tests/c/prof_bitpar_test.c holds the same on the CPU): table 0 [u] = least cost of the whole string inside target[u ..], table 1 [u] = of a prefix against target[u ..] to its end"""
+    rng = np.random.default_rng(77)
+
+    def plain(ts, ex):
+        tl, m = len(ts), len(ex)
+        T, big = np.frombuffer(ts, np.uint8), 1 << 20
+        f = np.full(tl + 1, 0, np.int64)                       # F[m][u] = 0
+        g = (tl - np.arange(tl + 1)).astype(np.int64)          # G[m][u] = tl - u
+        for i in range(m - 1, -1, -1):
+            neq = (T != ex[i]).astype(np.int64)
+            for tab, last in ((f, m - i), (g, 0)):
+                prev = tab.copy()
+                cand = np.minimum(np.concatenate((prev[1:] + neq, [big])), prev + 1)
+                cand[tl] = last
+                # tab[u] = min(cand[u], tab[u + 1] + 1): a min-plus scan from the right
+                idx = np.arange(tl + 1)
+                tab[:] = (np.minimum.accumulate((cand + idx)[::-1])[::-1]) - idx
+        return f.astype(np.int32), g.astype(np.int32)
+
+    jobs = []
+    for it in range(40):
+        tl = int(rng.integers(1, 700))
+        ts = A.rand_dna(rng, tl, [b"ACGT", b"AC"][it % 2])
+        m = int(rng.integers(1, 1001 if it % 3 else 60))
+        if it % 2 and m < tl:
+            at = int(rng.integers(0, tl - m + 1))
+            ex = mutate(rng, ts[at:at + m], int(rng.integers(0, 1 + m // 10)))[:1024]
+        else:
+            ex = A.rand_dna(rng, m, b"ACGT")
+        jobs.append((ts, ex))
+    got = hip.tables(jobs)
+    for (ts, ex), (t0, t1) in zip(jobs, got):
+        w0, w1 = plain(ts, ex)
+        assert np.array_equal(t0, w0), (len(ts), len(ex))
+        assert np.array_equal(t1, w1), (len(ts), len(ex))
