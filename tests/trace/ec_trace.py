@@ -13,9 +13,10 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 40000
 min_tried = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 out = sys.argv[3] if len(sys.argv) > 3 else "/tmp/ec_trace_%d.txt" % n
 K, S = 1001, 31
-cfg = dict(synth.CONFIG1S); c = cfg["min_k_cov"]
+which = os.environ.get("ECT_SET", "config1s")                 # config1s (the surrogate) or a key of synth.CONFIGS (plain reads of one genome)
+cfg = dict(synth.CONFIG1S if which == "config1s" else synth.CONFIGS[which]); c = cfg["min_k_cov"]
 t0 = time.time()
-rs = synth.MixReadSet(**cfg)
+rs = synth.MixReadSet(**cfg) if which == "config1s" else synth.ReadSet(**cfg)
 seq, off, lens = rs.slice(0, n)
 fa = "/tmp/ec_trace_%d.fa" % n
 synth.write_fasta(fa, seq, off, lens, mode=synth.FA_PLAIN)
