@@ -17,6 +17,7 @@
 // Results are those of ec_heavy.hpp (and of the reference) bit for bit.
 #pragma once
 #include "ec_heavy.hpp"
+#include "ec_rows.hpp"
 
 namespace oatk {
 
@@ -24,6 +25,9 @@ namespace oatk {
 #define ECF_OWN (64 - 2 * ECF_S)  // slots a wave owns
 #define ECF_NW 16                 // waves per block: 16 x 56 = 896 slots, 2 bw + 3 <= 896
 #define ECF_TIER 32u
+#define ECF_NT 24                 // (CERT) pairs of tables a workgroup keeps per block: one per arc with a long string (14 - 17 in the surrogate's heavy blocks)
+// (CERT) a workgroup's table region in HBM, 32-bit words: [0] pairs in use, [1 .. ECF_NT] their arcs, then ECF_NT x 2 x (cap_t + 1) numbers
+__host__ __device__ inline uint64_t ecf_tab_words(int32_t cap_t) { return 64 + (uint64_t) ECF_NT * 2 * (uint64_t) (cap_t + 1); }
 
 // LDS carve-up (32-bit words): [endt: 2 x NW][bnd: 2 x NW x 2 S][red: 2 x NW x 2][any: 2 x NW][bc: 8] ts cs frames
 __host__ __device__ inline uint32_t ecf_misc_words(int NW) { return (uint32_t) (2 * NW + 2 * NW * 2 * ECF_S + 2 * NW * 2 + 2 * NW + 8 + 1) & ~1u; }
@@ -40,6 +44,7 @@ struct EcfShared {
     uint32_t *os;
     uint64_t *c_path, *o_path;
     int32_t cap_t, cap_c, cap_path, cap_fl, cap_fh;
+    int32_t *tab;                 // (CERT) this workgroup's table region, ecf_tab_words(cap_t) words
 };
 
 // what one lane has to do in one step (levdist.c:156-205, extension mode, no traceback): its diagonal run down (kn, and whether that reached an end of a string), and the
@@ -303,7 +308,10 @@ __global__ __launch_bounds__(64 * NW) void ecf_wf_ed_kernel(const uint32_t *tw, 
 
 // Solve one block with the whole workgroup (ech_solve_block of ec_heavy.hpp with the wavefront one slot per lane and ecf_align for wf_ed_core).  Returns false when the
 // block outgrows the carve-up (it is then re-run by the next class or the slab tier of ec_wave.hpp).
-template <int NW>
+// CERT (experimental, OATK_DEBUG_EC_CERT=1; written after round 5's last GPU run and never executed): an arc that appends a long string is first asked whether it can be
+// alive at all -- min over the band of (what the parent's wavefront knows of its last row + the string's tables) beyond bw: dead by score, no step taken (DESIGN.md 8.3,
+// tests/trace/ec_trace.c ECT_ROWS: 92.8 % of such arcs' steps on the config-1 surrogate, no living arc).  Without CERT the code is what it was.
+template <int NW, bool CERT = false>
 __device__ bool ecf_solve_block(const EcLive &lv, const EcReads &rd, const EcWork &wk, const EcfShared &sh, double max_edist,
                                 uint32_t &status_out, uint32_t &np_out, uint32_t &tried_out, uint32_t &n_path_out, uint32_t &wf_steps_out, uint32_t &wf_diag_out)
 {
@@ -357,6 +365,8 @@ __device__ bool ecf_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
     bool vpend = false;
     uint32_t v_arc = 0;
     int32_t v_depth = 0;
+    int32_t aligned_len = 0;                          // (CERT) the consensus length the wavefront stands for: behind c_len where alignments were skipped
+    if (CERT) { if (t == 0 && sh.tab) sh.tab[0] = 0; }
 
     // workgroup-wide "any lane": rare paths only (ties between optimum paths)
     auto wg_any = [&](bool p) -> bool {
@@ -424,6 +434,7 @@ __device__ bool ecf_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
             // restore the state this level was entered with (syncerr.c:277-284)
             depth = ecw_uni(hd.depth);
             c_len = ecw_uni(hd.l0), score = ecw_uni(hd.score), t_end = ecw_uni(hd.t_end), q_end = ecw_uni(hd.q_end);
+            aligned_len = c_len;                      // (a frame is pushed right after an alignment)
             n = ecw_uni(hd.n), s_lo = ecw_uni(hd.s_lo);
             if (in_lds) {
                 const int32_t *sv = (const int32_t *) (sh.fl + top + sizeof(EchFrame));
@@ -475,8 +486,65 @@ __device__ bool ecf_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
             vpend = true, v_arc = w_lp, v_depth = depth + 1;
             continue;
         }
+        bool known_dead = false;
+        if constexpr (CERT) {
+            const int32_t l0 = c_len - ext;
+            // a long string, the wavefront standing for exactly the consensus before it, and no row before the new ones within reach of the target's last column
+            if (sh.tab && ext >= 32 && ext <= 1024 && aligned_len == l0 && l0 >= 1 && l0 - 1 + bw + 2 < tl - 1) {
+                int32_t *tabs = sh.tab + 64;
+                const uint64_t pair = 2 * (uint64_t) (sh.cap_t + 1);
+                int32_t idx = -1;
+                {
+                    const int32_t nt = ecw_uni(sh.tab[0]);
+                    const uint32_t key = lane < nt? (uint32_t) sh.tab[1 + lane] : 0xFFFFFFFFu;      // (ECF_NT <= 64: a lane per pair)
+                    const uint64_t hit = __ballot(lane < nt && key == a);
+                    if (hit) idx = __builtin_ctzll(hit);
+                    else if (nt < ECF_NT) {
+                        // the string's two tables, a wave each (ec_rows.hpp: ecb_table), kept for the block
+                        if (wave == 0) ecb_table(sh.ts, tl, sh.cs, l0, ext, 0, tabs + (uint64_t) nt * pair);
+                        if (wave == 1) ecb_table(sh.ts, tl, sh.cs, l0, ext, 1, tabs + (uint64_t) nt * pair + (uint64_t) (tl + 1));
+                        __syncthreads();
+                        if (t == 0) sh.tab[1 + nt] = (int32_t) a, sh.tab[0] = nt + 1;
+                        __syncthreads();
+                        idx = nt;
+                    }
+                }
+                if (idx >= 0) {
+                    const int32_t *t0 = tabs + (uint64_t) idx * pair, *t1 = t0 + (tl + 1);
+                    const bool far = c_len - 1 + bw < tl - 1;                                       // the new rows do not reach the target's last column either: the first table alone
+                    // this lane's diagonal run down as the child's first step would (against the consensus BEFORE the string), then what that says of the parent's last row
+                    const int32_t d = slot - OFF;
+                    int32_t s_lo_c = s_lo, n_c = n;
+                    const int32_t lim0 = (l0 - d < tl? l0 - d : tl) - 1;
+                    const EcfLane o = ecf_lane_step<NW>(sh.ts, sh.cs, tl, l0, bw, OFF, slot, d, lim0, k, s_lo_c, n_c, 0);
+                    const int32_t tp = l0 - 1 - d;                                                  // the cell of the parent's last row on this diagonal
+                    int32_t v = ECH_INF;
+                    if (owned && slot >= 0 && tp >= -1 && tp < tl) {
+                        const bool inwf = slot >= s_lo && slot < s_lo + n;
+                        const bool reached = inwf && o.kn >= tp;
+                        int32_t lb = d < 0? -d : d;
+                        if (!reached && score + 1 > lb) lb = score + 1;
+                        int32_t tv = t0[tp + 1];
+                        if (!far) { const int32_t t2 = t1[tp + 1]; tv = t2 < tv? t2 : tv; }
+                        v = lb + tv;
+                    }
+#pragma unroll
+                    for (int o2 = 32; o2 >= 1; o2 >>= 1) { const int32_t y = __shfl_xor(v, o2, 64); v = y < v? y : v; }
+                    int32_t *any = sh.any + apar * NW;
+                    apar ^= 1u;
+                    if (lane == 0) any[wave] = v;
+                    __syncthreads();
+                    int32_t best = ECH_INF;
+#pragma unroll
+                    for (int w2 = 0; w2 < NW; ++w2) { const int32_t y = ecw_uni(any[w2]); best = y < best? y : best; }
+                    known_dead = best > bw;
+                }
+            }
+        }
         // wf_ed_core (levdist.c:265-310)
-        ecf_align<NW>(sh, tl, c_len, bw, OFF, k, s_lo, n, score, t_end, q_end, par, wf_steps, wf_diag);
+        if (CERT && known_dead) score = bw + 1, t_end = -1, q_end = -1;                             // (what the steps would have left: levdist.c:303, syncerr.c:195 "zero if not aligned")
+        else ecf_align<NW>(sh, tl, c_len, bw, OFF, k, s_lo, n, score, t_end, q_end, par, wf_steps, wf_diag);
+        aligned_len = c_len;
         t_end += 1, q_end += 1;
         const int32_t ql = c_len;
         const int32_t sc = score + tl - t_end;        // syncerr.c:209
@@ -539,7 +607,7 @@ __device__ bool ecf_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
 }
 
 // One workgroup per block, blocks taken one at a time from the list.  EcwArgs as for ec_heavy_kernel.
-template <int NW>
+template <int NW, bool CERT = false>
 __global__ __launch_bounds__(64 * NW) void ec_fused_kernel(EcwArgs a)
 {
     extern __shared__ uint32_t ecf_lds[];
@@ -555,6 +623,7 @@ __global__ __launch_bounds__(64 * NW) void ec_fused_kernel(EcwArgs a)
     sh.c_path = (uint64_t *) slab, sh.o_path = sh.c_path + a.cap_path;
     sh.os = (uint32_t *) (sh.o_path + a.cap_path);
     sh.fh = (uint8_t *) (sh.os + ecw_words(a.cap_c));
+    sh.tab = CERT && a.os_slabs? (int32_t *) a.os_slabs + (uint64_t) blockIdx.x * ecf_tab_words(a.cap_t) : nullptr;      // (the fused launches do not use os_slabs otherwise)
     const uint64_t total = a.todo? a.n_todo : a.n_work;
     uint64_t pool_at = 0, pool_end = 0;
     for (;;) {
@@ -584,7 +653,7 @@ __global__ __launch_bounds__(64 * NW) void ec_fused_kernel(EcwArgs a)
             o.short_block = 1;                         // syncerr.c:502-504
         } else {
             uint32_t st = 0, np = 0;
-            if (ECW_RARE(!(ecf_solve_block<NW>(a.lv, a.rd, wk, sh, a.max_edist, st, np, o.tried, o.n_path, o.wf_steps, o.wf_diag)))) {
+            if (ECW_RARE(!(ecf_solve_block<NW, CERT>(a.lv, a.rd, wk, sh, a.max_edist, st, np, o.tried, o.n_path, o.wf_steps, o.wf_diag)))) {
                 o.flags = 1;
                 if (t == 0) a.todo_out[atomicAdd(a.todo_cnt, 1ULL)] = (uint32_t) wi;
             } else {

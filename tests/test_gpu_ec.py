@@ -145,9 +145,12 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("graph", ["host", "device", "device-tiers", "device-tiers-serial", "device-heavy", "device-heavy-mix", "device-heavy-spill", "device-tree", "device-tree-smalllog", "device-fused", "device-fused-spill"])
+@pytest.mark.parametrize("graph", ["host", "device", "device-tiers", "device-tiers-serial", "device-heavy", "device-heavy-mix", "device-heavy-spill", "device-tree", "device-tree-smalllog", "device-fused", "device-fused-spill", "device-fused-cert"])
 @pytest.mark.parametrize("case", range(len(CASES)))
 def test_device_ec_matches_reference(hip, case, graph, monkeypatch):
+    if graph == "device-fused-cert" and os.environ.get("OATK_TEST_EC_ROWS") != "1":
+        pytest.skip("the table test for long arcs (ec_fused.hpp CERT, OATK_DEBUG_EC_CERT=1) was written in round 5 after the last GPU run and never executed: OATK_TEST_EC_ROWS=1 runs its cases")
+    monkeypatch.setenv("OATK_DEBUG_EC_CERT", "1" if graph == "device-fused-cert" else "0")
     if graph.startswith("device-tree") and not os.environ.get("OATK_TEST_EC_TREE"):
         pytest.skip("the tree solver is an experiment that is switched off (DESIGN.md 8.3, round 5): OATK_TEST_EC_TREE=1 runs its cases")
     K, S, c, mk = CASES[case]
