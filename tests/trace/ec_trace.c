@@ -273,6 +273,10 @@ static int g_rows = -1;
 static int32_t **g_prof; static uint64_t *g_prof_key; static size_t g_prof_n, g_prof_cap;
 static uint64_t g_rw_rows, g_rw_tests, g_rw_dead_by_test, g_rw_wrong, g_rw_tables;
 static uint64_t g_lvc_arcs, g_lvc_steps, g_lvc_wrong, g_lvc_dead_arcs, g_lvc_dead_steps, g_rw_near;
+/* (the kernels skip the alignment of a vertex on an unbranched stretch -- ec_wave.hpp, DESIGN.md 8.3 -- so their wavefront may stand for a shorter consensus than the one a
+ *  long string is appended to: then they do not ask.  g_aligned = the consensus length the kernel's wavefront would stand for; g_lvk_*: what the kernel's switch would know) */
+static int64_t g_aligned;
+static uint64_t g_lvk_arcs, g_lvk_steps, g_lvk_lag;
 static const int32_t *prof_of(const S *s, uint64_t key, const char *ext, int32_t m)
 {
     size_t i;
@@ -395,6 +399,7 @@ static void dfs(S *s, uint64_t source, int depth)
     const int32_t n0 = s->n, d00 = s->d0, sc0 = s->score, te0 = s->t_end, qe0 = s->q_end;
     int32_t *sv = (int32_t *) malloc(sizeof(int32_t) * (size_t) (n0 + 1));
     memcpy(sv, s->k, sizeof(int32_t) * (size_t) n0);
+    const int64_t al0 = g_aligned;
     if (g_slots < 0) g_slots = getenv("ECT_SLOTS") != 0;
     int32_t *sl_sv = 0;
     if (g_slots) { sl_sv = (int32_t *) malloc(sizeof(int32_t) * (size_t) g_sl_n); memcpy(sl_sv, g_sl, sizeof(int32_t) * (size_t) g_sl_n); }
@@ -437,6 +442,13 @@ static void dfs(S *s, uint64_t source, int depth)
         s->cl += ext;
         const int32_t ql = (int32_t) s->cl;
         uint64_t st_before = s->c->steps, dg_before = s->c->diag; const int sib = live_seen++ > 0;
+        const int64_t al_before = g_aligned;
+        {   /* would the kernel align here?  (ec_fused.hpp: no success so far, a middle block whose end this is not, one way on, the counter below its cap, lengths in range) */
+            uint64_t w_live = 0, q_;
+            for (q_ = 0; q_ < g->idx_n[w]; ++q_) if (!g->arc_del[g->idx_p[w] + q_]) ++w_live;
+            const int skip = s->c->succ_events == 0 && s->sink != UINT64_MAX && s->sink != w && w_live == 1 && s->n_path < MAX_DFS_PATH && (int64_t) s->cl - l_seq <= (int64_t) s->tl + s->bw && (int64_t) s->cl >= s->bw + 3;
+            if (!skip) g_aligned = (int64_t) s->cl;
+        }
         for (;;) {
             if (wf_step(s, ql)) break;
             ++s->score;
@@ -500,6 +512,7 @@ static void dfs(S *s, uint64_t source, int depth)
                         if (lb + prof[t + 1] < lb_best) lb_best = lb + prof[t + 1];
                     }
                     if (lb_best > s->bw) { g_lvc_arcs++, g_lvc_steps += s->c->steps - st_before; if (!dead_a) g_lvc_wrong++; }
+                    if (lb_best > s->bw && ext <= 1024 && l0 >= 1) { if (al_before == (int64_t) l0) g_lvk_arcs++, g_lvk_steps += s->c->steps - st_before; else g_lvk_lag++; }
                     if (dead_a) g_lvc_dead_arcs++, g_lvc_dead_steps += s->c->steps - st_before;
                 }
                 const int dead_p = best > s->bw || (best < sc0? sc0 : best) > s->bw;
@@ -543,6 +556,7 @@ static void dfs(S *s, uint64_t source, int depth)
         wf_need(s, n0 + 4);
         memcpy(s->k, sv, sizeof(int32_t) * (size_t) n0);
         if (g_slots) memcpy(g_sl, sl_sv, sizeof(int32_t) * (size_t) g_sl_n);
+        g_aligned = al0;
     }
     free(sl_sv);
     if (live > 1 && g_fs_n > 0) --g_fs_n;
@@ -619,7 +633,7 @@ uint64_t ect_trace(const orc_graph_t *g, const uint8_t *scm_del, int K, double m
                     { size_t i_; for (i_ = 0; i_ < g_prof_n; ++i_) free(g_prof[i_]); g_prof_n = 0; }
                     const uint64_t lv_a0 = g_lvc_arcs, lv_s0 = g_lvc_steps;
                     const uint64_t rw_r0 = g_rw_rows, rw_t0 = g_rw_tests, rw_d0 = g_rw_dead_by_test, rw_b0 = g_rw_tables;
-                    g_cert_n = 0;
+                    g_cert_n = 0, g_aligned = 0;
                     const uint64_t c_a0 = g_cert_arcs, c_s0 = g_cert_steps, c_t0 = g_cert_tables, c_c0 = g_cert_cells, c_da0 = g_cert_dead_arcs, c_ds0 = g_cert_dead_steps;
                     if (getenv("ECT_SLOTS")) slots_init(&s);
                     g_dp_R = bw + 2, g_dp_W = 2 * g_dp_R + 1;
@@ -681,6 +695,9 @@ uint64_t ect_trace(const orc_graph_t *g, const uint8_t *scm_del, int K, double m
                 (unsigned long long) g_rw_rows, (unsigned long long) g_rw_tests, (unsigned long long) g_rw_dead_by_test, (unsigned long long) g_rw_wrong, (unsigned long long) g_rw_tables);
         fprintf(fo, "# ECT_ROWS, the table test fed from the parent's WAVEFRONT (lower bounds) instead of its row: %llu of %llu long arcs that die by score are known to (%llu of %llu wavefront steps); known to die but alive (must be 0): %llu\n",
                 (unsigned long long) g_lvc_arcs, (unsigned long long) g_lvc_dead_arcs, (unsigned long long) g_lvc_steps, (unsigned long long) g_lvc_dead_steps, (unsigned long long) g_lvc_wrong);
+        fprintf(fo, "# ... and as the kernel's switch would ask (only where its wavefront stands for the consensus before the string; strings of <= 1024 bases): %llu arcs, %llu steps known; %llu not asked for a lagging wavefront\n",
+                (unsigned long long) g_lvk_arcs, (unsigned long long) g_lvk_steps, (unsigned long long) g_lvk_lag);
+        fprintf(stderr, "ECT_ROWS/kernel's switch: %llu arcs, %llu steps known; %llu not asked (lag)\n", (unsigned long long) g_lvk_arcs, (unsigned long long) g_lvk_steps, (unsigned long long) g_lvk_lag);
         fprintf(stderr, "ECT_ROWS/wavefront bounds: %llu of %llu dead long arcs certified (%llu of %llu steps), wrong %llu\n", (unsigned long long) g_lvc_arcs, (unsigned long long) g_lvc_dead_arcs, (unsigned long long) g_lvc_steps,
                 (unsigned long long) g_lvc_dead_steps, (unsigned long long) g_lvc_wrong);
         fprintf(stderr, "ECT_ROWS: %llu of the tests with the last column within the new rows' reach\n", (unsigned long long) g_rw_near);
