@@ -5,7 +5,7 @@
 TAG=${1:-c1s}; N=${2:-200000}
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/tools/solverbench.py --workload config1s --reads $N --reps 1"
+CMD="python $R/tools/memcap.py --rss-gb 200 --timeout 500 -- python $R/tools/solverbench.py --workload config1s --reads $N --reps 1"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o t -- $CMD > $O/stats.log 2>&1; echo "stats rc=$?"
 f=$(find $O/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${TAG}_config1s_kernel_stats.csv && head -12 $f
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $O/a -o p -- $CMD > $O/a.log 2>&1; echo "pmc a rc=$?"
