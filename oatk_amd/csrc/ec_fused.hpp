@@ -25,9 +25,9 @@ namespace oatk {
 #define ECF_OWN (64 - 2 * ECF_S)  // slots a wave owns
 #define ECF_NW 16                 // waves per block: 16 x 56 = 896 slots, 2 bw + 3 <= 896
 #define ECF_TIER 32u
-#define ECF_NT 24                 // (CERT) pairs of tables a workgroup keeps per block: one per arc with a long string (14 - 17 in the surrogate's heavy blocks)
-// (CERT) a workgroup's table region in HBM, 32-bit words: [0] pairs in use, [1 .. ECF_NT] their arcs, then ECF_NT x 2 x (cap_t + 1) numbers
-__host__ __device__ inline uint64_t ecf_tab_words(int32_t cap_t) { return 64 + (uint64_t) ECF_NT * 2 * (uint64_t) (cap_t + 1); }
+#define ECF_NT 64                 // (CERT) pairs of tables a workgroup keeps per block: one per arc with a long string (14 - 17 in the heavy blocks of 40 k surrogate reads; at 200 k reads 24 were too few for half the long arcs that die: profiles/r06g)
+// (CERT) a workgroup's table region in HBM, 32-bit words: [0] pairs in use, [1 .. ECF_NT] their arcs, then (from word 128 on) ECF_NT x 2 x (cap_t + 1) numbers
+__host__ __device__ inline uint64_t ecf_tab_words(int32_t cap_t) { return 128 + (uint64_t) ECF_NT * 2 * (uint64_t) (cap_t + 1); }
 
 // LDS carve-up (32-bit words): [endt: 2 x NW][bnd: 2 x NW x 2 S][red: 2 x NW x 2][any: 2 x NW][bc: 8] ts cs frames
 __host__ __device__ inline uint32_t ecf_misc_words(int NW) { return (uint32_t) (2 * NW + 2 * NW * 2 * ECF_S + 2 * NW * 2 + 2 * NW + 8 + 1) & ~1u; }
@@ -36,6 +36,17 @@ __host__ __device__ inline uint32_t ecf_lds_words(int32_t cap_t, int32_t cap_c, 
     return ((ecf_misc_words(NW) + ecw_words(cap_t) + ecw_words(cap_c) + 1u) & ~1u) + (uint32_t) cap_fl / 4u;
 }
 
+#ifdef ECF_PROF2
+// development builds (-DECF_PROF2): cycles of thread 0 by phase of the per-arc loop, summed over blocks, one row per class of workgroups (tools/r06_prof_arcs.sh)
+//   0 arcs  1 from a frame  2 without alignment  3 known dead (CERT)  4 tables built  5 aligned  6 arcs of >= 32 bases  7 ... with a lagging wavefront
+//   8 top (barrier + restore + arc)  9 append + barrier  10 CERT test  11 alignment  12 outcome + frame push  13 table building  14 blocks  15 wavefront steps
+__device__ unsigned long long ecf_prof2[5][28];      // 16 .. 19 aligned arcs by (string >= 32 bases) x 2 + (dies by score), 20 .. 23 their wavefront steps
+#define ECF_P2_T(i) do { const uint64_t now_ = __builtin_readcyclecounter(); p2[i] += now_ - p2_last; p2_last = now_; } while (0)
+#define ECF_P2_C(i, v) (p2[i] += (uint64_t) (v))
+#else
+#define ECF_P2_T(i) do { } while (0)
+#define ECF_P2_C(i, v) do { } while (0)
+#endif
 struct EcfShared {
     int32_t *endt, *bnd, *red, *any, *bc;
     uint32_t *ts, *cs;
@@ -366,6 +377,9 @@ __device__ bool ecf_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
     uint32_t v_arc = 0;
     int32_t v_depth = 0;
     int32_t aligned_len = 0;                          // (CERT) the consensus length the wavefront stands for: behind c_len where alignments were skipped
+#ifdef ECF_PROF2
+    uint64_t p2[28] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, p2_last = __builtin_readcyclecounter();
+#endif
     if (CERT) { if (t == 0 && sh.tab) sh.tab[0] = 0; }
 
     // workgroup-wide "any lane": rare paths only (ties between optimum paths)
@@ -445,11 +459,13 @@ __device__ bool ecf_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
             }
         }
         ++tried;
+        ECF_P2_C(0, 1); ECF_P2_C(1, from_frame);
         if (ECW_RARE(pre_idx != a)) pre = ecw_arc_load(lv.arc, a);
         const uint64_t w = ecw_uniu(pre.a.x);
         const int32_t ls = (int32_t) ecw_uniu(pre.a.y), ext = K - ls;
         const uint32_t w_hs16 = ecw_uniu(pre.a.z), w_mpos = ecw_uniu(pre.a.w), w_lp = ecw_uniu(pre.b.x), w_ln = ecw_uniu(pre.b.y);
         const int32_t t_end0 = t_end;
+        ECF_P2_T(8);
         if (ECW_RARE(depth + 2 > sh.cap_path || c_len + ext > sh.cap_c)) return false;
         int32_t cn = depth + 2;                       // entries in c_path
         // the arc most likely to be tried next: the first one out of w (in flight during the gather and the alignment)
@@ -481,17 +497,20 @@ __device__ bool ecf_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
                 if (top < sh.cap_fl) ((EchFrame *) (sh.fl + top))->arc_i = a + 1; else ((EchFrame *) (sh.fh + (top - sh.cap_fl)))->arc_i = a + 1;
             }
         }
+        ECF_P2_T(9);
         // a vertex on an unbranched stretch that cannot be the end of the path needs no alignment of its own (ec_wave.hpp)
         if (edist == INT32_MAX && wk.end_utg != EC_NONE && wk.end_utg != w && w_ln == 1 && n_path < EC_MAX_DFS_PATH && c_len - K <= tl + bw && c_len >= bw + 3) {
             vpend = true, v_arc = w_lp, v_depth = depth + 1;
+            ECF_P2_C(2, 1);
             continue;
         }
         bool known_dead = false;
         if constexpr (CERT) {
             const int32_t l0 = c_len - ext;
+            if (ext >= 32) { ECF_P2_C(6, 1); if (aligned_len != l0) ECF_P2_C(7, 1); else if (ext > 1024) ECF_P2_C(24, 1); else if (!(l0 >= 1 && l0 - 1 + bw + 2 < tl - 1)) ECF_P2_C(25, 1); }
             // a long string, the wavefront standing for exactly the consensus before it, and no row before the new ones within reach of the target's last column
             if (sh.tab && ext >= 32 && ext <= 1024 && aligned_len == l0 && l0 >= 1 && l0 - 1 + bw + 2 < tl - 1) {
-                int32_t *tabs = sh.tab + 64;
+                int32_t *tabs = sh.tab + 128;
                 const uint64_t pair = 2 * (uint64_t) (sh.cap_t + 1);
                 int32_t idx = -1;
                 {
@@ -500,15 +519,16 @@ __device__ bool ecf_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
                     const uint64_t hit = __ballot(lane < nt && key == a);
                     if (hit) idx = __builtin_ctzll(hit);
                     else if (nt < ECF_NT) {
-                        // the string's two tables, a wave each (ec_rows.hpp: ecb_table), kept for the block
-                        if (wave == 0) ecb_table(sh.ts, tl, sh.cs, l0, ext, 0, tabs + (uint64_t) nt * pair);
-                        if (wave == 1) ecb_table(sh.ts, tl, sh.cs, l0, ext, 1, tabs + (uint64_t) nt * pair + (uint64_t) (tl + 1));
+                        // the string's two tables by all the waves (ec_rows.hpp: ecb_tables_wg), kept for the block
+                        ecb_tables_wg<NW>(sh.ts, tl, sh.cs, l0, ext, bw, tabs + (uint64_t) nt * pair, tabs + (uint64_t) nt * pair + (uint64_t) (tl + 1));
                         __syncthreads();
                         if (t == 0) sh.tab[1 + nt] = (int32_t) a, sh.tab[0] = nt + 1;
                         __syncthreads();
                         idx = nt;
+                        ECF_P2_C(4, 1); ECF_P2_T(13);
                     }
                 }
+                if (idx < 0) ECF_P2_C(26, 1); else ECF_P2_C(27, 1);
                 if (idx >= 0) {
                     const int32_t *t0 = tabs + (uint64_t) idx * pair, *t1 = t0 + (tl + 1);
                     const bool far = c_len - 1 + bw < tl - 1;                                       // the new rows do not reach the target's last column either: the first table alone
@@ -522,10 +542,14 @@ __device__ bool ecf_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
                     if (owned && slot >= 0 && tp >= -1 && tp < tl) {
                         const bool inwf = slot >= s_lo && slot < s_lo + n;
                         const bool reached = inwf && o.kn >= tp;
+                        // (round 6: a cell the wavefront HAS reached costs exactly the parent's score -- a call ends in the step that first reaches its consensus's last row, so no cell
+                        //  of that row was within reach of a lower score; tests/trace/ec_trace.c: 0 of 10^5 reached cells differ, and the test knows 99 % of the long arcs that die
+                        //  by score instead of 54 %.  Until round 6 such a cell was priced at |diagonal|.)
                         int32_t lb = d < 0? -d : d;
-                        if (!reached && score + 1 > lb) lb = score + 1;
+                        const int32_t fl = reached? score : score + 1;
+                        if (fl > lb) lb = fl;
                         int32_t tv = t0[tp + 1];
-                        if (!far) { const int32_t t2 = t1[tp + 1]; tv = t2 < tv? t2 : tv; }
+                        if (!far && tp + 1 >= ecb_table1_lo(tl, ext, bw)) { const int32_t t2 = t1[tp + 1]; tv = t2 < tv? t2 : tv; }      // (below that the second table is not written: it is beyond bw there)
                         v = lb + tv;
                     }
 #pragma unroll
@@ -542,8 +566,18 @@ __device__ bool ecf_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
             }
         }
         // wf_ed_core (levdist.c:265-310)
-        if (CERT && known_dead) score = bw + 1, t_end = -1, q_end = -1;                             // (what the steps would have left: levdist.c:303, syncerr.c:195 "zero if not aligned")
-        else ecf_align<NW>(sh, tl, c_len, bw, OFF, k, s_lo, n, score, t_end, q_end, par, wf_steps, wf_diag);
+        ECF_P2_T(10);
+        if (CERT && known_dead) { score = bw + 1, t_end = -1, q_end = -1; ECF_P2_C(3, 1); }          // (what the steps would have left: levdist.c:303, syncerr.c:195 "zero if not aligned")
+        else {
+#ifdef ECF_PROF2
+            const uint32_t st0_ = wf_steps;
+#endif
+            ecf_align<NW>(sh, tl, c_len, bw, OFF, k, s_lo, n, score, t_end, q_end, par, wf_steps, wf_diag); ECF_P2_C(5, 1);
+#ifdef ECF_PROF2
+            { const int cat_ = (ext >= 32? 2 : 0) + (score > bw? 1 : 0); p2[16 + cat_] += 1, p2[20 + cat_] += wf_steps - st0_; }
+#endif
+        }
+        ECF_P2_T(11);
         aligned_len = c_len;
         t_end += 1, q_end += 1;
         const int32_t ql = c_len;
@@ -600,8 +634,12 @@ __device__ bool ecf_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
         if (new_opt && (nfr > 0 || vpend)) {
             for (int32_t wi = t; wi < ((o_len + 15) >> 4); wi += T) sh.os[wi] = sh.cs[wi];
         }
+        ECF_P2_T(12);
     }
     ech_barrier<NW>();
+#ifdef ECF_PROF2
+    if (t == 0) { p2[14] = 1, p2[15] = wf_steps; const int row = NW == 2? 0 : (NW == 4? 1 : (NW == 8? 2 : (NW == 16? 3 : 4))); for (int i = 0; i < 28; ++i) atomicAdd(&ecf_prof2[row][i], (unsigned long long) p2[i]); }
+#endif
     status_out = (uint32_t) status, np_out = (uint32_t) np, tried_out = tried, n_path_out = (uint32_t) n_path, wf_steps_out = wf_steps, wf_diag_out = (uint32_t) (wf_diag >> 6);
     return true;
 }

@@ -131,6 +131,7 @@ struct EcwScratch {
     uint64_t *c_path, *o_path;    // current and optimum path
     uint8_t *frames;              // DFS frame arena
     int32_t cap_t, cap_c, cap_w, cap_path, cap_f;
+    int32_t arc_budget;           // arcs after which a block is given up here (0: never): a search inside a repeat tries tens of thousands (round 6)
 #ifdef ECW_PROF
     mutable unsigned long long prof[32], t_last;
 #endif
@@ -499,6 +500,7 @@ __device__ bool ecw_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
         }
         ECW_C(8, 1);                                   // 8: arcs tried
         ++tried;
+        if (ECW_RARE(s.arc_budget > 0 && (tried > (uint32_t) s.arc_budget || wf_steps > 2u * (uint32_t) s.arc_budget))) return false;      // a search inside a repeat (arcs, or twice as many wavefront steps): it starts again where it is given a workgroup
         if (ECW_RARE(pre_idx != a)) pre = ecw_arc_load(lv.arc, a);
         const uint64_t w = ecw_uniu(pre.a.x);
         const int32_t ls = (int32_t) ecw_uniu(pre.a.y), ext = K - ls;
@@ -648,6 +650,7 @@ struct EcwArgs {
     unsigned long long *todo_cnt;
     int32_t skip_l;               // blocks longer than this were routed to a larger tier before the launch (ec_route_kernel): not this launch's business
     int32_t batch;                // blocks taken from the queue per atomic: ECW_BATCH where the blocks are millions and small, 1 where they are few and long
+    int32_t arc_budget;           // first tier: arcs after which a block is left to the classes behind it (0: never)
 #ifdef ECW_PROF
     unsigned long long *prof;
 #endif
@@ -738,6 +741,7 @@ __global__ __launch_bounds__(64 * WPB) void ec_wave_kernel(EcwArgs a)
     const uint32_t wave = blockIdx.x * (uint32_t) WPB + ecw_uniu(threadIdx.x >> 6);      // the waves of a workgroup share nothing but the launch
     EcwScratch s;
     s.cap_t = a.cap_t, s.cap_c = a.cap_c, s.cap_w = a.cap_w, s.cap_path = a.cap_path, s.cap_f = a.cap_f;
+    s.arc_budget = MODE == 0? a.arc_budget : 0;
     uint32_t *const p0 = BIG? (uint32_t *) (a.slabs + (uint64_t) wave * a.slab_bytes)
                             : ecw_lds + (WPB > 1? ecw_uniu(threadIdx.x >> 6) * (MODE == 2? ecw_lds_words_hybrid(a.cap_t, a.cap_c, a.cap_w)
                                                                                                       : ecw_scratch_words(a.cap_t, a.cap_c, a.cap_w, a.cap_path, a.cap_f, false)) : 0u);

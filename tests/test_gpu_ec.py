@@ -145,12 +145,13 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("graph", ["host", "device", "device-tiers", "device-tiers-serial", "device-heavy", "device-heavy-mix", "device-heavy-spill", "device-tree", "device-tree-smalllog", "device-fused", "device-fused-spill", "device-fused-cert"])
+@pytest.mark.parametrize("graph", ["host", "device", "device-tiers", "device-tiers-serial", "device-heavy", "device-heavy-mix", "device-heavy-spill", "device-tree", "device-tree-smalllog", "device-fused", "device-fused-spill", "device-fused-nocert", "device-fused-nw4", "device-fused-nw8", "device-fused-nw16"])
 @pytest.mark.parametrize("case", range(len(CASES)))
 def test_device_ec_matches_reference(hip, case, graph, monkeypatch):
-    if graph == "device-fused-cert" and os.environ.get("OATK_TEST_EC_ROWS") != "1":
-        pytest.skip("the table test for long arcs (ec_fused.hpp CERT, OATK_DEBUG_EC_CERT=1) was written in round 5 after the last GPU run and never executed: OATK_TEST_EC_ROWS=1 runs its cases")
-    monkeypatch.setenv("OATK_DEBUG_EC_CERT", "1" if graph == "device-fused-cert" else "0")
+    # the table test for long arcs (ec_fused.hpp CERT) is on by default since round 6; device-fused-nocert: without.  device-fused-nw4 / 8 / 16: the second stage's narrowest
+    # class of workgroups has that many waves (by default the classes are 2, 4, 8 and 16 waves by the block's band, and these cases' blocks all fit two or four)
+    monkeypatch.setenv("OATK_DEBUG_EC_CERT", "0" if graph == "device-fused-nocert" else "1")
+    monkeypatch.setenv("OATK_DEBUG_EC_FUSED_MIN_NW", graph[len("device-fused-nw"):] if graph.startswith("device-fused-nw") else "0")
     if graph.startswith("device-tree") and not os.environ.get("OATK_TEST_EC_TREE"):
         pytest.skip("the tree solver is an experiment that is switched off (DESIGN.md 8.3, round 5): OATK_TEST_EC_TREE=1 runs its cases")
     K, S, c, mk = CASES[case]

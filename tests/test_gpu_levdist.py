@@ -191,8 +191,8 @@ def test_bad_arguments_are_refused(hip):
         hip.wf_ed([(b"ACGN", b"ACGT", 2, [4])])
 
 
-@pytest.mark.skipif(os.environ.get("OATK_TEST_EC_ROWS") != "1", reason="ec_rows.hpp was written in round 5 after the last GPU run and never executed: on request until it has been seen green")
-def test_tables_of_a_long_arc(hip):
+@pytest.mark.parametrize("seg", [None, (2, 6), (4, 40), (8, 25), (16, 120)])
+def test_tables_of_a_long_arc(hip, seg, monkeypatch):
     """the two tables by which a long arc can be known to die without a step (oatk_hip_debug_tables, ec_rows.hpp: ecb_table) against their plain recurrences
     (tests/c/prof_bitpar_test.c holds the same on the CPU): table 0 [u] = least cost of the whole string inside target[u ..], table 1 [u] = of a prefix against target[u ..] to its end"""
     rng = np.random.default_rng(77)
@@ -224,8 +224,21 @@ def test_tables_of_a_long_arc(hip):
         else:
             ex = A.rand_dna(rng, m, b"ACGT")
         jobs.append((ts, ex))
+    # seg = (waves, cut): as the solver's second stage builds them (round 6, ecb_tables_wg) -- table 0 in stretches by the waves, exact where it is <= cut and beyond cut
+    # elsewhere; table 1 only where it can be <= cut (near the target's end), not written (-1) below
+    if seg:
+        monkeypatch.setenv("OATK_DEBUG_TABLES_SEG", "%d:%d" % seg)
+        jobs += [(A.rand_dna(rng, 5000 + 1700 * i, b"ACGT"), A.rand_dna(rng, 970 - 200 * i, b"ACGT")) for i in range(3)]       # stretches with a run-up shorter than the target
+        tgt = A.rand_dna(rng, 6000, b"ACGT")
+        jobs += [(tgt, mutate(rng, tgt[at:at + 900], 12)[:1024]) for at in (0, 2500, 5100)]                                  # ... and a string that does fit somewhere
     got = hip.tables(jobs)
     for (ts, ex), (t0, t1) in zip(jobs, got):
         w0, w1 = plain(ts, ex)
-        assert np.array_equal(t0, w0), (len(ts), len(ex))
-        assert np.array_equal(t1, w1), (len(ts), len(ex))
+        if not seg:
+            assert np.array_equal(t0, w0), (len(ts), len(ex))
+            assert np.array_equal(t1, w1), (len(ts), len(ex))
+            continue
+        cut = seg[1]
+        assert np.array_equal(np.minimum(t0, cut + 1), np.minimum(w0, cut + 1)), (len(ts), len(ex), seg)
+        lo = max(0, len(ts) - (len(ex) + cut + 1))
+        assert np.array_equal(t1[lo:], w1[lo:]) and np.all(t1[:lo] == -1) and np.all(w1[:lo] > cut), (len(ts), len(ex), seg)

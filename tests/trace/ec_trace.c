@@ -277,6 +277,8 @@ static uint64_t g_lvc_arcs, g_lvc_steps, g_lvc_wrong, g_lvc_dead_arcs, g_lvc_dea
  *  long string is appended to: then they do not ask.  g_aligned = the consensus length the kernel's wavefront would stand for; g_lvk_*: what the kernel's switch would know) */
 static int64_t g_aligned;
 static uint64_t g_lvk_arcs, g_lvk_steps, g_lvk_lag;
+/* round 6: the same with a reached cell priced at the parent's SCORE (the call ended in the step that first reached the row): g_lv2_*; and how often that price is the cell's true value */
+static uint64_t g_lv2_arcs, g_lv2_steps, g_lv2_wrong, g_lv2k_arcs, g_lv2k_steps, g_hyp_cells, g_hyp_below, g_hyp_above;
 static const int32_t *prof_of(const S *s, uint64_t key, const char *ext, int32_t m)
 {
     size_t i;
@@ -497,7 +499,7 @@ static void dfs(S *s, uint64_t source, int depth)
                 g_rw_tests++;
                 {   /* the same test with what a WAVEFRONT knows of the parent's row instead of the row itself: a cell the parent's wavefront has passed (t' <= its k on that
                      * diagonal) costs at least |diagonal|, one it has not reached at least the parent's score + 1 */
-                    int32_t lb_best = DP_INF;
+                    int32_t lb_best = DP_INF, lb2_best = DP_INF;
                     for (t = qp - g_dp_R < -1? -1 : qp - g_dp_R; t <= qp + g_dp_R && t < s->tl; ++t) {
                         const int32_t d = qp - t, j = d - d00;
                         int reached = 0;
@@ -510,7 +512,16 @@ static void dfs(S *s, uint64_t source, int depth)
                         int32_t lb = d < 0? -d : d;
                         if (!reached && sc0 + 1 > lb) lb = sc0 + 1;
                         if (lb + prof[t + 1] < lb_best) lb_best = lb + prof[t + 1];
+                        {
+                            int32_t lb2 = d < 0? -d : d;
+                            const int32_t floor2 = reached? sc0 : sc0 + 1;
+                            if (floor2 > lb2) lb2 = floor2;
+                            if (lb2 + prof[t + 1] < lb2_best) lb2_best = lb2 + prof[t + 1];
+                            if (reached) { const int32_t tv = dp_get(s, qp, t); g_hyp_cells++; if (tv < sc0) { if (g_hyp_below++ < 8) fprintf(stderr, "[hyp] reached cell BELOW the parent's score: tl %d bw %d l0 %d t %d d %d value %d score %d\n", s->tl, s->bw, (int) l0, t, d, tv, sc0); } else if (tv > sc0) g_hyp_above++; }
+                        }
                     }
+                    if (lb2_best > s->bw) { g_lv2_arcs++, g_lv2_steps += s->c->steps - st_before; if (!dead_a) { if (g_lv2_wrong++ < 8) fprintf(stderr, "[lv2] WRONG: tl %d bw %d l0 %d ext %zu parent score %d, bound %d, wavefront score %d\n", s->tl, s->bw, (int) l0, ext, sc0, lb2_best, s->score); } }
+                    if (lb2_best > s->bw && ext <= 1024 && l0 >= 1 && al_before == (int64_t) l0) g_lv2k_arcs++, g_lv2k_steps += s->c->steps - st_before;
                     if (lb_best > s->bw) { g_lvc_arcs++, g_lvc_steps += s->c->steps - st_before; if (!dead_a) g_lvc_wrong++; }
                     if (lb_best > s->bw && ext <= 1024 && l0 >= 1) { if (al_before == (int64_t) l0) g_lvk_arcs++, g_lvk_steps += s->c->steps - st_before; else g_lvk_lag++; }
                     if (dead_a) g_lvc_dead_arcs++, g_lvc_dead_steps += s->c->steps - st_before;
@@ -697,6 +708,10 @@ uint64_t ect_trace(const orc_graph_t *g, const uint8_t *scm_del, int K, double m
                 (unsigned long long) g_lvc_arcs, (unsigned long long) g_lvc_dead_arcs, (unsigned long long) g_lvc_steps, (unsigned long long) g_lvc_dead_steps, (unsigned long long) g_lvc_wrong);
         fprintf(fo, "# ... and as the kernel's switch would ask (only where its wavefront stands for the consensus before the string; strings of <= 1024 bases): %llu arcs, %llu steps known; %llu not asked for a lagging wavefront\n",
                 (unsigned long long) g_lvk_arcs, (unsigned long long) g_lvk_steps, (unsigned long long) g_lvk_lag);
+        fprintf(stderr, "ECT_ROWS/reached cells priced at the parent's score: %llu arcs (%llu steps) known, %llu WRONG; as the kernel would ask: %llu arcs, %llu steps; reached cells %llu, %llu below the score, %llu above\n",
+                (unsigned long long) g_lv2_arcs, (unsigned long long) g_lv2_steps, (unsigned long long) g_lv2_wrong, (unsigned long long) g_lv2k_arcs, (unsigned long long) g_lv2k_steps, (unsigned long long) g_hyp_cells, (unsigned long long) g_hyp_below, (unsigned long long) g_hyp_above);
+        fprintf(fo, "# round 6 -- reached cells priced at the parent's score: %llu arcs (%llu steps) known, %llu wrong (must be 0); as the kernel would ask: %llu arcs, %llu steps; reached cells %llu, %llu below the score, %llu above\n",
+                (unsigned long long) g_lv2_arcs, (unsigned long long) g_lv2_steps, (unsigned long long) g_lv2_wrong, (unsigned long long) g_lv2k_arcs, (unsigned long long) g_lv2k_steps, (unsigned long long) g_hyp_cells, (unsigned long long) g_hyp_below, (unsigned long long) g_hyp_above);
         fprintf(stderr, "ECT_ROWS/kernel's switch: %llu arcs, %llu steps known; %llu not asked (lag)\n", (unsigned long long) g_lvk_arcs, (unsigned long long) g_lvk_steps, (unsigned long long) g_lvk_lag);
         fprintf(stderr, "ECT_ROWS/wavefront bounds: %llu of %llu dead long arcs certified (%llu of %llu steps), wrong %llu\n", (unsigned long long) g_lvc_arcs, (unsigned long long) g_lvc_dead_arcs, (unsigned long long) g_lvc_steps,
                 (unsigned long long) g_lvc_dead_steps, (unsigned long long) g_lvc_wrong);

@@ -40,3 +40,13 @@ for name, key in (("DFS steps", tried), ("diagonal extensions", wfd), ("time", t
     for i in np.argsort(-key)[:10]:
         print("  block %8d: read %7d len %6d %s arcs %7d dead ends %6d wavefront steps %8d diagonals %10d status %d path %d  %.2f ms (variant %d, %d sub-tasks): %.0f ns per step" % (
               i, w[i, 4], l[i], "leading" if r[i] else ("trailing" if end_none[i] else "middle"), tried[i], npath[i], wfs[i], wfd[i], status[i], o[i, 1], tk[i] * 1e-5, tier[i], steals[i], tk[i] * 10.0 / max(wfs[i], 1)))
+# the second stage's blocks by the waves their band needs (ec_fused.hpp: a wave owns 56 slots, 2 bw + 3 slots in all): what narrower workgroups would hold
+bw = np.maximum(6, np.ceil(l * 0.02)).astype(np.int64)
+need = (2 * bw + 3 + 55) // 56
+m2 = tier >= 32
+print("second-stage blocks by waves needed (2 bw + 3 slots, 56 owned per wave):")
+for lo, hi in ((1, 1), (2, 2), (3, 4), (5, 8), (9, 16), (17, 99)):
+    m = m2 & (need >= lo) & (need <= hi)
+    if m.any():
+        print("  %2d-%2d waves: %6d blocks, time %9.1f ms (longest %7.1f), arcs %10d, wavefront steps %10d, mean diagonals per step %6.1f" % (
+              lo, hi, m.sum(), tk[m].sum() * 1e-5, tk[m].max() * 1e-5, tried[m].sum(), wfs[m].sum(), wfd[m].sum() / max(wfs[m].sum(), 1)))
