@@ -145,11 +145,11 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("graph", ["host", "device", "device-tiers", "device-tiers-serial", "device-heavy", "device-heavy-mix", "device-heavy-spill", "device-tree", "device-tree-smalllog", "device-fused", "device-fused-spill", "device-fused-nocert", "device-fused-nw4", "device-fused-nw8", "device-fused-nw16"])
+@pytest.mark.parametrize("graph", ["host", "device", "device-tiers", "device-tiers-serial", "device-heavy", "device-heavy-mix", "device-heavy-spill", "device-tree", "device-tree-smalllog", "device-fused", "device-fused-spill", "device-fused-nocert", "device-fused-nw2", "device-fused-nw4", "device-fused-nw8", "device-fused-nw16"])
 @pytest.mark.parametrize("case", range(len(CASES)))
 def test_device_ec_matches_reference(hip, case, graph, monkeypatch):
     # the table test for long arcs (ec_fused.hpp CERT) is on by default since round 6; device-fused-nocert: without.  device-fused-nw4 / 8 / 16: the second stage's narrowest
-    # class of workgroups has that many waves (by default the classes are 2, 4, 8 and 16 waves by the block's band, and these cases' blocks all fit two or four)
+    # class of workgroups has that many waves (by default the classes are one wave -- ec_heavy.hpp without a budget -- and 4, 8 and 16 waves of ec_fused.hpp by the block's band, and these cases' blocks all fit one wave or four)
     monkeypatch.setenv("OATK_DEBUG_EC_CERT", "0" if graph == "device-fused-nocert" else "1")
     monkeypatch.setenv("OATK_DEBUG_EC_FUSED_MIN_NW", graph[len("device-fused-nw"):] if graph.startswith("device-fused-nw") else "0")
     if graph.startswith("device-tree") and not os.environ.get("OATK_TEST_EC_TREE"):

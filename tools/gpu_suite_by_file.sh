@@ -12,7 +12,7 @@ for f in tests/test_gpu_*.py; do
         rocm-smi --showmeminfo vram 2>/dev/null | grep -i "used" | head -1
         free -g | awk 'NR==2{print "host used GB", $3}'
     } >> gpurun_out/suite/progress.txt
-    timeout 900 python -m pytest "$f" -x -q -m gpu > "gpurun_out/suite/$(basename "$f" .py).txt" 2>&1
+    python tools/memcap.py --rss-gb 400 --timeout 900 -- python -m pytest "$f" -x -q -m gpu > "gpurun_out/suite/$(basename "$f" .py).txt" 2>&1
     echo "   rc $?  $(tail -n 1 "gpurun_out/suite/$(basename "$f" .py).txt")" >> gpurun_out/suite/progress.txt
 done
 cat gpurun_out/suite/progress.txt
