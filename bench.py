@@ -71,6 +71,7 @@ def parse_args():
     ap.add_argument("--back-reads", type=int, default=100000)
     ap.add_argument("--cli-reads", type=int, default=2000000, help="reads of the CLI comparison (BASELINE.json quotes the north-star target at 2 M reads; the reference binary takes ~5 min there)")
     ap.add_argument("--cli-threads", type=int, default=32, help="-t of both binaries in the CLI comparison")
+    ap.add_argument("--cli-settle-s", type=float, default=6.0, help="seconds between this process giving the device back and the CLI comparisons (see the note in the `cli` object)")
     ap.add_argument("--config1s-reads", type=int, default=200000, help="reads of the config-1 surrogate's resident step (0: leave the `config1s` object out)")
     ap.add_argument("--config1s-cpu-reads", type=int, default=40000, help="reads of the config-1 surrogate the compiled reference's read_error_correction is timed on (its `cpu_baseline`)")
     ap.add_argument("--config1s-cli-reads", type=int, default=100000, help="reads of its CLI comparison from the .fa.gz (0: none)")
@@ -399,6 +400,7 @@ def main():
             ec_summary["imported_kmers_rank0"] = n_imp[0]
 
     extras = {}
+    pending_cli_gz, hip_closed = None, False
     hip.set_timing(False)
     if comm and with_ec and not args.no_extras:
         # ---- what follows the EC round in syncasm() with sharded reads: every rank takes part (include/oatk_hip_multi.h, second half) ----
@@ -628,10 +630,7 @@ def main():
                 if not args.no_cpu_baseline:
                     extras["config1s"]["cpu_baseline"] = config1s_cpu_baseline(hip, sq, of, ln, min(args.config1s_cpu_reads, n1), K, S, cc1)
                 if args.config1s_cli_reads and not args.no_cpu_baseline:
-                    sys.path.insert(0, os.path.join(ROOT, "tests"))
-                    import cli_util
-                    hip.sync()
-                    extras["config1s"]["cli_fa_gz"] = cli_util.time_cli_gz(sq, of, ln, min(args.config1s_cli_reads, n1), K, cc1, args.cli_threads)
+                    pending_cli_gz = (sq, of, ln, min(args.config1s_cli_reads, n1), K, cc1)       # (run at the end, when this process has given the device back)
                 del sq
             except Exception as ex:         # noqa: BLE001
                 extras.setdefault("config1s", {})["error"] = "%s: %s" % (type(ex).__name__, ex)
@@ -690,12 +689,38 @@ def main():
         # ---- SURVEY 8d timing (iii): the syncasm CLI from a FASTA file, reference binary against the drop-in binary (the reference's own
         #      translation units with the hot-path functions replaced by liboatk_host.so's; built where the reference
         #      sources are).  Same file, same options; both GFA files compared byte for byte. ----
-        if world == 1 and not args.no_cpu_baseline:
+        # The CLI is a process of its own, and it is timed with the device to itself: this process first gives back what it holds there and waits --cli-settle-s.  While a
+        # parent holds a hundred GB of VRAM, or for some seconds after it has returned them (the driver clears what comes back), the child's allocations take tenths of a
+        # second to seconds each instead of milliseconds -- the same binary on the same file ran 2.1 s, 3.1 s and 5.6 s (tools/vram_churn_cli.py, profiles/r06v_vram_churn.txt);
+        # until round 6 these comparisons ran in the middle of the bench with ~100 GB held, and that is what was in their numbers.
+        if world == 1 and not args.no_cpu_baseline and (pending_cli_gz or args.cli_reads):
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import cli_util
+            import gc
+            hip.sync()
+            if comm:
+                hip.L.oatk_comm_destroy(comm)
+                comm = None
+            hip.close()
+            hip_closed = True
+            try:                                # (closures above hold the tensors: their storage is what goes)
+                for t_ in (d_seq, d_off, d_len):
+                    t_.untyped_storage().resize_(0)
+            except (NameError, UnboundLocalError, AttributeError):
+                pass
+            gc.collect()
+            torch.cuda.empty_cache()
+            time.sleep(args.cli_settle_s)
+            if pending_cli_gz:
+                try:
+                    extras["config1s"]["cli_fa_gz"] = cli_util.time_cli_gz(*pending_cli_gz, args.cli_threads)
+                    extras["config1s"]["cli_fa_gz"]["device_to_itself"] = "this process released its %s of the device %.0f s before" % ("share", args.cli_settle_s)
+                except Exception as ex:     # noqa: BLE001
+                    extras["config1s"]["cli_fa_gz"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+                pending_cli_gz = None
             try:
-                sys.path.insert(0, os.path.join(ROOT, "tests"))
-                import cli_util
-                hip.sync()
                 extras["cli"] = cli_util.time_cli(rs, first, min(args.cli_reads, per_gpu), K, S, c, args.cli_threads, devices="%d,%d" % (local_rank, local_rank))
+                extras["cli"]["device_to_itself"] = "this process released its share of the device %.0f s before the first run" % args.cli_settle_s
             except Exception as ex:         # noqa: BLE001
                 extras["cli"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
 
@@ -779,7 +804,8 @@ def main():
         print(json.dumps(out), file=_RESULT_OUT, flush=True)
     if comm:
         hip.L.oatk_comm_destroy(comm)
-    hip.close()
+    if not hip_closed:
+        hip.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

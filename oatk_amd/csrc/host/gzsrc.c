@@ -44,6 +44,9 @@ struct oatk_gzsrc {
     uint32_t crc; uint64_t member_out;
     oatk_gzpar_t *par;                       /* the member at hand is inflated on many threads (host/gzpar.c) */
     int par_kind;                            /* (statistics: 1 once a member went that way) */
+    int small_members;                       /* a member that went the many-thread way turned out smaller than the gate: the members behind it are read by zlib */
+    uint64_t par_least;                      /* the gate that member passed */
+    uint64_t n_par_opened;                   /* (statistics, tests) members the many-thread reader was opened for */
     /* pipe fallback */
     gzFile gzf;
     /* BGZF */
@@ -193,6 +196,7 @@ void oatk_gzsrc_close(oatk_gzsrc_t *g)
 uint64_t oatk_gzsrc_tell_in(const oatk_gzsrc_t *g) { return g->gzf? 0 : g->pos + (g->par? oatk_gzpar_in_used(g->par) : 0); }
 uint64_t oatk_gzsrc_size_in(const oatk_gzsrc_t *g) { return g->size; }
 int oatk_gzsrc_kind(const oatk_gzsrc_t *g) { return g->gzf? 3 : (g->bgzf? 2 : 1); }
+uint64_t oatk_gzsrc_members_on_many_threads(const oatk_gzsrc_t *g) { return g->n_par_opened; }
 
 /* the BGZF members from pos on that fit `cap` bytes of text, inflated on the pool; 0: the next member is not BGZF (or nothing fits) */
 static int64_t bgzf_read(oatk_gzsrc_t *g, uint8_t *dst, uint64_t cap)
@@ -242,7 +246,8 @@ static int64_t serial_read(oatk_gzsrc_t *g, uint8_t *dst, uint64_t cap)
 {
     uint64_t out = 0;
     if (!g->in_member) {
-        const uint32_t hl = g->pos < g->size? gzs_header(g->map + g->pos, g->size - g->pos, 0) : 0;
+        uint32_t bg_size = 0;                        /* (a BGZF member says how long it is: at most 64 KiB, never worth many threads) */
+        const uint32_t hl = g->pos < g->size? gzs_header(g->map + g->pos, g->size - g->pos, &bg_size) : 0;
         if (!hl) {                                   /* the end, or bytes that are no gzip member: ignored like gzread ignores them (gzread.c: "trailing garbage") */
             if (g->pos == 0 && g->size) return -1;
             g->eof = 1;
@@ -255,7 +260,12 @@ static int64_t serial_read(oatk_gzsrc_t *g, uint8_t *dst, uint64_t cap)
         {
             const char *e = getenv("OATK_HOST_GZ_PARALLEL");
             const uint64_t least = e && atoi(e) > 1? (uint64_t) atoi(e) : (8u << 20);
-            if (!(e && e[0] == '0' && !e[1]) && g->n_threads >= 4 && g->size - g->pos >= least) g->par = oatk_gzpar_open(g->map + g->pos, g->size - g->pos, g->n_threads);
+            /* (round 6: the gate looked at the rest of the FILE, not at the member -- a BGZF member cut by the end of the caller's buffer, one per 32 MB of text, opened the
+             *  many-thread reader on everything behind it: threads started, boundaries searched and megabytes decoded in LATER members, all thrown away when the member ended
+             *  64 KiB on; 1.7 s of the config-1 surrogate's 2.0 s sr_read from BGZF.  A member that says it is BGZF is inflated by zlib; and a file whose members turn out
+             *  small -- concatenated lanes, per-block gzip writers: ADVICE r05 -- is read by zlib from the first such member on.) */
+            if (!(e && e[0] == '0' && !e[1]) && g->n_threads >= 4 && g->size - g->pos >= least && !bg_size && !g->small_members)
+                g->par = oatk_gzpar_open(g->map + g->pos, g->size - g->pos, g->n_threads), g->par_least = least, ++g->n_par_opened;
         }
     }
     while (g->par && out < cap) {
@@ -265,6 +275,7 @@ static int64_t serial_read(oatk_gzsrc_t *g, uint8_t *dst, uint64_t cap)
         out += (uint64_t) n, g->member_out += (uint64_t) n, g->par_kind = 1;
         if (oatk_gzpar_done(g->par)) {
             uint32_t t[2];
+            if (oatk_gzpar_in_used(g->par) < g->par_least) g->small_members = 1;
             g->pos += oatk_gzpar_in_used(g->par);
             if (g->size - g->pos < 8) return -1;
             memcpy(t, g->map + g->pos, 8);

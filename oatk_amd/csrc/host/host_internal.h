@@ -41,6 +41,7 @@ oatk_gzsrc_t *oatk_gzsrc_open(const char *path, int n_threads, int *rc);
 int64_t oatk_gzsrc_read(oatk_gzsrc_t *g, uint8_t *dst, uint64_t cap);
 uint64_t oatk_gzsrc_tell_in(const oatk_gzsrc_t *g);
 uint64_t oatk_gzsrc_size_in(const oatk_gzsrc_t *g);
+uint64_t oatk_gzsrc_members_on_many_threads(const oatk_gzsrc_t *g);      /* (statistics, tests) */
 int oatk_gzsrc_kind(const oatk_gzsrc_t *g);          /* 1 plain member(s), 2 BGZF, 3 not a regular file (zlib's gzread) */
 void oatk_gzsrc_close(oatk_gzsrc_t *g);
 /* one member's deflate data inflated on many threads (host/gzpar.c) */

@@ -288,3 +288,44 @@ def test_the_position_in_the_file_moves_while_a_member_is_inflated_on_many_threa
     for (o0, a0), (o1, a1) in zip(seen[1:], seen[2:]):
         if o1 < len(text):
             assert (a1 - a0) * 40 >= (o1 - o0) or a1 == a0, (o0, a0, o1, a1)
+
+
+def _opened(H, path, cap, threads):
+    """(text, members the many-thread reader was opened for) reading `path` in calls of at most `cap` bytes"""
+    H.oatk_gzsrc_members_on_many_threads.restype = C.c_uint64
+    H.oatk_gzsrc_members_on_many_threads.argtypes = [C.c_void_p]
+    rc = C.c_int(0)
+    g = H.oatk_gzsrc_open(path.encode(), threads, C.byref(rc))
+    assert g
+    buf, out = np.empty(cap, np.uint8), bytearray()
+    while True:
+        n = H.oatk_gzsrc_read(g, buf.ctypes.data, cap)
+        assert n >= 0
+        if n == 0:
+            break
+        out += buf[:n].tobytes()
+    k = H.oatk_gzsrc_members_on_many_threads(g)
+    H.oatk_gzsrc_close(g)
+    return bytes(out), int(k)
+
+
+def test_the_many_thread_reader_is_not_opened_for_what_it_cannot_help(H, tmp_path, monkeypatch):
+    """Round 6 (sr_read from BGZF 0.35 -> 1.9 s on the driver's clock).  A BGZF member cut by the end of the caller's buffer goes through the serial path -- and
+    that path opened host/gzpar.c on the REST OF THE FILE: threads started, boundaries searched and chunks decoded in later members, all thrown away 64 KiB on, once per call.
+    A member that says it is BGZF is zlib's; and in a file of many small plain members only the first one pays for finding that out."""
+    rng = np.random.default_rng(23)
+    text = _reads_text(rng, 30_000_000)
+    monkeypatch.setenv("OATK_HOST_GZ_PARALLEL", "1000000")            # the gate: a megabyte of file left
+    p = str(tmp_path / "b.fa.gz")
+    open(p, "wb").write(_bgzf_blocks(text, 60_000))
+    for cap in (1 << 20, (1 << 22) + 12345):                          # every call ends inside a member
+        got, k = _opened(H, p, cap, 16)
+        assert got == text and k == 0, (cap, k)
+    q = str(tmp_path / "m.fa.gz")
+    open(q, "wb").write(b"".join(gzip.compress(text[a:a + 700_000], 6) for a in range(0, len(text), 700_000)))      # 43 members of ~200 kB
+    got, k = _opened(H, q, 1 << 22, 16)
+    assert got == text and k == 1, k
+    r = str(tmp_path / "one.fa.gz")
+    open(r, "wb").write(gzip.compress(text, 6))                       # ... and ONE large member still goes the many-thread way
+    got, k = _opened(H, r, 1 << 22, 16)
+    assert got == text and k == 1, k
