@@ -52,14 +52,15 @@ int oatk_hip_debug_ec_tiers(oatk_hip_ctx *ctx, int cap_t0, int cap_t1);
 int oatk_hip_debug_wf_ed(oatk_hip_ctx *ctx, uint64_t n_jobs, const uint8_t *t_codes, const uint64_t *t_off, const uint8_t *q_codes, const uint64_t *q_off,
                          const int32_t *bw, const int32_t *step_ql, const uint64_t *step_off, int32_t *out3);
 /* The same jobs through the step of the workgroup solver (round 5: the blocks that are not small, one workgroup per block with the wavefront in
- * registers, R = 1, 2 or 6 diagonals per lane).  A job needs 2 bw + 3 (no band: tl + ql + 3) <= 256 R diagonals; otherwise OATK_E_ARG. */
+ * registers, R = 1, 2 or 6 diagonals per lane; R = 16: the second stage's step, sixteen waves and four steps per barrier, 2 bw + 3 <= 896).  A job needs 2 bw + 3
+ * (no band: tl + ql + 3) <= 256 R diagonals; otherwise OATK_E_ARG. */
 int oatk_hip_debug_wf_ed_wg(oatk_hip_ctx *ctx, int R, uint64_t n_jobs, const uint8_t *t_codes, const uint64_t *t_off, const uint8_t *q_codes, const uint64_t *q_off,
                             const int32_t *bw, const int32_t *step_ql, const uint64_t *step_off, int32_t *out3);
-/* (R = 32, 33: the same outcomes by MATRIX ROWS -- a value per diagonal, 2 bw + 5 <= 512; the row in bits, banded jobs of 2 bw + 5 <= 640: oatk_amd/csrc/ec_rows.hpp, experimental.)
- * The two tables by which a long arc of the error-block search can be known to die by score without a step (ec_rows.hpp: ecb_table; experimental): for job j,
+/* The two tables by which a long arc of the error-block search is known to die by score without a step (oatk_amd/csrc/ec_tables.hpp: ecb_table): for job j,
  * target t_codes[t_off[j], t_off[j + 1]) of tl bases and string s_codes[s_off[j], s_off[j + 1]) of at most 1024, out[out_off[j] + u], u = 0 .. tl, receives the least edit
  * cost of fitting the WHOLE string into the target from position u on (any end), and out[out_off[j] + tl + 1 + u] that of some PREFIX of the string against the target from
- * u to its end.  out_off[j + 1] - out_off[j] >= 2 (tl + 1).  Host pointers. */
+ * u to its end.  out_off[j + 1] - out_off[j] >= 2 (tl + 1).  Host pointers.  (OATK_DEBUG_TABLES_SEG="<waves>:<cut>": as the solver builds them -- by that many waves, table 0
+ * in stretches that are exact up to `cut`, table 1 only near the target's end; entries that are not written come back as -1.) */
 int oatk_hip_debug_tables(oatk_hip_ctx *ctx, uint64_t n_jobs, const uint8_t *t_codes, const uint64_t *t_off, const uint8_t *s_codes, const uint64_t *s_off, int32_t *out, const uint64_t *out_off);
 
 /* Resident results of oatk_hip_ec (ids for oatk_hip_buffer):

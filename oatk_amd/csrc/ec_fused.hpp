@@ -4,7 +4,7 @@
 // (strings in LDS, frames in an LDS arena that spills into the HBM slab).  What differs is the wavefront step.  ec_heavy.hpp puts diagonal d into slot d + bw + 1, slot s
 // into lane s % 256 of four waves, and pays for every step a barrier and an LDS exchange of the entries at the waves' seams and of "has any lane reached an end": ~1 us a
 // step on the config-1 surrogate's tandem arrays, where a block runs into MAX_DFS_PATH = 10 000 dead ends, a hundred steps each on hundreds of diagonals (tools/stepbench.py,
-// profiles/r05e_stepbench.txt: the four waves save a third of a single wave's time, no more) -- and the tree of the search does not parallelise (ec_tree.hpp).  Here
+// profiles/r05e_stepbench.txt: the four waves save a third of a single wave's time, no more) -- and the tree of the search does not parallelise (tools/experiments/ec_tree.hpp).  Here
 //   * a wave's 64 lanes hold 64 CONSECUTIVE slots of which it OWNS the middle 64 - 2 ECF_S: ECF_S slots at either end are copies of its neighbours' (a halo).  The next
 //     wavefront takes max(k[d-1], k[d]+1, k[d+1]+1): after one step a wave's outermost lane at either end is stale, after ECF_S steps its halo is -- and its own slots are not.
 //     So a wave takes ECF_S steps on its own (extension against the strings in LDS, neighbours through DPP shifts), and only then do the waves meet: one barrier and one
@@ -17,7 +17,7 @@
 // Results are those of ec_heavy.hpp (and of the reference) bit for bit.
 #pragma once
 #include "ec_heavy.hpp"
-#include "ec_rows.hpp"
+#include "ec_tables.hpp"
 
 namespace oatk {
 
@@ -519,7 +519,7 @@ __device__ bool ecf_solve_block(const EcLive &lv, const EcReads &rd, const EcWor
                     const uint64_t hit = __ballot(lane < nt && key == a);
                     if (hit) idx = __builtin_ctzll(hit);
                     else if (nt < ECF_NT) {
-                        // the string's two tables by all the waves (ec_rows.hpp: ecb_tables_wg), kept for the block
+                        // the string's two tables by all the waves (ec_tables.hpp: ecb_tables_wg), kept for the block
                         ecb_tables_wg<NW>(sh.ts, tl, sh.cs, l0, ext, bw, tabs + (uint64_t) nt * pair, tabs + (uint64_t) nt * pair + (uint64_t) (tl + 1));
                         __syncthreads();
                         if (t == 0) sh.tab[1 + nt] = (int32_t) a, sh.tab[0] = nt + 1;

@@ -1,7 +1,7 @@
 /*
  * tests/c/rows_bitpar_test.c -- the row solver's row in BITS (round 5; CPU prototype for the next round's kernel, built and run by tests/test_rows_bitpar.py).
  *
- * oatk_amd/csrc/ec_rows.hpp keeps one VALUE per diagonal and pays ~67 instructions per 64 diagonals and row.  The same row as differences: along a row of the
+ * tools/experiments/ec_rows.hpp keeps one VALUE per diagonal and pays ~67 instructions per 64 diagonals and row.  The same row as differences: along a row of the
  * edit-distance matrix neighbouring cells differ by -1, 0 or +1, so a band of W diagonals is two bit vectors (Myers 1999), and a band that moves one cell down the
  * target per query base is Hyyro's diagonal band (2003): previous row's vectors shifted by one, one multiword addition, a dozen logical operations -- a few dozen
  * instructions per row whatever W <= 512 is.  Worked out here on 64-bit words and checked against the plain matrix:
@@ -126,7 +126,7 @@ static void ref_row(ref_t *r, int c)
     free(r->row), r->row = n, r->q = q + 1;
 }
 
-/* ---- the read-off as the device does it (oatk_amd/csrc/ec_rows.hpp: ecb_read): 32-bit words, per-word sums of differences, a cell's value from popcounts under a
+/* ---- the read-off as the device does it (tools/experiments/ec_rows.hpp: ecb_read): 32-bit words, per-word sums of differences, a cell's value from popcounts under a
  * mask, the last row's qualifying cell with the LARGEST band index against the last column's first qualifying row ---- */
 static uint32_t upto(int k) { return k == 31? 0xFFFFFFFFu : (1u << (k + 1)) - 1u; }
 static void dev_read(const bp_t *p, int tl, int ql, int bw, const int *lc /* by row */, int before, int *out)

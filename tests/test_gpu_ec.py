@@ -145,15 +145,13 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("graph", ["host", "device", "device-tiers", "device-tiers-serial", "device-heavy", "device-heavy-mix", "device-heavy-spill", "device-tree", "device-tree-smalllog", "device-fused", "device-fused-spill", "device-fused-nocert", "device-fused-nw2", "device-fused-nw4", "device-fused-nw8", "device-fused-nw16"])
+@pytest.mark.parametrize("graph", ["host", "device", "device-tiers", "device-tiers-serial", "device-heavy", "device-heavy-mix", "device-heavy-spill", "device-fused", "device-fused-spill", "device-fused-nocert", "device-fused-nw2", "device-fused-nw4", "device-fused-nw8", "device-fused-nw16"])
 @pytest.mark.parametrize("case", range(len(CASES)))
 def test_device_ec_matches_reference(hip, case, graph, monkeypatch):
     # the table test for long arcs (ec_fused.hpp CERT) is on by default since round 6; device-fused-nocert: without.  device-fused-nw4 / 8 / 16: the second stage's narrowest
     # class of workgroups has that many waves (by default the classes are one wave -- ec_heavy.hpp without a budget -- and 4, 8 and 16 waves of ec_fused.hpp by the block's band, and these cases' blocks all fit one wave or four)
     monkeypatch.setenv("OATK_DEBUG_EC_CERT", "0" if graph == "device-fused-nocert" else "1")
     monkeypatch.setenv("OATK_DEBUG_EC_FUSED_MIN_NW", graph[len("device-fused-nw"):] if graph.startswith("device-fused-nw") else "0")
-    if graph.startswith("device-tree") and not os.environ.get("OATK_TEST_EC_TREE"):
-        pytest.skip("the tree solver is an experiment that is switched off (DESIGN.md 8.3, round 5): OATK_TEST_EC_TREE=1 runs its cases")
     K, S, c, mk = CASES[case]
     reads = mk()
     # tiny first tier: most blocks run in the classes behind it -- routed there by length and run beside the first tier, or left over by it.
@@ -161,15 +159,11 @@ def test_device_ec_matches_reference(hip, case, graph, monkeypatch):
     #   device-heavy:          everything longer than 48 bases in the first class of the workgroup solver (ec_heavy.hpp, one diagonal per lane)
     #   device-heavy-mix:      48 < l <= 160 in the first class, <= 400 in the second (two diagonals per lane), the rest in the third (six)
     #   device-heavy-spill:    as device-heavy with an LDS frame arena of 64 bytes: every DFS frame goes to the HBM slab
-    #   device-tree:           everything longer than 48 bases in the tree solver (ec_tree.hpp: eight waves share a block's search tree; device-heavy-mix has it as its first class too)
-    #   device-tree-smalllog:  ... with a log arena of 512 bytes per wave: sub-tasks give their arcs back, the owners run them
-    t0, t1 = (48, 160) if graph.startswith("device-tiers") or graph == "device-heavy-mix" else ((48, 0) if graph.startswith("device-heavy") or graph.startswith("device-tree") or graph.startswith("device-fused") else (0, 0))
-    monkeypatch.setenv("OATK_DEBUG_EC_TREE", "1" if graph.startswith("device-tree") else "0")
+    t0, t1 = (48, 160) if graph.startswith("device-tiers") or graph == "device-heavy-mix" else ((48, 0) if graph.startswith("device-heavy") or graph.startswith("device-fused") else (0, 0))
     monkeypatch.setenv("OATK_DEBUG_EC_FUSED", "0" if graph in ("device-heavy", "device-heavy-spill") else "1")
     # device-fused: every block that takes more than one wavefront step goes past its budget and starts again in ec_fused.hpp (several steps per barrier); device-heavy-mix:
     # more than eight; by default three thousand
     monkeypatch.setenv("OATK_DEBUG_EC_STEP_BUDGET", "1" if graph.startswith("device-fused") else ("8" if graph == "device-heavy-mix" else "0"))
-    monkeypatch.setenv("OATK_DEBUG_EC_TREE_LOG", "512" if graph == "device-tree-smalllog" else "0")
     monkeypatch.setenv("OATK_DEBUG_EC_SERIAL_TIERS", "1" if graph == "device-tiers-serial" else "0")
     monkeypatch.setenv("OATK_DEBUG_EC_HEAVY", "0" if graph.startswith("device-tiers") else "1")
     monkeypatch.setenv("OATK_DEBUG_EC_HEAVY_CAP2", "400" if graph == "device-heavy-mix" else "0")
@@ -204,7 +198,7 @@ def test_device_ec_matches_reference(hip, case, graph, monkeypatch):
     assert total == summary["total"] and total > 0
     assert int(st[2] + st[7]) == summary["corrected"] and int(st[1] + st[6]) == summary["uncorrected"]
     assert int(st[3] + st[8]) == summary["ambiseq"] and int(st[4] + st[9]) == summary["ambipath"]   # the reference prints stats[3]+[8] under "ambiguous seqs"
-    if graph.startswith("device-tiers") or graph.startswith("device-heavy") or graph.startswith("device-tree") or graph.startswith("device-fused"):
+    if graph.startswith("device-tiers") or graph.startswith("device-heavy") or graph.startswith("device-fused"):
         assert int(st[11]) > 0                               # blocks did fall through
         hip._check(hip.L.oatk_hip_debug_ec_tiers(hip.h, 0, 0), "oatk_hip_debug_ec_tiers")
     L.refx_scg_destroy(g)

@@ -47,11 +47,10 @@ def fits(job, wg):
         return (2 * bw + 5 if bw >= 0 else len(ts) + len(qs) + 5) <= 512
     if wg == 33:
         return bw >= 0 and 2 * bw + 5 <= 640
-    return wg == 0 or (2 * bw + 3 if bw >= 0 else len(ts) + len(qs) + 3) <= (512 if wg == 8 else 896 if wg == 16 else 256 * wg)
+    return wg == 0 or (2 * bw + 3 if bw >= 0 else len(ts) + len(qs) + 3) <= (896 if wg == 16 else 256 * wg)
 
 
-# (32, 33: ec_rows.hpp, the alignment by matrix rows, as numbers and as bits -- written in round 5 after the last GPU run, never executed: on request until seen green)
-WG = pytest.mark.parametrize("wg", [0, 1, 2, 6, 8, 16] + ([32, 33] if os.environ.get("OATK_TEST_EC_ROWS") == "1" else []))       # 0: ecw_step (a wave per block); 1, 2, 6: ech_step, a workgroup per block with 1, 2, 6 diagonals per lane; 8: ect_step (the tree solver: ONE wave, 8 diagonals per lane); 16: ecf_align (sixteen waves, four steps per barrier)
+WG = pytest.mark.parametrize("wg", [0, 1, 2, 6, 16])       # 0: ecw_step (a wave per block); 1, 2, 6: ech_step, a workgroup per block with 1, 2, 6 diagonals per lane; 16: ecf_align (sixteen waves, four steps per barrier).  (The tree solver's step and the alignment by matrix rows live in tools/experiments/ since round 6.)
 
 
 @WG
@@ -193,7 +192,7 @@ def test_bad_arguments_are_refused(hip):
 
 @pytest.mark.parametrize("seg", [None, (2, 6), (4, 40), (8, 25), (16, 120)])
 def test_tables_of_a_long_arc(hip, seg, monkeypatch):
-    """the two tables by which a long arc can be known to die without a step (oatk_hip_debug_tables, ec_rows.hpp: ecb_table) against their plain recurrences
+    """the two tables by which a long arc can be known to die without a step (oatk_hip_debug_tables, ec_tables.hpp: ecb_table) against their plain recurrences
     (tests/c/prof_bitpar_test.c holds the same on the CPU): table 0 [u] = least cost of the whole string inside target[u ..], table 1 [u] = of a prefix against target[u ..] to its end"""
     rng = np.random.default_rng(77)
 

@@ -27,7 +27,7 @@
 // Results are the reference's bit for bit: status, optimum path, and the final n_path; `tried`, wf_steps and wf_diag count the work that was DONE, which
 // includes what thieves did beyond the cap.
 #pragma once
-#include "ec_heavy.hpp"
+#include "../../oatk_amd/csrc/ec_heavy.hpp"
 
 namespace oatk {
 
