@@ -157,12 +157,12 @@ static inline int huff_decode(const huff_t *h, br_t *b)
     return (int) (e >> 16);
 }
 
-typedef struct { uint16_t *s; uint64_t n, m, lim; } sym_t;          /* lim: more symbols than this are refused (0: no limit) -- a decoder that entered the stream at a wrong place must not eat the machine's memory */            /* a chunk's text as symbols: < 256 a byte, else 256 + position in the window before the chunk */
+typedef struct { uint16_t *s; uint64_t n, m, lim; int refused; } sym_t;      /* refused: room was denied because of lim (not for want of memory) */          /* lim: more symbols than this are refused (0: no limit) -- a decoder that entered the stream at a wrong place must not eat the machine's memory */            /* a chunk's text as symbols: < 256 a byte, else 256 + position in the window before the chunk */
 
 static int sym_room(sym_t *o, uint64_t more)
 {
     if (o->n + more <= o->m) return 0;
-    if (o->lim && o->n + more > o->lim) return -1;
+    if (o->lim && o->n + more > o->lim) { o->refused = 1; return -1; }
     uint64_t m = o->m? o->m : 1 << 20;
     while (m < o->n + more) m += m >> 1;
     uint16_t *s = (uint16_t *) realloc(o->s, m * 2);
@@ -441,16 +441,20 @@ static void decode_chunk(oatk_gzpar_t *p, int j, int bounded)
     chunk_t *c = &p->ch[j];
     const uint64_t total_bits = p->n_in * 8, stop = c->nominal + p->chunk_bits;
     br_t b;
-    c->o.n = 0, c->ok = 0, c->last = 0, c->capped = 0;
+    c->o.n = 0, c->ok = 0, c->last = 0, c->capped = 0, c->o.refused = 0;
     /* a chunk entered on a guess (every one but the batch's first) gets room for what two chunks of text compressed fortyfold would need: garbage that decodes as one long
-     * run of matches stops there, instead of at the end of a gigabyte of input */
-    c->o.lim = bounded? (p->chunk_bits >> 3) * 40 + (32u << 20) : 0;
+     * run of matches stops there, instead of at the end of a gigabyte of input.  And the batch as a whole holds at most 2^30 symbols, 2 GB (192 slots of
+     * 144 MB were 27 GB on text that deflates seventyfold): a chunk that is the text and wants more is decoded again without the bound, one at a time, as before. */
+    {
+        const uint64_t per_chunk = (p->chunk_bits >> 3) * 40 + (32u << 20), share = ((uint64_t) 1 << 30) / (uint64_t) (p->n_slots > 0? p->n_slots : 1);
+        c->o.lim = bounded? (per_chunk < share? per_chunk : (share > (4u << 20)? share : (4u << 20))) : 0;
+    }
     if (c->start == GP_INF) return;
     br_init(&b, p->in, p->n_in, c->start);
     for (;;) {
         br_refill(&b);
         const uint32_t h = br_get(&b, 3);
-        if (decode_block(&b, (int) (h >> 1), &c->o, 0, total_bits, c->have)) { c->capped = c->o.lim && c->o.n + 288 > c->o.lim; return; }
+        if (decode_block(&b, (int) (h >> 1), &c->o, 0, total_bits, c->have)) { c->capped = c->o.refused; return; }      /* (a stored block is refused room for up to 65535 symbols, not 288: the flag says so, the arithmetic did not) */
         const uint64_t at = br_pos(&b);
         if (h & 1) { c->last = 1, c->end = at, c->ok = 1; return; }
         if (at >= stop) { c->end = at, c->ok = 1; return; }
