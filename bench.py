@@ -738,6 +738,7 @@ def main():
         achieved = alg_bytes[dom] / dur_s / 1e9 if dur_s > 0 else 0.0
         traffic, traffic_src = pmc_traffic({"hpc": "oatk::hpc_pack_kernel", "syncmer": "void oatk::syncmer_fast_kernel"}[dom], args.workload, per_gpu)
         valu_per_64, valu_src = pmc_valu_per_64()
+        clk_ghz, clk_src = pmc_clock_ghz()
         # cycles per wave64 VALU instruction weighted by the opcode mix of kernel B's tile loop (tools/isa_mix.py over `hipcc -S`, per-opcode rates measured
         # on the box: profiles/r02c_valu_rates.txt) -- 2.9 for the simple 32-bit forms, 4.5 - 5.5 for 64-bit shifts, v_mad_u64_u32, v_alignbit
         import glob
@@ -754,11 +755,11 @@ def main():
                     "share_of_step": round(phase_ms[dom] / (dt / args.steps * 1e3), 3),
                     "note": "kernel B reads 0.25 B and hashes one 31-mer per hoco position: it is integer-VALU issue bound, not HBM bound (DESIGN.md 5); "
                             "`valu` prices it against the bound that binds",
-                    # wave-instructions issued (PMC count per 64 positions, profiles/) against the issue ceiling of THIS opcode mix: 1024 SIMDs x 2.4 GHz /
+                    # wave-instructions issued (PMC count per 64 positions, profiles/) against the issue ceiling of THIS opcode mix: 1024 SIMDs x the measured clock /
                     # (cycles per instruction weighted by the mix, per-opcode rates measured on the box).  (Up to r03g a second figure priced every
                     # instruction at a flat four cycles; the kernel has since run at 1.12 of that "peak", which settles what it was worth.)
-                    "valu": {"achieved": round(valu_rate, 1), "peak": round(1024 * 2.4 / cpi, 1), "unit": "G wave-instr/s",
-                             "frac": round(valu_rate * cpi / (1024 * 2.4), 3), "valu_per_64_positions": valu_per_64, "valu_count_source": valu_src, "cycles_per_instr_mix": cpi,
+                    "valu": {"achieved": round(valu_rate, 1), "peak": round(1024 * clk_ghz / cpi, 1), "unit": "G wave-instr/s",
+                             "frac": round(valu_rate * cpi / (1024 * clk_ghz), 3), "clock_GHz": clk_ghz, "clock_source": clk_src, "valu_per_64_positions": valu_per_64, "valu_count_source": valu_src, "cycles_per_instr_mix": cpi,
                              "mix_source": os.path.basename(mix_files[-1]) if mix_files else None},
                     "scan_bytes_per_base": round((alg_bytes["hpc"] + 28 * n_occ) / bases, 4),
                     # the scan of SURVEY.md 8(d) is kernel A + kernel B + the k-mer hash
@@ -845,6 +846,22 @@ def scale_model(n1, ms1, tr1, n8, ms8, tr8, bases1, ms_headline):
                                     "efficiency": round(ms_headline / t / n, 3),
                                     "parts_ms": {"compute": round(comp, 2), "latencies": round(calls * lat_ms, 2), "exchange": round(t_ex, 3), "allgather": round(t_ag, 3), "allreduce": round(t_ar, 3)}}
     return out
+
+
+def pmc_clock_ghz(kernel="syncmer_fast_kernel"):
+    """the clock kernel B ran at, from the NEWEST committed GRBM_GUI_ACTIVE pass (profiles/*_pmc_clock_config3.csv, tools/pmc_r02.sh); 2.4 (the part's peak) without one"""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_clock_config3.csv")), reverse=True):
+        try:
+            for ln in open(f).read().splitlines()[1:]:
+                parts = ln.rsplit(",", 3)
+                if len(parts) == 4 and kernel in parts[0]:
+                    g = float(parts[3])
+                    if 1.0 < g < 2.6:
+                        return round(g, 3), os.path.basename(f)
+        except (OSError, ValueError, IndexError):
+            continue
+    return 2.4, "the part's peak engine clock (no GRBM_GUI_ACTIVE pass under profiles/)"
 
 
 def pmc_valu_per_64():

@@ -185,8 +185,14 @@ __device__ inline void rab_backtrace(const RabArgs &q, uint64_t f0, uint32_t nf,
     const RaArgs &a = q.a;
     uint64_t *st = q.stack + f0;
     n_a = 0, n_fr = 0;
-    for (uint32_t j = 0; j < nf; ++j) {
-        if (q.g_score[f0 + j] < max_score) continue;
+    // (round 6: the whole wave looks for the fragments of maximal score, sixty-four at a time; lane 0 walks from each.  One lane used to read every fragment's score, a round
+    //  trip to HBM each)
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t jb = 0; jb < nf; jb += 64) {
+      uint64_t top = __ballot(jb + lane < nf && !(q.g_score[f0 + jb + lane] < max_score));
+      if (lane == 0) while (top) {          // (the others wait at the end of this statement: the next turn's ballot is the whole wave's again)
+        const uint32_t j = jb + (uint32_t) __builtin_ctzll(top);
+        top &= top - 1;
         int64_t d = 0;
         st[0] = j;
         while (d >= 0) {
@@ -215,6 +221,7 @@ __device__ inline void rab_backtrace(const RabArgs &q, uint64_t f0, uint32_t nf,
                 st[d] = c;
             } else --d;
         }
+      }
     }
 }
 
@@ -237,38 +244,54 @@ __global__ __launch_bounds__(64) void rab_chain_kernel(RabArgs q)
     }
     __threadfence_block();
     bool over = false;
-    for (uint32_t j = 0; j < nf && !over; ++j) {
-        const uint64_t fu = q.g_uid[f0 + j];
-        const int64_t p = q.g_send[f0 + j];
-        if ((int64_t) a.utg_n[fu >> 1] - (int64_t) q.g_uend[f0 + j] - 1 > 0) continue;
-        const int64_t score = q.g_score[f0 + j];
-        for (uint32_t kb = j + 1; kb < nf; kb += 64) {
-            const uint32_t k = kb + lane;
-            bool past = false, ov = false;
-            if (k < nf) {
-                const uint64_t g = f0 + k;
-                const int64_t p1 = q.g_sbeg[g];
-                if (p1 > p + 1) past = true;                                       // (sorted by s_beg: so is everything behind k)
-                else if (q.g_ubeg[g] == 0) {
-                    const int64_t ln = ra_arc_ln(a, fu, q.g_uid[g]);
-                    if (ln >= 0) {
-                        const int64_t u_ovl = ln < p + 1? ln : p + 1;
-                        if (p1 + u_ovl == p + 1) {
-                            const int64_t score1 = score + q.g_score0[g] - u_ovl, sk = q.g_score[g];
-                            uint32_t pn = q.g_prevn[g];
-                            if (!(score1 <= score || score1 < sk || (score1 == sk && pn == 0))) {
-                                if (score1 > sk) q.g_score[g] = (int32_t) score1, pn = 0;
-                                if (pn == RAB_PREV) ov = true;
-                                else q.g_prev[g * RAB_PREV + pn] = j, q.g_prevn[g] = pn + 1;
+    // (round 6: what decides whether fragment j can be a predecessor at all -- its unitig, its end on the read, whether it reaches its unitig's end -- never changes: sixty-four
+    //  fragments' worth is fetched at once, a lane each, and only those that can go on take a turn.  The loop used to fetch them fragment by fragment: three dependent
+    //  round trips to HBM per fragment, 10^4 - 10^5 fragments a read, and a batch of reads with many hits costs what its slowest read costs.)
+    for (uint32_t jb = 0; jb < nf && !over; jb += 64) {
+        const uint32_t jm = jb + lane;
+        uint64_t my_fu = 0;
+        int64_t my_p = 0;
+        bool my_go = false;
+        if (jm < nf) {
+            my_fu = q.g_uid[f0 + jm], my_p = q.g_send[f0 + jm];
+            my_go = !((int64_t) a.utg_n[my_fu >> 1] - (int64_t) q.g_uend[f0 + jm] - 1 > 0);
+        }
+        uint64_t go = __ballot(my_go);
+        while (go && !over) {
+            const int l = __builtin_ctzll(go);
+            go &= go - 1;
+            const uint32_t j = jb + (uint32_t) l;
+            const uint64_t fu = (uint64_t) __shfl((long long) my_fu, l);
+            const int64_t p = (int64_t) __shfl((long long) my_p, l);
+            const int64_t score = q.g_score[f0 + j];                                // (as the fragments before it have left it)
+            for (uint32_t kb = j + 1; kb < nf; kb += 64) {
+                const uint32_t k = kb + lane;
+                bool past = false, ov = false;
+                if (k < nf) {
+                    const uint64_t g = f0 + k;
+                    const int64_t p1 = q.g_sbeg[g];
+                    if (p1 > p + 1) past = true;                                   // (sorted by s_beg: so is everything behind k)
+                    else if (q.g_ubeg[g] == 0) {
+                        const int64_t ln = ra_arc_ln(a, fu, q.g_uid[g]);
+                        if (ln >= 0) {
+                            const int64_t u_ovl = ln < p + 1? ln : p + 1;
+                            if (p1 + u_ovl == p + 1) {
+                                const int64_t score1 = score + q.g_score0[g] - u_ovl, sk = q.g_score[g];
+                                uint32_t pn = q.g_prevn[g];
+                                if (!(score1 <= score || score1 < sk || (score1 == sk && pn == 0))) {
+                                    if (score1 > sk) q.g_score[g] = (int32_t) score1, pn = 0;
+                                    if (pn == RAB_PREV) ov = true;
+                                    else q.g_prev[g * RAB_PREV + pn] = j, q.g_prevn[g] = pn + 1;
+                                }
                             }
                         }
                     }
-                }
-            } else past = true;
-            if (__ballot(ov)) { over = true; break; }
-            if (__ballot(past)) break;
+                } else past = true;
+                if (__ballot(ov)) { over = true; break; }
+                if (__ballot(past)) break;
+            }
+            __threadfence_block();                                                 // the scores this j raised are the next j's input
         }
-        __threadfence_block();                                                     // the scores this j raised are the next j's input
     }
     if (q.mode != 1 && lane == 0) a.cnt_aln[r] = 0, a.cnt_frg[r] = 0, a.skipped[r] = over? 3 : 0;
     if (over) return;
@@ -277,18 +300,21 @@ __global__ __launch_bounds__(64) void rab_chain_kernel(RabArgs q)
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { const int64_t o = __shfl_xor(max_score, d); if (o > max_score) max_score = o; }
     if (max_score < (old >> 1)) return;                                            // :505
-    if (lane != 0) return;                                                         // the walk is one lane's
+    // (the walk is lane 0's; the wave finds where it starts)
     uint32_t n_a = 0, n_fr = 0, x, y;
     if (q.mode == 1) {
         rab_backtrace<true>(q, f0, nf, max_score, n, r, a.cnt_aln[r], a.aln_off[r], a.frg_off[r], 0, x, y);
         return;
     }
     rab_backtrace<false>(q, f0, nf, max_score, n, r, 0, 0, 0, 0, n_a, n_fr);
-    a.cnt_aln[r] = n_a, a.cnt_frg[r] = n_fr;
+    n_a = (uint32_t) __shfl((int) n_a, 0), n_fr = (uint32_t) __shfl((int) n_fr, 0);
+    if (lane == 0) a.cnt_aln[r] = n_a, a.cnt_frg[r] = n_fr;
     if (q.mode == 2 && n_a) {
-        const uint64_t wa = atomicAdd(&a.pool_used[0], (unsigned long long) n_a), wf = atomicAdd(&a.pool_used[1], (unsigned long long) n_fr);
-        if (wa + n_a > a.pool_cap_a || wf + n_fr > a.pool_cap_f) { a.pool_used[2] = 1ULL; return; }
-        a.pool_a[r] = wa, a.pool_f[r] = wf;
+        unsigned long long wa = 0, wf = 0;
+        if (lane == 0) wa = atomicAdd(&a.pool_used[0], (unsigned long long) n_a), wf = atomicAdd(&a.pool_used[1], (unsigned long long) n_fr);
+        wa = (unsigned long long) __shfl((long long) wa, 0), wf = (unsigned long long) __shfl((long long) wf, 0);
+        if (wa + n_a > a.pool_cap_a || wf + n_fr > a.pool_cap_f) { if (lane == 0) a.pool_used[2] = 1ULL; return; }
+        if (lane == 0) a.pool_a[r] = wa, a.pool_f[r] = wf;
         rab_backtrace<true>(q, f0, nf, max_score, n, r, n_a, wa, wf, wf, x, y);
     }
 }

@@ -36,6 +36,9 @@ struct ConsArgs {
     uint32_t *cons_rl;            // [n_sel * K] lround(mean run length) per forward position
     uint32_t *m_seq;              // [n_sel] occurrences that took part
     uint64_t *first_occ;          // [n_sel] the first of them, ~0 if none
+    // (round 6) a syncmer's occurrence list is walked in chunks of CONS_CHUNK, a workgroup each: ch_off[s] = the first workgroup of syncmer s (n_sel + 1 entries)
+    const uint64_t *ch_off;
+    uint64_t n_wg;
 };
 
 __device__ __forceinline__ uint32_t cons_long_run(const ConsArgs &a, uint64_t key)
@@ -46,6 +49,18 @@ __device__ __forceinline__ uint32_t cons_long_run(const ConsArgs &a, uint64_t ke
 }
 
 #define CONS_Q 16                 // positions per lane per pass: a pass covers 1024 positions
+// Occurrences a workgroup walks.  (Until round 6 a workgroup walked its syncmer's whole list: a syncmer inside a tandem array of the config-1 surrogate occurs 10^5 times --
+// several times per read -- and ONE workgroup spent 131 ms on it, 6 % of that read set's CLI run, while the device idled: tools/prof_cli_config1s.sh.)
+#define CONS_CHUNK 1024
+
+__global__ void cons_chunks_kernel(uint64_t n_sel, const uint32_t *sel, const uint64_t *occ_off, uint64_t *nch)
+{
+    const uint64_t s = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > n_sel) return;
+    if (s == n_sel) { nch[s] = 0; return; }
+    const uint64_t n = occ_off[sel[s] + 1] - occ_off[sel[s]];
+    nch[s] = n > CONS_CHUNK? (n + CONS_CHUNK - 1) / CONS_CHUNK : 1;
+}
 
 __global__ __launch_bounds__(256) void cons_rl_kernel(ConsArgs a)
 {
@@ -53,9 +68,19 @@ __global__ __launch_bounds__(256) void cons_rl_kernel(ConsArgs a)
     __shared__ uint32_t s_m;
     __shared__ unsigned long long s_first;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const uint64_t s = blockIdx.x;
+    // which syncmer, which chunk of its list: the last s with ch_off[s] <= this workgroup
+    uint64_t s;
+    {
+        uint64_t lo = 0, hi = a.n_sel;
+        const uint64_t w = blockIdx.x;
+        while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (a.ch_off[mid] <= w) lo = mid; else hi = mid; }
+        s = lo;
+    }
+    const uint64_t chunk = (uint64_t) blockIdx.x - a.ch_off[s];
+    const bool shared_row = a.ch_off[s + 1] - a.ch_off[s] > 1;                  // several workgroups add into this syncmer's row (zeroed before the launch)
     const uint32_t id = a.sel[s];
-    const uint64_t o0 = a.occ_off[id], n = a.occ_off[id + 1] - o0;
+    const uint64_t o0 = a.occ_off[id], n_all = a.occ_off[id + 1] - o0;
+    const uint64_t c_lo = shared_row? chunk * CONS_CHUNK : 0, n = shared_row? (c_lo + CONS_CHUNK < n_all? c_lo + CONS_CHUNK : n_all) : n_all;
     const int K = a.K;
     for (int t0 = 0; t0 < K; t0 += CONS_Q * 64) {
         for (uint32_t i = tid; i < CONS_Q * 64; i += 256) tot[i] = 0;
@@ -66,7 +91,7 @@ __global__ __launch_bounds__(256) void cons_rl_kernel(ConsArgs a)
         for (int q = 0; q < CONS_Q; ++q) acc[q] = 0;
         uint32_t m_mine = 0;
         uint64_t first_mine = ~0ULL;
-        for (uint64_t b0 = (uint64_t) wid * 64; b0 < n; b0 += 256) {
+        for (uint64_t b0 = c_lo + (uint64_t) wid * 64; b0 < n; b0 += 256) {
             // metadata of one occurrence per lane
             bool valid = b0 + lane < n;
             uint64_t addr = 0, key0 = 0;
@@ -122,16 +147,44 @@ __global__ __launch_bounds__(256) void cons_rl_kernel(ConsArgs a)
         }
         __syncthreads();
         const uint32_t m = s_m;
-        for (uint32_t i = tid; i < CONS_Q * 64 && t0 + (int) i < K; i += 256) {
-            a.cons_rl[s * (uint64_t) K + (uint64_t) (t0 + (int) i)] = m? (uint32_t) lround((double) tot[i] / (double) m) : 0u;
-            a.cons_tot[s * (uint64_t) K + (uint64_t) (t0 + (int) i)] = tot[i];
-        }
-        if (tid == 0 && t0 == 0) {
-            a.m_seq[s] = m;
-            a.first_occ[s] = s_first == ~0ULL? ~0ULL : a.occ[o0 + s_first];
+        if (shared_row) {                                  // totals, count and the first occurrence's INDEX are added up over the chunks; cons_finish_kernel does the rest
+            for (uint32_t i = tid; i < CONS_Q * 64 && t0 + (int) i < K; i += 256)
+                if (tot[i]) atomicAdd(&a.cons_tot[s * (uint64_t) K + (uint64_t) (t0 + (int) i)], tot[i]);
+            if (tid == 0 && t0 == 0) {
+                if (m) atomicAdd(&a.m_seq[s], m);
+                if (s_first != ~0ULL) atomicMin((unsigned long long *) &a.first_occ[s], s_first);
+            }
+        } else {
+            for (uint32_t i = tid; i < CONS_Q * 64 && t0 + (int) i < K; i += 256) {
+                a.cons_rl[s * (uint64_t) K + (uint64_t) (t0 + (int) i)] = m? (uint32_t) lround((double) tot[i] / (double) m) : 0u;
+                a.cons_tot[s * (uint64_t) K + (uint64_t) (t0 + (int) i)] = tot[i];
+            }
+            if (tid == 0 && t0 == 0) {
+                a.m_seq[s] = m;
+                a.first_occ[s] = s_first == ~0ULL? ~0ULL : a.occ[o0 + s_first];
+            }
         }
         __syncthreads();
     }
+}
+
+// the rows several workgroups add into: zeroed before, finished after (a workgroup per such syncmer)
+__global__ __launch_bounds__(256) void cons_zero_shared_kernel(ConsArgs a)
+{
+    const uint64_t s = blockIdx.x;
+    if (a.ch_off[s + 1] - a.ch_off[s] <= 1) return;
+    for (int i = (int) threadIdx.x; i < a.K; i += 256) a.cons_tot[s * (uint64_t) a.K + (uint64_t) i] = 0;
+    if (threadIdx.x == 0) a.m_seq[s] = 0, a.first_occ[s] = ~0ULL;
+}
+__global__ __launch_bounds__(256) void cons_finish_shared_kernel(ConsArgs a)
+{
+    const uint64_t s = blockIdx.x;
+    if (a.ch_off[s + 1] - a.ch_off[s] <= 1) return;
+    const uint32_t m = a.m_seq[s];
+    for (int i = (int) threadIdx.x; i < a.K; i += 256)
+        a.cons_rl[s * (uint64_t) a.K + (uint64_t) i] = m? (uint32_t) lround((double) a.cons_tot[s * (uint64_t) a.K + (uint64_t) i] / (double) m) : 0u;
+    __syncthreads();
+    if (threadIdx.x == 0) { const uint64_t f = a.first_occ[s]; a.first_occ[s] = f == ~0ULL? ~0ULL : a.occ[a.occ_off[a.sel[s]] + f]; }
 }
 
 __global__ void cons_flag_kernel(uint64_t n, const uint32_t *cov, const uint8_t *del, uint32_t min_cov, uint32_t *flag)
