@@ -217,9 +217,13 @@ def config1s_cpu_baseline(hip, sq, of, ln, n, K, S, c):
             L.refx_scg_destroy(g); L.refx_scmdb_destroy(scm); L.refx_srdb_destroy(db)
         os.close(saved)
         # the device on the same reads: mark + solve + refresh, the graph (light) built on the device
-        hip.scan_host(sq[:nb], off_n, len_n, K, S); hip.count(); hip.ec_graph(light_c=c)
-        hip.sync(); t0 = time.perf_counter(); hip.ec(0.02, c, 0.35); hip.sync()
-        out["device_ec_s"] = round(time.perf_counter() - t0, 4)
+        # (twice: the first call sizes the solver's slabs for this read set -- hipMalloc -- and is reported beside the second, which is what a resident step costs)
+        times = []
+        for _ in range(2):
+            hip.scan_host(sq[:nb], off_n, len_n, K, S); hip.count(); hip.ec_graph(light_c=c)
+            hip.sync(); t0 = time.perf_counter(); hip.ec(0.02, c, 0.35); hip.sync()
+            times.append(round(time.perf_counter() - t0, 4))
+        out["device_ec_s"], out["device_ec_first_call_s"] = times[1], times[0]
         out["value"] = out["threads"]["8"]; out["cores"] = 8
         out["device_over_reference_t8"] = round(out["threads"]["8"] / max(out["device_ec_s"], 1e-9), 1)
         out["device_over_reference_all_cores"] = round(out["threads"][str(cores)] / max(out["device_ec_s"], 1e-9), 1)
