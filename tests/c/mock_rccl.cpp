@@ -104,6 +104,11 @@ ncclResult_t run(Comm *c, hipStream_t st, std::vector<Op> &mine)
             if (rc == ncclSuccess && o.bytes && hipMemcpy(o.recv, acc.data(), o.bytes, hipMemcpyHostToDevice) != hipSuccess) rc = ncclUnhandledCudaError;
         }
     }
+    // (round 6) The copies above are hipMemcpy device-to-device on the NULL stream: asynchronous to the host, and not ordered with the callers' streams, which are created
+    // hipStreamNonBlocking -- a kernel the caller launches on its stream right after this call could read a buffer the copy had not filled yet.  It did, once, in the
+    // 20th run of tests/test_gpu_multi_c.py this round (one rank's refreshed `del` flags): the mock now drains the null stream before anybody goes on.  Real RCCL
+    // orders a collective on the stream it is given.
+    if (hipStreamSynchronize(nullptr) != hipSuccess && rc == ncclSuccess) rc = ncclUnhandledCudaError;
     if (!g->barrier()) return ncclSystemError;       // nobody's buffers go away before everybody has read them
     return rc;
 }
