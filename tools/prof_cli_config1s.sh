@@ -12,7 +12,7 @@ cfg = dict(synth.CONFIG1S); rs = synth.MixReadSet(**cfg)
 seq, off, lens = rs.slice(0, $N)
 synth.write_fasta("/tmp/prof_c1s.fa.gz", seq, off, lens, mode=synth.FA_BGZF)
 PY
-BIN=$R/oracle/_ref/syncasm_dropin
+BIN=$(cd $R/tests && python -c "import cli_util; print(cli_util.CLI_DROPIN)")   # the drop-in CLI the tests build
 OATK_DROPIN_LOG=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cli_stats -o t -- $BIN -k 1001 -c 30 -t 32 -o /tmp/prof_c1s_out /tmp/prof_c1s.fa.gz > $O/cli.log 2>&1; echo "rc $?"
 f=$(find $O/cli_stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${TAG}_cli_config1s_kernel_stats.csv && cut -c1-150 $f | head -32
 grep "oatk_dropin\] [a-z_]* *[0-9]" $O/cli.log | head -12
