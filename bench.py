@@ -164,7 +164,7 @@ def pmc_traffic(kernel_name, workload, per_gpu):
     if not files:
         return None, None
     for row in csv.reader(open(files[-1])):
-        if row and row[0].startswith(kernel_name):
+        if row and kernel_name in row[0]:
             return int((2.0 * float(row[1]) + float(row[2])) * 1024), os.path.basename(files[-1])
     return None, None
 
@@ -740,7 +740,7 @@ def main():
         kname = {"hpc": "oatk::hpc_pack_kernel", "syncmer": "oatk::syncmer_fast_kernel"}[dom]
         dur_s = phase_ms[dom] / 1e3
         achieved = alg_bytes[dom] / dur_s / 1e9 if dur_s > 0 else 0.0
-        traffic, traffic_src = pmc_traffic({"hpc": "oatk::hpc_pack_kernel", "syncmer": "void oatk::syncmer_fast_kernel"}[dom], args.workload, per_gpu)
+        traffic, traffic_src = pmc_traffic(kname, args.workload, per_gpu)
         valu_per_64, valu_src = pmc_valu_per_64()
         clk_ghz, clk_src = pmc_clock_ghz()
         # cycles per wave64 VALU instruction weighted by the opcode mix of kernel B's tile loop (tools/isa_mix.py over `hipcc -S`, per-opcode rates measured

@@ -309,13 +309,14 @@ static int launch_scan_kernels(oatk_hip_ctx *ctx)
     h.nn_cap = ctx->nn_cap, h.lrl_cap = ctx->lrl_cap, h.counters = ctx->counters.as<uint32_t>();
     t_begin(ctx, OATK_T_HPC);
     h.n_reads = (uint32_t) n;
-    uint64_t hpc_grid = (uint64_t) ctx->n_cu * 8 * 16;        // workgroups stride over the reads: eight to fourteen resident per CU, ten to sixteen rounds of them to even out read lengths
-                                                              // (config 3: 2048 workgroups 20.4 ms, 8192 17.0, 32768 16.5, one per read 17.4)
+    constexpr int HPC_NW = 4;                                 // waves per workgroup, each on reads of its own (16.3 KB of LDS: eight workgroups = 32 waves per CU)
+    uint64_t hpc_grid = (uint64_t) ctx->n_cu * 8 * 8;         // the waves stride over the reads: 32 resident per CU, eight rounds of them to even out read lengths
+                                                              // (400 k reads: 4096 workgroups 3.50 ms, 8192 3.10, 16384 2.94, 32768 2.91, 65536 2.94)
     { const char *ev = getenv("OATK_DEBUG_HPC_GRID"); if (ev && atoi(ev) > 0) hpc_grid = (uint64_t) atoi(ev); }
-    if (hpc_grid > n) hpc_grid = n;
-    unsigned hpc_dyn = 0;                          // development aid: unused LDS on top of the kernel's own lowers its residency (8 workgroups per CU without)
+    if (hpc_grid * HPC_NW > n) hpc_grid = (n + HPC_NW - 1) / HPC_NW;
+    unsigned hpc_dyn = 0;                          // development aid: unused LDS on top of the kernel's own lowers its residency
     { const char *ev = getenv("OATK_DEBUG_HPC_LDS"); if (ev && atoi(ev) > 0) hpc_dyn = (unsigned) atoi(ev); }
-    hipLaunchKernelGGL(hpc_pack_kernel, dim3((unsigned) (hpc_grid? hpc_grid : 1)), dim3(HPC_NT), hpc_dyn, ctx->stream, h);
+    hipLaunchKernelGGL((hpc_pack_kernel<HPC_NW>), dim3((unsigned) (hpc_grid? hpc_grid : 1)), dim3(HPC_NW * OATK_WAVE), hpc_dyn, ctx->stream, h);
     t_end(ctx, OATK_T_HPC);
 
     SynArgs s;

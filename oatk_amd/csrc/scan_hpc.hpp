@@ -7,17 +7,17 @@
 // coordinate goes to n_nucl (:316-321).
 //
 // MI355X mapping: the HBM-streaming kernel of the scan (1 B read + 1.25*rho B written per raw base).
-// One 128-thread workgroup per read walks 2 KiB tiles; each lane owns one aligned 16-byte vector (reads
-// start on 64-byte boundaries of the packed stream) and the next tile's vector is requested before the
+// One WAVE per read walks 1 KiB tiles (four waves to a workgroup, which share the tables and nothing else); each lane owns one
+// aligned 16-byte vector (reads start on 64-byte boundaries of the packed stream) and the next tile's vector is requested before the
 // current one is processed.  Bytes are classified through a 256-entry LDS table (the reference's own
-// table semantics, syncmer.c:47-64); a workgroup scan of (run-start count, last run-start position) --
-// DPP row shifts inside a wave, one LDS exchange across waves -- turns raw coordinates into hoco
-// coordinates; finished runs are staged in an LDS ring (one byte store per run, the 2-bit codes of a lane
+// table semantics, syncmer.c:47-64); a wave scan of (run-start count, last run-start position) -- DPP row shifts -- turns raw
+// coordinates into hoco coordinates; finished runs are staged in the wave's LDS ring (one byte store per run, the 2-bit codes of a lane
 // OR-ed in as at most two words) and leave as full 16-byte stores.  Ambiguous bases and runs > 255 are
 // rare and handled off the fast path.
 //
-// The kernel is bound by VALU issue, not by HBM (PMC: 481 VALU wave-instructions per wave and tile = 30 per raw base, times
-// 4 cycles, over 1024 SIMDs IS its run time), so what counts is instructions per 16-byte lane:
+// The kernel is bound by VALU issue, not by HBM (PMC, r06: 259 VALU wave-instructions per wave and KiB before the waves went their own ways, times
+// 4 cycles, over 1024 SIMDs at the 2.0 GHz it runs at IS its run time: profiles/r07z_pmc_scan.csv, r07z_pmc_clock_config3.csv), so what counts is
+// instructions per 16-byte lane:
 //  * a lane whose sixteen bytes (and the byte before them) are all ACGTU in either case -- every lane of a HiFi read -- never
 //    touches the table: the low three bits of such a byte are distinct (A 1, C 3, T 4, U 5, G 7), so one v_perm_b32 turns
 //    four bytes into four codes and a second one into the four bytes they SHOULD be; any difference sends the lane to the
@@ -38,13 +38,7 @@ namespace oatk {
 // r03p: 128 threads.  A read's last tile takes a tile's time however little of it lies inside the read (a 15 kb read is 3.7 tiles of 4 KiB: an eighth of the
 // kernel), two waves meet at the tile's two barriers sooner than four, and the rings shrink with the tile (11.3 KB with the tables: 14 workgroups = 28 waves per CU,
 // where the kernel is saturated): 3.50 -> 3.15 ms at 400 k reads; one wave per workgroup: 3.7 ms (18 waves per CU: the tables are 6.3 KB per workgroup).
-#ifndef OATK_HPC_NT
-#define OATK_HPC_NT 128
-#endif
-constexpr int HPC_NT = OATK_HPC_NT;
 constexpr int HPC_BPT = 16;
-constexpr int HPC_TILE = HPC_NT * HPC_BPT;
-constexpr int HPC_RING = 2 * HPC_TILE;   // staged hoco positions; > one tile + one unflushed 64-group
 
 // squeeze table: index = keep << 8 | four 2-bit codes (position i in bits 2i+1:2i); value = the kept codes in position
 // order, the first in bits 7:6
@@ -97,7 +91,7 @@ struct HpcArgs {
     uint32_t *lrl_val;        // run length - 1
     uint32_t nn_cap, lrl_cap;
     uint32_t *counters;       // [0] appended to nn, [1] appended to lrl (may exceed the capacities)
-    uint32_t n_reads;         // workgroups stride over the reads (the tables and the zeroed rings are set up once per workgroup, not once per read)
+    uint32_t n_reads;         // the waves stride over the reads (the tables and the zeroed rings are set up once per workgroup, not once per read)
 };
 
 template <int CTRL, int ROW_MASK = 0xf>
@@ -132,32 +126,47 @@ __device__ __forceinline__ int32_t wave_incl_max_dpp(int32_t v, uint32_t lane)
     return v;
 }
 
-__global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
+// Every wave of the workgroup walks reads of its own, in tiles of 64 x 16 bytes, on rings of its own: the three tables are all the waves share, and there is no
+// barrier and no exchange between waves inside a read (r06; until then the two waves of a workgroup walked one read together in tiles of 2 KiB, with an exchange of
+// their counts through LDS and two barriers per tile: 3.14 -> 2.94 ms at 400 k reads, profiles/r08a_hpc_wave_per_read.txt).
+template <int NW>
+__global__ __launch_bounds__(NW * OATK_WAVE) void hpc_pack_kernel(HpcArgs a)
 {
-    __shared__ uint4 ring_rl4[HPC_RING / 16];      // run lengths, one byte per staged hoco position
-    __shared__ uint4 ring_hs4[HPC_RING / 64];      // 2-bit codes, 16 per word, MSB-first words (byte-swapped on the way out)
+    constexpr int NT = NW * OATK_WAVE;
+    constexpr int TILE = OATK_WAVE * HPC_BPT;       // bytes a wave takes at a time
+    constexpr int RING = 2 * TILE;                  // staged hoco positions; > one tile + one unflushed 64-group
+    __shared__ uint4 ring_rl4_all[NW][RING / 16];   // run lengths, one byte per staged hoco position
+    __shared__ uint4 ring_hs4_all[NW][RING / 64];   // 2-bit codes, 16 per word, MSB-first words (byte-swapped on the way out)
     __shared__ uint8_t lut[256];
     __shared__ uint4 sq4[256];                      // the squeeze table, 4 KiB
     __shared__ uint64_t gap8[256];                  // the gap table, 2 KiB
-    __shared__ uint32_t w_cnt[HPC_NT / OATK_WAVE];
-    __shared__ int32_t w_max[HPC_NT / OATK_WAVE];
-    __shared__ uint32_t s_nn, s_lrl;
+    __shared__ uint32_t s_rare[NW][2];              // ambiguous bases, runs > 255 of the wave's read
 
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    uint4 *ring_rl4 = ring_rl4_all[wid], *ring_hs4 = ring_hs4_all[wid];
+    uint32_t &s_nn = s_rare[wid][0], &s_lrl = s_rare[wid][1];
     uint8_t *ring_rl = (uint8_t *) ring_rl4;
     uint32_t *ring_hs = (uint32_t *) ring_hs4;
 
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    for (uint32_t i = tid; i < 256; i += HPC_NT) {
+    for (uint32_t i = tid; i < 256; i += NT) {
         lut[i] = (uint8_t) nt4_code(i);
         sq4[i] = ((const uint4 *) hpc_squeeze_tab.v)[i];
         gap8[i] = hpc_gap_tab.v[i];
     }
     const uint8_t *sq = (const uint8_t *) sq4;
-    for (uint32_t i = tid; i < HPC_RING / 16; i += HPC_NT) ring_hs[i] = 0;
-    for (uint32_t i = tid; i < HPC_RING / 16; i += HPC_NT) ring_rl4[i] = make_uint4(0, 0, 0, 0);      // runs of one base (most) never write their 0
+    for (uint32_t i = tid; i < NW * RING / 64; i += NT) (&ring_hs4_all[0][0])[i] = make_uint4(0, 0, 0, 0);
+    for (uint32_t i = tid; i < NW * RING / 16; i += NT) (&ring_rl4_all[0][0])[i] = make_uint4(0, 0, 0, 0);      // runs of one base (most) never write their 0
     // (a read leaves the rings as it found them: what is flushed is zeroed, and everything staged is flushed at the read's end)
+    __syncthreads();
+    // between the lanes of the wave: what one wrote to LDS the others may read behind this (the wave's LDS operations are carried out in the order they were issued;
+    // this keeps the compiler from changing that order)
+    auto sync = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
 
-    for (uint32_t r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
+    for (uint32_t r = blockIdx.x * NW + wid; r < a.n_reads; r += gridDim.x * NW) {
     const uint64_t o = a.off[r];
     const uint32_t L = a.len[r];
     const uint64_t sid = a.sid0 + r;
@@ -165,21 +174,21 @@ __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
     uint8_t *out_rl = a.ho_rl + o;
     uint8_t *out_hs = a.hoco_s + (o >> 2);
     uint32_t *out_nb = a.nbits + (o >> 5);
-    if (tid == 0) s_nn = 0, s_lrl = 0;
+    if (lane == 0) s_nn = 0, s_lrl = 0;
 
     // move finished 64-position groups [g0, g1) from the LDS ring to HBM as 16-byte stores: four vectors of run lengths per group
     // (consecutive in the ring and in HBM alike), then one vector of codes per group; what leaves is zeroed for its next use
     auto flush = [&](uint32_t g0, uint32_t g1) {
         const uint32_t n_rl = (g1 - g0) * 4u, n_item = n_rl + (g1 - g0);
-        for (uint32_t it = tid; it < n_item; it += HPC_NT) {
+        for (uint32_t it = lane; it < n_item; it += OATK_WAVE) {
             if (it < n_rl) {
                 const uint32_t idx = g0 * 4u + it;
-                ((uint4 *) out_rl)[idx] = ring_rl4[idx & (HPC_RING / 16 - 1)];
-                ring_rl4[idx & (HPC_RING / 16 - 1)] = make_uint4(0, 0, 0, 0);
+                ((uint4 *) out_rl)[idx] = ring_rl4[idx & (RING / 16 - 1)];
+                ring_rl4[idx & (RING / 16 - 1)] = make_uint4(0, 0, 0, 0);
             } else {
                 const uint32_t g = g0 + (it - n_rl);
-                uint4 v = ring_hs4[g & (HPC_RING / 64 - 1)];
-                ring_hs4[g & (HPC_RING / 64 - 1)] = make_uint4(0, 0, 0, 0);
+                uint4 v = ring_hs4[g & (RING / 64 - 1)];
+                ring_hs4[g & (RING / 64 - 1)] = make_uint4(0, 0, 0, 0);
                 v.x = __builtin_bswap32(v.x), v.y = __builtin_bswap32(v.y), v.z = __builtin_bswap32(v.z), v.w = __builtin_bswap32(v.w);
                 ((uint4 *) out_hs)[g] = v;
             }
@@ -206,23 +215,21 @@ __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
 
     uint4 vnext = make_uint4(0, 0, 0, 0);
     uint32_t upnext = 0;      // lane 0 of a wave: the byte before the wave's first (the other lanes get theirs from their neighbour)
-    if (tid * HPC_BPT < L) vnext = *(const uint4 *) (in + tid * HPC_BPT);
-    if (lane == 0 && tid && tid * HPC_BPT <= L) upnext = in[tid * HPC_BPT - 1];
-    __syncthreads();
+    if (lane * HPC_BPT < L) vnext = *(const uint4 *) (in + lane * HPC_BPT);
 
-    for (uint32_t t0 = 0; t0 < L; t0 += HPC_TILE) {
-        const uint32_t b0 = t0 + tid * HPC_BPT;
+    for (uint32_t t0 = 0; t0 < L; t0 += TILE) {
+        const uint32_t b0 = t0 + lane * HPC_BPT;
         const uint4 v = vnext;
         uint32_t upb = hpc_dpp<0x138>(0u, v.w >> 24);                             // wave_shr:1 -- the previous lane's last byte
         if (lane == 0) upb = upnext;
-        if (b0 + HPC_TILE < L) vnext = *(const uint4 *) (in + b0 + HPC_TILE);      // next tile's bytes, in flight while this one is processed
-        if (lane == 0 && b0 + HPC_TILE <= L) upnext = in[b0 + HPC_TILE - 1];
+        if (b0 + TILE < L) vnext = *(const uint4 *) (in + b0 + TILE);      // next tile's bytes, in flight while this one is processed
+        if (lane == 0 && b0 + TILE <= L) upnext = in[b0 + TILE - 1];
         const int nvalid = b0 < L? (int) (L - b0 < (uint32_t) HPC_BPT? L - b0 : (uint32_t) HPC_BPT) : 0;
 #if OATK_HPC_EXP == 1
         // (timing experiment: the kernel's HBM traffic and nothing else -- 16 bytes in, 12 bytes of "run lengths" and 3 of "codes" out per lane)
         if (b0 < L) {
             *(uint3 *) (out_rl + (size_t) (b0 / 16) * 12) = make_uint3(v.x, v.y, v.z);
-            if ((tid & 3) == 0) *(uint3 *) (out_hs + (size_t) (b0 / 64) * 12) = make_uint3(v.w, v.x, v.y);
+            if ((lane & 3) == 0) *(uint3 *) (out_hs + (size_t) (b0 / 64) * 12) = make_uint3(v.w, v.x, v.y);
         }
         continue;
 #endif
@@ -309,29 +316,19 @@ __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
         }
         const uint32_t cnt = __builtin_popcount(smask);
         const int32_t lpos = smask? (int32_t) (b0 + 31 - __builtin_clz(smask)) : -1;
-        // ---- workgroup scan: run starts before this lane, and the position of the latest one ----
+        // ---- wave scan: run starts before this lane, and the position of the latest one ----
         const uint32_t icnt = wave_incl_sum_dpp(cnt, lane);
         // latest start at or before this lane: positions grow with the lane, so when every lane holds a start (always, outside
         // homopolymers of 16+ bases and the tail of the read) it is the lane's own
         const int32_t imax = __ballot(lpos < 0)? wave_incl_max_dpp(lpos, lane) : lpos;
-        if (lane == 63) w_cnt[wid] = icnt, w_max[wid] = imax;
-        __syncthreads();
+        // the tile's totals are lane 63's: scalar registers
+        const uint32_t tot = (uint32_t) __builtin_amdgcn_readlane((int) icnt, 63);
+        const int32_t wmax = __builtin_amdgcn_readlane(imax, 63), tmax = wmax > last_start? wmax : last_start;
+        sync();                     // (the flush of the tile before zeroed ring slots: the wave's LDS operations stay in this order)
         int32_t ls = (int32_t) hpc_dpp<0x138>((uint32_t) -1, (uint32_t) imax);   // wave_shr:1 -> the previous lane's inclusive max
         if (lane == 0) ls = -1;
-        // the other waves' totals are the same for every lane: scalar registers and scalar arithmetic
-        const uint32_t swid = (uint32_t) __builtin_amdgcn_readfirstlane((int) wid);
-        uint32_t before = 0, tot = 0;
-        int32_t mbefore = last_start, tmax = last_start;
-#pragma unroll
-        for (uint32_t ww = 0; ww < HPC_NT / OATK_WAVE; ++ww) {
-            const uint32_t c = (uint32_t) __builtin_amdgcn_readfirstlane((int) w_cnt[ww]);
-            const int32_t m = __builtin_amdgcn_readfirstlane(w_max[ww]);
-            if (ww < swid) { before += c; mbefore = m > mbefore? m : mbefore; }
-            tot += c;
-            tmax = m > tmax? m : tmax;
-        }
-        const uint32_t n = nstart + before + icnt - cnt;
-        if (mbefore > ls) ls = mbefore;
+        const uint32_t n = nstart + icnt - cnt;
+        if (last_start > ls) ls = last_start;
         // ---- a run is finished when the next one starts: this lane finishes one run per start it holds ----
         if (smask) {
             // hoco index of the run finished by the k-th start of this lane: (n + k) - 1; the very first start of a
@@ -366,10 +363,10 @@ __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
                 const uint32_t hfirst = n - 1u + (b0 == 0? 1u : 0u);
                 const uint32_t off = (hfirst & 15u) * 2u;
                 const uint64_t sh = ((uint64_t) rv << 32) >> off;
-                const uint32_t w0 = (hfirst & (HPC_RING - 1)) >> 4;
+                const uint32_t w0 = (hfirst & (RING - 1)) >> 4;
                 const uint32_t hiw = (uint32_t) (sh >> 32), low = (uint32_t) sh;
                 if (hiw) atomicOr(&ring_hs[w0], hiw);
-                if (low) atomicOr(&ring_hs[(w0 + 1) & (HPC_RING / 16 - 1)], low);
+                if (low) atomicOr(&ring_hs[(w0 + 1) & (RING / 16 - 1)], low);
                 // the run that enters the lane from the left ends at the lane's first start: the only one that can be long
                 const uint32_t bf = (uint32_t) __builtin_ctz(smask);
                 uint32_t first = 0;                                        // its length - 1, clamped (0 for the start at position 0 of the read)
@@ -396,16 +393,16 @@ __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
                     const uint64_t H0 = (uint64_t) (uint32_t) ghi << t, H1 = (ghi >> 32) << t;
                     const uint32_t l0 = (uint32_t) L0, l1 = (uint32_t) (L0 >> 32) | (uint32_t) L1, l2 = (uint32_t) (L1 >> 32);
                     const uint32_t g0 = (uint32_t) H0, g1 = (uint32_t) (H0 >> 32) | (uint32_t) H1, g2 = (uint32_t) (H1 >> 32);
-                    const uint32_t ab = h0 & (uint32_t) (HPC_RING - 1) & ~3u;                              // byte address of the first word
+                    const uint32_t ab = h0 & (uint32_t) (RING - 1) & ~3u;                              // byte address of the first word
 #if OATK_HPC_EXP == 2
                     if (a.n_reads == 0xFFFFFFFFu)               // (timing experiment: no run lengths into the ring)
 #endif
-                    if (ab <= (uint32_t) HPC_RING - 24u) {                                                 // (five words at most)
+                    if (ab <= (uint32_t) RING - 24u) {                                                 // (five words at most)
                         uint32_t *pl = (uint32_t *) ((char *) ring_rl4 + ab), *ph = (uint32_t *) ((char *) ring_rl4 + ab + q4);
                         atomicOr(pl, l0), atomicOr(pl + 1, l1), atomicOr(pl + 2, l2);
                         atomicOr(ph, g0), atomicOr(ph + 1, g1), atomicOr(ph + 2, g2);
                     } else {                                                                                // ... that wrap around the ring
-                        auto at = [&](uint32_t b) -> uint32_t * { return (uint32_t *) ((char *) ring_rl4 + (b & (uint32_t) (HPC_RING - 1))); };
+                        auto at = [&](uint32_t b) -> uint32_t * { return (uint32_t *) ((char *) ring_rl4 + (b & (uint32_t) (RING - 1))); };
                         atomicOr(at(ab), l0), atomicOr(at(ab + 4u), l1), atomicOr(at(ab + 8u), l2);
                         atomicOr(at(ab + q4), g0), atomicOr(at(ab + q4 + 4u), g1), atomicOr(at(ab + q4 + 8u), g2);
                     }
@@ -427,7 +424,7 @@ __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
                 }
             }
         }
-        __syncthreads();
+        sync();
         nstart += tot;
         last_start = tmax;
         const uint32_t done = nstart? (nstart - 1u) >> 6 : 0u;   // complete 64-groups among finished runs
@@ -436,24 +433,23 @@ __global__ __launch_bounds__(HPC_NT) void hpc_pack_kernel(HpcArgs a)
 #endif
         flush(flushed, done);
         flushed = done;
-        // (no barrier here: the next tile writes to the rings only behind ITS first barrier, which every wave reaches after this flush; what it
-        //  zeroes and what the next tile fills are different 64-groups, and the per-wave totals are not touched before that barrier either)
+        // (what this zeroes and what the next tile fills are different 64-groups)
     }
     // the last run ends with the read
-    if (tid == 0 && nstart) {
+    if (lane == 0 && nstart) {
         const uint32_t h = nstart - 1u, rl = L - (uint32_t) last_start, c = lut[in[L - 1]];
-        ring_rl[h & (HPC_RING - 1)] = (uint8_t) ((rl > 256u? 256u : rl) - 1u);
-        if (c & 3u & (c < 4u? 3u : 0u)) atomicOr(&ring_hs[(h & (HPC_RING - 1)) >> 4], (c & 3u) << (30u - 2u * (h & 15u)));
+        ring_rl[h & (RING - 1)] = (uint8_t) ((rl > 256u? 256u : rl) - 1u);
+        if (c & 3u & (c < 4u? 3u : 0u)) atomicOr(&ring_hs[(h & (RING - 1)) >> 4], (c & 3u) << (30u - 2u * (h & 15u)));
         rare(h, (uint32_t) last_start, rl, c);
     }
-    __syncthreads();
+    sync();
     flush(flushed, (nstart + 63u) >> 6);
-    if (tid == 0) {
+    if (lane == 0) {
         a.hoco_l[r] = nstart;
         a.n_nn[r] = s_nn;
         a.n_lrl[r] = s_lrl;
     }
-    __syncthreads();          // the rings are clean and the counters read before the next read touches them
+    sync();                   // the rings are clean and the counters read before the next read touches them
     }
 }
 
