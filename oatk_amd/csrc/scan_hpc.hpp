@@ -28,13 +28,11 @@
 //  * runs longer than one base that begin and end inside the lane are at most 15 long: their loop carries no clamp and no
 //    overflow test; the one run that enters the lane from the left is handled before it.
 #pragma once
+#include <type_traits>
 #include "common.hpp"
 
 namespace oatk {
 
-#ifndef OATK_HPC_EXP
-#define OATK_HPC_EXP 0                    // timing experiments (development aid; results are wrong with any of them)
-#endif
 // r03p: 128 threads.  A read's last tile takes a tile's time however little of it lies inside the read (a 15 kb read is 3.7 tiles of 4 KiB: an eighth of the
 // kernel), two waves meet at the tile's two barriers sooner than four, and the rings shrink with the tile (11.3 KB with the tables: 14 workgroups = 28 waves per CU,
 // where the kernel is saturated): 3.50 -> 3.15 ms at 400 k reads; one wave per workgroup: 3.7 ms (18 waves per CU: the tables are 6.3 KB per workgroup).
@@ -142,7 +140,8 @@ __global__ __launch_bounds__(NW * OATK_WAVE) void hpc_pack_kernel(HpcArgs a)
     __shared__ uint64_t gap8[256];                  // the gap table, 2 KiB
     __shared__ uint32_t s_rare[NW][2];              // ambiguous bases, runs > 255 of the wave's read
 
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wid = (uint32_t) __builtin_amdgcn_readfirstlane((int) (tid >> 6));        // (a scalar: the read, its length and its addresses are the wave's)
     uint4 *ring_rl4 = ring_rl4_all[wid], *ring_hs4 = ring_hs4_all[wid];
     uint32_t &s_nn = s_rare[wid][0], &s_lrl = s_rare[wid][1];
     uint8_t *ring_rl = (uint8_t *) ring_rl4;
@@ -217,28 +216,23 @@ __global__ __launch_bounds__(NW * OATK_WAVE) void hpc_pack_kernel(HpcArgs a)
     uint32_t upnext = 0;      // lane 0 of a wave: the byte before the wave's first (the other lanes get theirs from their neighbour)
     if (lane * HPC_BPT < L) vnext = *(const uint4 *) (in + lane * HPC_BPT);
 
-    for (uint32_t t0 = 0; t0 < L; t0 += TILE) {
+    // one tile.  FULL: it lies inside the read and is not the read's first -- sixteen valid bytes in every lane and a byte before every lane, known when the code
+    // is compiled (r06: the tests for the read's two ends were a twelfth of the kernel's instructions; 2.94 -> 2.79 ms at 400 k reads)
+    auto tile = [&](const uint32_t t0, auto full_tag) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;
         const uint32_t b0 = t0 + lane * HPC_BPT;
         const uint4 v = vnext;
         uint32_t upb = hpc_dpp<0x138>(0u, v.w >> 24);                             // wave_shr:1 -- the previous lane's last byte
         if (lane == 0) upb = upnext;
         if (b0 + TILE < L) vnext = *(const uint4 *) (in + b0 + TILE);      // next tile's bytes, in flight while this one is processed
         if (lane == 0 && b0 + TILE <= L) upnext = in[b0 + TILE - 1];
-        const int nvalid = b0 < L? (int) (L - b0 < (uint32_t) HPC_BPT? L - b0 : (uint32_t) HPC_BPT) : 0;
-#if OATK_HPC_EXP == 1
-        // (timing experiment: the kernel's HBM traffic and nothing else -- 16 bytes in, 12 bytes of "run lengths" and 3 of "codes" out per lane)
-        if (b0 < L) {
-            *(uint3 *) (out_rl + (size_t) (b0 / 16) * 12) = make_uint3(v.x, v.y, v.z);
-            if ((lane & 3) == 0) *(uint3 *) (out_hs + (size_t) (b0 / 64) * 12) = make_uint3(v.w, v.x, v.y);
-        }
-        continue;
-#endif
+        const int nvalid = FULL? HPC_BPT : b0 < L? (int) (L - b0 < (uint32_t) HPC_BPT? L - b0 : (uint32_t) HPC_BPT) : 0;
 
         uint32_t smask = 0;       // run starts among the lane's sixteen positions
         uint32_t pf = 0;          // sixteen 2-bit fields: the code of the byte BEFORE position b in field b
         uint32_t cx = 0, cy = 0, up = 0;      // classes as nibbles, table path only (ambiguous bases need them further down)
-        bool slow = nvalid > 0 && nvalid < HPC_BPT;
-        const bool wave_slow = __ballot(slow) != 0;        // the wave with the read's last, partial vector takes the table path as a whole
+        bool slow = !FULL && nvalid > 0 && nvalid < HPC_BPT;
+        const bool wave_slow = !FULL && __ballot(slow) != 0;        // the wave with the read's last, partial vector takes the table path as a whole
         if (nvalid == HPC_BPT && wave_slow) slow = true;   // (it would run both paths otherwise)
         else if (nvalid == HPC_BPT) {
             // ---- all ACGTU?  index = byte & 7 into two 8-byte tables: the code, and the case-folded byte that has this code ----
@@ -258,7 +252,7 @@ __global__ __launch_bounds__(NW * OATK_WAVE) void hpc_pack_kernel(HpcArgs a)
             }
             f = __builtin_amdgcn_perm(__builtin_amdgcn_perm(pk[3], pk[2], 0x00000703u), __builtin_amdgcn_perm(pk[1], pk[0], 0x00000703u), 0x05040100u);      // the four top bytes, word 0's lowest
             uint32_t cu = 0;
-            if (b0) {
+            if (FULL || b0) {
                 const uint32_t sel = upb & 7u;
                 cu = __builtin_amdgcn_perm(TH, TL, sel) & 3u;
                 diff |= ((upb & 0xDFu) ^ __builtin_amdgcn_perm(EH, EL, sel)) & 0xFFu;
@@ -270,7 +264,7 @@ __global__ __launch_bounds__(NW * OATK_WAVE) void hpc_pack_kernel(HpcArgs a)
             s = (s | s >> 2) & 0x0F0F0F0Fu;
             s = (s | s >> 4) & 0x00FF00FFu;
             smask = (s | s >> 8) & 0xFFFFu;
-            if (b0 == 0) smask |= 1u;
+            if (!FULL && b0 == 0) smask |= 1u;
             slow = diff != 0;
         }
         if (slow) {
@@ -289,7 +283,7 @@ __global__ __launch_bounds__(NW * OATK_WAVE) void hpc_pack_kernel(HpcArgs a)
                 cc = (cc & keep) | (0x7777777777777777ULL & ~keep);
                 cx = (uint32_t) cc, cy = (uint32_t) (cc >> 32);
             }
-            if (b0 > 0) up = lut[upb & 0xffu];
+            if (FULL || b0 > 0) up = lut[upb & 0xffu];
             // run starts: class differs from the previous byte's, or the byte is ambiguous (class 4); nibble-parallel:
             // d = c ^ prev; start <=> d != 0 or c == 4; positions past the end (class 7) never start
             const uint32_t px = cx << 4 | up, py = cy << 4 | cx >> 28;
@@ -339,7 +333,7 @@ __global__ __launch_bounds__(NW * OATK_WAVE) void hpc_pack_kernel(HpcArgs a)
             //            start finish a longer run (a loop over ~3 set bits)
             const uint64_t cls64 = (uint64_t) cy << 32 | cx;               // zero unless the lane took the table path
             uint32_t fin = smask;                                          // starts that finish a run
-            if (b0 == 0) fin &= ~1u;
+            if (!FULL && b0 == 0) fin &= ~1u;
             uint32_t special = 0;
             if (slow) {     // an ambiguous byte (class 4) before a finishing start?
                 const uint64_t prevc = cls64 << 4 | up;                    // class of the byte before position b, nibble b
@@ -360,7 +354,7 @@ __global__ __launch_bounds__(NW * OATK_WAVE) void hpc_pack_kernel(HpcArgs a)
                 const uint32_t c1 = (uint32_t) __builtin_popcount(fin & 0xFu), c2 = (uint32_t) __builtin_popcount(fin & 0xFFu),
                                c3 = (uint32_t) __builtin_popcount(fin & 0xFFFu);
                 const uint32_t rv = t0b << 24 | t1b << (24u - 2u * c1) | t2b << (24u - 2u * c2) | t3b << (24u - 2u * c3);
-                const uint32_t hfirst = n - 1u + (b0 == 0? 1u : 0u);
+                const uint32_t hfirst = n - 1u + (!FULL && b0 == 0? 1u : 0u);
                 const uint32_t off = (hfirst & 15u) * 2u;
                 const uint64_t sh = ((uint64_t) rv << 32) >> off;
                 const uint32_t w0 = (hfirst & (RING - 1)) >> 4;
@@ -394,9 +388,6 @@ __global__ __launch_bounds__(NW * OATK_WAVE) void hpc_pack_kernel(HpcArgs a)
                     const uint32_t l0 = (uint32_t) L0, l1 = (uint32_t) (L0 >> 32) | (uint32_t) L1, l2 = (uint32_t) (L1 >> 32);
                     const uint32_t g0 = (uint32_t) H0, g1 = (uint32_t) (H0 >> 32) | (uint32_t) H1, g2 = (uint32_t) (H1 >> 32);
                     const uint32_t ab = h0 & (uint32_t) (RING - 1) & ~3u;                              // byte address of the first word
-#if OATK_HPC_EXP == 2
-                    if (a.n_reads == 0xFFFFFFFFu)               // (timing experiment: no run lengths into the ring)
-#endif
                     if (ab <= (uint32_t) RING - 24u) {                                                 // (five words at most)
                         uint32_t *pl = (uint32_t *) ((char *) ring_rl4 + ab), *ph = (uint32_t *) ((char *) ring_rl4 + ab + q4);
                         atomicOr(pl, l0), atomicOr(pl + 1, l1), atomicOr(pl + 2, l2);
@@ -428,13 +419,15 @@ __global__ __launch_bounds__(NW * OATK_WAVE) void hpc_pack_kernel(HpcArgs a)
         nstart += tot;
         last_start = tmax;
         const uint32_t done = nstart? (nstart - 1u) >> 6 : 0u;   // complete 64-groups among finished runs
-#if OATK_HPC_EXP == 3
-        if (a.n_reads == 0xFFFFFFFFu)                           // (timing experiment: nothing leaves the rings)
-#endif
         flush(flushed, done);
         flushed = done;
         // (what this zeroes and what the next tile fills are different 64-groups)
+    };
+    for (uint32_t t0 = 0; t0 < L; t0 += TILE) {
+        if (t0 && t0 + TILE <= L) tile(t0, std::true_type()); else tile(t0, std::false_type());
     }
+    // (tried, r06: two vectors per lane and tile, classified and finished one after the other by the same code, one scan and one prefetch for both --
+    //  79 registers and 27 KB of LDS for a tenth fewer instructions: 2.77 against 2.79 ms at 400 k reads, within the noise; profiles/r08e_*)
     // the last run ends with the read
     if (lane == 0 && nstart) {
         const uint32_t h = nstart - 1u, rl = L - (uint32_t) last_start, c = lut[in[L - 1]];
