@@ -59,6 +59,15 @@ const char *oatk_hip_last_error(oatk_hip_ctx *ctx);
 void *oatk_hip_stream(oatk_hip_ctx *ctx);
 int oatk_hip_sync(oatk_hip_ctx *ctx);
 
+/* Device memory in pieces, for a process that streams a file through the device (the drop-in CLI calls this before sr_read; nothing in the reference corresponds:
+ * it malloc's as it goes, syncmer.c:505-533).  From this call on the larger buffers of every handle of this process on ctx's device are address ranges backed by
+ * 64 MB pieces: they grow by mapping more pieces (no copy), a released buffer's pieces serve the next buffer (nothing returns to the driver before the process
+ * ends), and a thread of the pool's own takes `warm_bytes` of pieces from the driver ahead of the need.  Why: the driver clears memory when it hands it out for
+ * the first time since the GPU was reset (30 ms per GB inside the call) and clears what comes back behind the process's back while the next request for memory
+ * waits -- seconds at 2 M reads (tools/ubench/alloc_*.hip).  Results are the same bytes either way; OATK_POOL=0 makes the call do nothing.  Returns OATK_OK
+ * also where the device has no virtual-memory management (the buffers then stay hipMalloc's). */
+int oatk_hip_mem_pool(oatk_hip_ctx *ctx, uint64_t warm_bytes);
+
 /* largest k the device scan supports for a given s (LDS ring geometry); the reference asserts
  * 0 < s < 32 < ... < k (syncmer.c:251) */
 int oatk_hip_max_k(void);

@@ -45,7 +45,7 @@ EXPORTS = [
     "oatk_comm_unique_id", "oatk_comm_create", "oatk_comm_group_create", "oatk_comm_group_rank", "oatk_comm_group_destroy", "oatk_comm_destroy",
     "oatk_comm_rank", "oatk_comm_size", "oatk_comm_backend", "oatk_comm_traffic", "oatk_hip_merge_counts", "oatk_hip_multi_range", "oatk_hip_ec_sharded",
     "oatk_hip_gather_table", "oatk_hip_asm_graph_sharded", "oatk_hip_consensus_sharded", "oatk_hip_overlap_hist_sharded", "oatk_hip_stat_sharded",
-    "oatk_hip_scan_begin", "oatk_hip_scan_reserve", "oatk_hip_scan_append", "oatk_hip_device", "oatk_hip_d2d",
+    "oatk_hip_scan_begin", "oatk_hip_scan_reserve", "oatk_hip_scan_append", "oatk_hip_device", "oatk_hip_d2d", "oatk_hip_mem_pool",
     "oatk_hip_info", "oatk_hip_buffer", "oatk_hip_d2h", "oatk_hip_d2h_async", "oatk_hip_h2d_async", "oatk_hip_staging", "oatk_hip_ingest_text_buffer", "oatk_hip_set_timing", "oatk_hip_get_timing",
     "oatk_hip_debug_hash_mask", "oatk_hip_debug_force_general", "oatk_hip_debug_list_cap",
     "oatk_hip_ec_graph", "oatk_hip_ec_graph_light", "oatk_hip_ec", "oatk_hip_ec_stats", "oatk_hip_debug_ec_tiers", "oatk_hip_debug_wf_ed", "oatk_hip_debug_wf_ed_wg", "oatk_hip_ec_mark", "oatk_hip_ec_correct",
@@ -138,6 +138,7 @@ def load():
     L.oatk_hip_scan_reserve.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64]
     L.oatk_hip_scan_append.argtypes = [vp, vp]
     L.oatk_hip_device.argtypes = [vp]
+    L.oatk_hip_mem_pool.argtypes = [vp, C.c_uint64]
     L.oatk_hip_d2d.argtypes = [vp, vp, vp, C.c_uint64]
     L.oatk_hip_info.argtypes = [vp, C.POINTER(Info)]
     L.oatk_hip_buffer.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_uint64)]

@@ -9,7 +9,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <sys/mman.h>
+#include <condition_variable>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -24,15 +27,203 @@
 
 namespace {
 
+// OATK_DEBUG_ALLOC_LOG=1: every call into the driver for device memory on stderr, with its size and what it took (development aid)
+static int dev_alloc_log()
+{
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("OATK_DEBUG_ALLOC_LOG"); on = e && e[0] && e[0] != '0'; }
+    return on;
+}
+static double dev_now() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double) t.tv_sec + 1e-9 * (double) t.tv_nsec; }
+
+// ---- Device memory in pieces (oatk_hip_mem_pool, include/oatk_hip.h) ----
+// What the driver does with device memory (tools/ubench/alloc_*.hip, profiles/r08l_alloc_rates.txt): memory nobody has had since the GPU was reset is cleared when it
+// is handed out -- 30 ms per GB INSIDE hipMalloc / hipMemCreate --, memory a process gives back is cleared behind its back at ~33 GB/s, and the next call that wants
+// memory (of any size, from any process) waits until that is done.  A process that takes 50 GB for its batch at once therefore stands still for up to 1.5 s on a
+// fresh GPU, and one that gives a slab back and takes another stands still for the clearing of the first.  With a pool switched on the larger buffers of this process
+// are address ranges backed by 64 MB pieces (hipMemAddressReserve / hipMemCreate / hipMemMap): a buffer grows by mapping more pieces where it is (no copy, no
+// slack for growth), a buffer that is released hands its pieces to the next one (nothing goes back to the driver before the process ends), and a thread of the
+// pool's own takes pieces from the driver AHEAD of the need -- beside the host's work on the reads, which is what a reader that fills structs is bound by.
+constexpr size_t DM_CHUNK = 64ull << 20;          // a piece
+constexpr size_t DM_MIN = 32ull << 20;            // buffers below this stay hipMalloc's
+struct ChunkPool {
+    int device = -1;
+    bool on = false;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<hipMemGenericAllocationHandle_t> ready;       // pieces nobody has mapped
+    size_t created = 0, target = 0;                           // pieces taken from the driver so far; what the thread works towards
+    bool warming = false, stop = false, failed = false;
+    std::thread th;
+    hipMemAllocationProp prop;
+    hipMemAccessDesc acc;
+    double t_wait = 0;                                        // seconds callers stood waiting for a piece
+
+    bool create(hipMemGenericAllocationHandle_t *h)
+    {
+        const double t0 = dev_alloc_log()? dev_now() : 0;
+        const hipError_t e = hipMemCreate(h, DM_CHUNK, &prop, 0);
+        if (dev_alloc_log() && (e != hipSuccess || dev_now() - t0 > 0.01)) fprintf(stderr, "[oatk alloc] %.3f hipMemCreate %zu MB: %.4f s%s\n", dev_now(), DM_CHUNK >> 20, dev_now() - t0, e == hipSuccess? "" : " FAILED");
+        if (e != hipSuccess) (void) hipGetLastError();
+        return e == hipSuccess;
+    }
+    void run()
+    {
+        (void) hipSetDevice(device);
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                if (stop || created >= target) { warming = false; cv.notify_all(); return; }
+            }
+            hipMemGenericAllocationHandle_t h;
+            const bool ok = create(&h);
+            std::unique_lock<std::mutex> lk(mu);
+            if (!ok) { failed = true, warming = false; cv.notify_all(); return; }
+            ready.push_back(h), ++created;
+            cv.notify_all();
+        }
+    }
+    void warm(size_t bytes)
+    {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && bytes > fr / 10 * 7) bytes = fr / 10 * 7;        // (never more than most of what is free now)
+        std::unique_lock<std::mutex> lk(mu);
+        const size_t want = created + bytes / DM_CHUNK;                        // on top of what the process holds already
+        if (want > target) target = want;
+        if (!warming && !failed && created < target) {
+            if (th.joinable()) th.join();
+            warming = true;
+            th = std::thread([this] { run(); });
+        }
+    }
+    bool take(hipMemGenericAllocationHandle_t *h)
+    {
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            const double t0 = dev_now();
+            for (;;) {
+                if (!ready.empty()) { *h = ready.back(); ready.pop_back(); t_wait += dev_now() - t0; return true; }
+                if (warming && !failed && created < target) { cv.wait(lk); continue; }     // the thread is at it: two callers inside the driver would only take turns
+                break;
+            }
+            t_wait += dev_now() - t0;
+        }
+        if (!create(h)) return false;
+        std::unique_lock<std::mutex> lk(mu);
+        ++created;
+        return true;
+    }
+    void give(hipMemGenericAllocationHandle_t h)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        ready.push_back(h);
+    }
+    // what nobody has mapped goes back to the driver (a hipMalloc failed: the pool must not be the reason)
+    size_t trim()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        const size_t n = ready.size();
+        for (auto h : ready) (void) hipMemRelease(h);
+        ready.clear();
+        created -= n, target = created;
+        return n;
+    }
+    void end()                                                 // at exit, before the runtime's own handlers: no thread of ours inside the driver when they run
+    {
+        { std::unique_lock<std::mutex> lk(mu); stop = true; cv.notify_all(); }
+        if (th.joinable()) th.join();
+    }
+};
+static ChunkPool *g_pool[64];                                  // by device; made by oatk_hip_mem_pool, never destroyed
+static std::mutex g_pool_mu;
+static void pools_end() { for (ChunkPool *p : g_pool) if (p) p->end(); }
+static ChunkPool *pool_of_current_device()
+{
+    int d = -1;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return nullptr;
+    ChunkPool *p = g_pool[d];
+    return p && p->on? p : nullptr;
+}
+
+static hipError_t dev_malloc(void **p, size_t bytes)
+{
+    const double t0 = dev_alloc_log()? dev_now() : 0;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {
+        ChunkPool *pl = pool_of_current_device();
+        if (pl && pl->trim()) { (void) hipGetLastError(); e = hipMalloc(p, bytes); }
+    }
+    if (dev_alloc_log()) fprintf(stderr, "[oatk alloc] %.3f hipMalloc %10.3f MB: %.4f s%s\n", dev_now(), (double) bytes / 1e6, dev_now() - t0, e == hipSuccess? "" : " FAILED");
+    return e;
+}
+static void dev_free(void *p, size_t bytes)
+{
+    const double t0 = dev_alloc_log()? dev_now() : 0;
+    (void) hipFree(p);
+    if (dev_alloc_log()) fprintf(stderr, "[oatk alloc] %.3f hipFree   %10.3f MB: %.4f s\n", dev_now(), (double) bytes / 1e6, dev_now() - t0);
+}
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    // the form in pieces: p is an address range of `va` bytes, its first ch.size() * DM_CHUNK bytes backed
+    size_t va = 0;
+    ChunkPool *pool = nullptr;
+    std::vector<hipMemGenericAllocationHandle_t> ch;
+
+    static size_t up(size_t b) { return (b + DM_CHUNK - 1) / DM_CHUNK * DM_CHUNK; }
+    // an address range of at least `bytes`; what is mapped moves along (no copy).  false: nothing changed
+    bool vm_range(size_t bytes, hipStream_t st)
+    {
+        if (bytes <= va) return true;
+        const size_t nva = up(bytes < (1ull << 30)? 4 * bytes : bytes + bytes / 2 + (4ull << 30));     // room to grow in place: address space costs nothing
+        void *np = nullptr;
+        if (hipMemAddressReserve(&np, nva, 2 << 20, nullptr, 0) != hipSuccess) { (void) hipGetLastError(); return false; }
+        if (!ch.empty()) {
+            (void) hipStreamSynchronize(st);
+            (void) hipDeviceSynchronize();
+            for (size_t i = 0; i < ch.size(); ++i) {
+                (void) hipMemUnmap((char *) p + i * DM_CHUNK, DM_CHUNK);
+                if (hipMemMap((char *) np + i * DM_CHUNK, DM_CHUNK, 0, ch[i], 0) != hipSuccess) return false;       // (cannot happen on a range just reserved)
+            }
+            if (hipMemSetAccess(np, ch.size() * DM_CHUNK, &pool->acc, 1) != hipSuccess) return false;
+        }
+        if (p) (void) hipMemAddressFree(p, va);
+        if (dev_alloc_log()) fprintf(stderr, "[oatk alloc] %.3f address range %10.3f MB (%zu pieces moved)\n", dev_now(), (double) nva / 1e6, ch.size());
+        p = np, va = nva;
+        return true;
+    }
+    bool vm_grow(size_t bytes, hipStream_t st)
+    {
+        const size_t want = up(bytes);
+        if (!vm_range(want, st)) return false;
+        const size_t have = ch.size() * DM_CHUNK;
+        const double t0 = dev_alloc_log()? dev_now() : 0;
+        while (ch.size() * DM_CHUNK < want) {
+            hipMemGenericAllocationHandle_t h;
+            if (!pool->take(&h)) break;
+            if (hipMemMap((char *) p + ch.size() * DM_CHUNK, DM_CHUNK, 0, h, 0) != hipSuccess) { (void) hipGetLastError(); pool->give(h); break; }
+            ch.push_back(h);
+        }
+        const size_t now_b = ch.size() * DM_CHUNK;
+        if (now_b > have && hipMemSetAccess((char *) p + have, now_b - have, &pool->acc, 1) != hipSuccess) return false;
+        if (dev_alloc_log()) fprintf(stderr, "[oatk alloc] %.3f pieces    %10.3f MB -> %10.3f MB: %.4f s\n", dev_now(), (double) have / 1e6, (double) now_b / 1e6, dev_now() - t0);
+        cap = now_b;
+        return now_b >= want;
+    }
     bool ensure(size_t bytes, hipStream_t st, bool zero_new = false)
     {
         if (bytes <= cap) return true;
-        if (p) { (void) hipStreamSynchronize(st); (void) hipFree(p); p = nullptr; cap = 0; }
+        if (!va) pool = bytes >= DM_MIN? pool_of_current_device() : nullptr;
+        if (pool && p && !va) { (void) hipStreamSynchronize(st); dev_free(p, cap); p = nullptr; cap = 0; }      // (a small hipMalloc'ed buffer that has outgrown DM_MIN)
+        if (pool) {
+            if (!vm_grow(bytes + bytes / 16, st)) return false;
+            if (zero_new) (void) hipMemsetAsync(p, 0, cap, st);
+            return true;
+        }
+        if (p) { (void) hipStreamSynchronize(st); dev_free(p, cap); p = nullptr; cap = 0; }
         size_t want = bytes + bytes / 8 + 256;
-        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return false; }
+        if (dev_malloc(&p, want) != hipSuccess) { p = nullptr; return false; }
         cap = want;
         if (zero_new) (void) hipMemsetAsync(p, 0, want, st);
         return true;
@@ -41,16 +232,51 @@ struct DevBuf {
     bool grow_keep(size_t bytes, size_t used, hipStream_t st)
     {
         if (bytes <= cap) return true;
+        if (!va) pool = bytes >= DM_MIN? pool_of_current_device() : nullptr;
+        if (pool && p && !va) {                                     // from a hipMalloc'ed buffer to pieces: the one copy of this buffer's life
+            void *old = p;
+            const size_t old_cap = cap;
+            p = nullptr, cap = 0;
+            if (!vm_grow(bytes, st)) { release(); p = old, cap = old_cap, pool = nullptr; }
+            else {
+                if (used && hipMemcpyAsync(p, old, used, hipMemcpyDeviceToDevice, st) != hipSuccess) return false;
+                (void) hipStreamSynchronize(st);
+                dev_free(old, old_cap);
+                return true;
+            }
+        }
+        if (pool) return vm_grow(bytes, st);
         void *np = nullptr;
         size_t want = bytes + bytes / 4 + 256;
-        if (hipMalloc(&np, want) != hipSuccess) return false;
-        if (p && used && hipMemcpyAsync(np, p, used, hipMemcpyDeviceToDevice, st) != hipSuccess) { (void) hipFree(np); return false; }
+        if (dev_malloc(&np, want) != hipSuccess) return false;
+        if (p && used && hipMemcpyAsync(np, p, used, hipMemcpyDeviceToDevice, st) != hipSuccess) { dev_free(np, want); return false; }
         (void) hipStreamSynchronize(st);
-        if (p) (void) hipFree(p);
+        if (p) dev_free(p, cap);
         p = np, cap = want;
         return true;
     }
-    void release() { if (p) (void) hipFree(p); p = nullptr; cap = 0; }
+    // room for `bytes` LATER: in pieces that is an address range and nothing else (the pieces come as the buffer fills); otherwise the memory itself, now
+    bool reserve(size_t bytes, size_t used, hipStream_t st)
+    {
+        if (bytes <= cap) return true;
+        if (!va && !p) pool = bytes >= DM_MIN? pool_of_current_device() : nullptr;
+        if (pool && (va || !p)) return vm_range(up(bytes), st);
+        return grow_keep(bytes, used, st);
+    }
+    void release()
+    {
+        if (va) {
+            (void) hipDeviceSynchronize();
+            for (size_t i = 0; i < ch.size(); ++i) { (void) hipMemUnmap((char *) p + i * DM_CHUNK, DM_CHUNK); pool->give(ch[i]); }
+            ch.clear();
+            (void) hipMemAddressFree(p, va);
+            if (dev_alloc_log()) fprintf(stderr, "[oatk alloc] %.3f pieces    %10.3f MB back to the pool\n", dev_now(), (double) cap / 1e6);
+            p = nullptr, cap = 0, va = 0;
+            return;
+        }
+        if (p) dev_free(p, cap);
+        p = nullptr; cap = 0;
+    }
     template <class T> T *as() const { return (T *) p; }
 };
 
@@ -238,6 +464,38 @@ void oatk_hip_destroy(oatk_hip_ctx *ctx)
     staging_free(ctx);
     (void) hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+int oatk_hip_mem_pool(oatk_hip_ctx *ctx, uint64_t warm_bytes)
+{
+    if (!ctx) return OATK_E_NODEV;
+    { const char *e = getenv("OATK_POOL"); if (e && e[0] == '0') return OATK_OK; }      // (switch for comparisons: everything stays hipMalloc's)
+    CK(hipSetDevice(ctx->device));
+    if (ctx->device < 0 || ctx->device >= 64) return OATK_E_ARG;
+    ChunkPool *pl;
+    {
+        std::unique_lock<std::mutex> lk(g_pool_mu);
+        pl = g_pool[ctx->device];
+        if (!pl) {
+            int vmm = 0;
+            if (hipDeviceGetAttribute(&vmm, hipDeviceAttributeVirtualMemoryManagementSupported, ctx->device) != hipSuccess || !vmm) { (void) hipGetLastError(); return OATK_OK; }
+            pl = new ChunkPool();
+            pl->device = ctx->device;
+            memset(&pl->prop, 0, sizeof(pl->prop));
+            pl->prop.type = hipMemAllocationTypePinned;
+            pl->prop.location.type = hipMemLocationTypeDevice;
+            pl->prop.location.id = ctx->device;
+            memset(&pl->acc, 0, sizeof(pl->acc));
+            pl->acc.location = pl->prop.location;
+            pl->acc.flags = hipMemAccessFlagsProtReadWrite;
+            static bool at_exit = false;
+            if (!at_exit) { at_exit = true; atexit(pools_end); }
+            pl->on = true;
+            g_pool[ctx->device] = pl;
+        }
+    }
+    if (warm_bytes) pl->warm((size_t) warm_bytes);
+    return OATK_OK;
 }
 
 const char *oatk_hip_last_error(oatk_hip_ctx *ctx) { return ctx? ctx->err.c_str() : "no device context"; }
@@ -583,6 +841,15 @@ int oatk_hip_scan_reserve(oatk_hip_ctx *ctx, uint64_t seq_bytes, uint64_t n_read
     CK(hipSetDevice(ctx->device));
     if (!ctx->scanned || ctx->d_seq) { ctx->err = "oatk_hip_scan_reserve: call oatk_hip_scan_begin first"; return OATK_E_STATE; }
     seq_bytes = (seq_bytes + 63) & ~63ULL;
+    if (pool_of_current_device()) {
+        // in pieces (oatk_hip_mem_pool) the two large arrays only get their address ranges here; the pieces are mapped append by append, as the pool's thread delivers them
+        const uint64_t sb = ctx->seq_bytes + seq_bytes;
+        if (!ctx->ho_rl.reserve(sb + 64, ctx->seq_bytes, ctx->stream) || !ctx->hoco_s.reserve(sb / 4 + 128 + 16 + ctx->import_reserve, ctx->seq_bytes / 4 + 64, ctx->stream)) {
+            ctx->err = "oatk_hip_scan_reserve: no address range for the batch";
+            return OATK_E_NOMEM;
+        }
+        return OATK_OK;
+    }
     return append_ensure(ctx, ctx->n_reads + n_reads, ctx->seq_bytes + seq_bytes, ctx->n_occ + n_occ, ctx->tot_nn, ctx->tot_lrl);
 }
 

@@ -22,6 +22,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <time.h>
 
 #include "oatk_dropin.h"
@@ -196,6 +197,18 @@ void sr_read(dropin_sstream_t *s_stream, oatk_sr_db_t *sr_db, size_t mD, int n_t
     if (!why) {
         oatk_host_set_threads(n_threads);                                /* the struct filling uses as many host threads as the caller grants (-t) */
         oatk_sr_db_clean(sr_db);                                         /* syncmer.c:494-495: k and s stay */
+        if (!D.multi) {                                                  /* device memory in pieces, taken from the driver ahead of the need (include/oatk_hip.h) */
+            uint64_t text = 0;
+            int i;
+            for (i = 0; i < s_stream->n_files; ++i) {
+                struct stat sb;
+                const size_t ln = strlen(s_stream->files[i]);
+                if (stat(s_stream->files[i], &sb) == 0 && S_ISREG(sb.st_mode))
+                    text += (uint64_t) sb.st_size * (ln > 3 && strcmp(s_stream->files[i] + ln - 3, ".gz") == 0? 4u : 1u);
+            }
+            if (mD && text > (uint64_t) mD) text = (uint64_t) mD;
+            (void) oatk_hip_mem_pool(D.ctx, text + text + text / 2 + (2ull << 30));      /* the batch is ~1.6 bytes per base, scan pieces, count, correction and alignment on top */
+        }
         const int rc = D.multi? oatk_multi_sr_read_files_capped(D.multi, sr_db, s_stream->files, s_stream->n_files, (uint64_t) mD)
                               : oatk_sr_read_files_capped(D.ctx, sr_db, s_stream->files, s_stream->n_files, (uint64_t) mD);
         if (rc == OATK_OK) {

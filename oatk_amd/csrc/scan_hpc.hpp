@@ -143,7 +143,6 @@ __global__ __launch_bounds__(NW * OATK_WAVE) void hpc_pack_kernel(HpcArgs a)
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wid = (uint32_t) __builtin_amdgcn_readfirstlane((int) (tid >> 6));        // (a scalar: the read, its length and its addresses are the wave's)
     uint4 *ring_rl4 = ring_rl4_all[wid], *ring_hs4 = ring_hs4_all[wid];
-    uint32_t &s_nn = s_rare[wid][0], &s_lrl = s_rare[wid][1];
     uint8_t *ring_rl = (uint8_t *) ring_rl4;
     uint32_t *ring_hs = (uint32_t *) ring_hs4;
 
@@ -173,7 +172,7 @@ __global__ __launch_bounds__(NW * OATK_WAVE) void hpc_pack_kernel(HpcArgs a)
     uint8_t *out_rl = a.ho_rl + o;
     uint8_t *out_hs = a.hoco_s + (o >> 2);
     uint32_t *out_nb = a.nbits + (o >> 5);
-    if (lane == 0) s_nn = 0, s_lrl = 0;
+    if (lane == 0) s_rare[wid][0] = 0, s_rare[wid][1] = 0;
 
     // move finished 64-position groups [g0, g1) from the LDS ring to HBM as 16-byte stores: four vectors of run lengths per group
     // (consecutive in the ring and in HBM alike), then one vector of codes per group; what leaves is zeroed for its next use
@@ -198,13 +197,13 @@ __global__ __launch_bounds__(NW * OATK_WAVE) void hpc_pack_kernel(HpcArgs a)
         if (rl > 255u) {
             uint32_t idx = atomicAdd(&a.counters[1], 1u);
             if (idx < a.lrl_cap) a.lrl_key[idx] = sid << 32 | h, a.lrl_val[idx] = rl - 1u;
-            atomicAdd(&s_lrl, 1u);
+            atomicAdd(&s_rare[wid][1], 1u);
         }
         if (c == 4u) {
             atomicOr(&out_nb[h >> 5], 1u << (h & 31u));
             uint32_t idx = atomicAdd(&a.counters[0], 1u);
             if (idx < a.nn_cap) a.nn_key[idx] = sid << 32 | p0;
-            atomicAdd(&s_nn, 1u);
+            atomicAdd(&s_rare[wid][0], 1u);
         }
     };
 
@@ -216,10 +215,10 @@ __global__ __launch_bounds__(NW * OATK_WAVE) void hpc_pack_kernel(HpcArgs a)
     uint32_t upnext = 0;      // lane 0 of a wave: the byte before the wave's first (the other lanes get theirs from their neighbour)
     if (lane * HPC_BPT < L) vnext = *(const uint4 *) (in + lane * HPC_BPT);
 
-    // one tile.  FULL: it lies inside the read and is not the read's first -- sixteen valid bytes in every lane and a byte before every lane, known when the code
-    // is compiled (r06: the tests for the read's two ends were a twelfth of the kernel's instructions; 2.94 -> 2.79 ms at 400 k reads)
-    auto tile = [&](const uint32_t t0, auto full_tag) __attribute__((always_inline)) {
-        constexpr bool FULL = decltype(full_tag)::value;
+    // one tile.  FULL: it lies inside the read -- sixteen valid bytes in every lane; HP: it is not the read's first -- a byte before every lane; both known when the
+    // code is compiled (r06: the tests for the read's two ends were a twelfth of the kernel's instructions; 2.94 -> 2.79 ms at 400 k reads)
+    auto tile = [&](const uint32_t t0, auto full_tag, auto hp_tag) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value, HP = decltype(hp_tag)::value;
         const uint32_t b0 = t0 + lane * HPC_BPT;
         const uint4 v = vnext;
         uint32_t upb = hpc_dpp<0x138>(0u, v.w >> 24);                             // wave_shr:1 -- the previous lane's last byte
@@ -252,7 +251,7 @@ __global__ __launch_bounds__(NW * OATK_WAVE) void hpc_pack_kernel(HpcArgs a)
             }
             f = __builtin_amdgcn_perm(__builtin_amdgcn_perm(pk[3], pk[2], 0x00000703u), __builtin_amdgcn_perm(pk[1], pk[0], 0x00000703u), 0x05040100u);      // the four top bytes, word 0's lowest
             uint32_t cu = 0;
-            if (FULL || b0) {
+            if (HP || b0) {
                 const uint32_t sel = upb & 7u;
                 cu = __builtin_amdgcn_perm(TH, TL, sel) & 3u;
                 diff |= ((upb & 0xDFu) ^ __builtin_amdgcn_perm(EH, EL, sel)) & 0xFFu;
@@ -264,7 +263,7 @@ __global__ __launch_bounds__(NW * OATK_WAVE) void hpc_pack_kernel(HpcArgs a)
             s = (s | s >> 2) & 0x0F0F0F0Fu;
             s = (s | s >> 4) & 0x00FF00FFu;
             smask = (s | s >> 8) & 0xFFFFu;
-            if (!FULL && b0 == 0) smask |= 1u;
+            if (!HP && b0 == 0) smask |= 1u;
             slow = diff != 0;
         }
         if (slow) {
@@ -283,7 +282,7 @@ __global__ __launch_bounds__(NW * OATK_WAVE) void hpc_pack_kernel(HpcArgs a)
                 cc = (cc & keep) | (0x7777777777777777ULL & ~keep);
                 cx = (uint32_t) cc, cy = (uint32_t) (cc >> 32);
             }
-            if (FULL || b0 > 0) up = lut[upb & 0xffu];
+            if (HP || b0 > 0) up = lut[upb & 0xffu];
             // run starts: class differs from the previous byte's, or the byte is ambiguous (class 4); nibble-parallel:
             // d = c ^ prev; start <=> d != 0 or c == 4; positions past the end (class 7) never start
             const uint32_t px = cx << 4 | up, py = cy << 4 | cx >> 28;
@@ -333,7 +332,7 @@ __global__ __launch_bounds__(NW * OATK_WAVE) void hpc_pack_kernel(HpcArgs a)
             //            start finish a longer run (a loop over ~3 set bits)
             const uint64_t cls64 = (uint64_t) cy << 32 | cx;               // zero unless the lane took the table path
             uint32_t fin = smask;                                          // starts that finish a run
-            if (!FULL && b0 == 0) fin &= ~1u;
+            if (!HP && b0 == 0) fin &= ~1u;
             uint32_t special = 0;
             if (slow) {     // an ambiguous byte (class 4) before a finishing start?
                 const uint64_t prevc = cls64 << 4 | up;                    // class of the byte before position b, nibble b
@@ -354,7 +353,7 @@ __global__ __launch_bounds__(NW * OATK_WAVE) void hpc_pack_kernel(HpcArgs a)
                 const uint32_t c1 = (uint32_t) __builtin_popcount(fin & 0xFu), c2 = (uint32_t) __builtin_popcount(fin & 0xFFu),
                                c3 = (uint32_t) __builtin_popcount(fin & 0xFFFu);
                 const uint32_t rv = t0b << 24 | t1b << (24u - 2u * c1) | t2b << (24u - 2u * c2) | t3b << (24u - 2u * c3);
-                const uint32_t hfirst = n - 1u + (!FULL && b0 == 0? 1u : 0u);
+                const uint32_t hfirst = n - 1u + (!HP && b0 == 0? 1u : 0u);
                 const uint32_t off = (hfirst & 15u) * 2u;
                 const uint64_t sh = ((uint64_t) rv << 32) >> off;
                 const uint32_t w0 = (hfirst & (RING - 1)) >> 4;
@@ -424,7 +423,8 @@ __global__ __launch_bounds__(NW * OATK_WAVE) void hpc_pack_kernel(HpcArgs a)
         // (what this zeroes and what the next tile fills are different 64-groups)
     };
     for (uint32_t t0 = 0; t0 < L; t0 += TILE) {
-        if (t0 && t0 + TILE <= L) tile(t0, std::true_type()); else tile(t0, std::false_type());
+        if (t0 && t0 + TILE <= L) tile(t0, std::true_type(), std::true_type()); else tile(t0, std::false_type(), std::false_type());
+        // (a third form for a read's first tile -- FULL, not HP -- takes 79 registers for the three of them: six waves per SIMD instead of eight)
     }
     // (tried, r06: two vectors per lane and tile, classified and finished one after the other by the same code, one scan and one prefetch for both --
     //  79 registers and 27 KB of LDS for a tenth fewer instructions: 2.77 against 2.79 ms at 400 k reads, within the noise; profiles/r08e_*)
@@ -439,8 +439,8 @@ __global__ __launch_bounds__(NW * OATK_WAVE) void hpc_pack_kernel(HpcArgs a)
     flush(flushed, (nstart + 63u) >> 6);
     if (lane == 0) {
         a.hoco_l[r] = nstart;
-        a.n_nn[r] = s_nn;
-        a.n_lrl[r] = s_lrl;
+        a.n_nn[r] = s_rare[wid][0];
+        a.n_lrl[r] = s_rare[wid][1];
     }
     sync();                   // the rings are clean and the counters read before the next read touches them
     }

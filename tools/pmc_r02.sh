@@ -54,7 +54,7 @@ try:
         if ("oatk::" in k or "ec_" in k) and r["Dispatch_Id"] in dur:
             agg[k].append((int(r["Grid_Size"]) if "Grid_Size" in r else 0, float(r["Counter_Value"]), dur[r["Dispatch_Id"]]))
     out = open("$O/${TAG}_pmc_clock_config3.csv", "w")
-    out.write('kernel,GRBM_GUI_ACTIVE_per_dispatch,duration_ns_per_dispatch,GHz,"note: tools/pmc_r02.sh, bench.py config3, the dispatches with the largest grid of each kernel; kernels of >= 1 ms only (the counter is per dispatch, its window a little wider than the kernel); rocprofv3 reports the SUM over the part's eight XCDs (one GRBM each), so GHz = counter / 8 / duration"\n')
+    out.write('kernel,GRBM_GUI_ACTIVE_per_dispatch,duration_ns_per_dispatch,GHz,"note: tools/pmc_r02.sh, bench.py config3, the dispatches with the largest grid of each kernel; kernels of >= 1 ms only (the counter is per dispatch, its window a little wider than the kernel); rocprofv3 reports the SUM over the eight XCDs of the part (one GRBM each), so GHz = counter / 8 / duration"\n')
     for k, v in sorted(agg.items(), key=lambda kv: -max(x[2] for x in kv[1])):
         g = max(x[0] for x in v)
         big = [x for x in v if x[0] == g]

@@ -8,13 +8,13 @@ cd /tmp && export TMPDIR=/tmp
 CMD="python $R/tools/memcap.py --rss-gb 200 --timeout 500 -- python $R/tools/solverbench.py --workload config1s --reads $N --reps 1"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o t -- $CMD > $O/stats.log 2>&1; echo "stats rc=$?"
 f=$(find $O/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${TAG}_config1s_kernel_stats.csv && head -12 $f
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $O/a -o p -- $CMD > $O/a.log 2>&1; echo "pmc a rc=$?"
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA --output-format csv -d $O/b -o p -- $CMD > $O/b.log 2>&1; echo "pmc b rc=$?"
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $O/c1s_a -o p -- $CMD > $O/c1s_a.log 2>&1; echo "pmc a rc=$?"
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA --output-format csv -d $O/c1s_b -o p -- $CMD > $O/c1s_b.log 2>&1; echo "pmc b rc=$?"
 python - <<PY
 import csv, collections, glob
 out = open("$O/${TAG}_config1s_pmc_ec.csv", "w")
 out.write('kernel,counter,"sum over dispatches (tools/prof_config1s.sh: tools/solverbench.py --workload config1s --reads $N --reps 1; rocprofv3 --kernel-trace --pmc, two passes)"\n')
-for d in "ab":
+for d in ("c1s_a", "c1s_b"):
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     for fn in glob.glob("$O/%s/**/p_counter_collection.csv" % d, recursive=True):
         for r in csv.DictReader(open(fn)):
