@@ -10,11 +10,13 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <execinfo.h>
 #include <sys/mman.h>
 #include <condition_variable>
 #include <mutex>
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../include/oatk_hip.h"
@@ -45,13 +47,19 @@ static double dev_now() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
 // slack for growth), a buffer that is released hands its pieces to the next one (nothing goes back to the driver before the process ends), and a thread of the
 // pool's own takes pieces from the driver AHEAD of the need -- beside the host's work on the reads, which is what a reader that fills structs is bound by.
 constexpr size_t DM_CHUNK = 64ull << 20;          // a piece
-constexpr size_t DM_MIN = 32ull << 20;            // buffers below this stay hipMalloc's
+static size_t dm_min()                             // buffers below this stay hipMalloc's (32 MB; OATK_DEBUG_POOL_MIN: tests put small buffers into pieces too)
+{
+    static size_t v = 0;
+    if (!v) { const char *e = getenv("OATK_DEBUG_POOL_MIN"); v = e && atoll(e) > 0? (size_t) atoll(e) : (32ull << 20); }
+    return v;
+}
 struct ChunkPool {
     int device = -1;
     bool on = false;
     std::mutex mu;
     std::condition_variable cv;
-    std::vector<hipMemGenericAllocationHandle_t> ready;       // pieces nobody has mapped
+    std::vector<hipMemGenericAllocationHandle_t> ready;       // pieces nobody has mapped ...
+    std::vector<char> used;                                   // ... and whether a buffer has had them (what the driver hands out is zero, and so is what a buffer gets: vm_grow)
     size_t created = 0, target = 0;                           // pieces taken from the driver so far; what the thread works towards
     bool warming = false, stop = false, failed = false;
     std::thread th;
@@ -79,7 +87,7 @@ struct ChunkPool {
             const bool ok = create(&h);
             std::unique_lock<std::mutex> lk(mu);
             if (!ok) { failed = true, warming = false; cv.notify_all(); return; }
-            ready.push_back(h), ++created;
+            ready.push_back(h), used.push_back(0), ++created;
             cv.notify_all();
         }
     }
@@ -96,13 +104,14 @@ struct ChunkPool {
             th = std::thread([this] { run(); });
         }
     }
-    bool take(hipMemGenericAllocationHandle_t *h)
+    bool take(hipMemGenericAllocationHandle_t *h, bool *was_used)
     {
+        *was_used = false;
         {
             std::unique_lock<std::mutex> lk(mu);
             const double t0 = dev_now();
             for (;;) {
-                if (!ready.empty()) { *h = ready.back(); ready.pop_back(); t_wait += dev_now() - t0; return true; }
+                if (!ready.empty()) { *h = ready.back(), *was_used = used.back() != 0; ready.pop_back(), used.pop_back(); t_wait += dev_now() - t0; return true; }
                 if (warming && !failed && created < target) { cv.wait(lk); continue; }     // the thread is at it: two callers inside the driver would only take turns
                 break;
             }
@@ -116,7 +125,7 @@ struct ChunkPool {
     void give(hipMemGenericAllocationHandle_t h)
     {
         std::unique_lock<std::mutex> lk(mu);
-        ready.push_back(h);
+        ready.push_back(h), used.push_back(1);
     }
     // what nobody has mapped goes back to the driver (a hipMalloc failed: the pool must not be the reason)
     size_t trim()
@@ -124,7 +133,7 @@ struct ChunkPool {
         std::unique_lock<std::mutex> lk(mu);
         const size_t n = ready.size();
         for (auto h : ready) (void) hipMemRelease(h);
-        ready.clear();
+        ready.clear(), used.clear();
         created -= n, target = created;
         return n;
     }
@@ -144,6 +153,23 @@ static ChunkPool *pool_of_current_device()
     ChunkPool *p = g_pool[d];
     return p && p->on? p : nullptr;
 }
+// (development aid) OATK_DEBUG_POOL_SEQ="lo:hi": only the lo-th .. (hi-1)-th decisions of a buffer to live in pieces are taken; the others stay hipMalloc's
+static ChunkPool *pool_for_new_buffer()
+{
+    ChunkPool *p = pool_of_current_device();
+    if (!p) return nullptr;
+    static long lo = -1, hi = -1, seq = 0;
+    if (lo < 0) { const char *e = getenv("OATK_DEBUG_POOL_SEQ"); lo = 0, hi = 1L << 60; if (e) sscanf(e, "%ld:%ld", &lo, &hi); }
+    const long k = seq++;
+    if (dev_alloc_log()) {
+        void *bt[6];
+        const int nb = backtrace(bt, 6);
+        char **sy = backtrace_symbols(bt, nb);
+        fprintf(stderr, "[oatk alloc] decision %ld%s  <- %s <- %s <- %s\n", k, k >= lo && k < hi? "" : " (hipMalloc)", nb > 2? sy[2] : "", nb > 3? sy[3] : "", nb > 4? sy[4] : "");
+        free(sy);
+    }
+    return k >= lo && k < hi? p : nullptr;
+}
 
 static hipError_t dev_malloc(void **p, size_t bytes)
 {
@@ -154,6 +180,11 @@ static hipError_t dev_malloc(void **p, size_t bytes)
         if (pl && pl->trim()) { (void) hipGetLastError(); e = hipMalloc(p, bytes); }
     }
     if (dev_alloc_log()) fprintf(stderr, "[oatk alloc] %.3f hipMalloc %10.3f MB: %.4f s%s\n", dev_now(), (double) bytes / 1e6, dev_now() - t0, e == hipSuccess? "" : " FAILED");
+    {   // OATK_DEBUG_POISON=1 (tests): new memory is 0xA5 all over instead of the driver's zeros -- whatever relies on zeros it did not write shows
+        static int poison = -1;
+        if (poison < 0) { const char *ev = getenv("OATK_DEBUG_POISON"); poison = ev && ev[0] == '1'; }
+        if (poison && e == hipSuccess) { (void) hipMemset(*p, 0xA5, bytes); (void) hipDeviceSynchronize(); }
+    }
     return e;
 }
 static void dev_free(void *p, size_t bytes)
@@ -169,6 +200,7 @@ struct DevBuf {
     // the form in pieces: p is an address range of `va` bytes, its first ch.size() * DM_CHUNK bytes backed
     size_t va = 0;
     ChunkPool *pool = nullptr;
+    bool decided = false;                     // whether this buffer lives in pieces was settled (at its first request of the threshold's size)
     std::vector<hipMemGenericAllocationHandle_t> ch;
 
     static size_t up(size_t b) { return (b + DM_CHUNK - 1) / DM_CHUNK * DM_CHUNK; }
@@ -176,7 +208,7 @@ struct DevBuf {
     bool vm_range(size_t bytes, hipStream_t st)
     {
         if (bytes <= va) return true;
-        const size_t nva = up(bytes < (1ull << 30)? 4 * bytes : bytes + bytes / 2 + (4ull << 30));     // room to grow in place: address space costs nothing
+        const size_t nva = up(bytes < (1ull << 30)? 4 * bytes + (256ull << 20) : bytes + bytes / 2 + (2ull << 30));     // room to grow in place
         void *np = nullptr;
         if (hipMemAddressReserve(&np, nva, 2 << 20, nullptr, 0) != hipSuccess) { (void) hipGetLastError(); return false; }
         if (!ch.empty()) {
@@ -188,7 +220,11 @@ struct DevBuf {
             }
             if (hipMemSetAccess(np, ch.size() * DM_CHUNK, &pool->acc, 1) != hipSuccess) return false;
         }
-        if (p) (void) hipMemAddressFree(p, va);
+        // An address range, once reserved, is never given back while the process lives -- not the one the pieces have just moved out of, not a released buffer's.
+        // With hipMemAddressFree in either place a range reserved LATER (at the same addresses, presumably) showed other contents than were written to it: the
+        // correction's results changed in 8 - 14 of 158 cases of tests/test_gpu_ec.py + levdist + light_graph + overlap run over pieces, every run, and in none with the
+        // ranges kept (ROCm 7.0.2; translations of the old mapping that outlive it is the guess, not looked into further).  Address space is what this costs: a buffer's
+        // range is a few times its size, a process of the CLI has some hundreds of such buffers in its life -- a terabyte of a 47-bit space at the outside.
         if (dev_alloc_log()) fprintf(stderr, "[oatk alloc] %.3f address range %10.3f MB (%zu pieces moved)\n", dev_now(), (double) nva / 1e6, ch.size());
         p = np, va = nva;
         return true;
@@ -199,14 +235,20 @@ struct DevBuf {
         if (!vm_range(want, st)) return false;
         const size_t have = ch.size() * DM_CHUNK;
         const double t0 = dev_alloc_log()? dev_now() : 0;
+        bool any_used = false;
         while (ch.size() * DM_CHUNK < want) {
             hipMemGenericAllocationHandle_t h;
-            if (!pool->take(&h)) break;
+            bool was_used;
+            if (!pool->take(&h, &was_used)) break;
             if (hipMemMap((char *) p + ch.size() * DM_CHUNK, DM_CHUNK, 0, h, 0) != hipSuccess) { (void) hipGetLastError(); pool->give(h); break; }
             ch.push_back(h);
+            any_used |= was_used;
         }
         const size_t now_b = ch.size() * DM_CHUNK;
         if (now_b > have && hipMemSetAccess((char *) p + have, now_b - have, &pool->acc, 1) != hipSuccess) return false;
+        // memory from hipMalloc is zero, always (the driver clears what it hands out): pieces that served another buffer are made so (5 TB/s: 13 us a piece)
+        // -- and waited for: the buffer's first user may be a kernel on another stream than `st`
+        if (any_used && now_b > have && (hipMemsetAsync((char *) p + have, 0, now_b - have, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) return false;
         if (dev_alloc_log()) fprintf(stderr, "[oatk alloc] %.3f pieces    %10.3f MB -> %10.3f MB: %.4f s\n", dev_now(), (double) have / 1e6, (double) now_b / 1e6, dev_now() - t0);
         cap = now_b;
         return now_b >= want;
@@ -214,8 +256,8 @@ struct DevBuf {
     bool ensure(size_t bytes, hipStream_t st, bool zero_new = false)
     {
         if (bytes <= cap) return true;
-        if (!va) pool = bytes >= DM_MIN? pool_of_current_device() : nullptr;
-        if (pool && p && !va) { (void) hipStreamSynchronize(st); dev_free(p, cap); p = nullptr; cap = 0; }      // (a small hipMalloc'ed buffer that has outgrown DM_MIN)
+        if (!va && !decided) pool = bytes >= dm_min()? pool_for_new_buffer() : nullptr, decided = bytes >= dm_min();
+        if (pool && p && !va) { (void) hipStreamSynchronize(st); dev_free(p, cap); p = nullptr; cap = 0; }      // (a small hipMalloc'ed buffer that has outgrown the threshold)
         if (pool) {
             if (!vm_grow(bytes + bytes / 16, st)) return false;
             if (zero_new) (void) hipMemsetAsync(p, 0, cap, st);
@@ -232,7 +274,7 @@ struct DevBuf {
     bool grow_keep(size_t bytes, size_t used, hipStream_t st)
     {
         if (bytes <= cap) return true;
-        if (!va) pool = bytes >= DM_MIN? pool_of_current_device() : nullptr;
+        if (!va && !decided) pool = bytes >= dm_min()? pool_for_new_buffer() : nullptr, decided = bytes >= dm_min();
         if (pool && p && !va) {                                     // from a hipMalloc'ed buffer to pieces: the one copy of this buffer's life
             void *old = p;
             const size_t old_cap = cap;
@@ -259,7 +301,7 @@ struct DevBuf {
     bool reserve(size_t bytes, size_t used, hipStream_t st)
     {
         if (bytes <= cap) return true;
-        if (!va && !p) pool = bytes >= DM_MIN? pool_of_current_device() : nullptr;
+        if (!va && !p && !decided) pool = bytes >= dm_min()? pool_for_new_buffer() : nullptr, decided = bytes >= dm_min();
         if (pool && (va || !p)) return vm_range(up(bytes), st);
         return grow_keep(bytes, used, st);
     }
@@ -269,13 +311,13 @@ struct DevBuf {
             (void) hipDeviceSynchronize();
             for (size_t i = 0; i < ch.size(); ++i) { (void) hipMemUnmap((char *) p + i * DM_CHUNK, DM_CHUNK); pool->give(ch[i]); }
             ch.clear();
-            (void) hipMemAddressFree(p, va);
+            // (the address range is NOT given back: see vm_range)
             if (dev_alloc_log()) fprintf(stderr, "[oatk alloc] %.3f pieces    %10.3f MB back to the pool\n", dev_now(), (double) cap / 1e6);
-            p = nullptr, cap = 0, va = 0;
+            p = nullptr, cap = 0, va = 0, decided = false;
             return;
         }
         if (p) dev_free(p, cap);
-        p = nullptr; cap = 0;
+        p = nullptr; cap = 0, decided = false;
     }
     template <class T> T *as() const { return (T *) p; }
 };

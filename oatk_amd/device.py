@@ -4,6 +4,7 @@ Vocabulary follows the reference: reads, hoco (homopolymer-compressed) strings, 
 `scan` stands for sr_read's per-read analysis (syncmer.c:243-421), `count` for
 collect_syncmer_from_reads (syncmer.c:1397-1451).
 """
+import os
 import ctypes as C
 
 import numpy as np
@@ -57,6 +58,12 @@ class HipSyncasm:
         if not self.h:
             raise _lib.OatkHipError("oatk_hip_create(%d) failed: no usable MI355X (gfx950) device" % device)
         self.device = device
+        if os.environ.get("OATK_TEST_POOL"):        # tests/test_gpu_pool.py: the whole suite of a file over device memory in pieces (include/oatk_hip.h: oatk_hip_mem_pool)
+            self.mem_pool(int(os.environ["OATK_TEST_POOL"]))
+
+    def mem_pool(self, warm_bytes=0):
+        """device memory in pieces from here on, for every handle of this process on this device (oatk_hip_mem_pool)"""
+        self._check(self.L.oatk_hip_mem_pool(self.h, warm_bytes), "oatk_hip_mem_pool")
 
     def close(self):
         if self.h:
