@@ -55,6 +55,7 @@ static const char *F_NAME[F_COUNT_] = {"sr_read", "sr_db_stat", "collect_syncmer
 static struct {
     int init, enabled, log;
     oatk_hip_ctx *ctx;
+    int multi_one_device;          /* ... all of them on one GPU */
     oatk_multi *multi;             /* OATK_DEVICES names several handles: the reads are spread over them (include/oatk_multi.h); ctx is then its handle 0 */
     int corrected;                 /* the resident chains are read_error_correction's */
     int resident;                  /* the device batch mirrors sr_db (its reads, and every rewrite of their chains since) */
@@ -132,6 +133,9 @@ static void init(void)
             if (*end != ',') break;
         }
         if (nd > 1) {
+            int i, same = 1;
+            for (i = 1; i < nd; ++i) same &= dev[i] == dev[0];
+            D.multi_one_device = same;
             D.multi = oatk_multi_create(dev, nd);
             if (D.multi) D.ctx = oatk_multi_ctx(D.multi, 0);
             else fprintf(stderr, "[W::oatk_dropin] OATK_DEVICES: the %d handles or their communicators could not be made: every call runs the original body\n", nd);
@@ -197,7 +201,8 @@ void sr_read(dropin_sstream_t *s_stream, oatk_sr_db_t *sr_db, size_t mD, int n_t
     if (!why) {
         oatk_host_set_threads(n_threads);                                /* the struct filling uses as many host threads as the caller grants (-t) */
         oatk_sr_db_clean(sr_db);                                         /* syncmer.c:494-495: k and s stay */
-        if (!D.multi) {                                                  /* device memory in pieces, taken from the driver ahead of the need (include/oatk_hip.h) */
+        if (!D.multi || D.multi_one_device) {                            /* device memory in pieces, taken from the driver ahead of the need (include/oatk_hip.h); over several
+                                                                          * DEVICES the buffers stay hipMalloc's: RCCL has never been run on anything else here */
             uint64_t text = 0;
             int i;
             for (i = 0; i < s_stream->n_files; ++i) {
