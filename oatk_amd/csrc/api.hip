@@ -259,9 +259,12 @@ struct DevBuf {
         if (!va && !decided) pool = bytes >= dm_min()? pool_for_new_buffer() : nullptr, decided = bytes >= dm_min();
         if (pool && p && !va) { (void) hipStreamSynchronize(st); dev_free(p, cap); p = nullptr; cap = 0; }      // (a small hipMalloc'ed buffer that has outgrown the threshold)
         if (pool) {
-            if (!vm_grow(bytes + bytes / 16, st)) return false;
-            if (zero_new) (void) hipMemsetAsync(p, 0, cap, st);
-            return true;
+            if (vm_grow(bytes + bytes / 16, st)) {
+                if (zero_new) (void) hipMemsetAsync(p, 0, cap, st);
+                return true;
+            }
+            if (!ch.empty()) return false;          // (out of memory with pieces in place)
+            pool = nullptr, p = nullptr, cap = 0, va = 0;      // no range or no piece to start with: this buffer is hipMalloc's (a range that was reserved stays reserved)
         }
         if (p) { (void) hipStreamSynchronize(st); dev_free(p, cap); p = nullptr; cap = 0; }
         size_t want = bytes + bytes / 8 + 256;
