@@ -203,13 +203,17 @@ __global__ void ec_live_flag_kernel(uint64_t n_arc, const uint8_t *arc_del, uint
     uint64_t a = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (a < n_arc) live[a] = !arc_del[a];
 }
-__global__ void ec_live_idx_kernel(uint64_t n_ovtx, const uint64_t *idx_p, const uint32_t *idx_n, const uint64_t *live_off, uint32_t *lidx_p, uint32_t *lidx_n)
+// ... and whether the live graph BRANCHES anywhere: *branches becomes nonzero when some oriented vertex has more than one live arc out (api_ec.inc: a graph that
+// does not is searched by walking, and the solver without budgets and second stage is the faster one for it)
+__global__ void ec_live_idx_kernel(uint64_t n_ovtx, const uint64_t *idx_p, const uint32_t *idx_n, const uint64_t *live_off, uint32_t *lidx_p, uint32_t *lidx_n, uint32_t *branches)
 {
     uint64_t v = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n_ovtx) return;
     const uint32_t n = idx_n[v];
     const uint64_t p = n? live_off[idx_p[v]] : 0;
-    lidx_p[v] = (uint32_t) p, lidx_n[v] = n? (uint32_t) (live_off[idx_p[v] + n] - p) : 0u;
+    const uint32_t ln = n? (uint32_t) (live_off[idx_p[v] + n] - p) : 0u;
+    lidx_p[v] = (uint32_t) p, lidx_n[v] = ln;
+    if (ln > 1u && *(volatile uint32_t *) branches == 0u) atomicOr(branches, 1u);       // (read first: a graph may have millions of them, and they would all queue on one address)
 }
 __global__ void ec_live_arc_kernel(uint64_t n_arc, const uint8_t *arc_del, const uint64_t *live_off, const uint64_t *arc_w, const uint32_t *arc_ls,
                                    const uint64_t *vtx_hs_off, const uint32_t *vtx_mpos, const uint32_t *lidx_p, const uint32_t *lidx_n, EcLiveArc *larc,
