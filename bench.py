@@ -717,14 +717,14 @@ def main():
             time.sleep(args.cli_settle_s)
             if pending_cli_gz:
                 try:
-                    extras["config1s"]["cli_fa_gz"] = cli_util.time_cli_gz(*pending_cli_gz, args.cli_threads)
-                    extras["config1s"]["cli_fa_gz"]["device_to_itself"] = "this process released its %s of the device %.0f s before" % ("share", args.cli_settle_s)
+                    extras["config1s"]["cli_fa_gz"] = cli_util.time_cli_gz(*pending_cli_gz, args.cli_threads, settle_s=args.cli_settle_s)
+                    extras["config1s"]["cli_fa_gz"]["device_to_itself"] = "this process released its share of the device %.0f s before the first run; %.0f s between the runs (the driver clears what a process gives back while the next one waits: DESIGN.md 11.1)" % (args.cli_settle_s, args.cli_settle_s)
                 except Exception as ex:     # noqa: BLE001
                     extras["config1s"]["cli_fa_gz"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
                 pending_cli_gz = None
             try:
-                extras["cli"] = cli_util.time_cli(rs, first, min(args.cli_reads, per_gpu), K, S, c, args.cli_threads, devices="%d,%d" % (local_rank, local_rank))
-                extras["cli"]["device_to_itself"] = "this process released its share of the device %.0f s before the first run" % args.cli_settle_s
+                extras["cli"] = cli_util.time_cli(rs, first, min(args.cli_reads, per_gpu), K, S, c, args.cli_threads, devices="%d,%d" % (local_rank, local_rank), settle_s=args.cli_settle_s)
+                extras["cli"]["device_to_itself"] = "this process released its share of the device %.0f s before the first run; %.0f s between the two drop-in runs" % (args.cli_settle_s, args.cli_settle_s)
             except Exception as ex:         # noqa: BLE001
                 extras["cli"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
 

@@ -38,7 +38,7 @@ def served_table(stderr_text):
     return out
 
 
-def time_cli(readset, first, n_reads, k, s, c, threads, workdir=None, strict=True, devices=None):
+def time_cli(readset, first, n_reads, k, s, c, threads, workdir=None, strict=True, devices=None, settle_s=0.0):
     """strict: the leg FAILS (raises) when the two GFA files differ or when any of the six hot-path calls was served by its original body -- a drop-in
     number is only worth reporting when the device did the work and the bytes are the reference's"""
     if not available():
@@ -65,6 +65,10 @@ def time_cli(readset, first, n_reads, k, s, c, threads, workdir=None, strict=Tru
         multi = None
         if devices:
             # the same file once more with the reads spread over several handles (OATK_DEVICES; include/oatk_multi.h)
+            # (settle_s: the driver clears what the run before gave back -- 80 GB at 2 M reads, ~33 GB/s -- and whoever touches the device next waits for that,
+            #  a run is timed with the device to itself)
+            if settle_s:
+                time.sleep(settle_s)
             t_m, err_m = run_cli(CLI_DROPIN, fa, os.path.join(d, "mul"), k, c, threads, {"OATK_DROPIN_LOG": "1", "OATK_DEVICES": devices})
             same_m = all(filecmp.cmp(os.path.join(d, "ref" + x), os.path.join(d, "mul" + x), shallow=False) for x in (".utg.gfa", ".utg.final.gfa"))
             tab_m = served_table(err_m)
@@ -86,7 +90,7 @@ def time_cli(readset, first, n_reads, k, s, c, threads, workdir=None, strict=Tru
         os.rmdir(d)
 
 
-def time_cli_gz(seq, off, lens, n_reads, k, c, threads, workdir=None, forms=("one", "bgzf")):
+def time_cli_gz(seq, off, lens, n_reads, k, c, threads, workdir=None, forms=("one", "bgzf"), settle_s=0.0):
     """the same comparison on a gzip'ed file (BASELINE.json configs[0] is a .fa.gz): the reference binary on the single-member file, the drop-in binary on
     every form asked for; zcat's time beside it (what the reference's reader waits for); GFA files compared, original bodies counted"""
     if not available():
@@ -105,7 +109,9 @@ def time_cli_gz(seq, off, lens, n_reads, k, c, threads, workdir=None, forms=("on
         out["file_MB"] = os.path.getsize(os.path.join(d, forms[0] + ".fa.gz")) >> 20
         t_ref, _ = run_cli(CLI_REF, os.path.join(d, forms[0] + ".fa.gz"), os.path.join(d, "ref"), k, c, threads)
         out["reference_s"] = round(t_ref, 2)
-        for f in forms:
+        for i, f in enumerate(forms):
+            if settle_s and i:
+                time.sleep(settle_s)            # (see time_cli)
             t_dev, err = run_cli(CLI_DROPIN, os.path.join(d, f + ".fa.gz"), os.path.join(d, f), k, c, threads, {"OATK_DROPIN_LOG": "1"})
             same = all(filecmp.cmp(os.path.join(d, "ref" + x), os.path.join(d, f + x), shallow=False) for x in (".utg.gfa", ".utg.final.gfa"))
             tab = served_table(err)
