@@ -240,7 +240,6 @@ def test_cli_over_several_handles_without_ec_falls_back_after_the_count(tmp_path
     assert tab["make_syncmer_graph"][2] == 1
 
 
-@pytest.mark.skipif(os.environ.get("OATK_TEST_THREAD_FAIL") != "1", reason="written in round 5 after the GPU boxes were gone: runs on request (OATK_TEST_THREAD_FAIL=1) until it has been seen green on a GPU once")
 def test_cli_over_several_handles_when_a_host_thread_cannot_start(tmp_path):
     """one host thread per handle runs every collective step (host/multi_host.c run_ranks); when one of them cannot be started the threads that did start
     are sent home before any of them is inside a collective, the call fails as a whole, and the original body serves it: the reference's bytes still,
