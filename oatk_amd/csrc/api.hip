@@ -210,7 +210,8 @@ struct DevBuf {
         if (bytes <= va) return true;
         const size_t nva = up(bytes < (1ull << 30)? 4 * bytes + (256ull << 20) : bytes + bytes / 2 + (2ull << 30));     // room to grow in place
         void *np = nullptr;
-        if (hipMemAddressReserve(&np, nva, 2 << 20, nullptr, 0) != hipSuccess) { (void) hipGetLastError(); return false; }
+        { const hipError_t er = hipMemAddressReserve(&np, nva, 2 << 20, nullptr, 0);
+          if (er != hipSuccess) { if (dev_alloc_log()) fprintf(stderr, "[oatk alloc] hipMemAddressReserve of %.1f MB FAILED: %s\n", (double) nva / 1e6, hipGetErrorString(er)); (void) hipGetLastError(); return false; } }
         if (!ch.empty()) {
             (void) hipStreamSynchronize(st);
             (void) hipDeviceSynchronize();
@@ -239,13 +240,15 @@ struct DevBuf {
         while (ch.size() * DM_CHUNK < want) {
             hipMemGenericAllocationHandle_t h;
             bool was_used;
-            if (!pool->take(&h, &was_used)) break;
-            if (hipMemMap((char *) p + ch.size() * DM_CHUNK, DM_CHUNK, 0, h, 0) != hipSuccess) { (void) hipGetLastError(); pool->give(h); break; }
+            if (!pool->take(&h, &was_used)) { if (dev_alloc_log()) fprintf(stderr, "[oatk alloc] no piece to be had\n"); break; }
+            { const hipError_t er = hipMemMap((char *) p + ch.size() * DM_CHUNK, DM_CHUNK, 0, h, 0);
+              if (er != hipSuccess) { if (dev_alloc_log()) fprintf(stderr, "[oatk alloc] hipMemMap FAILED: %s\n", hipGetErrorString(er)); (void) hipGetLastError(); pool->give(h); break; } }
             ch.push_back(h);
             any_used |= was_used;
         }
         const size_t now_b = ch.size() * DM_CHUNK;
-        if (now_b > have && hipMemSetAccess((char *) p + have, now_b - have, &pool->acc, 1) != hipSuccess) return false;
+        if (now_b > have) { const hipError_t er = hipMemSetAccess((char *) p + have, now_b - have, &pool->acc, 1);
+                            if (er != hipSuccess) { if (dev_alloc_log()) fprintf(stderr, "[oatk alloc] hipMemSetAccess FAILED: %s\n", hipGetErrorString(er)); (void) hipGetLastError(); return false; } }
         // memory from hipMalloc is zero, always (the driver clears what it hands out): pieces that served another buffer are made so (5 TB/s: 13 us a piece)
         // -- and waited for: the buffer's first user may be a kernel on another stream than `st`
         if (any_used && now_b > have && (hipMemsetAsync((char *) p + have, 0, now_b - have, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) return false;
